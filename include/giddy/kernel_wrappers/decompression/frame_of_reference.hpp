@@ -1,0 +1,80 @@
+// Kernel wrapper for Frame-of-Reference decompression: typed and type-erased launch-configuration
+// resolution, type-erased enqueue, factory registration.  Argument-map keys and their exact C++
+// types follow the reference's src/kernel_wrappers/decompression/frame_of_reference.cu:58-102.
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/frame_of_reference.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace frame_of_reference {
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using size_type               = size_type_by_index_size<IndexSize>;
+	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t           device_properties,
+		device_function::attributes_t  kernel_function_attributes,
+		size_t                         length,
+		size_t                         segment_length,
+		launch_configuration_limits_t  limits = { nullopt, nullopt, nullopt }) const
+	{
+		launch_config_resolution_params_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction> params(
+			device_properties, kernel_function_attributes, length, segment_length);
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+launch_configuration_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::resolve_launch_configuration(
+	device::properties_t           device_properties,
+	device_function::attributes_t  kernel_function_attributes,
+	arguments_type                 extra_arguments,
+	launch_configuration_limits_t  limits) const
+{
+	auto length         = any_cast<size_t>(extra_arguments.at("length"));
+	auto segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_launch(
+	stream::id_t                   stream,
+	const launch_configuration_t&  launch_config,
+	arguments_type                 arguments) const
+{
+	using index_type = uint_t<IndexSize>;
+
+	auto decompressed               = any_cast<Uncompressed*                  >(arguments.at("decompressed"));
+	auto compressed_input           = any_cast<const Compressed*              >(arguments.at("compressed_input"));
+	auto segment_model_coefficients = any_cast<const model_coefficients_type* >(arguments.at("segment_model_coefficients"));
+	auto length                     = any_cast<index_type                     >(arguments.at("length"));
+	auto segment_length             = any_cast<index_type                     >(arguments.at("segment_length"));
+
+	// One model record per segment.  The kernel's last parameter exists for signature parity
+	// with the reference (frame_of_reference.cu:93-100 computes it the same way).
+	auto num_segments = util::div_rounding_up(length, segment_length);
+	auto num_blocks = launch_config.grid_dimensions.x;
+	index_type segments_per_block = num_blocks ? util::div_rounding_up(num_segments, num_blocks) : 0;
+
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, compressed_input, segment_model_coefficients,
+		(size_type) length, (size_type) segment_length, segments_per_block);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+const device_function_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::get_device_function() const
+{
+	return reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
+}
+
+} // namespace frame_of_reference
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,58 @@
+// cuda::registered::kernel_t — a kernel wrapper that registers itself in a string-keyed factory
+// during static initialisation — and the per-wrapper boilerplate macro.  Interface and key
+// construction follow the reference's src/kernel_wrappers/registered_wrapper.h:28-39,63-88:
+// key = demangled type name with everything up to and including "cuda::kernels::" removed.
+#pragma once
+#include <string>
+
+#include "giddy/kernel_wrapper.hpp"
+#include "giddy/util/factory.hpp"
+#include "giddy/util/type_name.hpp"
+
+namespace cuda {
+namespace registered {
+
+class kernel_t : public cuda::kernel_t, protected util::mixins::FactoryProducible<std::string, kernel_t> {
+public:
+	using factory_key_type = std::string;
+	using parent = cuda::kernel_t;
+	using factory_producible_mixin_type = util::mixins::FactoryProducible<factory_key_type, kernel_t>;
+	using factory_producible_mixin_type::produceSubclass;
+	using factory_producible_mixin_type::getSubclassFactory;
+	using factory_producible_mixin_type::canProduce;
+};
+
+namespace detail {
+inline std::string factory_key_of(const std::string& type_name)
+{
+	static const std::string prefix = "cuda::kernels::";
+	auto pos = type_name.find(prefix);
+	return pos == std::string::npos ? type_name : type_name.substr(pos + prefix.length());
+}
+} // namespace detail
+
+} // namespace registered
+} // namespace cuda
+
+#define REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(subclass_name) \
+	using parent          = cuda::registered::kernel_t; \
+	using arguments_type  = parent::arguments_type; \
+	using parent::resolve_launch_configuration; \
+	static void registerInSubclassFactory() { \
+		FactoryProducible::registerInSubclassFactory<subclass_name>( \
+			cuda::registered::detail::factory_key_of(util::type_name<subclass_name>())); \
+	} \
+public: \
+	launch_configuration_t resolve_launch_configuration( \
+		device::properties_t           device_properties, \
+		device_function::attributes_t  kernel_function_attributes, \
+		arguments_type                 extra_arguments, \
+		launch_configuration_limits_t  limits = { nullopt, nullopt, nullopt }) const override final; \
+	\
+	/* Note: the stream is assumed to be on the current device */ \
+	void enqueue_launch( \
+		stream::id_t                   stream, \
+		const launch_configuration_t&  launch_config, \
+		arguments_type                 arguments) const override final; \
+	\
+	const device_function_t get_device_function() const override final

@@ -1,0 +1,80 @@
+// Naive scatter ("patching"):   target[indices[i]] = data[i],  i < data_length,  distinct indices.
+//
+// Same kernel template name, parameter list and semantics as the reference's
+// src/kernels/data_layout/scatter.cuh:26-46.  Patches are ~0.1 % of a column (SURVEY.md §8d,
+// config C3), so the kernel is tiny next to the decoder it follows on the same stream; it reads
+// indices and data with wide coalesced loads (4 patches per lane per step) and issues the
+// unavoidable scattered element stores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace scatter {
+
+static const serialization_factor_t DefaultSerializationFactor { 16 };
+
+namespace detail { enum : unsigned { patches_per_lane = 4 }; }
+
+template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+__global__ void scatter(
+	uint_t<ElementSize>*            __restrict__  target,
+	const uint_t<ElementSize>*      __restrict__  data,
+	const uint_t<OutputIndexSize>*  __restrict__  indices,
+	size_type_by_index_size<InputIndexSize>       data_length)
+{
+	using namespace memory_access;
+	using element_type = uint_t<ElementSize>;
+	using index_type = uint_t<OutputIndexSize>;
+	constexpr unsigned G = detail::patches_per_lane;
+	const uint64_t n = data_length;
+	const bool vectorizable = is_aligned(data, G * ElementSize >= 16 ? 16 : G * ElementSize)
+		&& is_aligned(indices, G * OutputIndexSize >= 16 ? 16 : G * OutputIndexSize);
+	const uint64_t num_groups = vectorizable ? n / G : 0;
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+
+	for (uint64_t g = global_thread; g < num_groups; g += num_threads) {
+		auto where = load_group<index_type, G>(indices + g * G);
+		auto what = load_group<element_type, G>(data + g * G);
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) { target[where[j]] = what[j]; }
+	}
+	for (uint64_t i = num_groups * G + global_thread; i < n; i += num_threads) { target[indices[i]] = data[i]; }
+}
+
+template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_,
+		size_t input_data_length_)
+	: parent(device_properties_, kernel_function_attributes_, nullopt)
+	{
+		grid_construction_resolution  = thread;
+		length                        = util::div_rounding_up(input_data_length_, (size_t) detail::patches_per_lane);
+		serialization_option          = auto_maximized;
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+		default_serialization_factor  = SerializationFactor;
+	}
+
+	launch_config_resolution_params_t(device::properties_t device_properties_, size_t input_data_length_)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(scatter<OutputIndexSize, ElementSize, InputIndexSize, SerializationFactor>).attributes(),
+		input_data_length_) { }
+};
+
+} // namespace scatter
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,313 @@
+// Delta decompression for CDNA4:
+//
+//   out[s*L + i] = anchor_values[s] + sum_{j <= i} compressed_input[s*L + j]      (mod 2^(8*UncompressedSize))
+//
+// i.e. a per-segment inclusive prefix sum of UNSIGNED deltas seeded with the segment's anchor —
+// the element semantics of the reference's src/kernels/decompression/delta.cuh:66-108 (+
+// src/kernels/reduction/scan.cuh:285-381), same kernel template name and parameter list.
+//
+// The reference scans one element per thread per block-wide chunk: a 5-step shuffle scan, a
+// shared-memory exchange, two __syncthreads and a second scan by warp 0 for every blockDim
+// elements — synchronisation-bound, and only correct when segment_length >= blockDim (it indexes
+// anchors by a block-sized pseudo-segment, delta.cuh:80-92).  Here:
+//
+//  * rows.  A wavefront works on rows of 64*E consecutive elements, E = 16/UncompressedSize, lane l
+//    owning elements [l*E, l*E+E): one 2..16-byte load of E deltas, E-1 adds in registers, a
+//    wave-wide DPP inclusive sum of the 64 lane totals (6 VALU steps, no LDS), one 16-byte store
+//    that is contiguous across the wavefront.  R rows are in flight per wavefront; their scans are
+//    independent and only the R row totals chain.  When the deltas are <= 2 bytes wide the
+//    in-row scan runs in 32 bits even for 64-bit outputs (a row's prefix cannot overflow).
+//  * wave path (segment_length % row == 0, segment_length <= 16384): one wavefront per anchored
+//    segment, carry in a register, NO barriers and no LDS at all.
+//  * block path (longer segments): the wavefronts of a workgroup take consecutive rows of one
+//    segment in lock-step; carries cross wavefronts through a double-buffered 16-entry LDS table,
+//    one barrier per 64*E*waves elements.
+//  * general path (any other segment_length >= 1, or unaligned pointers): a segmented scan
+//    (reset flags at segment heads) over rows, anchors gathered per element.  Slower, correct for
+//    every L — including L < blockDim, which the reference gets wrong.
+//
+// HBM traffic per element: CompressedSize read + UncompressedSize written (+ one anchor per
+// segment): 10.002 B for 64-bit <- 16-bit at L = 4096.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace delta {
+
+namespace detail {
+
+enum : unsigned {
+	rows_in_flight = 4,
+	longest_segment_for_wave_path = 16384,
+	max_waves_per_block = 16,
+};
+
+template <unsigned UncompressedSize, unsigned CompressedSize>
+struct row_traits {
+	enum : unsigned { E = 16 / UncompressedSize, row = 64 * E };
+	using uncompressed_type = uint_t<UncompressedSize>;
+	using compressed_type = uint_t<CompressedSize>;
+	// type the in-row prefix is formed in: 64*E elements of at most 2^(8*CompressedSize)-1 each
+	using scan_type = typename std::conditional<(UncompressedSize <= 4 || CompressedSize <= 2), uint32_t, uint64_t>::type;
+};
+
+/// One row: load, scan, return the exclusive-of-row prefixes; `valid` = elements of the row inside the input
+template <unsigned UncompressedSize, unsigned CompressedSize>
+struct row_t {
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using scan_type = typename traits::scan_type;
+	enum : unsigned { E = traits::E };
+	memory_access::group<typename traits::compressed_type, E> deltas;
+	scan_type prefix[E];     // inclusive prefix within the row, per owned element
+	scan_type total;         // sum of the whole row (uniform)
+
+	__device__ __forceinline__ void load(const typename traits::compressed_type* __restrict__ in, uint64_t row_start, uint64_t end, unsigned lane)
+	{
+		uint64_t p = row_start + (uint64_t) lane * E;
+		if (p + E <= end) { deltas = memory_access::load_group<typename traits::compressed_type, E>(in + p); }
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { deltas[j] = (p + j < end) ? in[p + j] : (typename traits::compressed_type) 0; }
+		}
+	}
+	__device__ __forceinline__ void scan()
+	{
+		scan_type running = 0;
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) { running += deltas[j]; prefix[j] = running; }
+		scan_type inclusive = wave64::inclusive_sum(running);
+		scan_type exclusive = inclusive - running;
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) { prefix[j] += exclusive; }
+		total = wave64::read_last_lane(inclusive);
+	}
+	__device__ __forceinline__ void store(typename traits::uncompressed_type* __restrict__ out, uint64_t row_start, uint64_t end, unsigned lane,
+		typename traits::uncompressed_type base) const
+	{
+		using U = typename traits::uncompressed_type;
+		uint64_t p = row_start + (uint64_t) lane * E;
+		memory_access::group<U, E> values;
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
+		if (p + E <= end) { memory_access::store_group(out + p, values); }
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { if (p + j < end) { out[p + j] = values[j]; } }
+		}
+	}
+};
+
+/// wave path: this wavefront decompresses whole segments on its own
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__device__ __forceinline__ void wave_per_segment(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	constexpr unsigned R = rows_in_flight;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t num_segments = (n + L - 1) / L;
+
+	for (uint64_t s = wave; s < num_segments; s += num_waves) {
+		const uint64_t start = s * L;
+		const uint64_t end = (start + L < n) ? start + L : n;
+		U base = anchors[s];
+		for (uint64_t row_start = start; row_start < end; row_start += (uint64_t) R * traits::row) {
+			row_t<UncompressedSize, CompressedSize> rows[R];
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].load(in, row_start + (uint64_t) k * traits::row, end, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				rows[k].store(out, row_start + (uint64_t) k * traits::row, end, lane, base);
+				base += (U) rows[k].total;
+			}
+		}
+	}
+}
+
+/// block path: the workgroup's wavefronts sweep one long segment together
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__device__ __forceinline__ void block_per_segment(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	__shared__ U wave_totals[2][max_waves_per_block];
+	const unsigned lane = wave64::lane_id();
+	const unsigned w = wave64::index_in_block();
+	const unsigned num_waves = wave64::per_block();
+	const uint64_t num_segments = (n + L - 1) / L;
+	unsigned buffer = 0;
+
+	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+		const uint64_t start = s * L;
+		const uint64_t end = (start + L < n) ? start + L : n;
+		U base = anchors[s];
+		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * traits::row) {
+			row_t<UncompressedSize, CompressedSize> r;
+			const uint64_t row_start = sweep_start + (uint64_t) w * traits::row;
+			r.load(in, row_start, end, lane);   // rows past `end` load zeros
+			r.scan();
+			if (lane == 0) { wave_totals[buffer][w] = (U) r.total; }
+			__syncthreads();
+			U before = 0, all = 0;
+			for (unsigned v = 0; v < num_waves; v++) {
+				U t = wave_totals[buffer][v];
+				if (v < w) { before += t; }
+				all += t;
+			}
+			r.store(out, row_start, end, lane, (U) (base + before));
+			base += all;
+			buffer ^= 1;   // the next sweep writes the other table; this one is re-written only after another barrier
+		}
+	}
+}
+
+/// general path: any segment length, any alignment — segmented scan with reset at segment heads
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__device__ __forceinline__ void segmented(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+{
+	using U = uint_t<UncompressedSize>;
+	enum : unsigned { E = 4, row = 64 * E };
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	// a wavefront owns a run of whole segments spanning at least one row
+	const uint64_t segments_per_chunk = L >= row ? 1 : (row + L - 1) / L;
+	const uint64_t chunk_length = segments_per_chunk * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t start = c * chunk_length;
+		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
+		U carry = 0;   // sum since the last segment head before the current row (the chunk starts on a head)
+		for (uint64_t row_start = start; row_start < end; row_start += row) {
+			const uint64_t p0 = row_start + (uint64_t) lane * E;
+			uint64_t seg, within;
+			if (IndexSize <= 4 || ((p0 | L) >> 32) == 0) { uint32_t q = (uint32_t) p0 / (uint32_t) L; seg = q; within = (uint32_t) p0 - q * (uint32_t) L; }
+			else { seg = p0 / L; within = p0 - seg * L; }
+			U value[E]; uint64_t seg_of[E]; bool before_head[E];
+			U running = 0; bool has_head = false;
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				U d = (p0 + j < end) ? (U) in[p0 + j] : (U) 0;
+				if (within == 0) { running = 0; has_head = true; }
+				running += d;
+				value[j] = running; seg_of[j] = seg; before_head[j] = !has_head;
+				if (++within == L) { within = 0; seg++; }
+			}
+			// wave-wide segmented inclusive scan of (has_head, running): Kogge-Stone over shuffles
+			U acc = running; bool flag = has_head;
+			#pragma unroll
+			for (unsigned d = 1; d < 64; d <<= 1) {
+				U other = __shfl_up(acc, d, 64);
+				int other_flag = __shfl_up((int) flag, d, 64);
+				if (lane >= d) { if (!flag) { acc += other; } flag = flag || other_flag; }
+			}
+			U incoming = wave64::shift_up_by_one<U>(acc, 0);              // sum since the last head, over lanes < l
+			bool head_before = (bool) wave64::shift_up_by_one<int>((int) flag, 0);   // is there a head in lanes < l
+			U lane_carry = head_before ? incoming : (U) (incoming + carry);
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				if (p0 + j < end) {
+					U v = before_head[j] ? (U) (value[j] + lane_carry) : value[j];
+					out[p0 + j] = (U) (anchors[seg_of[j]] + v);
+				}
+			}
+			U last_acc = wave64::read_last_lane(acc);
+			bool any_head = wave64::ballot(flag) >> 63;   // lane 63's inclusive flag
+			carry = any_head ? last_acc : (U) (carry + last_acc);
+		}
+	}
+}
+
+} // namespace detail
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*        __restrict__  decompressed,
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*  __restrict__  anchor_values,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length)
+{
+	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+	const uint64_t n = length, L = segment_length;
+	if (n == 0 || L == 0) { return; }
+	const bool rows_fit_segments = (L % traits::row == 0)
+		&& memory_access::is_aligned(decompressed, 16)
+		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
+	if (rows_fit_segments && L <= detail::longest_segment_for_wave_path) {
+		detail::wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
+	}
+	else if (rows_fit_segments && wave64::per_block() <= detail::max_waves_per_block) {
+		detail::block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
+	}
+	else {
+		detail::segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
+	}
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t            device_properties_,
+		device_function::attributes_t   kernel_function_attributes_,
+		size_t                          data_length,
+		size_t                          segment_length,
+		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
+	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
+	{
+		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		auto num_segments = util::div_rounding_up(data_length, segment_length);
+		bool wave_path = segment_length % traits::row == 0 && segment_length <= detail::longest_segment_for_wave_path;
+		bool block_path = segment_length % traits::row == 0 && !wave_path;
+		if (block_path) {
+			// one workgroup per (long) segment, at grid stride
+			grid_construction_resolution = block;
+			length = num_segments;
+			block_resolution_constraints.max_threads_per_block = 1024;
+		}
+		else {
+			// one wavefront per segment (or per row-sized run of short segments), at grid stride
+			grid_construction_resolution = warp;
+			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
+			length = wave_path ? num_segments : util::div_rounding_up(num_segments, per_chunk);
+			upper_limits.threads_in_block = 256;
+		}
+		serialization_option = auto_maximized;
+		keep_gpu_busy_factor = 8;
+		quanta.threads_in_block = warp_size;
+	}
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, size_t data_length, size_t segment_length,
+		optional<shared_memory_size_t> dynamic_shared_mem_limit = nullopt)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<IndexSize, UncompressedSize, CompressedSize>).attributes(),
+		data_length, segment_length, dynamic_shared_mem_limit) { }
+};
+
+} // namespace delta
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,171 @@
+// Dictionary decompression for CDNA4:   out[p] = dictionary_entries[compressed_input[p]]
+//
+// Kernel template name and parameter list as in the reference's
+// src/kernels/decompression/dictionary.cuh:61-75 (which forwards to gather,
+// src/kernels/data_layout/gather.cuh:16-146).  Execution shape, re-designed:
+//
+//  * the reference reads one key per thread and chases it with a dependent global load of the
+//    entry; its shared-memory dictionary cache is commented out and force-disabled
+//    (gather.cuh:33-90, :202-205);
+//  * here the dictionary is staged ONCE per workgroup into LDS (the launch configuration asks for
+//    num_entries * sizeof(entry) bytes of dynamic LDS whenever that fits) and workgroups are
+//    persistent — they walk tiles at grid stride, so the staging cost is amortised over the whole
+//    column.  A lane loads G keys as a single 4/8/16-byte load, performs G LDS look-ups
+//    (ds_read; random keys cost a few bank-conflict cycles, far below the HBM budget of ~10 B/clk/CU)
+//    and writes 16-byte stores that are contiguous across the wavefront.
+//  * dictionaries that do not fit in LDS fall back to look-ups through L1/L2.
+//
+// HBM traffic per element: sizeof(key) read + sizeof(entry) written (+ the dictionary once per
+// workgroup, L2-resident) — 5 B for 8-bit keys -> 32-bit values.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace dictionary {
+
+/// the reference's (ignored) run-time serialization factor default, gather.cuh:9-11
+constexpr serialization_factor_t get_default_serialization_factor(bool cache_all_data_in_shared_memory)
+{
+	return cache_all_data_in_shared_memory ? 128 : 16;
+}
+
+namespace detail {
+
+enum : unsigned { steps_per_tile = 4 };
+
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
+struct tiling {
+	enum : unsigned {
+		by_store = 16 / UncompressedSize,        // one 16-byte store
+		by_load  = 4 / DictionaryIndexSize,      // at least a 4-byte key load
+		elements_per_step = by_store > by_load ? by_store : (by_load > 0 ? by_load : 1),
+	};
+};
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup>
+__device__ __forceinline__ void translate(
+	uint_t<UncompressedSize>*           __restrict__  decompressed,
+	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
+	uint64_t                                          n,
+	Lookup                                            lookup)
+{
+	using namespace memory_access;
+	using key_type = uint_t<DictionaryIndexSize>;
+	using value_type = uint_t<UncompressedSize>;
+	constexpr unsigned G = tiling<UncompressedSize, DictionaryIndexSize>::elements_per_step;
+	constexpr unsigned K = steps_per_tile;
+
+	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * sizeof(key_type) >= 16 ? 16 : G * sizeof(key_type));
+	const uint64_t num_groups = vectorizable ? n / G : 0;
+	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+
+	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		group<key_type, G> keys[K];
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g < num_groups) { keys[k] = load_group<key_type, G>(compressed_input + g * G); }
+		}
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g >= num_groups) { continue; }
+			group<value_type, G> out;
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[k][j]); }
+			store_group(decompressed + g * G, out);
+		}
+	}
+
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
+		decompressed[p] = lookup(compressed_input[p]);
+	}
+}
+
+} // namespace detail
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*           __restrict__  decompressed,
+	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*     __restrict__  dictionary_entries,
+	size_type_by_index_size<IndexSize>                length,
+	size_type_by_index_size<DictionaryIndexSize>      num_dictionary_entries,
+	bool                                              cache_dictionary_in_shared_memory,
+	serialization_factor_t                            serialization_factor) // accepted and ignored, as in gather.cuh:24
+{
+	using value_type = uint_t<UncompressedSize>;
+	using key_type = uint_t<DictionaryIndexSize>;
+	(void) serialization_factor;
+	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
+
+	if (cache_dictionary_in_shared_memory) {
+		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
+		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
+		__syncthreads();
+		detail::translate<IndexSize, UncompressedSize, DictionaryIndexSize>(
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; });
+	}
+	else {
+		detail::translate<IndexSize, UncompressedSize, DictionaryIndexSize>(
+			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; });
+	}
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	/// whether a dictionary of this many entries is staged in LDS (unless overridden)
+	bool should_cache_dictionary_in_shared_memory(size_t num_dictionary_entries) const
+	{
+		return num_dictionary_entries * UncompressedSize <= available_dynamic_shared_memory_per_block;
+	}
+
+	launch_config_resolution_params_t(
+		device::properties_t            device_properties_,
+		device_function::attributes_t   kernel_function_attributes_,
+		size_t                          num_dictionary_entries,
+		size_t                          data_length,
+		optional<bool>                  cache_dictionary_in_shared_memory_override = nullopt,
+		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
+	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
+	{
+		constexpr unsigned elements_per_thread_per_tile =
+			detail::tiling<UncompressedSize, DictionaryIndexSize>::elements_per_step * detail::steps_per_tile;
+		bool cache = cache_dictionary_in_shared_memory_override.value_or(
+			should_cache_dictionary_in_shared_memory(num_dictionary_entries));
+		grid_construction_resolution  = thread;
+		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
+		serialization_option          = auto_maximized;   // persistent workgroups: stage once, walk tiles at grid stride
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) (num_dictionary_entries * UncompressedSize); }
+		default_serialization_factor  = get_default_serialization_factor(cache);
+	}
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, size_t num_dictionary_entries, size_t data_length,
+		optional<bool> cache_dictionary_in_shared_memory_override = nullopt,
+		optional<shared_memory_size_t> dynamic_shared_mem_limit = nullopt)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>).attributes(),
+		num_dictionary_entries, data_length, cache_dictionary_in_shared_memory_override, dynamic_shared_mem_limit) { }
+};
+
+} // namespace dictionary
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

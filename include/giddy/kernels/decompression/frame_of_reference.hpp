@@ -1,0 +1,150 @@
+// Frame-of-reference decompression for CDNA4.
+//
+//   out[p] = Uncompressed( Uncompressed(model_s(p - s*L)) + compressed_input[p] ),   s = p / L
+//
+// Same kernel template name, parameter list and element semantics as the reference's
+// src/kernels/decompression/frame_of_reference.cuh:35-80 (so a direct `cuda::launch` of
+// `decompress<...>` keeps working), with a different execution shape:
+//
+//  * the reference gives one thread one element and ties the grid to the segmentation
+//    (segments-per-block, a fixed block length for a single segment — which makes a 1-segment,
+//    >1024-element column un-launchable, frame_of_reference.cuh:111-113);
+//  * here the kernel is a plain HBM stream: a lane owns G = 16/sizeof(Uncompressed) consecutive
+//    elements per step, reads them as one 4/8-byte load, writes them as one 16-byte store, and
+//    every workgroup walks tiles of K steps at grid stride.  Segments only matter for picking the
+//    coefficient record: one integer division per G elements, record fetched through L1/L2
+//    (neighbouring lanes hit the same record).  Any grid/block shape is correct.
+//
+// HBM traffic per element: sizeof(Compressed) read + sizeof(Uncompressed) written (+ one record per
+// segment) — the algorithmic minimum (6 B for int32 <- int16).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <stdexcept>
+
+#include "giddy/common.hpp"
+#include "giddy/functors/model_functors.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace frame_of_reference {
+
+enum : serialization_factor_t { DefaultSerializationFactor = 16 };
+
+namespace detail {
+
+enum : unsigned { steps_per_tile = 4 };
+
+template <unsigned IndexSize>
+__device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotient, uint64_t& remainder)
+{
+	if (IndexSize <= 4 || ((p | l) >> 32) == 0) {
+		uint32_t q = (uint32_t) p / (uint32_t) l;
+		quotient = q; remainder = (uint32_t) p - q * (uint32_t) l;
+	}
+	else { quotient = p / l; remainder = p - quotient * l; }
+}
+
+} // namespace detail
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+__global__ void decompress(
+	Uncompressed*       __restrict__    decompressed,
+	const Compressed*   __restrict__    compressed_input,
+	const typename UnaryModelFunction::coefficients_type*
+	                    __restrict__    segment_model_coefficients,
+	size_type_by_index_size<IndexSize>  length,
+	size_type_by_index_size<IndexSize>  segment_length,
+	uint_t<IndexSize>                   num_segments_to_decompress_per_block) // kept for signature parity; the tiling here does not depend on it
+{
+	using namespace memory_access;
+	using model_index_type = typename UnaryModelFunction::index_type;
+	constexpr unsigned G = 16 / sizeof(Uncompressed);
+	constexpr unsigned K = detail::steps_per_tile;
+	(void) num_segments_to_decompress_per_block;
+
+	const uint64_t n = length, L = segment_length;
+	auto element = [&](uint64_t segment, uint64_t within, Compressed offset) -> Uncompressed {
+		UnaryModelFunction segment_model(segment_model_coefficients[segment]);
+		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
+		return (Uncompressed) (predicted_value + offset);
+	};
+
+	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * sizeof(Compressed));
+	const uint64_t num_groups = vectorizable ? n / G : 0;
+	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+
+	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		group<Compressed, G> in[K];
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g < num_groups) { in[k] = load_group<Compressed, G>(compressed_input + g * G); }
+		}
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g >= num_groups) { continue; }
+			uint64_t segment, within;
+			detail::divide<IndexSize>(g * G, L, segment, within);
+			group<Uncompressed, G> out;
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) {
+				out[j] = element(segment, within, in[k][j]);
+				if (++within == L) { within = 0; segment++; }
+			}
+			store_group(decompressed + g * G, out);
+		}
+	}
+
+	// whatever the vector path did not cover: the ragged tail, or everything if a base pointer is unaligned
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
+		uint64_t segment, within;
+		detail::divide<IndexSize>(p, L, segment, within);
+		decompressed[p] = element(segment, within, compressed_input[p]);
+	}
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t           device_properties_,
+		device_function::attributes_t  kernel_function_attributes_,
+		size_t                         data_length,
+		size_t                         segment_length)
+	: parent(device_properties_, kernel_function_attributes_)
+	{
+		// same argument validation as frame_of_reference.cuh:99-104
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		if (segment_length % sizeof(native_word_t) != 0) {
+			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
+		}
+		constexpr unsigned elements_per_thread_per_tile = (16 / sizeof(Uncompressed)) * detail::steps_per_tile;
+		grid_construction_resolution  = thread;
+		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
+		serialization_option          = auto_maximized;   // tiles at grid stride
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;               // 256 CUs x 4 SIMDs x 8 / 4 waves = 2048 workgroups
+	}
+
+	launch_config_resolution_params_t(device::properties_t device_properties_, size_t data_length, size_t segment_length)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>).attributes(),
+		data_length, segment_length) { }
+};
+
+} // namespace frame_of_reference
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

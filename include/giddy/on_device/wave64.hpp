@@ -1,0 +1,161 @@
+// Wave64 device primitives for CDNA4 (gfx950): lane ids, DPP prefix sums, broadcasts, 16-byte
+// vector memory access.  These are the building blocks the kernels in giddy/kernels/** use where the
+// reference uses 32-lane shuffles and a two-level shared-memory block scan (SURVEY.md §2b:
+// primitives/warp.cuh:127-168, primitives/block.cuh:404-464) — re-thought for a 64-lane wavefront:
+// a full-wave inclusive sum is 4 row_shr steps + 2 row_bcast steps on the VALU's DPP path, no LDS.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <type_traits>
+
+namespace cuda {
+namespace wave64 {
+
+enum : unsigned { size = 64, log_size = 6 };
+
+__device__ __forceinline__ unsigned lane_id()
+{
+	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+}
+
+/// index of this wavefront within its workgroup / number of wavefronts in the workgroup (1-D blocks)
+__device__ __forceinline__ unsigned index_in_block() { return threadIdx.x >> log_size; }
+__device__ __forceinline__ unsigned per_block() { return (blockDim.x + size - 1) >> log_size; }
+
+// DPP controls (LLVM AMDGPU: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
+enum : int { row_shr_1 = 0x111, row_shr_2 = 0x112, row_shr_4 = 0x114, row_shr_8 = 0x118, row_bcast_15 = 0x142, row_bcast_31 = 0x143 };
+
+/// lanes with no valid source (shifted in from outside the row, or masked out by RowMask) read 0
+template <int Control, int RowMask = 0xf>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v)
+{
+	return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) v, Control, RowMask, 0xf, false);
+}
+template <int Control, int RowMask = 0xf>
+__device__ __forceinline__ uint64_t dpp_or_zero(uint64_t v)
+{
+	uint32_t lo = dpp_or_zero<Control, RowMask>((uint32_t) v);
+	uint32_t hi = dpp_or_zero<Control, RowMask>((uint32_t) (v >> 32));
+	return ((uint64_t) hi << 32) | lo;
+}
+
+/// Inclusive prefix sum across the 64 lanes (wrapping arithmetic), T = uint32_t or uint64_t.
+template <typename T>
+__device__ __forceinline__ T inclusive_sum(T v)
+{
+	v += dpp_or_zero<row_shr_1>(v);
+	v += dpp_or_zero<row_shr_2>(v);
+	v += dpp_or_zero<row_shr_4>(v);
+	v += dpp_or_zero<row_shr_8>(v);          // each 16-lane row is scanned
+	v += dpp_or_zero<row_bcast_15, 0xA>(v);  // rows 1,3 += last lane of rows 0,2
+	v += dpp_or_zero<row_bcast_31, 0xC>(v);  // rows 2,3 += lane 31
+	return v;
+}
+
+/// Inclusive prefix maximum across the 64 lanes (values >= 0 assumed: identity is 0)
+__device__ __forceinline__ uint32_t inclusive_max(uint32_t v)
+{
+	auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+	v = mx(v, dpp_or_zero<row_shr_1>(v));
+	v = mx(v, dpp_or_zero<row_shr_2>(v));
+	v = mx(v, dpp_or_zero<row_shr_4>(v));
+	v = mx(v, dpp_or_zero<row_shr_8>(v));
+	v = mx(v, dpp_or_zero<row_bcast_15, 0xA>(v));
+	v = mx(v, dpp_or_zero<row_bcast_31, 0xC>(v));
+	return v;
+}
+
+template <typename T>
+__device__ __forceinline__ T read_lane(T v, unsigned lane)
+{
+	if constexpr (sizeof(T) <= 4) { return (T) __builtin_amdgcn_readlane((int) v, (int) lane); }
+	else {
+		uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) lane);
+		uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ((uint64_t) v >> 32), (int) lane);
+		return (T) (((uint64_t) hi << 32) | lo);
+	}
+}
+template <typename T> __device__ __forceinline__ T read_last_lane(T v) { return read_lane(v, 63u); }
+template <typename T>
+__device__ __forceinline__ T read_first_lane(T v)
+{
+	if constexpr (sizeof(T) <= 4) { return (T) __builtin_amdgcn_readfirstlane((int) v); }
+	else {
+		uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+		uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) ((uint64_t) v >> 32));
+		return (T) (((uint64_t) hi << 32) | lo);
+	}
+}
+
+__device__ __forceinline__ uint64_t ballot(bool predicate) { return __builtin_amdgcn_ballot_w64(predicate); }
+
+/// value of lane (l - 1); lane 0 gets `first`
+template <typename T>
+__device__ __forceinline__ T shift_up_by_one(T v, T first)
+{
+	T r = __shfl_up(v, 1, 64);
+	return lane_id() == 0 ? first : r;
+}
+
+/// orders this wavefront's LDS traffic: writes by any lane before, reads by any lane after
+__device__ __forceinline__ void lds_fence()
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+} // namespace wave64
+
+// ---- 16-byte-and-narrower vector access --------------------------------------------------------
+
+namespace memory_access {
+
+template <unsigned Bytes> struct chunk;   // a naturally aligned power-of-two byte group
+template <> struct chunk<1>  { using type = uint8_t; };
+template <> struct chunk<2>  { using type = uint16_t; };
+template <> struct chunk<4>  { using type = uint32_t; };
+template <> struct chunk<8>  { using type = uint32_t __attribute__((ext_vector_type(2))); };
+template <> struct chunk<16> { using type = uint32_t __attribute__((ext_vector_type(4))); };
+
+/// N elements of T moved as one memory instruction when N*sizeof(T) <= 16 (more: 16-byte pieces)
+template <typename T, unsigned N>
+struct alignas(N * sizeof(T) >= 16 ? 16 : N * sizeof(T)) group {
+	T e[N];
+	__device__ __forceinline__ T& operator[](unsigned i) { return e[i]; }
+	__device__ __forceinline__ const T& operator[](unsigned i) const { return e[i]; }
+};
+
+template <typename T, unsigned N>
+__device__ __forceinline__ group<T, N> load_group(const T* __restrict__ p)
+{
+	constexpr unsigned bytes = N * sizeof(T);
+	constexpr unsigned piece = bytes >= 16 ? 16 : bytes;
+	using piece_t = typename chunk<piece>::type;
+	group<T, N> g;
+	#pragma unroll
+	for (unsigned i = 0; i < bytes / piece; i++) {
+		reinterpret_cast<piece_t*>(&g)[i] = reinterpret_cast<const piece_t*>(p)[i];
+	}
+	return g;
+}
+
+template <bool NonTemporal = true, typename T, unsigned N>
+__device__ __forceinline__ void store_group(T* __restrict__ p, const group<T, N>& g)
+{
+	constexpr unsigned bytes = N * sizeof(T);
+	constexpr unsigned piece = bytes >= 16 ? 16 : bytes;
+	using piece_t = typename chunk<piece>::type;
+	#pragma unroll
+	for (unsigned i = 0; i < bytes / piece; i++) {
+		if (NonTemporal) { __builtin_nontemporal_store(reinterpret_cast<const piece_t*>(&g)[i], reinterpret_cast<piece_t*>(p) + i); }
+		else { reinterpret_cast<piece_t*>(p)[i] = reinterpret_cast<const piece_t*>(&g)[i]; }
+	}
+}
+
+template <typename P>
+__device__ __forceinline__ bool is_aligned(const P* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
+
+} // namespace memory_access
+} // namespace cuda

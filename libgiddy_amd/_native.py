@@ -1,0 +1,68 @@
+"""Loads libgiddy_amd.so (HIP kernels + C++ wrappers + C ABI, see include/giddy.h) through ctypes.
+
+There is deliberately no fallback: if the shared library is missing or fails to load, importing
+this module raises — the product path never runs without the native extension.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIBRARY_PATH = os.path.join(_HERE, "libgiddy_amd.so")
+
+
+class giddy_value(ctypes.Union):
+    _fields_ = [("u64", ctypes.c_uint64), ("i64", ctypes.c_int64), ("pointer", ctypes.c_void_p),
+                ("i32", ctypes.c_int32 * 2), ("i16", ctypes.c_int16 * 2)]
+
+
+class giddy_argument(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char_p), ("type", ctypes.c_int32), ("reserved", ctypes.c_int32),
+                ("value", giddy_value)]
+
+
+class giddy_launch_configuration(ctypes.Structure):
+    _fields_ = [("grid_dimensions", ctypes.c_uint32 * 3), ("block_dimensions", ctypes.c_uint32 * 3),
+                ("dynamic_shared_memory_size", ctypes.c_uint32)]
+
+
+class giddy_launch_configuration_limits(ctypes.Structure):
+    _fields_ = [("has_block_size", ctypes.c_int32), ("block_size", ctypes.c_uint32),
+                ("has_grid_size", ctypes.c_int32), ("grid_size", ctypes.c_uint32),
+                ("has_dynamic_shared_memory", ctypes.c_int32), ("dynamic_shared_memory", ctypes.c_uint32)]
+
+
+# every symbol include/giddy.h declares
+EXPORTED_SYMBOLS = (
+    "giddy_kernel_count", "giddy_kernel_key", "giddy_can_produce", "giddy_produce", "giddy_release",
+    "giddy_resolve_launch_configuration", "giddy_enqueue_launch", "giddy_device_function",
+    "giddy_last_error", "giddy_version",
+)
+
+
+def _load():
+    if not os.path.exists(LIBRARY_PATH):
+        raise ImportError(
+            "libgiddy_amd.so is not built (%s). Build it with `make -C libgiddy_amd/csrc -j8` or "
+            "`python -c 'import __graft_entry__ as g; g.build()'`; there is no non-native fallback." % LIBRARY_PATH)
+    lib = ctypes.CDLL(LIBRARY_PATH, mode=ctypes.RTLD_GLOBAL)
+    lib.giddy_kernel_count.restype = ctypes.c_int
+    lib.giddy_kernel_key.restype = ctypes.c_char_p
+    lib.giddy_kernel_key.argtypes = [ctypes.c_int]
+    lib.giddy_can_produce.argtypes = [ctypes.c_char_p]
+    lib.giddy_produce.argtypes = [ctypes.c_char_p, ctypes.POINTER(ctypes.c_void_p)]
+    lib.giddy_release.argtypes = [ctypes.c_void_p]
+    lib.giddy_release.restype = None
+    lib.giddy_resolve_launch_configuration.argtypes = [
+        ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(giddy_argument), ctypes.c_size_t,
+        ctypes.POINTER(giddy_launch_configuration_limits), ctypes.POINTER(giddy_launch_configuration)]
+    lib.giddy_enqueue_launch.argtypes = [
+        ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(giddy_launch_configuration),
+        ctypes.POINTER(giddy_argument), ctypes.c_size_t]
+    lib.giddy_device_function.restype = ctypes.c_void_p
+    lib.giddy_device_function.argtypes = [ctypes.c_void_p]
+    lib.giddy_last_error.restype = ctypes.c_char_p
+    lib.giddy_version.restype = ctypes.c_char_p
+    return lib
+
+
+lib = _load()

@@ -1,0 +1,200 @@
+// C ABI of libgiddy_amd.so (declared in include/giddy.h): a non-throwing facade over the C++
+// factory / wrapper API.  No compute happens here; every call forwards to one method of
+// cuda::registered::kernel_t.
+#include "giddy.h"
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "giddy/array.hpp"
+#include "giddy/kernel_wrappers/registered_wrapper.hpp"
+
+struct giddy_kernel {
+	std::unique_ptr<cuda::registered::kernel_t> wrapper;
+};
+
+namespace {
+
+thread_local std::string last_error;
+
+template <typename F>
+int guarded(F&& f) noexcept
+{
+	try { f(); last_error.clear(); return GIDDY_SUCCESS; }
+	catch (const std::bad_any_cast& e)     { last_error = std::string("bad_any_cast: an argument does not hold the exact type the wrapper expects (") + e.what() + ")"; return GIDDY_BAD_ANY_CAST; }
+	catch (const std::out_of_range& e)     { last_error = std::string("out_of_range (missing argument?): ") + e.what(); return GIDDY_OUT_OF_RANGE; }
+	catch (const std::invalid_argument& e) { last_error = std::string("invalid_argument: ") + e.what(); return GIDDY_INVALID_ARGUMENT; }
+	catch (const std::logic_error& e)      { last_error = std::string("logic_error: ") + e.what(); return GIDDY_LOGIC_ERROR; }
+	catch (const cuda::runtime_error& e)   { last_error = std::string("HIP runtime error: ") + e.what(); return GIDDY_RUNTIME_ERROR; }
+	catch (const std::exception& e)        { last_error = std::string("exception: ") + e.what(); return GIDDY_UNKNOWN_ERROR; }
+	catch (...)                            { last_error = "unknown exception"; return GIDDY_UNKNOWN_ERROR; }
+}
+
+const std::vector<std::string>& sorted_keys()
+{
+	static const std::vector<std::string> keys = [] {
+		std::vector<std::string> k;
+		for (const auto& entry : cuda::registered::kernel_t::getSubclassFactory().getInsantiators()) { k.push_back(entry.first); }
+		std::sort(k.begin(), k.end());
+		return k;
+	}();
+	return keys;
+}
+
+template <typename T, size_t N>
+cuda::array<T, N> coefficients_from(const T* values)
+{
+	cuda::array<T, N> a;
+	for (size_t i = 0; i < N; i++) { a[i] = values[i]; }
+	return a;
+}
+
+cuda::any to_any(const giddy_argument_t& a)
+{
+	void* p = a.value.pointer;
+	switch (a.type) {
+	case GIDDY_BOOL: return cuda::any((bool) (a.value.u64 != 0));
+	case GIDDY_U8:   return cuda::any((uint8_t)  a.value.u64);
+	case GIDDY_U16:  return cuda::any((uint16_t) a.value.u64);
+	case GIDDY_U32:  return cuda::any((uint32_t) a.value.u64);
+	case GIDDY_U64:  return cuda::any((uint64_t) a.value.u64);
+	case GIDDY_I8:   return cuda::any((int8_t)   a.value.i64);
+	case GIDDY_I16:  return cuda::any((int16_t)  a.value.i64);
+	case GIDDY_I32:  return cuda::any((int32_t)  a.value.i64);
+	case GIDDY_I64:  return cuda::any((int64_t)  a.value.i64);
+	case GIDDY_PTR_U8:   return cuda::any(static_cast<uint8_t*>(p));
+	case GIDDY_PTR_U16:  return cuda::any(static_cast<uint16_t*>(p));
+	case GIDDY_PTR_U32:  return cuda::any(static_cast<uint32_t*>(p));
+	case GIDDY_PTR_U64:  return cuda::any(static_cast<uint64_t*>(p));
+	case GIDDY_PTR_I8:   return cuda::any(static_cast<int8_t*>(p));
+	case GIDDY_PTR_I16:  return cuda::any(static_cast<int16_t*>(p));
+	case GIDDY_PTR_I32:  return cuda::any(static_cast<int32_t*>(p));
+	case GIDDY_PTR_I64:  return cuda::any(static_cast<int64_t*>(p));
+	case GIDDY_CPTR_U8:  return cuda::any(static_cast<const uint8_t*>(p));
+	case GIDDY_CPTR_U16: return cuda::any(static_cast<const uint16_t*>(p));
+	case GIDDY_CPTR_U32: return cuda::any(static_cast<const uint32_t*>(p));
+	case GIDDY_CPTR_U64: return cuda::any(static_cast<const uint64_t*>(p));
+	case GIDDY_CPTR_I8:  return cuda::any(static_cast<const int8_t*>(p));
+	case GIDDY_CPTR_I16: return cuda::any(static_cast<const int16_t*>(p));
+	case GIDDY_CPTR_I32: return cuda::any(static_cast<const int32_t*>(p));
+	case GIDDY_CPTR_I64: return cuda::any(static_cast<const int64_t*>(p));
+	case GIDDY_COEF_I16X1: return cuda::any(coefficients_from<int16_t, 1>(a.value.i16));
+	case GIDDY_COEF_I16X2: return cuda::any(coefficients_from<int16_t, 2>(a.value.i16));
+	case GIDDY_COEF_I32X1: return cuda::any(coefficients_from<int32_t, 1>(a.value.i32));
+	case GIDDY_COEF_I32X2: return cuda::any(coefficients_from<int32_t, 2>(a.value.i32));
+	case GIDDY_CPTR_COEF_I16X1: return cuda::any(static_cast<const cuda::array<int16_t, 1>*>(p));
+	case GIDDY_CPTR_COEF_I16X2: return cuda::any(static_cast<const cuda::array<int16_t, 2>*>(p));
+	case GIDDY_CPTR_COEF_I32X1: return cuda::any(static_cast<const cuda::array<int32_t, 1>*>(p));
+	case GIDDY_CPTR_COEF_I32X2: return cuda::any(static_cast<const cuda::array<int32_t, 2>*>(p));
+	default: throw std::invalid_argument("unknown giddy_type_t tag " + std::to_string(a.type) + " for argument \"" + (a.name ? a.name : "(null)") + "\"");
+	}
+}
+
+cuda::kernel_t::arguments_type to_map(const giddy_argument_t* arguments, size_t n)
+{
+	cuda::kernel_t::arguments_type map;
+	for (size_t i = 0; i < n; i++) {
+		if (arguments[i].name == nullptr) { throw std::invalid_argument("argument without a name"); }
+		map[arguments[i].name] = to_any(arguments[i]);
+	}
+	return map;
+}
+
+const giddy_kernel& checked(const giddy_kernel_t* kernel)
+{
+	if (kernel == nullptr || !kernel->wrapper) { throw std::invalid_argument("null kernel handle"); }
+	return *kernel;
+}
+
+} // namespace
+
+extern "C" {
+
+int giddy_kernel_count(void) { return (int) sorted_keys().size(); }
+
+const char* giddy_kernel_key(int index)
+{
+	const auto& keys = sorted_keys();
+	return (index < 0 || (size_t) index >= keys.size()) ? nullptr : keys[index].c_str();
+}
+
+int giddy_can_produce(const char* key)
+{
+	return key != nullptr && cuda::registered::kernel_t::getSubclassFactory().canProduce(key) ? 1 : 0;
+}
+
+int giddy_produce(const char* key, giddy_kernel_t** kernel)
+{
+	return guarded([&] {
+		if (key == nullptr || kernel == nullptr) { throw std::invalid_argument("null key or output handle"); }
+		auto wrapper = cuda::registered::kernel_t::produceSubclass(key);
+		*kernel = new giddy_kernel { std::move(wrapper) };
+	});
+}
+
+void giddy_release(giddy_kernel_t* kernel) { delete kernel; }
+
+int giddy_resolve_launch_configuration(
+	const giddy_kernel_t* kernel, int device_id,
+	const giddy_argument_t* arguments, size_t num_arguments,
+	const giddy_launch_configuration_limits_t* limits,
+	giddy_launch_configuration_t* launch_configuration)
+{
+	return guarded([&] {
+		const auto& k = checked(kernel);
+		if (launch_configuration == nullptr) { throw std::invalid_argument("null output launch configuration"); }
+		cuda::launch_configuration_limits_t l { cuda::nullopt, cuda::nullopt, cuda::nullopt };
+		if (limits != nullptr) {
+			if (limits->has_block_size) { l.block_size = limits->block_size; }
+			if (limits->has_grid_size) { l.grid_size = limits->grid_size; }
+			if (limits->has_dynamic_shared_memory) { l.dynamic_shared_memory = limits->dynamic_shared_memory; }
+		}
+		auto map = to_map(arguments, num_arguments);
+		cuda::launch_configuration_t config;
+		if (device_id == GIDDY_NOMINAL_MI355X_DEVICE) {
+			config = k.wrapper->resolve_launch_configuration(
+				cuda::device::properties_t::nominal_mi355x(), cuda::device_function::attributes_t(), map, l);
+		}
+		else {
+			auto properties = cuda::device::get(device_id).properties();
+			cuda::device::current::scoped_override_t<> use(device_id);
+			config = k.wrapper->resolve_launch_configuration(properties, k.wrapper->get_device_function().attributes(), map, l);
+		}
+		launch_configuration->grid_dimensions[0] = config.grid_dimensions.x;
+		launch_configuration->grid_dimensions[1] = config.grid_dimensions.y;
+		launch_configuration->grid_dimensions[2] = config.grid_dimensions.z;
+		launch_configuration->block_dimensions[0] = config.block_dimensions.x;
+		launch_configuration->block_dimensions[1] = config.block_dimensions.y;
+		launch_configuration->block_dimensions[2] = config.block_dimensions.z;
+		launch_configuration->dynamic_shared_memory_size = config.dynamic_shared_memory_size;
+	});
+}
+
+int giddy_enqueue_launch(
+	const giddy_kernel_t* kernel, void* hip_stream,
+	const giddy_launch_configuration_t* launch_configuration,
+	const giddy_argument_t* arguments, size_t num_arguments)
+{
+	return guarded([&] {
+		const auto& k = checked(kernel);
+		if (launch_configuration == nullptr) { throw std::invalid_argument("null launch configuration"); }
+		cuda::launch_configuration_t config(
+			cuda::dimensions_t(launch_configuration->grid_dimensions[0], launch_configuration->grid_dimensions[1], launch_configuration->grid_dimensions[2]),
+			cuda::dimensions_t(launch_configuration->block_dimensions[0], launch_configuration->block_dimensions[1], launch_configuration->block_dimensions[2]),
+			launch_configuration->dynamic_shared_memory_size);
+		k.wrapper->enqueue_launch(static_cast<hipStream_t>(hip_stream), config, to_map(arguments, num_arguments));
+	});
+}
+
+const void* giddy_device_function(const giddy_kernel_t* kernel)
+{
+	return (kernel != nullptr && kernel->wrapper) ? kernel->wrapper->get_device_function().ptr() : nullptr;
+}
+
+const char* giddy_last_error(void) { return last_error.c_str(); }
+
+const char* giddy_version(void) { return "libgiddy_amd 0.1 (gfx950)"; }
+
+} // extern "C"

@@ -1,0 +1,262 @@
+"""One convenience function per decompression scheme: builds the factory key for the requested
+instantiation, resolves the launch configuration and enqueues the kernel — i.e. exactly the three
+calls of the reference's type-erased mode of use, through libgiddy_amd.registered (C ABI ->
+C++ wrappers -> HIP kernels).  Nothing here computes anything on the host.
+
+Buffers are device buffers (torch tensors, or raw device addresses); element types are stated by
+the caller as byte sizes / dtype codes because they select the kernel instantiation.
+Argument names and types: SURVEY.md §8b (reference file:line cited there and in INTEGRATION.md).
+"""
+import numpy as np
+
+from . import registered as r
+
+_SIGNED_NAMES = {1: "signed char", 2: "short", 4: "int", 8: "long"}
+_kernels = {}
+
+
+def kernel(key):
+    """factory-produced wrapper, cached per key (wrappers are stateless)"""
+    if key not in _kernels:
+        _kernels[key] = r.kernel_t.produceSubclass(key)
+    return _kernels[key]
+
+
+def _run(key, resolve_arguments, launch_arguments, stream, device, limits, launch_config):
+    k = kernel(key)
+    if launch_config is None:
+        launch_config = k.resolve_launch_configuration(device, resolve_arguments, limits)
+    k.enqueue_launch(stream, launch_config, launch_arguments)
+    return launch_config
+
+
+def _model_name(model, model_index_size, coefficient_size):
+    return "cuda::functors::unary::parametric_model::%s<%du, %s>" % (model, model_index_size, _SIGNED_NAMES[coefficient_size])
+
+
+# ---- factory keys (libstdc++-demangled type names, "cuda::kernels::" stripped) --------------------
+
+def key_frame_of_reference(index_size, uncompressed_size, compressed_size, model="constant", model_index_size=4, coefficient_size=4):
+    return "decompression::frame_of_reference::kernel_t<%du, %s, %s, %s >" % (
+        index_size, _SIGNED_NAMES[uncompressed_size], _SIGNED_NAMES[compressed_size],
+        _model_name(model, model_index_size, coefficient_size))
+
+
+def key_model(index_size, uncompressed_size, model="linear", model_index_size=None, coefficient_size=None):
+    return "decompression::model::kernel_t<%du, %s, %s >" % (
+        index_size, _SIGNED_NAMES[uncompressed_size],
+        _model_name(model, model_index_size or index_size, coefficient_size or uncompressed_size))
+
+
+def key_dictionary(index_size, uncompressed_size, dictionary_index_size):
+    return "decompression::dictionary::kernel_t<%du, %du, %du>" % (index_size, uncompressed_size, dictionary_index_size)
+
+
+def key_delta(index_size, uncompressed_size, compressed_size):
+    return "decompression::delta::kernel_t<%du, %du, %du>" % (index_size, uncompressed_size, compressed_size)
+
+
+def key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size):
+    return ("decompression::discard_zero_bytes::fixed_width::kernel_t<%du, %du, %du, (util::endianness_t)1, (unsigned short)32>"
+            % (index_size, uncompressed_size, compressed_size))
+
+
+def key_discard_zero_bytes_variable(index_size, uncompressed_size, container_size=4):
+    return "decompression::discard_zero_bytes::variable_width::kernel_t<%du, %du, %du>" % (index_size, uncompressed_size, container_size)
+
+
+def key_incidence_bitmaps(index_size, uncompressed_size, alignment_in_ints=2, use_dictionary=True):
+    return "decompression::incidence_bitmaps::kernel_t<%du, %du, %du, %s>" % (
+        index_size, uncompressed_size, alignment_in_ints, "true" if use_dictionary else "false")
+
+
+def key_run_length_encoding(index_size, uncompressed_size, run_length_size, run_index_size=None):
+    return "decompression::run_length_encoding::kernel_t<%du, %du, %du, %du>" % (
+        index_size, uncompressed_size, run_length_size, run_index_size or index_size)
+
+
+def key_run_position_encoding(index_size, uncompressed_size, position_size, relative, run_index_size=None):
+    return "decompression::run_position_encoding::kernel_t<%du, %du, %du, %s, %du>" % (
+        index_size, uncompressed_size, position_size, "true" if relative else "false", run_index_size or index_size)
+
+
+def key_scatter(output_index_size, element_size, input_index_size):
+    return "scatter::kernel_t<%du, %du, %du, (unsigned short)16>" % (output_index_size, element_size, input_index_size)
+
+
+def key_compressed_indices_scatter(output_index_size, element_size, input_index_size, run_length_size=None):
+    return "scatter::compressed_indices::kernel_t<%du, %du, %du, %du>" % (
+        output_index_size, element_size, input_index_size, run_length_size or input_index_size)
+
+
+# ---- launches -------------------------------------------------------------------------------------
+
+def frame_of_reference(decompressed, compressed_input, segment_model_coefficients, length, segment_length, *,
+                       uncompressed_size=4, compressed_size=2, model="constant", index_size=4, model_index_size=4,
+                       stream=0, device=0, limits=None, launch_config=None):
+    dim = 1 if model == "constant" else 2
+    return _run(
+        key_frame_of_reference(index_size, uncompressed_size, compressed_size, model, model_index_size, 4),
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
+        {"decompressed": r.pointer(decompressed, "i%d" % (8 * uncompressed_size)),
+         "compressed_input": r.const_pointer(compressed_input, "i%d" % (8 * compressed_size)),
+         "segment_model_coefficients": r.const_coefficients_pointer(segment_model_coefficients, "i32", dim),
+         "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)},
+        stream, device, limits, launch_config)
+
+
+def model(decompressed, model_coefficients, length, *, uncompressed_size=4, model="linear", index_size=4,
+          stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_model(index_size, uncompressed_size, model),
+        {"length": r.size_t(length)},
+        {"decompressed": r.pointer(decompressed, "i%d" % (8 * uncompressed_size)),
+         "model_coefficients": r.coefficients(model_coefficients, "i%d" % (8 * uncompressed_size)),
+         "length": r.uint_t(index_size)(length)},
+        stream, device, limits, launch_config)
+
+
+def dictionary(decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, *,
+               uncompressed_size=4, dictionary_index_size=1, index_size=4, cache_dictionary_in_shared_mem=None,
+               stream=0, device=0, limits=None, launch_config=None):
+    resolve = {"num_dictionary_entries": r.size_t(num_dictionary_entries), "data_length": r.size_t(length)}
+    launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * dictionary_index_size)),
+              "dictionary_entries": r.const_pointer(dictionary_entries, "u%d" % (8 * uncompressed_size)),
+              "length": r.size_type_by_index_size(index_size)(length),
+              "num_dictionary_entries": r.size_type_by_index_size(dictionary_index_size)(num_dictionary_entries)}
+    if cache_dictionary_in_shared_mem is not None:
+        # the reference spells the flag differently at resolve and launch time (dictionary.cu:59 vs :78)
+        resolve["cache_input_data_in_shared_mem"] = r.boolean(cache_dictionary_in_shared_mem)
+        launch["cache_dictionary_in_shared_mem"] = r.boolean(cache_dictionary_in_shared_mem)
+    return _run(key_dictionary(index_size, uncompressed_size, dictionary_index_size), resolve, launch,
+                stream, device, limits, launch_config)
+
+
+def delta(decompressed, compressed_input, anchor_values, length, segment_length, *,
+          uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_delta(index_size, uncompressed_size, compressed_size),
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
+         "anchor_values": r.const_pointer(anchor_values, "u%d" % (8 * uncompressed_size)),
+         "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)},
+        stream, device, limits, launch_config)
+
+
+def discard_zero_bytes_fixed(decompressed, compressed_input, length, *, uncompressed_size=8, compressed_size=4,
+                             index_size=4, stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size),
+        {"length": r.size_t(length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
+         "length": r.uint_t(index_size)(length)},
+        stream, device, limits, launch_config)
+
+
+def discard_zero_bytes_variable(decompressed, compressed_data, packed_element_sizes, position_anchors,
+                                segment_length, length, min_represented_element_size, bits_per_element_size, *,
+                                uncompressed_size=8, container_size=4, index_size=8,
+                                stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_discard_zero_bytes_variable(index_size, uncompressed_size, container_size),
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "compressed_data": r.const_pointer(compressed_data, "u8"),
+         "packed_element_sizes": r.const_pointer(packed_element_sizes, "u%d" % (8 * container_size)),
+         "position_anchors": r.const_pointer(position_anchors, "u%d" % (8 * index_size)),
+         "segment_length": r.uint_t(index_size)(segment_length), "length": r.uint_t(index_size)(length),
+         "min_represented_element_size": r.uint32(min_represented_element_size),
+         "bits_per_element_size": r.uint32(bits_per_element_size)},
+        stream, device, limits, launch_config)
+
+
+def incidence_bitmaps(decompressed, bitmaps, dictionary_entries, bitmap_length, num_bitmaps, *,
+                      uncompressed_size=4, alignment_in_ints=2, use_dictionary=True, index_size=4,
+                      stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_incidence_bitmaps(index_size, uncompressed_size, alignment_in_ints, use_dictionary),
+        {"length": r.size_t(32 * bitmap_length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "incidence_bitmaps": r.const_pointer(bitmaps, "u32"),
+         "dictionary_entries": r.const_pointer(dictionary_entries, "u%d" % (8 * uncompressed_size)),
+         "bitmap_length": r.size_type_by_index_size(index_size)(bitmap_length),
+         "num_bitmaps": r.uint32(num_bitmaps)},
+        stream, device, limits, launch_config)
+
+
+def run_length_encoding(decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
+                        segment_length, num_segments, num_element_runs, length, *,
+                        uncompressed_size=4, run_length_size=2, index_size=4, run_index_size=None,
+                        stream=0, device=0, limits=None, launch_config=None):
+    run_index_size = run_index_size or index_size
+    return _run(
+        key_run_length_encoding(index_size, uncompressed_size, run_length_size, run_index_size),
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "run_data": r.const_pointer(run_data, "u%d" % (8 * uncompressed_size)),
+         "run_lengths": r.const_pointer(run_lengths, "u%d" % (8 * run_length_size)),
+         "position_anchors": r.const_pointer(position_anchors, "u%d" % (8 * run_index_size)),
+         "intra_run_anchor_offsets": r.const_pointer(intra_run_anchor_offsets, "u%d" % (8 * run_length_size)),
+         "segment_length": r.size_type_by_index_size(index_size)(segment_length),
+         "num_segments": r.size_type_by_index_size(index_size)(num_segments),
+         "num_element_runs": r.size_type_by_index_size(run_index_size)(num_element_runs),
+         "length": r.size_type_by_index_size(index_size)(length)},
+        stream, device, limits, launch_config)
+
+
+def run_position_encoding(decompressed, run_data, run_start_positions, position_anchors, segment_length,
+                          num_anchors, num_element_runs, length, *, uncompressed_size=4, position_size=2,
+                          relative=True, index_size=4, run_index_size=None,
+                          stream=0, device=0, limits=None, launch_config=None):
+    run_index_size = run_index_size or index_size
+    return _run(
+        key_run_position_encoding(index_size, uncompressed_size, position_size, relative, run_index_size),
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
+        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+         "run_data": r.const_pointer(run_data, "u%d" % (8 * uncompressed_size)),
+         "run_start_positions": r.const_pointer(run_start_positions, "u%d" % (8 * position_size)),
+         "position_anchors": r.const_pointer(position_anchors, "u%d" % (8 * run_index_size)),
+         "segment_length": r.size_type_by_index_size(position_size)(segment_length),
+         "num_anchors": r.size_type_by_index_size(index_size)(num_anchors),
+         "num_element_runs": r.size_type_by_index_size(run_index_size)(num_element_runs),
+         "length": r.size_type_by_index_size(index_size)(length)},
+        stream, device, limits, launch_config)
+
+
+def scatter(target, data, indices, data_length, *, output_index_size=4, element_size=8, input_index_size=4,
+            stream=0, device=0, limits=None, launch_config=None):
+    return _run(
+        key_scatter(output_index_size, element_size, input_index_size),
+        {"data_length": r.size_t(data_length)},
+        {"target": r.pointer(target, "u%d" % (8 * element_size)),
+         "data": r.const_pointer(data, "u%d" % (8 * element_size)),
+         "indices": r.const_pointer(indices, "u%d" % (8 * output_index_size)),
+         "data_length": r.size_type_by_index_size(input_index_size)(data_length)},
+        stream, device, limits, launch_config)
+
+
+def compressed_indices_scatter(target, data_to_scatter, scatter_position_run_lengths,
+                               scatter_position_run_individual_offset_sizes, scatter_position_run_baseline_values,
+                               scatter_position_run_offsets_start_pos, scatter_position_offset_bytes,
+                               scatter_position_anchors, anchoring_period, num_scatter_position_runs,
+                               input_data_length, *, output_index_size=4, element_size=4, input_index_size=4,
+                               run_length_size=None, stream=0, device=0, limits=None, launch_config=None):
+    run_length_size = run_length_size or input_index_size
+    return _run(
+        key_compressed_indices_scatter(output_index_size, element_size, input_index_size, run_length_size),
+        {"input_data_length": r.size_t(input_data_length), "anchoring_period": r.size_t(anchoring_period)},
+        {"target": r.pointer(target, "u%d" % (8 * element_size)),
+         "data_to_scatter": r.const_pointer(data_to_scatter, "u%d" % (8 * element_size)),
+         "scatter_position_run_lengths": r.const_pointer(scatter_position_run_lengths, "u%d" % (8 * run_length_size)),
+         "scatter_position_run_individual_offset_sizes": r.const_pointer(scatter_position_run_individual_offset_sizes, "u8"),
+         "scatter_position_run_baseline_values": r.const_pointer(scatter_position_run_baseline_values, "u%d" % (8 * output_index_size)),
+         "scatter_position_run_offsets_start_pos": r.const_pointer(scatter_position_run_offsets_start_pos, "u%d" % (8 * input_index_size)),
+         "scatter_position_offset_bytes": r.const_pointer(scatter_position_offset_bytes, "u8"),
+         "scatter_position_anchors": r.const_pointer(scatter_position_anchors, "u%d" % (8 * input_index_size)),
+         "anchoring_period": r.uint_t(input_index_size)(anchoring_period),
+         "num_scatter_position_runs": r.uint_t(input_index_size)(num_scatter_position_runs),
+         "input_data_length": r.size_type_by_index_size(input_index_size)(input_data_length)},
+        stream, device, limits, launch_config)

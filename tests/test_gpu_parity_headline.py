@@ -1,0 +1,170 @@
+"""GPU parity (bit-exact) of the HIP kernels against the CPU oracle, through the C ABI:
+Frame-of-Reference, Dictionary, Delta and the naive scatter.  Run with `-m gpu` on an MI355X."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _imports():
+    from libgiddy_amd import schemes, registered
+    import gpu_util
+    return schemes, registered, gpu_util
+
+
+def test_kat_for_1_on_gpu():
+    """the reference's own known-answer test (examples/src/modes_of_use/common.cuh:31-49,91-102)"""
+    schemes, r, g = _imports()
+    length, seglen = 2 << 12, 2 << 10
+    nseg = length // seglen
+    comp = np.tile(np.arange(seglen, dtype=np.int16), nseg)
+    coefs = (np.arange(nseg, dtype=np.int32) * 100).reshape(nseg, 1)
+    out = g.dev_empty(length, np.int32)
+    schemes.frame_of_reference(out, g.dev(comp), g.dev(coefs), length, seglen, stream=g.stream())
+    got = g.host(out, np.int32, length)
+    for s in range(nseg):
+        assert (got[s * seglen:(s + 1) * seglen] == 100 * s + np.arange(seglen)).all()
+
+
+FOR_TUPLES = [  # (index_size, uncompressed, compressed, model, model_index_size) — frame_of_reference.cu:132-142
+    (4, 2, 1, "linear", 4), (4, 4, 1, "linear", 4), (4, 4, 2, "linear", 4), (8, 4, 2, "linear", 4),
+    (8, 4, 2, "linear", 8), (4, 2, 1, "constant", 4), (4, 4, 1, "constant", 4), (4, 4, 2, "constant", 4)]
+
+
+@pytest.mark.parametrize("index_size,usize,csize,model,model_index_size", FOR_TUPLES)
+@pytest.mark.parametrize("n,seglen", [(1, 4), (4099, 64), (1 << 20, 1 << 20), (1000003, 4096), (70000, 12), (333, 1000)])
+def test_frame_of_reference(index_size, usize, csize, model, model_index_size, n, seglen):
+    schemes, r, g = _imports()
+    ud, cd = np.dtype("i%d" % usize), np.dtype("i%d" % csize)
+    f = cases.for_case(n, seglen, ud, cd, model, seed=n + usize)
+    expect = oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, seglen, ud, model,
+                                       model_index_size=model_index_size)
+    out = g.dev_empty(n, ud)
+    schemes.frame_of_reference(out, g.dev(f["compressed_input"]), g.dev(f["segment_model_coefficients"]), n, seglen,
+                               uncompressed_size=usize, compressed_size=csize, model=model, index_size=index_size,
+                               model_index_size=model_index_size, stream=g.stream())
+    assert (g.host(out, ud, n) == expect).all()
+
+
+def test_frame_of_reference_unaligned_and_limits():
+    schemes, r, g = _imports()
+    n, seglen = 50001, 256
+    f = cases.for_case(n + 3, seglen, np.int32, np.int16, "linear", seed=5)
+    comp = f["compressed_input"]
+    # misaligned input pointer (2 bytes off) -> scalar path
+    buf = g.dev(comp)
+    expect = oracle.frame_of_reference(comp[1:], f["segment_model_coefficients"], n, seglen, np.int32, "linear")
+    out = g.dev_empty(n, np.int32)
+    schemes.frame_of_reference(out, buf.data_ptr() + 2, g.dev(f["segment_model_coefficients"]), n, seglen,
+                               model="linear", stream=g.stream())
+    assert (g.host(out, np.int32, n) == expect).all()
+    # one-time limits: tiny grid and block still decode everything
+    out = g.dev_empty(n, np.int32)
+    cfg = schemes.frame_of_reference(out, buf.data_ptr() + 2, g.dev(f["segment_model_coefficients"]), n, seglen,
+                                     model="linear", stream=g.stream(),
+                                     limits=r.launch_configuration_limits_t(block_size=64, grid_size=3))
+    assert cfg.block_dimensions[0] == 64 and cfg.grid_dimensions[0] <= 3
+    assert (g.host(out, np.int32, n) == expect).all()
+
+
+DICT_TUPLES = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]  # dictionary.cu:113-139
+
+
+@pytest.mark.parametrize("usize,dsize", DICT_TUPLES)
+@pytest.mark.parametrize("index_size", [4, 8])
+def test_dictionary(usize, dsize, index_size):
+    schemes, r, g = _imports()
+    ud, kd = np.dtype("u%d" % usize), np.dtype("u%d" % dsize)
+    for n, entries in [(0, 4), (1, 1), (1027, 256 if dsize == 1 else 3000), (1 << 20, 256 if dsize == 1 else 40000)]:
+        entries = min(entries, 1 << (8 * dsize))
+        f = cases.dictionary_case(n, entries, ud, kd, seed=n + usize)
+        expect = oracle.dictionary(f["compressed_input"], f["dictionary_entries"])
+        for cache in (None, False):
+            out = g.dev_empty(n, ud)
+            schemes.dictionary(out, g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"]), n, entries,
+                               uncompressed_size=usize, dictionary_index_size=dsize, index_size=index_size,
+                               cache_dictionary_in_shared_mem=cache, stream=g.stream())
+            assert (g.host(out, ud, n) == expect).all(), (n, entries, cache)
+
+
+def test_dictionary_too_large_for_lds_falls_back():
+    schemes, r, g = _imports()
+    n, entries = 300000, 1 << 16
+    f = cases.dictionary_case(n, entries, np.uint64, np.uint16, seed=3)   # 512 KiB dictionary
+    out = g.dev_empty(n, np.uint64)
+    cfg = schemes.dictionary(out, g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"]), n, entries,
+                             uncompressed_size=8, dictionary_index_size=2, stream=g.stream())
+    assert cfg.dynamic_shared_memory_size == 0
+    assert (g.host(out, np.uint64, n) == oracle.dictionary(f["compressed_input"], f["dictionary_entries"])).all()
+
+
+DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]  # delta.cu:94-106
+
+
+@pytest.mark.parametrize("usize,csize", DELTA_TUPLES)
+@pytest.mark.parametrize("index_size", [4, 8])
+@pytest.mark.parametrize("n,seglen", [
+    (1, 1), (63, 7), (4096, 4096), (1000003, 4096), (300000, 512), (100000, 1), (50000, 100), (100, 1000),
+    (1 << 20, 1 << 18), (3000000, 1 << 20), (70000, 65536 + 512), (12345, 1024)])
+def test_delta(usize, csize, index_size, n, seglen):
+    schemes, r, g = _imports()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + seglen + usize)
+    expect = oracle.delta(f["compressed_input"], f["anchor_values"], seglen)
+    assert (expect == truth).all()
+    out = g.dev_empty(n, ud)
+    schemes.delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), n, seglen,
+                  uncompressed_size=usize, compressed_size=csize, index_size=index_size, stream=g.stream())
+    got = g.host(out, ud, n)
+    bad = np.flatnonzero(got != expect)
+    assert len(bad) == 0, (bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
+def test_delta_with_limits():
+    schemes, r, g = _imports()
+    n, seglen = 500000, 4096
+    f, truth = cases.delta_case(n, seglen, np.uint64, np.uint16, seed=77)
+    for limits in (r.launch_configuration_limits_t(block_size=64), r.launch_configuration_limits_t(grid_size=5),
+                   r.launch_configuration_limits_t(block_size=128, grid_size=1)):
+        out = g.dev_empty(n, np.uint64)
+        schemes.delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), n, seglen, stream=g.stream(), limits=limits)
+        assert (g.host(out, np.uint64, n) == truth).all()
+
+
+@pytest.mark.parametrize("osize,esize,isize", [(4, 1, 4), (4, 2, 2), (4, 4, 4), (4, 8, 4), (8, 8, 8), (8, 4, 1), (4, 8, 2), (8, 1, 4)])
+def test_scatter(osize, esize, isize):
+    schemes, r, g = _imports()
+    ed = np.dtype("u%d" % esize)
+    n = 1 << 20
+    for npatch in (0, 1, 5, 1001, 200 if isize == 1 else 50000):
+        npatch = min(npatch, (1 << (8 * isize)) - 1)
+        target = cases.rng(npatch).integers(0, 255, size=n).astype(ed)
+        p = cases.patch_case(n, npatch, ed, osize, seed=npatch + 1) if npatch else {"indices": np.zeros(0, "u%d" % osize), "data": np.zeros(0, ed)}
+        expect = oracle.scatter(target.copy(), p["data"], p["indices"]) if npatch else target
+        t = g.dev(target)
+        schemes.scatter(t, g.dev(p["data"]), g.dev(p["indices"]), npatch, output_index_size=osize, element_size=esize,
+                        input_index_size=isize, stream=g.stream())
+        assert (g.host(t, ed, n) == expect).all()
+
+
+def test_delta_then_patch_pipeline_full_fixture():
+    """C3 in miniature: delta decode + naive patches on one stream, vs the golden fixture."""
+    import os
+    schemes, r, g = _imports()
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "delta_u64_u16_patched.npz"))
+    n, seglen = int(fx["length"]), int(fx["segment_length"])
+    out = g.dev_empty(n, np.uint64)
+    schemes.delta(out, g.dev(fx["compressed_input"]), g.dev(fx["anchor_values"]), n, seglen, stream=g.stream())
+    schemes.scatter(out, g.dev(fx["patch_data"]), g.dev(fx["patch_indices"]), len(fx["patch_data"]), stream=g.stream())
+    assert (g.host(out, np.uint64, n) == fx["expected_patched"]).all()
