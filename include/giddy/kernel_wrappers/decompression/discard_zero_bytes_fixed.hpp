@@ -1,0 +1,72 @@
+// Kernel wrapper for fixed-width discard-zero-bytes decompression.  Argument-map keys and exact
+// types follow the reference's src/kernel_wrappers/decompression/discard_zero_bytes_fixed.cu:60-97;
+// the two defaulted template arguments are part of the factory key.
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/discard_zero_bytes_fixed.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace discard_zero_bytes {
+namespace fixed_width {
+
+using util::endianness_t;
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	endianness_t UncompressedEndianness = util::compilation_target_endianness(),
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using uncompressed_type = uint_t<UncompressedSize>;
+	using compressed_type   = uint_t<CompressedSize>;
+	using size_type         = size_type_by_index_size<IndexSize>;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+		size_t length, launch_configuration_limits_t limits) const
+	{
+		launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>
+			params(device_properties, kernel_function_attributes, length);
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+#define GIDDY_DZBF_TEMPLATE template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, endianness_t UncompressedEndianness, serialization_factor_t SerializationFactor>
+#define GIDDY_DZBF_KERNEL kernel_t<IndexSize, UncompressedSize, CompressedSize, UncompressedEndianness, SerializationFactor>
+
+GIDDY_DZBF_TEMPLATE
+launch_configuration_t GIDDY_DZBF_KERNEL::resolve_launch_configuration(
+	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+	arguments_type extra_arguments, launch_configuration_limits_t limits) const
+{
+	auto length = any_cast<size_t>(extra_arguments.at("length"));
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
+}
+
+GIDDY_DZBF_TEMPLATE
+void GIDDY_DZBF_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	auto decompressed     = any_cast<uncompressed_type*     >(arguments.at("decompressed"));
+	auto compressed_input = any_cast<const compressed_type* >(arguments.at("compressed_input"));
+	auto length           = any_cast<uint_t<IndexSize>      >(arguments.at("length"));
+	cuda::kernel::enqueue_launch(*this, stream, launch_config, decompressed, compressed_input, (size_type) length);
+}
+
+GIDDY_DZBF_TEMPLATE
+const device_function_t GIDDY_DZBF_KERNEL::get_device_function() const
+{
+	return reinterpret_cast<const void*>(
+		decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
+}
+
+#undef GIDDY_DZBF_TEMPLATE
+#undef GIDDY_DZBF_KERNEL
+
+} // namespace fixed_width
+} // namespace discard_zero_bytes
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

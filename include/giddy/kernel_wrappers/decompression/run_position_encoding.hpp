@@ -1,0 +1,82 @@
+// Kernel wrapper for run-position decoding.  Argument-map keys and exact types follow the
+// reference's src/kernel_wrappers/decompression/run_position_encoding.cu:64-105.
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/run_position_encoding.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace run_position_encoding {
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using run_index_type                = uint_t<RunIndexSize>;
+	using uncompressed_index_type       = uint_t<UncompressedIndexSize>;
+	using position_offset_type          = uint_t<PositionOffsetSize>;
+	using uncompressed_type             = uint_t<UncompressedSize>;
+	using index_type                    = uncompressed_index_type;
+	using uncompressed_index_size_type  = size_type_by_index_size<UncompressedIndexSize>;
+	using run_index_size_type           = size_type_by_index_size<RunIndexSize>;
+	using position_offset_size_type     = size_type_by_index_size<PositionOffsetSize>;
+	using size_type                     = uncompressed_index_size_type;
+	using run_length_type               = position_offset_size_type;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+		size_t uncompressed_length, size_t uncompressed_segment_length, launch_configuration_limits_t limits) const
+	{
+		launch_config_resolution_params_t<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize> params(
+			device_properties, kernel_function_attributes, uncompressed_length, uncompressed_segment_length);
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+#define GIDDY_RPE_TEMPLATE template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize>
+#define GIDDY_RPE_KERNEL kernel_t<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>
+
+GIDDY_RPE_TEMPLATE
+launch_configuration_t GIDDY_RPE_KERNEL::resolve_launch_configuration(
+	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+	arguments_type extra_arguments, launch_configuration_limits_t limits) const
+{
+	auto uncompressed_length         = any_cast<size_t>(extra_arguments.at("length"));
+	auto uncompressed_segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));
+	return resolve_launch_configuration(device_properties, kernel_function_attributes,
+		uncompressed_length, uncompressed_segment_length, limits);
+}
+
+GIDDY_RPE_TEMPLATE
+void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	auto decompressed                = any_cast<uncompressed_type*           >(arguments.at("decompressed"));
+	auto run_data                    = any_cast<const uncompressed_type*     >(arguments.at("run_data"));
+	auto run_start_positions         = any_cast<const position_offset_type*  >(arguments.at("run_start_positions"));
+	auto position_anchors            = any_cast<const run_index_type*        >(arguments.at("position_anchors"));
+	auto uncompressed_segment_length = any_cast<position_offset_size_type    >(arguments.at("segment_length"));
+	auto num_anchors                 = any_cast<uncompressed_index_size_type >(arguments.at("num_anchors"));
+	auto num_element_runs            = any_cast<run_index_size_type          >(arguments.at("num_element_runs"));
+	auto uncompressed_length         = any_cast<uncompressed_index_size_type >(arguments.at("length"));
+
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, run_data, run_start_positions, position_anchors,
+		uncompressed_segment_length, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);
+}
+
+GIDDY_RPE_TEMPLATE
+const device_function_t GIDDY_RPE_KERNEL::get_device_function() const
+{
+	return reinterpret_cast<const void*>(
+		decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);
+}
+
+#undef GIDDY_RPE_TEMPLATE
+#undef GIDDY_RPE_KERNEL
+
+} // namespace run_position_encoding
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

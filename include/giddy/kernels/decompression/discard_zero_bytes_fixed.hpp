@@ -1,0 +1,109 @@
+// Discard-zero-bytes (null suppression), fixed width:   out[p] = zero_extend(compressed_input[p])
+//
+// Kernel template name, parameter list and semantics as in the reference's
+// src/kernels/decompression/discard_zero_bytes_fixed.cuh:108-124 (pad_high_bytes, :41-77; output is
+// little-endian on every supported target).  Execution: a pure HBM stream — a lane widens G
+// elements from one 2..8-byte load into one 16-byte store (G = 16/UncompressedSize), K steps per
+// tile, tiles at grid stride.  HBM bytes per element: CompressedSize + UncompressedSize.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace discard_zero_bytes {
+namespace fixed_width {
+
+enum : serialization_factor_t { DefaultSerializationFactor = 32 };
+
+namespace detail { enum : unsigned { steps_per_tile = 4 }; }
+
+template <unsigned UncompressedSize, unsigned CompressedSize, cuda::endianness_t OutputEndianness>
+struct pad_high_bytes {
+	using argument_type = uint_t<CompressedSize>;
+	using result_type = uint_t<UncompressedSize>;
+	static_assert(UncompressedSize > CompressedSize, "Uncompressed size isn't higher than Compressed size");
+	static_assert(OutputEndianness == cuda::endianness_t::little, "only little-endian output is implemented (CDNA4 and x86-64 are little-endian)");
+	__host__ __device__ result_type operator()(const argument_type& x) const { return (result_type) x; }
+};
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+__global__ void decompress(
+	uint_t<UncompressedSize>*      __restrict__  decompressed,
+	const uint_t<CompressedSize>*  __restrict__  compressed_input,
+	size_type_by_index_size<IndexSize>           length)
+{
+	using namespace memory_access;
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	constexpr unsigned G = 16 / UncompressedSize;
+	constexpr unsigned K = detail::steps_per_tile;
+	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
+
+	const uint64_t n = length;
+	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * CompressedSize);
+	const uint64_t num_groups = vectorizable ? n / G : 0;
+	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+
+	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		group<C, G> in[K];
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g < num_groups) { in[k] = load_group<C, G>(compressed_input + g * G); }
+		}
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g >= num_groups) { continue; }
+			group<U, G> out;
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[k][j]); }
+			store_group(decompressed + g * G, out);
+		}
+	}
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) { decompressed[p] = widen(compressed_input[p]); }
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_, size_t length_)
+	: parent(device_properties_, kernel_function_attributes_)
+	{
+		constexpr unsigned elements_per_thread_per_tile = (16 / UncompressedSize) * detail::steps_per_tile;
+		grid_construction_resolution  = thread;
+		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
+		serialization_option          = auto_maximized;
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+		default_serialization_factor  = DefaultSerializationFactor;
+	}
+
+	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<IndexSize, UncompressedSize, CompressedSize, UncompressedEndianness, SerializationFactor>).attributes(),
+		length_) { }
+};
+
+} // namespace fixed_width
+} // namespace discard_zero_bytes
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

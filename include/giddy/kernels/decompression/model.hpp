@@ -1,0 +1,86 @@
+// Model decompression:   out[p] = Uncompressed(model(p)),  one coefficient record passed BY VALUE.
+//
+// Kernel template name, parameter list and semantics as in the reference's
+// src/kernels/decompression/model.cuh:38-53.  Nothing is read from memory: the kernel is a pure
+// 16-byte-per-lane store stream (G = 16/sizeof(Uncompressed) consecutive elements per lane per
+// step, K steps per tile, tiles at grid stride).  HBM bytes per element: sizeof(Uncompressed).
+// (The reference's decompress_with_intervals, model.cuh:55-98, has no wrapper and no launch
+// parameters and is unreachable; it is not part of the hot path.)
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/functors/model_functors.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/wave64.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace model {
+
+namespace detail { enum : unsigned { steps_per_tile = 4 }; }
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+__global__ void decompress(
+	Uncompressed* __restrict__                      decompressed,
+	typename UnaryModelFunction::coefficients_type  model_coefficients,
+	size_type_by_index_size<IndexSize>              length)
+{
+	using namespace memory_access;
+	using model_index_type = typename UnaryModelFunction::index_type;
+	constexpr unsigned G = 16 / sizeof(Uncompressed);
+	constexpr unsigned K = detail::steps_per_tile;
+	UnaryModelFunction model(model_coefficients);
+
+	const uint64_t n = length;
+	const uint64_t num_groups = is_aligned(decompressed, 16) ? n / G : 0;
+	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			if (g >= num_groups) { continue; }
+			group<Uncompressed, G> out;
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (g * G + j))); }
+			store_group(decompressed + g * G, out);
+		}
+	}
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
+		decompressed[p] = static_cast<Uncompressed>(model((model_index_type) p));
+	}
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_, size_t length_)
+	: parent(device_properties_, kernel_function_attributes_)
+	{
+		constexpr unsigned elements_per_thread_per_tile = (16 / sizeof(Uncompressed)) * detail::steps_per_tile;
+		grid_construction_resolution  = thread;
+		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
+		serialization_option          = auto_maximized;
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+		default_serialization_factor  = warp_size / sizeof(Uncompressed);
+	}
+
+	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<IndexSize, Uncompressed, UnaryModelFunction>).attributes(), length_) { }
+};
+
+} // namespace model
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,112 @@
+// Shared machinery of the run-length (RLE) and run-position (RPE) decoders on CDNA4.
+//
+// Both schemes reduce to:  "given the start positions of the runs that begin inside a tile of the
+// output, write run_data[rank] at every position, where rank = number of run starts at or before
+// it".  The reference lets every thread re-walk the run arrays from the segment's first run
+// (run_length_encoding.cuh:129-157, run_position_encoding.cuh:111-150: 1 + W/A loop iterations per
+// element by its own cost model, at most two warps per block).  Here a WAVEFRONT owns a tile of up
+// to 4096 outputs and uses a rank/select structure in LDS:
+//
+//   1. clear a 4096-bit tile bitmap (128 words, two per lane)                      — ds_write
+//   2. mark: one LDS atomic-or per run start inside the tile                        — ds_or
+//   3. rank: popcount per word + one 64-lane DPP prefix sum -> runs before each word — 6 VALU steps
+//   4. expand: a lane owning E = 16/size consecutive outputs reads ONE {word, rank} pair (8-byte
+//      LDS read), derives its E ranks with masked popcounts, gathers run_data (L1/L2-resident:
+//      ~128 distinct values per tile) and issues one 16-byte store, contiguous across the wave.
+//
+// No __syncthreads anywhere: a wavefront's LDS traffic is ordered by wavefront-scope fences, so
+// wavefronts never wait for each other.  Work per output is constant, independent of run lengths.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/on_device/wave64.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace run_expansion {
+
+enum : unsigned {
+	words_per_lane      = 2,
+	tile_words          = 64 * words_per_lane,     // 128
+	tile_length         = 32 * tile_words,         // 4096 outputs per tile
+	runs_per_lane       = 4,                       // run descriptors examined per lane per batch
+	runs_per_batch      = 64 * runs_per_lane,
+	max_waves_per_block = 16,
+};
+
+struct tile_entry {
+	uint32_t bits;         // bit j: a run starts at tile position 32*word + j   (position 0 is never marked)
+	uint32_t rank_before;  // number of marked positions in all lower words
+};
+
+__device__ __forceinline__ void clear(tile_entry* table, unsigned lane)
+{
+	table[words_per_lane * lane].bits = 0;
+	table[words_per_lane * lane + 1].bits = 0;
+	wave64::lds_fence();
+}
+
+__device__ __forceinline__ void mark(tile_entry* table, uint32_t position_in_tile)
+{
+	atomicOr(&table[position_in_tile >> 5].bits, 1u << (position_in_tile & 31));
+}
+
+__device__ __forceinline__ void rank(tile_entry* table, unsigned lane)
+{
+	wave64::lds_fence();
+	uint32_t a = __builtin_popcount(table[words_per_lane * lane].bits);
+	uint32_t b = __builtin_popcount(table[words_per_lane * lane + 1].bits);
+	uint32_t inclusive = wave64::inclusive_sum(a + b);
+	uint32_t exclusive = inclusive - (a + b);
+	table[words_per_lane * lane].rank_before = exclusive;
+	table[words_per_lane * lane + 1].rank_before = exclusive + a;
+	wave64::lds_fence();
+}
+
+/// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
+template <unsigned ElementSize>
+__device__ __forceinline__ void expand(
+	uint_t<ElementSize>* __restrict__ out, uint32_t tile_len, const tile_entry* table,
+	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane)
+{
+	using namespace memory_access;
+	using element_type = uint_t<ElementSize>;
+	constexpr unsigned E = 16 / ElementSize;
+	const bool aligned = is_aligned(out, 16);
+
+	for (uint32_t row_start = 0; row_start < tile_len; row_start += 64 * E) {
+		const uint32_t p = row_start + lane * E;
+		if (p >= tile_len) { continue; }
+		const tile_entry entry = table[p >> 5];   // E divides 32: all E positions share the word
+		uint32_t ranks[E];
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) {
+			unsigned bit = (p + j) & 31;
+			ranks[j] = entry.rank_before + __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - bit)));
+		}
+		group<element_type, E> values;
+		element_type first = first_run_data[ranks[0]];
+		if (ranks[E - 1] == ranks[0]) {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { values[j] = first; }
+		}
+		else {
+			values[0] = first;
+			#pragma unroll
+			for (unsigned j = 1; j < E; j++) { values[j] = first_run_data[ranks[j]]; }
+		}
+		if (aligned && p + E <= tile_len) { store_group(out + p, values); }
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { if (p + j < tile_len) { out[p + j] = values[j]; } }
+		}
+	}
+	wave64::lds_fence();   // the table may be cleared for the next tile after this
+}
+
+} // namespace run_expansion
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,148 @@
+// Run-length decoding for CDNA4:   out[p] = run_data[r(p)],  r(p) = the run covering output p,
+// with periodic anchors: segment s (outputs [s*L, (s+1)*L)) begins inside run
+// segment_position_anchors[s] at offset segment_position_anchor_intra_run_offsets[s].
+//
+// Same kernel template name, parameter list and element semantics as the reference's
+// src/kernels/decompression/run_length_encoding.cuh:342-374 (per-segment parameters :271-326).
+// Execution (see run_expansion.hpp): one WAVEFRONT per anchored segment, segments at grid stride;
+// the segment is cut into tiles of <= 4096 outputs; per tile the run lengths are read 4 per lane,
+// prefix-summed across the wave with DPP (lengths clamped just past the tile length, so 32 bits always
+// suffice) to get run START positions, which are marked in an LDS bitmap, ranked, and expanded
+// with 16-byte stores.  The run that straddles the end of a tile is carried to the next tile as
+// (run index, elements left), so segments of any length work; run lengths must be >= 1, as the
+// reference requires.
+//
+// HBM bytes per output: element + (element + length)/mean_run + anchors/L  (4.19 B for 32-bit values,
+// 16-bit lengths, mean run 32, L = 4096 — SURVEY.md §8d, config C4).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/decompression/run_expansion.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace run_length_encoding {
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*             __restrict__  decompressed,
+	const uint_t<UncompressedSize>*       __restrict__  run_data,
+	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*           __restrict__  segment_position_anchors,
+	const uint_t<RunLengthSize>*          __restrict__  segment_position_anchor_intra_run_offsets,
+	size_type_by_index_size<UncompressedIndexSize>      segment_length,
+	size_type_by_index_size<UncompressedIndexSize>      num_segments,
+	size_type_by_index_size<RunIndexSize>               num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+{
+	using namespace run_expansion;
+	__shared__ tile_entry tables[max_waves_per_block][tile_words];
+
+	const unsigned lane = wave64::lane_id();
+	tile_entry* table = tables[wave64::index_in_block() % max_waves_per_block];
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t L = segment_length, n = total_uncompressed_length, num_runs = num_element_runs;
+
+	for (uint64_t s = wave; s < num_segments; s += num_waves) {
+		const uint64_t segment_start = s * L;
+		if (segment_start >= n) { break; }
+		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
+		uint64_t first_run = segment_position_anchors[s];
+		uint64_t left_in_first_run = (uint64_t) run_lengths[first_run] - segment_position_anchor_intra_run_offsets[s];
+		uint64_t run_limit = num_runs;   // exclusive
+		if (s + 1 < num_segments) {
+			uint64_t through = (uint64_t) segment_position_anchors[s + 1] + 1;
+			if (through < run_limit) { run_limit = through; }
+		}
+
+		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
+			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
+			const bool need_carry = tile_start + tile_len < segment_end;
+			clear(table, lane);
+
+			uint32_t running = 0;      // clamped lengths summed over earlier batches = start of this batch's first run
+			uint64_t batch_base = 0;   // index (relative to first_run) of this batch's first run
+			bool found = false; uint64_t carried_run = 0, carried_left = 0;
+			do {
+				uint64_t lengths[runs_per_lane]; uint32_t clamped[runs_per_lane]; bool have[runs_per_lane];
+				uint32_t lane_total = 0;
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					uint64_t k = batch_base + (uint64_t) lane * runs_per_lane + j;
+					have[j] = first_run + k < run_limit;
+					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) run_lengths[first_run + k]);
+					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
+					lane_total += clamped[j];
+				}
+				uint32_t inclusive = wave64::inclusive_sum(lane_total);
+				uint32_t start = running + inclusive - lane_total;
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					if (have[j]) {
+						if (start > 0 && start < tile_len) { mark(table, start); }
+						if (need_carry && start <= tile_len && lengths[j] > tile_len - start) {
+							found = true;
+							carried_run = first_run + batch_base + (uint64_t) lane * runs_per_lane + j;
+							carried_left = lengths[j] - (tile_len - start);
+						}
+					}
+					start += clamped[j];
+				}
+				running += wave64::read_last_lane(inclusive);
+				batch_base += runs_per_batch;
+			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
+
+			rank(table, lane);
+			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+
+			if (need_carry) {
+				uint64_t who = wave64::ballot(found);
+				if (who != 0) {
+					unsigned source = (unsigned) __builtin_ctzll(who);
+					first_run = wave64::read_lane(carried_run, source);
+					left_in_first_run = wave64::read_lane(carried_left, source);
+				}
+			}
+		}
+	}
+}
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t            device_properties_,
+		device_function::attributes_t   kernel_function_attributes_,
+		size_t                          uncompressed_length,
+		size_t                          segment_length,
+		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
+	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
+	{
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		grid_construction_resolution  = warp;                // one wavefront per anchored segment
+		length                        = util::div_rounding_up(uncompressed_length, segment_length);
+		serialization_option          = auto_maximized;      // segments at grid stride
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+	}
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, size_t uncompressed_length, size_t segment_length,
+		optional<shared_memory_size_t> dynamic_shared_mem_limit = nullopt)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>).attributes(),
+		uncompressed_length, segment_length, dynamic_shared_mem_limit) { }
+};
+
+} // namespace run_length_encoding
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,133 @@
+// Run-position decoding for CDNA4:   out[p] = run_data[r(p)],  r(p) = the last run whose start is <= p.
+// Run starts are stored directly — absolute, or relative to the start of the anchored segment the run
+// begins in (PositionsAreRelative) — and position_anchors[s] is the run covering output s*L.
+//
+// Same kernel template name, parameter list and element semantics as the reference's
+// src/kernels/decompression/run_position_encoding.cuh:327-359 (per-segment parameters :255-308), with
+// one deliberate difference: a run that starts exactly on a segment boundary belongs to the NEXT
+// segment only.  The reference admits it into the previous segment when positions are relative
+// (it compares a relative position with an absolute boundary, :296-297) and then mis-decodes that
+// segment's last run; here the test is "0 < relative start < L".
+//
+// Execution (see run_expansion.hpp): one WAVEFRONT per anchored segment at grid stride, tiles of
+// <= 4096 outputs; no scan is needed — start positions are marked straight into the tile bitmap,
+// 4 candidates per lane per batch, until a batch reaches past the tile; rank; expand.  For segments
+// longer than one tile the last run starting at or before the tile's end is carried forward.
+//
+// HBM bytes per output: element + (element + position)/mean_run + anchor/L  (4.19 B relative /
+// 4.25 B absolute at 32-bit values, mean run 32, L = 4096 — SURVEY.md §8d, config C4).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "giddy/common.hpp"
+#include "giddy/kernels/decompression/run_expansion.hpp"
+#include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/util/math.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace run_position_encoding {
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
+	size_type_by_index_size<PositionOffsetSize>      anchoring_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	static_assert(PositionsAreRelative || PositionOffsetSize >= UncompressedIndexSize,
+		"If run positions are in absolute values, their type must be able to cover the entire potential range of data");
+	using namespace run_expansion;
+	__shared__ tile_entry tables[max_waves_per_block][tile_words];
+
+	const unsigned lane = wave64::lane_id();
+	tile_entry* table = tables[wave64::index_in_block() % max_waves_per_block];
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
+
+	for (uint64_t s = wave; s < num_anchors; s += num_waves) {
+		const uint64_t segment_start = s * L;
+		if (segment_start >= n) { break; }
+		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
+		uint64_t first_run = position_anchors[s];
+		// candidates for runs starting inside this segment: first_run+1 .. last_candidate (inclusive)
+		const uint64_t last_candidate = (s + 1 < num_anchors) ? (uint64_t) position_anchors[s + 1] : num_runs - 1;
+
+		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
+			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
+			const uint64_t tile_end = tile_start + tile_len;
+			const bool need_carry = tile_end < segment_end;
+			clear(table, lane);
+
+			uint64_t batch_base = first_run + 1;
+			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= tile_end
+			bool reached_past_tile;
+			do {
+				bool past = false;
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					uint64_t r = batch_base + (uint64_t) lane * runs_per_lane + j;
+					if (r > last_candidate) { past = true; continue; }
+					uint64_t position = run_start_positions[r];
+					uint64_t start = PositionsAreRelative ? segment_start + position : position;
+					// a run at relative position 0 (absolute: at/after the segment's end) opens the NEXT segment
+					bool starts_in_segment = PositionsAreRelative ? (position != 0) : (start < segment_start + L);
+					if (!starts_in_segment || start > tile_end) { past = true; continue; }
+					if (start > tile_start && start < tile_end) { mark(table, (uint32_t) (start - tile_start)); }
+					last_at_or_before_end = (uint32_t) (r - first_run) + 1;   // r increases with j
+				}
+				reached_past_tile = wave64::ballot(past) != 0;
+				batch_base += runs_per_batch;
+			} while (!reached_past_tile);
+
+			rank(table, lane);
+			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+
+			if (need_carry) {
+				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
+				if (furthest != 0) { first_run += furthest - 1; }
+			}
+		}
+	}
+}
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
+public:
+	using parent = kernels::launch_config_resolution_params_t;
+
+	launch_config_resolution_params_t(
+		device::properties_t            device_properties_,
+		device_function::attributes_t   kernel_function_attributes_,
+		size_t                          uncompressed_length,
+		size_t                          position_anchoring_period,
+		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
+	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
+	{
+		if (position_anchoring_period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
+		grid_construction_resolution  = warp;                // one wavefront per anchored segment
+		length                        = util::div_rounding_up(uncompressed_length, position_anchoring_period);
+		serialization_option          = auto_maximized;
+		quanta.threads_in_block       = warp_size;
+		upper_limits.threads_in_block = 256;
+		keep_gpu_busy_factor          = 8;
+	}
+
+	launch_config_resolution_params_t(
+		device::properties_t device_properties_, size_t uncompressed_length, size_t position_anchoring_period,
+		optional<shared_memory_size_t> dynamic_shared_mem_limit = nullopt)
+	: launch_config_resolution_params_t(device_properties_,
+		device_function_t(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>).attributes(),
+		uncompressed_length, position_anchoring_period, dynamic_shared_mem_limit) { }
+};
+
+} // namespace run_position_encoding
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

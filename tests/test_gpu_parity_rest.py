@@ -1,0 +1,175 @@
+"""GPU parity (bit-exact) of the remaining HIP kernels against the CPU oracle, through the C ABI:
+DZB fixed / variable, Model, Incidence bitmaps, RLE, RPE, compressed-indices scatter — every
+registered instantiation at least once, plus the edge shapes of tests/test_oracle.py."""
+import numpy as np
+import pytest
+
+import cases
+from libgiddy_amd import formats
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _imports():
+    from libgiddy_amd import schemes, registered
+    import gpu_util
+    return schemes, registered, gpu_util
+
+
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
+@pytest.mark.parametrize("index_size", [4, 8])
+def test_dzb_fixed(usize, csize, index_size):
+    schemes, r, g = _imports()
+    for n in (0, 1, 1237, 1 << 20):
+        c = cases.rng(n).integers(0, np.iinfo("u%d" % csize).max, size=n, endpoint=True).astype("u%d" % csize)
+        out = g.dev_empty(n, "u%d" % usize)
+        schemes.discard_zero_bytes_fixed(out, g.dev(c), n, uncompressed_size=usize, compressed_size=csize,
+                                         index_size=index_size, stream=g.stream())
+        assert (g.host(out, "u%d" % usize, n) == oracle.dzb_fixed(c, "u%d" % usize)).all()
+
+
+@pytest.mark.parametrize("index_size,usize,model", [(4, 2, "linear"), (4, 4, "linear"), (8, 4, "linear"), (4, 2, "constant"), (4, 4, "constant")])
+def test_model(index_size, usize, model):
+    schemes, r, g = _imports()
+    dt = np.dtype("i%d" % usize)
+    coefs = np.array([12345, -7] if model == "linear" else [-321], dtype=dt)
+    for n in (1, 70001, 1 << 20):
+        out = g.dev_empty(n, dt)
+        schemes.model(out, coefs, n, uncompressed_size=usize, model=model, index_size=index_size, stream=g.stream())
+        assert (g.host(out, dt, n) == oracle.model(coefs, n, dt, model, model_index_size=index_size)).all()
+
+
+DZBV_TUPLES = [(4, 2, 4), (4, 4, 4), (4, 8, 4), (8, 2, 4), (8, 4, 4), (8, 8, 4), (4, 2, 8), (4, 4, 8), (4, 8, 8)]
+
+
+@pytest.mark.parametrize("index_size,usize,container", DZBV_TUPLES)
+@pytest.mark.parametrize("min_size,bits", [(1, 2), (1, 3), (0, 2), (2, 1), (0, 4)])
+def test_dzb_variable(index_size, usize, container, min_size, bits):
+    schemes, r, g = _imports()
+    if min_size > usize:
+        pytest.skip("min size exceeds element width")
+    ud = np.dtype("u%d" % usize)
+    for n, seglen in [(1, 32), (1000, 64), (1024, 1024), (333333, 1024), (50, 7), (100000, 4096), (70000, 1000)]:
+        col, sizes = cases.dzbv_column(n, ud, min_size, bits, seed=n + bits + usize)
+        f = formats.discard_zero_bytes_variable(col, seglen, min_size, bits, "u%d" % container, index_size, element_sizes=sizes)
+        out = g.dev_empty(n, ud)
+        # exact-size device buffer for the compressed bytes: nothing may be read past its last 16-byte chunk
+        schemes.discard_zero_bytes_variable(out, g.dev(f["compressed_data"]), g.dev(f["packed_element_sizes"]),
+                                            g.dev(f["position_anchors"]), seglen, n, min_size, bits,
+                                            uncompressed_size=usize, container_size=container, index_size=index_size,
+                                            stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != col)
+        assert len(bad) == 0, (n, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
+
+
+@pytest.mark.parametrize("usize,use_dictionary", [(1, True), (2, True), (4, True), (8, True), (1, False)])
+def test_incidence_bitmaps(usize, use_dictionary):
+    schemes, r, g = _imports()
+    ud = np.dtype("u%d" % usize)
+    for n_words, num_values in [(1, 1), (5, 3), (64, 17), (1001, 200), (50000, 33)]:
+        rr = cases.rng(n_words + usize)
+        if use_dictionary:
+            num_values = min(num_values, int(np.iinfo(ud).max) + 1)
+            pool = rr.choice(min(int(np.iinfo(ud).max) + 1, 1 << 40), size=num_values, replace=False).astype(ud)
+            col = pool[rr.integers(0, num_values, size=32 * n_words)]
+        else:
+            col = rr.integers(0, min(num_values, 200), size=32 * n_words).astype(ud)
+        f = formats.incidence_bitmaps(col, 2, use_dictionary)
+        out = g.dev_empty(32 * n_words, ud)
+        schemes.incidence_bitmaps(out, g.dev(f["incidence_bitmaps"]), g.dev(f["dictionary_entries"]), f["bitmap_length"],
+                                  f["num_bitmaps"], uncompressed_size=usize, use_dictionary=use_dictionary, stream=g.stream())
+        assert (g.host(out, ud, 32 * n_words) == col).all(), (n_words, num_values)
+
+
+def _run_columns():
+    yield "geom32", cases.runs_column(300000, 32, np.uint32, seed=6)
+    yield "geom2", cases.runs_column(50000, 2, np.uint32, seed=7)
+    yield "geom1000", cases.runs_column(400000, 1000, np.uint32, seed=8)
+    yield "single", np.full(50000, 77, dtype=np.uint32)
+    yield "one", np.array([5], dtype=np.uint32)
+    yield "alldistinct", np.arange(30000, dtype=np.uint32)
+    yield "boundary", np.repeat(np.arange(10, dtype=np.uint32) * 3 + 1, [1024, 512, 512, 2048, 1, 1023, 1024, 100, 924, 1000])
+    yield "tileboundary", np.repeat(np.arange(6, dtype=np.uint32) + 9, [4096, 4096, 8192, 1, 4095, 12288])
+
+
+RLE_TUPLES = [(4, u, l, 4) for l in (1, 2, 4) for u in (1, 2, 4, 8)] + [(8, 4, 1, 8), (8, 4, 2, 8), (8, 4, 4, 8), (8, 1, 8, 8), (8, 4, 8, 8), (8, 8, 8, 8)]
+
+
+@pytest.mark.parametrize("index_size,usize,lsize,run_index_size", RLE_TUPLES)
+def test_rle(index_size, usize, lsize, run_index_size):
+    schemes, r, g = _imports()
+    ud = np.dtype("u%d" % usize)
+    for name, col in _run_columns():
+        col = col.astype(np.uint64).astype(ud)
+        n = len(col)
+        for seglen in (1024, 4096, 100, 20000, 65536):
+            f = formats.run_length_encoding(col, seglen, "u%d" % lsize, run_index_size)
+            expect = oracle.run_length_encoding(f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], seglen, n)
+            assert (expect == col).all()
+            out = g.dev_empty(n, ud)
+            schemes.run_length_encoding(out, g.dev(f["run_data"]), g.dev(f["run_lengths"]), g.dev(f["position_anchors"]),
+                                        g.dev(f["intra_run_anchor_offsets"]), seglen, f["num_segments"], f["num_element_runs"], n,
+                                        uncompressed_size=usize, run_length_size=lsize, index_size=index_size,
+                                        run_index_size=run_index_size, stream=g.stream())
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != col)
+            assert len(bad) == 0, (name, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
+
+
+RPE_TUPLES = [(4, 1, 2, True), (4, 2, 2, True), (4, 4, 2, True), (4, 8, 2, True), (8, 4, 2, True),
+              (4, 1, 4, False), (4, 2, 4, False), (4, 4, 4, False), (4, 8, 4, False), (8, 4, 8, False)]
+
+
+@pytest.mark.parametrize("index_size,usize,psize,relative", RPE_TUPLES)
+def test_rpe(index_size, usize, psize, relative):
+    schemes, r, g = _imports()
+    ud = np.dtype("u%d" % usize)
+    for name, col in _run_columns():
+        col = col.astype(np.uint64).astype(ud)
+        n = len(col)
+        for seglen in (1024, 4096, 100, 20000, 65536):
+            f = formats.run_position_encoding(col, seglen, "u%d" % psize, relative, index_size)
+            expect = oracle.run_position_encoding(f["run_data"], f["run_start_positions"], f["position_anchors"], seglen, n, relative)
+            assert (expect == col).all()
+            out = g.dev_empty(n, ud)
+            schemes.run_position_encoding(out, g.dev(f["run_data"]), g.dev(f["run_start_positions"]), g.dev(f["position_anchors"]),
+                                          seglen, f["num_anchors"], f["num_element_runs"], n, uncompressed_size=usize,
+                                          position_size=psize, relative=relative, index_size=index_size, stream=g.stream())
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != col)
+            assert len(bad) == 0, (name, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
+
+
+@pytest.mark.parametrize("osize", [4, 8])
+@pytest.mark.parametrize("esize", [1, 2, 4, 8])
+@pytest.mark.parametrize("isize", [1, 2, 4, 8])
+def test_compressed_indices_scatter(osize, esize, isize):
+    schemes, r, g = _imports()
+    ed = np.dtype("u%d" % esize)
+    n = 300000
+    rr = cases.rng(esize * 100 + osize + isize)
+    target = rr.integers(0, 255, size=n).astype(ed)
+    npatch = {1: 200, 2: 5000}.get(isize, 20000)
+    period = {1: 64, 2: 1024}.get(isize, 1024)
+    p = cases.patch_case(n, npatch, ed, osize, seed=esize + osize)
+    expect = oracle.scatter(target.copy(), p["data"], p["indices"])
+    for maxrun in (None, 5, 1):
+        c = formats.compressed_indices(p["indices"], p["data"], period, osize, isize, max_run_length=maxrun)
+        t = g.dev(target)
+        schemes.compressed_indices_scatter(
+            t, g.dev(c["data_to_scatter"]), g.dev(c["scatter_position_run_lengths"]),
+            g.dev(c["scatter_position_run_individual_offset_sizes"]), g.dev(c["scatter_position_run_baseline_values"]),
+            g.dev(c["scatter_position_run_offsets_start_pos"]), g.dev(c["scatter_position_offset_bytes"]),
+            g.dev(c["scatter_position_anchors"]), period, c["num_scatter_position_runs"], npatch,
+            output_index_size=osize, element_size=esize, input_index_size=isize, stream=g.stream())
+        got = g.host(t, ed, n)
+        assert (got == expect).all(), (maxrun, np.flatnonzero(got != expect)[:5])
