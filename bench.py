@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the lightweight-decompression hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 30] [--workload dictionary]
+                    [--schemes all|none|name,...] [--no-cpu-baseline]
+
+One "step" = one pass of the hot path over one batch of synthetic, device-resident input.
+The N=1 workload is BASELINE.json configs[1]: Dictionary, 8-bit keys -> 32-bit values, 256-entry
+dictionary, 2^30 elements on one MI355X.  `value` = decompressed GB/s of the whole job (all ranks'
+output bytes / max-over-ranks time), inputs resident in HBM when the timed region starts.  For N > 1
+(launched by torch.distributed.run, one rank per GPU) every rank decodes its own 2^30-element shard —
+columns shard by independent anchored segment ranges, there is no data-path collective — so scaling
+is "weak".
+
+The JSON line also carries
+  roofline      algorithmic HBM bytes of one launch / that kernel's mean duration (HIP events on
+                the launch stream), against the 8 TB/s HBM3E peak;
+  cpu_baseline  the CPU oracle (a port: the reference has no CPU path) on a bounded sample of the same
+                workload on this host's cores (OpenMP, thread count stated; single-thread beside it);
+  schemes       the same measurement for the other BASELINE.json configs that fit one GPU
+                (FOR, Delta + patches, RLE, RPE, DZB-variable) — bit-exactness of every one of them is
+                asserted against the oracle before anything is timed.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md (≈6.3 TB/s achievable)
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=20)
+    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--log2n", type=int, default=30)
+    p.add_argument("--workload", default="dictionary")
+    p.add_argument("--schemes", default="all", help="extra per-scheme measurements at N=1: all | none | comma list")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--cpu-sample-log2", type=int, default=27)
+    return p.parse_args()
+
+
+def make_workload(name, n, device):
+    import workloads as w
+    table = {
+        "dictionary": lambda: w.Dictionary(n, device),
+        "dictionary_zipf": lambda: w.Dictionary(n, device, zipf=True),
+        "frame_of_reference": lambda: w.FrameOfReference(n, device),
+        "delta_patched": lambda: w.DeltaPatched(n, device),
+        "run_length_encoding": lambda: w.RunLength(n, device),
+        "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
+        "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),
+        "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device),
+    }
+    return table[name]()
+
+
+def timed_steps(work, steps, warmup, barrier):
+    """EXACTLY `steps` timed passes between barrier+synchronize brackets; per-launch durations from
+    HIP events recorded on the launch stream (torch's current stream, the one the kernels are enqueued on)."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    for _ in range(warmup):
+        work.run(stream)
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for begin, end in events:
+        begin.record()
+        work.run(stream)
+        end.record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    per_launch_ms = [b.elapsed_time(e) for b, e in events]
+    return elapsed, sum(per_launch_ms) / len(per_launch_ms)
+
+
+def roofline(work, mean_launch_ms, traffic):
+    achieved = work.algorithmic_bytes / (mean_launch_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "kernel": work.kernel, "algorithmic_bytes_per_launch": work.algorithmic_bytes,
+            "mean_launch_ms": round(mean_launch_ms, 4)}
+
+
+def committed_traffic(kernel):
+    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f).get(kernel, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(work, sample, unit_bytes_label="decompressed GB/s"):
+    from oracle import oracle
+    cores = oracle.max_threads()
+    results = {}
+    for threads in (1, cores):
+        fn, out_bytes = work.cpu_run(oracle, sample, threads)
+        fn()  # warm
+        best = float("inf")
+        deadline = time.perf_counter() + 6.0
+        reps = 0
+        while reps < 3 or (time.perf_counter() < deadline and reps < 20):
+            t = time.perf_counter(); fn(); best = min(best, time.perf_counter() - t); reps += 1
+        results[threads] = out_bytes / best / 1e9
+    return {"value": round(results[cores], 3), "unit": unit_bytes_label, "cores": cores, "kind": "port",
+            "sample": "first %d elements of the same workload, CPU oracle (oracle/giddy_oracle.c, gcc -O3 -fopenmp), best of >=3" % sample,
+            "single_thread_value": round(results[1], 3)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with: python -m torch.distributed.run --nnodes=1 --nproc-per-node %d "
+                     "--master-addr 127.0.0.1 --master-port P bench.py --gpus %d ..." % (args.gpus, args.gpus, args.gpus))
+        args.gpus = world
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device is visible")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    from oracle import oracle
+    n = 1 << args.log2n
+
+    # ---- the headline workload ------------------------------------------------------------------
+    work = make_workload(args.workload, n, device)
+    work.run(torch.cuda.current_stream().cuda_stream)
+    work.verify(oracle)                                   # bit-exact before anything is reported
+    elapsed, mean_launch_ms = timed_steps(work, args.steps, args.warmup, barrier)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t[0])
+    value = world * work.decompressed_bytes * args.steps / elapsed / 1e9
+
+    line = {
+        "metric": "decompressed GB/s (whole job; per-GPU = value / n_gpus), %s, 2^%d elements per GPU" % (work.name, args.log2n),
+        "value": round(value, 1), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "BASELINE.json configs[1]: Dictionary, 8-bit keys -> int32 values, 256-entry dictionary, 2^%d elements per GPU" % args.log2n
+                   if args.workload == "dictionary" else args.workload,
+                   "instantiation": work.name, "elements_per_gpu": n, "sharding": "independent segment ranges, one shard per GPU, no collective",
+                   "launch": repr(work.config)},
+        "per_gpu_value": round(value / world, 1),
+        "pct_hbm_peak_decompressed": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
+        "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel)),
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(work, min(n, 1 << args.cpu_sample_log2))
+
+    # ---- the other single-GPU configs, same treatment (rank 0 of a 1-GPU run only) ----------------
+    if world == 1 and args.schemes != "none":
+        names = ["frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
+                 "run_position_encoding_absolute", "discard_zero_bytes_variable"]
+        if args.schemes != "all":
+            names = [s for s in args.schemes.split(",") if s]
+        del work
+        torch.cuda.empty_cache()
+        schemes_out = {}
+        for name in names:
+            w = make_workload(name, n, device)
+            w.run(torch.cuda.current_stream().cuda_stream)
+            w.verify(oracle)
+            el, launch_ms = timed_steps(w, max(5, args.steps // 2), 2, barrier)
+            steps = max(5, args.steps // 2)
+            entry = {"instantiation": w.name, "elements": w.n,
+                     "decompressed_GBps": round(w.decompressed_bytes * steps / el / 1e9, 1),
+                     "ms_per_step": round(el / steps * 1e3, 4),
+                     "roofline": roofline(w, launch_ms, committed_traffic(w.kernel)), "bit_exact": True}
+            if not args.no_cpu_baseline:
+                entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
+            schemes_out[name] = entry
+            del w
+            torch.cuda.empty_cache()
+        line["schemes"] = schemes_out
+
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

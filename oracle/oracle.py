@@ -46,8 +46,9 @@ MODEL_KINDS = {"constant": 0, "linear": 1}
 
 
 def frame_of_reference(compressed, coefficients, length, segment_length, out_dtype, model="constant",
-                       model_index_size=4, threads=1):
-    out = np.zeros(length, dtype=out_dtype)
+                       model_index_size=4, threads=1, out=None):
+    if out is None:
+        out = np.zeros(length, dtype=out_dtype)
     coefficients = np.ascontiguousarray(coefficients)
     rc = lib().oracle_frame_of_reference(_p(out), out.itemsize, _p(compressed), compressed.itemsize,
                                          _p(coefficients), coefficients.itemsize, MODEL_KINDS[model],
@@ -92,8 +93,9 @@ def dzb_fixed(compressed, out_dtype, threads=1):
 
 
 def dzb_variable(compressed_data, packed_sizes, anchors, segment_length, length, min_size, bits, out_dtype,
-                 threads=1):
-    out = np.zeros(length, dtype=out_dtype)
+                 threads=1, out=None):
+    if out is None:
+        out = np.zeros(length, dtype=out_dtype)
     rc = lib().oracle_dzb_variable(_p(out), out.itemsize, _p(compressed_data), _p(packed_sizes),
                                    packed_sizes.itemsize, _p(anchors), anchors.itemsize, _u64(segment_length),
                                    _u64(length), ctypes.c_uint(min_size), ctypes.c_uint(bits), threads)

@@ -1,0 +1,378 @@
+"""Synthetic, seeded, device-resident workloads for bench.py — the BASELINE.json configs.
+
+Inputs are generated ON THE GPU with torch (torch is the allocator / RNG here, nothing more), each
+workload exposes:
+    run(stream)            enqueue one pass of the hot path (one "step") through libgiddy_amd.schemes
+    output                 the decompressed device buffer
+    algorithmic_bytes      compulsory HBM bytes of one step (reads + writes)
+    decompressed_bytes     bytes of decompressed output per step
+    kernel                 name of the dominant kernel (for the rocprof summary)
+    verify(oracle)         bit-exact checks: a bounded sample against the CPU oracle + full-size identities
+    cpu_sample(...)        host copies of a bounded sample for the CPU baseline
+"""
+import numpy as np
+import torch
+
+from libgiddy_amd import schemes
+
+
+def _gen(seed, device):
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    return g
+
+
+def _np(t, dtype=None):
+    a = t.detach().cpu().numpy()
+    return a.view(dtype) if dtype is not None else a
+
+
+class Dictionary:
+    """C2: 8-bit keys -> 32-bit values, 256-entry dictionary, uniform keys (seed 2)."""
+    name = "dictionary<4,4,1>"
+    kernel = "dictionary::decompress"
+    dtype = "u32"
+
+    def __init__(self, n, device, seed=2, zipf=False):
+        g = _gen(seed, device)
+        self.n = n
+        self.entries = torch.randperm(1 << 24, generator=g, device=device)[:256].to(torch.int32) * 251 + 7
+        if zipf:
+            u = torch.rand(n, generator=g, device=device)
+            self.keys = torch.clamp((u ** (-1.0 / 0.2)).to(torch.int64) - 1, 0, 255).to(torch.uint8)
+        else:
+            self.keys = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g, device=device)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 5 * n + 1024
+        self.decompressed_bytes = 4 * n
+        self.config = schemes.dictionary(self.output, self.keys, self.entries, n, 256, stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.dictionary(self.output, self.keys, self.entries, self.n, 256, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n = self.n
+        # (1) a bounded sample, bit-exact against the CPU oracle: head and tail
+        entries = _np(self.entries, np.uint32)
+        for lo, hi in ((0, min(sample, n)), (max(0, n - sample), n)):
+            expect = oracle.dictionary(_np(self.keys[lo:hi]), entries)
+            assert (expect == _np(self.output[lo:hi], np.uint32)).all(), "dictionary: sample mismatch vs oracle"
+        # (2) full size: sum of outputs == sum_k count_k * entry_k (size-independent identity), and
+        #     an independent torch gather, bit for bit
+        counts = torch.bincount(self.keys.to(torch.int64), minlength=256)
+        assert int((counts * self.entries.to(torch.int64)).sum()) == int(self.output.sum(dtype=torch.int64))
+        step = 1 << 28
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            assert bool((self.entries[self.keys[lo:hi].to(torch.int64)] == self.output[lo:hi]).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        keys = _np(self.keys[:sample]).copy()
+        entries = _np(self.entries, np.uint32).copy()
+        out = np.empty(sample, dtype=np.uint32)
+        return (lambda: oracle.dictionary(keys, entries, threads=threads, out=out)), 4 * sample
+
+
+class FrameOfReference:
+    """FOR int32 <- int16, constant model, segment 4096 (the north-star FOR target; C1 is its 1-segment 2^20 plumbing case)."""
+    name = "frame_of_reference<4,int,short,constant>"
+    kernel = "frame_of_reference::decompress"
+
+    def __init__(self, n, device, seed=1, segment_length=4096):
+        g = _gen(seed, device)
+        self.n, self.L = n, segment_length
+        nseg = (n + segment_length - 1) // segment_length
+        self.comp = torch.randint(-32768, 32768, (n,), dtype=torch.int16, generator=g, device=device)
+        self.coefs = torch.randint(-1000000, 1000000, (nseg, 1), dtype=torch.int32, generator=g, device=device)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 6 * n + 4 * nseg
+        self.decompressed_bytes = 4 * n
+        self.config = schemes.frame_of_reference(self.output, self.comp, self.coefs, n, segment_length,
+                                                 stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.frame_of_reference(self.output, self.comp, self.coefs, self.n, self.L, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, L = self.n, self.L
+        sample = (sample // L) * L
+        for lo, hi in ((0, min(sample, n)), (max(0, (n - sample) // L * L), n)):
+            expect = oracle.frame_of_reference(_np(self.comp[lo:hi]), _np(self.coefs[lo // L:(hi + L - 1) // L]), hi - lo, L, np.int32)
+            assert (expect == _np(self.output[lo:hi])).all(), "FOR: sample mismatch vs oracle"
+        # full size: out - in == per-segment constant
+        step = 1 << 28
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            ref = self.coefs[lo // L:(hi + L - 1) // L].view(-1).repeat_interleave(L)[: hi - lo]
+            assert bool(((self.output[lo:hi] - self.comp[lo:hi].to(torch.int32)) == ref).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        sample = (sample // self.L) * self.L
+        comp = _np(self.comp[:sample]).copy()
+        coefs = _np(self.coefs[: sample // self.L]).copy()
+        out = np.empty(sample, dtype=np.int32)
+        return (lambda: oracle.frame_of_reference(comp, coefs, sample, self.L, np.int32, threads=threads, out=out)), 4 * sample
+
+
+class DeltaPatched:
+    """C3: Delta, uint64 <- uint16 deltas, segment 4096, anchors = exact prefix at segment starts (base 2^40),
+    then 0.1 % naive patches (scatter<4,8,4>) on the same stream."""
+    name = "delta<4,8,2>+scatter<4,8,4>"
+    kernel = "delta::decompress"
+
+    def __init__(self, n, device, seed=3, segment_length=4096, patch_fraction=0.001):
+        g = _gen(seed, device)
+        self.n, self.L = n, segment_length
+        self.deltas = torch.randint(0, 65536, (n,), dtype=torch.int32, generator=g, device=device).to(torch.int16)  # bit pattern of uint16
+        nseg = (n + segment_length - 1) // segment_length
+        seg_sums = (self.deltas.view(-1)[: nseg * segment_length if n % segment_length == 0 else n].to(torch.int32) & 0xFFFF)
+        if n % segment_length == 0:
+            per_segment = seg_sums.view(nseg, segment_length).sum(dim=1, dtype=torch.int64)
+        else:
+            per_segment = torch.zeros(nseg, dtype=torch.int64, device=device)
+            per_segment.index_add_(0, torch.arange(n, device=device) // segment_length, seg_sums.to(torch.int64))
+        self.anchors = ((1 << 40) + torch.cumsum(per_segment, 0) - per_segment).contiguous()
+        self.p = max(1, int(round(n * patch_fraction)))
+        self.patch_idx = torch.sort(torch.randperm(n, generator=_gen(seed + 1, device), device=device)[: self.p])[0].to(torch.int32)
+        self.patch_val = torch.randint(0, 1 << 62, (self.p,), dtype=torch.int64, generator=_gen(seed + 2, device), device=device)
+        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.algorithmic_bytes = 10 * n + 8 * nseg + self.p * 20
+        self.decompressed_bytes = 8 * n
+        st = torch.cuda.current_stream().cuda_stream
+        self.config = schemes.delta(self.output, self.deltas, self.anchors, n, segment_length, stream=st)
+        self.patch_config = schemes.scatter(self.output, self.patch_val, self.patch_idx, self.p, stream=st)
+
+    def run(self, stream):
+        schemes.delta(self.output, self.deltas, self.anchors, self.n, self.L, stream=stream, launch_config=self.config)
+        schemes.scatter(self.output, self.patch_val, self.patch_idx, self.p, stream=stream, launch_config=self.patch_config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, L = self.n, self.L
+        sample = (sample // L) * L
+        pidx = _np(self.patch_idx, np.uint32).astype(np.int64)
+        pval = _np(self.patch_val, np.uint64)
+        for lo, hi in ((0, min(sample, n)), (max(0, (n - sample) // L * L), n)):
+            expect = oracle.delta(_np(self.deltas[lo:hi], np.uint16), _np(self.anchors[lo // L:(hi + L - 1) // L], np.uint64), L)
+            inside = (pidx >= lo) & (pidx < hi)
+            expect[pidx[inside] - lo] = pval[inside]
+            assert (expect == _np(self.output[lo:hi], np.uint64)).all(), "delta+patch: sample mismatch vs oracle"
+        # full size: un-patched positions satisfy out[p] - out[p-1] == delta[p] inside a segment; patched hold the patch
+        assert bool((self.output[self.patch_idx.to(torch.int64)] == self.patch_val).all())
+        step = 1 << 27
+        is_patch = torch.zeros(n, dtype=torch.bool, device=self.output.device)
+        is_patch[self.patch_idx.to(torch.int64)] = True
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            a = max(lo, 1)
+            d = self.output[a:hi] - self.output[a - 1:hi - 1]
+            want = self.deltas[a:hi].to(torch.int64) & 0xFFFF
+            pos = torch.arange(a, hi, device=d.device)
+            skip = is_patch[a:hi] | is_patch[a - 1:hi - 1] | (pos % L == 0)
+            assert bool(((d == want) | skip).all())
+        heads = torch.arange(0, n, L, device=self.output.device)
+        ok = (self.output[heads] == self.anchors + (self.deltas[heads].to(torch.int64) & 0xFFFF)) | is_patch[heads]
+        assert bool(ok.all())
+
+    def cpu_run(self, oracle, sample, threads):
+        sample = (sample // self.L) * self.L
+        d = _np(self.deltas[:sample], np.uint16).copy()
+        a = _np(self.anchors[: sample // self.L], np.uint64).copy()
+        out = np.empty(sample, dtype=np.uint64)
+        return (lambda: oracle.delta(d, a, self.L, threads=threads, out=out)), 8 * sample
+
+
+def _geometric_runs(n, mean_run, device, seed, max_run=65535):
+    g = _gen(seed, device)
+    est = int(n / mean_run * 1.15) + 1024
+    u = torch.rand(est, generator=g, device=device, dtype=torch.float64)
+    lengths = torch.clamp(torch.floor(torch.log(u) / np.log(1.0 - 1.0 / mean_run)).to(torch.int64) + 1, 1, max_run)
+    ends = torch.cumsum(lengths, 0)
+    assert int(ends[-1]) >= n, "not enough runs generated"
+    count = int(torch.searchsorted(ends, torch.tensor([n], device=device), right=False)[0]) + 1
+    lengths = lengths[:count].clone()
+    lengths[-1] -= int(ends[count - 1]) - n
+    starts = torch.cumsum(lengths, 0) - lengths
+    values = torch.randint(0, 1 << 31, (count,), dtype=torch.int64, generator=g, device=device)
+    values = (values * 2 + (torch.arange(count, device=device) & 1)).to(torch.int32)  # adjacent runs distinct
+    return lengths, starts, values
+
+
+class RunLength:
+    """C4 (RLE): uint32 values, uint16 lengths i.i.d. geometric mean 32, segment 4096."""
+    name = "run_length_encoding<4,4,2>"
+    kernel = "run_length_encoding::decompress"
+
+    def __init__(self, n, device, seed=6, segment_length=4096, mean_run=32):
+        self.n, self.L = n, segment_length
+        lengths, starts, values = _geometric_runs(n, mean_run, device, seed)
+        self.num_runs = len(lengths)
+        seg_starts = torch.arange(0, n, segment_length, device=device)
+        self.num_segments = len(seg_starts)
+        anchor = torch.searchsorted(starts, seg_starts, right=True) - 1
+        self.starts = starts
+        self.run_data = values
+        self.run_lengths = lengths.to(torch.int16)
+        self.anchors = anchor.to(torch.int32)
+        self.intra = (seg_starts - starts[anchor]).to(torch.int16)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 4 * n + 6 * self.num_runs + 6 * self.num_segments
+        self.decompressed_bytes = 4 * n
+        self.config = self._launch(torch.cuda.current_stream().cuda_stream, None)
+
+    def _launch(self, stream, config):
+        return schemes.run_length_encoding(self.output, self.run_data, self.run_lengths, self.anchors, self.intra, self.L,
+                                           self.num_segments, self.num_runs, self.n, stream=stream, launch_config=config)
+
+    def run(self, stream):
+        self._launch(stream, self.config)
+
+    def _expected_slice(self, lo, hi):
+        pos = torch.arange(lo, hi, device=self.output.device)
+        return self.run_data[torch.searchsorted(self.starts, pos, right=True) - 1]
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, L = self.n, self.L
+        sample = min((sample // L) * L, n)
+        # oracle on the head of the column (anchors + the runs they reach)
+        nseg = (sample + L - 1) // L
+        last_run = int(self.anchors[min(nseg, self.num_segments - 1)]) + 1 if nseg < self.num_segments else self.num_runs
+        expect = oracle.run_length_encoding(_np(self.run_data[:last_run], np.uint32), _np(self.run_lengths[:last_run], np.uint16),
+                                            _np(self.anchors[:nseg], np.uint32), _np(self.intra[:nseg], np.uint16), L, sample)
+        assert (expect == _np(self.output[:sample], np.uint32)).all(), "RLE: sample mismatch vs oracle"
+        step = 1 << 27
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            assert bool((self._expected_slice(lo, hi) == self.output[lo:hi]).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        L = self.L
+        sample = min((sample // L) * L, self.n)
+        nseg = sample // L
+        last_run = int(self.anchors[nseg]) + 1 if nseg < self.num_segments else self.num_runs
+        rd = _np(self.run_data[:last_run], np.uint32).copy(); rl = _np(self.run_lengths[:last_run], np.uint16).copy()
+        an = _np(self.anchors[:nseg], np.uint32).copy(); it = _np(self.intra[:nseg], np.uint16).copy()
+        out = np.empty(sample, dtype=np.uint32)
+        return (lambda: oracle.run_length_encoding(rd, rl, an, it, L, sample, threads=threads, out=out)), 4 * sample
+
+
+class RunPosition(RunLength):
+    """C4 (RPE): same runs as RLE, start positions relative to the segment (uint16) or absolute (uint32)."""
+    kernel = "run_position_encoding::decompress"
+
+    def __init__(self, n, device, seed=6, segment_length=4096, mean_run=32, relative=True):
+        self.relative = relative
+        self.name = "run_position_encoding<4,4,%d,%s>" % (2 if relative else 4, "true" if relative else "false")
+        self.n, self.L = n, segment_length
+        lengths, starts, values = _geometric_runs(n, mean_run, device, seed)
+        self.num_runs = len(lengths)
+        seg_starts = torch.arange(0, n, segment_length, device=device)
+        self.num_segments = len(seg_starts)
+        self.starts = starts
+        self.run_data = values
+        self.positions = (starts % segment_length).to(torch.int16) if relative else starts.to(torch.int32)
+        self.anchors = (torch.searchsorted(starts, seg_starts, right=True) - 1).to(torch.int32)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        psize = 2 if relative else 4
+        self.algorithmic_bytes = 4 * n + (4 + psize) * self.num_runs + 4 * self.num_segments
+        self.decompressed_bytes = 4 * n
+        self.config = self._launch(torch.cuda.current_stream().cuda_stream, None)
+
+    def _launch(self, stream, config):
+        return schemes.run_position_encoding(self.output, self.run_data, self.positions, self.anchors, self.L, self.num_segments,
+                                             self.num_runs, self.n, position_size=2 if self.relative else 4,
+                                             relative=self.relative, stream=stream, launch_config=config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, L = self.n, self.L
+        sample = min((sample // L) * L, n)
+        nseg = (sample + L - 1) // L
+        last_run = int(self.anchors[nseg]) + 1 if nseg < self.num_segments else self.num_runs
+        pd = np.uint16 if self.relative else np.uint32
+        anchors = _np(self.anchors[:nseg + (1 if nseg < self.num_segments else 0)], np.uint32)
+        expect = oracle.run_position_encoding(_np(self.run_data[:last_run], np.uint32), _np(self.positions[:last_run], pd),
+                                              anchors, L, min(sample + (L if nseg < self.num_segments else 0), n), self.relative)[:sample]
+        assert (expect == _np(self.output[:sample], np.uint32)).all(), "RPE: sample mismatch vs oracle"
+        step = 1 << 27
+        for lo in range(0, n, step):
+            hi = min(n, lo + step)
+            assert bool((self._expected_slice(lo, hi) == self.output[lo:hi]).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        L = self.L
+        sample = min((sample // L) * L, self.n)
+        nseg = sample // L
+        last_run = int(self.anchors[nseg]) + 1 if nseg < self.num_segments else self.num_runs
+        pd = np.uint16 if self.relative else np.uint32
+        rd = _np(self.run_data[:last_run], np.uint32).copy(); ps = _np(self.positions[:last_run], pd).copy()
+        an = _np(self.anchors[:nseg + (1 if nseg < self.num_segments else 0)], np.uint32).copy()
+        total = min(sample + (L if nseg < self.num_segments else 0), self.n)
+        out = np.empty(total, dtype=np.uint32)
+        return (lambda: oracle.run_position_encoding(rd, ps, an, L, total, self.relative, threads=threads, out=out)), 4 * total
+
+
+class DiscardZeroBytesVariable:
+    """C5 (per-GPU shard): uint64 out, sizes 1..4 bytes uniform (2-bit fields, min 1), 32-bit containers, segment 1024, 64-bit anchors."""
+    name = "discard_zero_bytes::variable_width<8,8,4>"
+    kernel = "variable_width::decompress"
+
+    def __init__(self, n, device, seed=8, segment_length=1024, bits=2, min_size=1):
+        g = _gen(seed, device)
+        self.n, self.L, self.bits, self.min_size = n, segment_length, bits, min_size
+        per = 32 // bits
+        sizes = torch.randint(min_size, min_size + (1 << bits), (n,), dtype=torch.int64, generator=g, device=device).clamp_(max=8)
+        offsets = torch.cumsum(sizes, 0) - sizes
+        total = int(offsets[-1] + sizes[-1])
+        values = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, generator=g, device=device)
+        mask = torch.where(sizes >= 8, torch.full_like(sizes, -1), (torch.ones_like(sizes) << (8 * sizes)) - 1)
+        values = (values & mask) | (torch.ones_like(sizes) << (8 * (sizes - 1)).clamp_(min=0))
+        values = values & mask
+        self.values = values
+        # packed size fields, LSB first, `per` fields per 32-bit container
+        ncont = (n + per - 1) // per
+        fields = torch.zeros(ncont * per, dtype=torch.int64, device=device)
+        fields[:n] = sizes - min_size
+        shifts = torch.arange(per, device=device, dtype=torch.int64) * bits
+        self.packed = (fields.view(ncont, per) << shifts).sum(dim=1).to(torch.int32)
+        # compressed bytes: byte k of element i at offsets[i] + k for k < sizes[i]
+        data = torch.empty(total + 0, dtype=torch.uint8, device=device)
+        for k in range(min(8, min_size + (1 << bits) - 1)):
+            sel = sizes > k
+            data[(offsets[sel] + k)] = ((values[sel] >> (8 * k)) & 0xFF).to(torch.uint8)
+        self.data = data
+        self.anchors = offsets[torch.arange(0, n, segment_length, device=device)].contiguous()
+        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.total_bytes = total
+        self.algorithmic_bytes = total + 4 * ncont + 8 * n + 8 * len(self.anchors)
+        self.decompressed_bytes = 8 * n
+        self.config = self._launch(torch.cuda.current_stream().cuda_stream, None)
+
+    def _launch(self, stream, config):
+        return schemes.discard_zero_bytes_variable(self.output, self.data, self.packed, self.anchors, self.L, self.n, self.min_size,
+                                                   self.bits, stream=stream, launch_config=config)
+
+    def run(self, stream):
+        self._launch(stream, self.config)
+
+    def verify(self, oracle, sample=1 << 21):
+        torch.cuda.synchronize()
+        n, L = self.n, self.L
+        sample = min((sample // L) * L, n)
+        nbytes = int(self.anchors[sample // L]) if sample < n else self.total_bytes
+        expect = oracle.dzb_variable(_np(self.data[:nbytes]), _np(self.packed[: (sample * self.bits + 31) // 32 + 1], np.uint32),
+                                     _np(self.anchors[: (sample + L - 1) // L], np.uint64), L, sample, self.min_size, self.bits, np.uint64)
+        assert (expect == _np(self.output[:sample], np.uint64)).all(), "DZB-V: sample mismatch vs oracle"
+        assert bool((self.output == self.values).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        L = self.L
+        sample = min((sample // L) * L, self.n)
+        nbytes = int(self.anchors[sample // L]) if sample < self.n else self.total_bytes
+        data = _np(self.data[:nbytes]).copy(); packed = _np(self.packed[: (sample * self.bits + 31) // 32 + 1], np.uint32).copy()
+        an = _np(self.anchors[: sample // L], np.uint64).copy()
+        out = np.empty(sample, dtype=np.uint64)
+        return (lambda: oracle.dzb_variable(data, packed, an, L, sample, self.min_size, self.bits, np.uint64, threads=threads, out=out)), 8 * sample
