@@ -18,10 +18,12 @@
 //    independent and only the R row totals chain.  When the deltas are <= 2 bytes wide the
 //    in-row scan runs in 32 bits even for 64-bit outputs (a row's prefix cannot overflow).
 //  * wave path (segment_length % row == 0, segment_length <= 16384): one wavefront per anchored
-//    segment, carry in a register, NO barriers and no LDS at all.
-//  * block path (longer segments): the wavefronts of a workgroup take consecutive rows of one
-//    segment in lock-step; carries cross wavefronts through a double-buffered 16-entry LDS table,
-//    one barrier per 64*E*waves elements.
+//    segment, carry in a register, NO barriers and no LDS at all.  (Measured on MI355X: 2 rows in
+//    flight per wavefront is the best setting; the block path is no faster at 4096-element segments.)
+//  * block path (longer segments): a workgroup of ceil(rows per segment / 8) wavefronts (at most 16)
+//    owns a segment; wavefront w takes 8 consecutive rows of each sweep, all its loads are issued
+//    before the single barrier of the sweep, carries cross wavefronts through a double-buffered
+//    16-entry LDS table: one barrier per waves*8 rows.
 //  * general path (any other segment_length >= 1, or unaligned pointers): a segmented scan
 //    (reset flags at segment heads) over rows, anchors gathered per element.  Slower, correct for
 //    every L — including L < blockDim, which the reference gets wrong.
@@ -30,6 +32,9 @@
 // segment): 10.002 B for 64-bit <- 16-bit at L = 4096.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <stdexcept>
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
@@ -43,9 +48,25 @@ namespace delta {
 
 namespace detail {
 
+// build-time tuning knobs (defaults measured on MI355X)
+#ifndef GIDDY_DELTA_ROWS_IN_FLIGHT
+#define GIDDY_DELTA_ROWS_IN_FLIGHT 2
+#endif
+#ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
+#define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
+#endif
+#ifndef GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH
+#define GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH 16384
+#endif
+#ifndef GIDDY_DELTA_WAVE_PATH_THREADS
+#define GIDDY_DELTA_WAVE_PATH_THREADS 256
+#endif
+
 enum : unsigned {
-	rows_in_flight = 4,
-	longest_segment_for_wave_path = 16384,
+	rows_in_flight = GIDDY_DELTA_ROWS_IN_FLIGHT,                                  // wave path
+	rows_per_wave_per_sweep = GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP,                // block path
+	longest_segment_for_wave_path = GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH,    // longer segments are swept by a whole workgroup
+	wave_path_threads = GIDDY_DELTA_WAVE_PATH_THREADS,
 	max_waves_per_block = 16,
 };
 
@@ -137,7 +158,8 @@ __device__ __forceinline__ void wave_per_segment(
 	}
 }
 
-/// block path: the workgroup's wavefronts sweep one long segment together
+/// block path: the workgroup's wavefronts sweep one segment together — wavefront w takes R consecutive
+/// rows of every sweep, so a segment of up to waves*R rows needs ONE barrier
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __device__ __forceinline__ void block_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
@@ -145,6 +167,7 @@ __device__ __forceinline__ void block_per_segment(
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
+	constexpr unsigned R = rows_per_wave_per_sweep;
 	__shared__ U wave_totals[2][max_waves_per_block];
 	const unsigned lane = wave64::lane_id();
 	const unsigned w = wave64::index_in_block();
@@ -156,12 +179,15 @@ __device__ __forceinline__ void block_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
-		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * traits::row) {
-			row_t<UncompressedSize, CompressedSize> r;
-			const uint64_t row_start = sweep_start + (uint64_t) w * traits::row;
-			r.load(in, row_start, end, lane);   // rows past `end` load zeros
-			r.scan();
-			if (lane == 0) { wave_totals[buffer][w] = (U) r.total; }
+		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * R * traits::row) {
+			const uint64_t mine = sweep_start + (uint64_t) w * R * traits::row;
+			row_t<UncompressedSize, CompressedSize> rows[R];
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].load(in, mine + (uint64_t) k * traits::row, end, lane); }   // rows past `end` load zeros
+			U my_total = 0;
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); my_total += (U) rows[k].total; }
+			if (lane == 0) { wave_totals[buffer][w] = my_total; }
 			__syncthreads();
 			U before = 0, all = 0;
 			for (unsigned v = 0; v < num_waves; v++) {
@@ -169,7 +195,12 @@ __device__ __forceinline__ void block_per_segment(
 				if (v < w) { before += t; }
 				all += t;
 			}
-			r.store(out, row_start, end, lane, (U) (base + before));
+			U running = (U) (base + before);
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running);
+				running += (U) rows[k].total;
+			}
 			base += all;
 			buffer ^= 1;   // the next sweep writes the other table; this one is re-written only after another barrier
 		}
@@ -282,20 +313,24 @@ public:
 		bool wave_path = segment_length % traits::row == 0 && segment_length <= detail::longest_segment_for_wave_path;
 		bool block_path = segment_length % traits::row == 0 && !wave_path;
 		if (block_path) {
-			// one workgroup per (long) segment, at grid stride
+			// one workgroup per segment (segments at grid stride), as many wavefronts as one sweep needs
+			size_t rows_per_segment = segment_length / traits::row;
+			size_t waves = std::min<size_t>(detail::max_waves_per_block,
+				util::div_rounding_up(rows_per_segment, (size_t) detail::rows_per_wave_per_sweep));
 			grid_construction_resolution = block;
 			length = num_segments;
-			block_resolution_constraints.max_threads_per_block = 1024;
+			block_resolution_constraints.max_threads_per_block = (grid_block_dimension_t) (waves * warp_size);
+			upper_limits.threads_in_block = (grid_block_dimension_t) (waves * warp_size);
 		}
 		else {
 			// one wavefront per segment (or per row-sized run of short segments), at grid stride
 			grid_construction_resolution = warp;
 			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
 			length = wave_path ? num_segments : util::div_rounding_up(num_segments, per_chunk);
-			upper_limits.threads_in_block = 256;
+			upper_limits.threads_in_block = detail::wave_path_threads;
 		}
 		serialization_option = auto_maximized;
-		keep_gpu_busy_factor = 8;
+		keep_gpu_busy_factor = 1024;
 		quanta.threads_in_block = warp_size;
 	}
 

@@ -151,7 +151,7 @@ public:
 		serialization_option          = auto_maximized;   // persistent workgroups: stage once, walk tiles at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 8;
+		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) (num_dictionary_entries * UncompressedSize); }
 		default_serialization_factor  = get_default_serialization_factor(cache);
 	}

@@ -22,7 +22,8 @@
 //      kernel never touches a chunk holding no valid byte: nothing is read past the buffer's end);
 //   4. each element is cut out of LDS with aligned 32-bit reads + a funnel shift and masked to n_i bytes;
 //   5. one 16-byte store per lane, contiguous across the wavefront.
-// No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +
+// Rows are processed four at a time so that four rows' requests are in flight behind each dependent
+// step (size words -> byte ranges -> elements).  No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +
 // UncompressedSize + anchor/segment_length  (10.76 B for 1..4-byte sizes into 64 bits, config C5).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -43,7 +44,8 @@ using element_size_t = native_word_t;
 namespace detail {
 
 enum : unsigned {
-	max_waves_per_block = 16,
+	max_waves_per_block = 4,          // the launch parameters cap the workgroup at 256 threads
+	rows_in_flight = 4,
 	staging_bytes = 1024 + 16 + 16,   // a row's bytes + head misalignment + over-read slack for the aligned dword reads
 	staging_words = staging_bytes / 4,
 };
@@ -71,12 +73,16 @@ __global__ void decompress(
 	constexpr unsigned row = 64 * E;
 	using chunk_t = typename chunk<16>::type;
 
-	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][detail::staging_words];
-	uint32_t* stage = staging[wave64::index_in_block() % detail::max_waves_per_block];
+	constexpr unsigned R = detail::rows_in_flight;
+	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][R * detail::staging_words];
+	// staging exists for max_waves_per_block wavefronts; in a larger workgroup the extra wavefronts sit idle
+	const unsigned working_waves = wave64::per_block() < detail::max_waves_per_block ? wave64::per_block() : detail::max_waves_per_block;
+	if (wave64::index_in_block() >= working_waves) { return; }
+	uint32_t* stage = staging[wave64::index_in_block()];
 
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = segment_length, n = length;
 	if (L == 0 || bits_per_element_size == 0) { return; }
 	const uint64_t num_segments = (n + L - 1) / L;
@@ -87,66 +93,84 @@ __global__ void decompress(
 	for (uint64_t s = wave; s < num_segments; s += num_waves) {
 		const uint64_t segment_start = s * L;
 		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
-		uint64_t row_bytes_start = position_anchors[s];   // byte offset of the row's first element
+		uint64_t bytes_start = position_anchors[s];   // byte offset of the next row's first element
 
-		for (uint64_t row_start = segment_start; row_start < segment_end; row_start += row) {
-			// 1. element sizes
-			const uint64_t i0 = row_start + (uint64_t) lane * E;
-			uint64_t container_index; unsigned field;
-			if (IndexSize <= 4 || (i0 >> 32) == 0) { uint32_t q = (uint32_t) i0 / per; container_index = q; field = (uint32_t) i0 - q * per; }
-			else { container_index = i0 / per; field = (unsigned) (i0 - container_index * per); }
-			unsigned sizes[E]; unsigned lane_bytes = 0;
-			container_type container = (i0 < segment_end) ? packed_element_sizes[container_index] : (container_type) 0;
+		// R rows per iteration: all size words first, then all byte ranges, then all extractions, so that
+		// R rows' worth of HBM requests are in flight behind each dependent step
+		for (uint64_t rows_start = segment_start; rows_start < segment_end; rows_start += (uint64_t) R * row) {
+			unsigned sizes[R][E]; unsigned offset[R]; unsigned row_bytes[R];
+			// 1. element sizes of R rows
 			#pragma unroll
-			for (unsigned j = 0; j < E; j++) {
-				unsigned size = 0;
-				if (i0 + j < segment_end) {
-					size = min_represented_element_size + (unsigned) ((container >> (field * bits)) & field_mask);
-					if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+			for (unsigned k = 0; k < R; k++) {
+				const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
+				uint64_t container_index; unsigned field;
+				if (IndexSize <= 4 || (i0 >> 32) == 0) { uint32_t q = (uint32_t) i0 / per; container_index = q; field = (uint32_t) i0 - q * per; }
+				else { container_index = i0 / per; field = (unsigned) (i0 - container_index * per); }
+				unsigned lane_bytes = 0;
+				container_type container = (i0 < segment_end) ? packed_element_sizes[container_index] : (container_type) 0;
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) {
+					unsigned size = 0;
+					if (i0 + j < segment_end) {
+						size = min_represented_element_size + (unsigned) ((container >> (field * bits)) & field_mask);
+						if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+					}
+					sizes[k][j] = size; lane_bytes += size;
+					if (++field == per) { field = 0; container_index++; if (j + 1 < E && i0 + j + 1 < segment_end) { container = packed_element_sizes[container_index]; } }
 				}
-				sizes[j] = size; lane_bytes += size;
-				if (++field == per) { field = 0; container_index++; if (j + 1 < E && i0 + j + 1 < segment_end) { container = packed_element_sizes[container_index]; } }
+				offset[k] = lane_bytes;
 			}
-			// 2. byte offsets within the row
-			const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
-			const unsigned row_bytes = wave64::read_last_lane(inclusive);
-			unsigned offset = inclusive - lane_bytes;
-
-			// 3. stage the row's bytes: 16-byte chunks overlapping [address, address + row_bytes)
-			const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + row_bytes_start;
-			const uintptr_t first_chunk = address & ~(uintptr_t) 15;
-			const unsigned head = (unsigned) (address - first_chunk);
-			const unsigned num_chunks = row_bytes == 0 ? 0 : (head + row_bytes + 15) / 16;
-			for (unsigned c = lane; c < num_chunks; c += 64) {
-				reinterpret_cast<chunk_t*>(stage)[c] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) c);
+			// 2. byte offsets within each row (one DPP prefix sum per row; row byte counts < 2^11)
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				const unsigned inclusive = wave64::inclusive_sum(offset[k]);
+				row_bytes[k] = wave64::read_last_lane(inclusive);
+				offset[k] = inclusive - offset[k];
 			}
+			// 3. stage each row's bytes: the 16-byte chunks overlapping [address, address + row_bytes)
+			uint64_t row_bytes_start = bytes_start;
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + row_bytes_start;
+				const uintptr_t first_chunk = address & ~(uintptr_t) 15;
+				const unsigned head = (unsigned) (address - first_chunk);
+				const unsigned num_chunks = row_bytes[k] == 0 ? 0 : (head + row_bytes[k] + 15) / 16;
+				for (unsigned c = lane; c < num_chunks; c += 64) {
+					reinterpret_cast<chunk_t*>(stage + k * detail::staging_words)[c] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) c);
+				}
+				offset[k] += head;
+				row_bytes_start += row_bytes[k];
+			}
+			bytes_start = row_bytes_start;
 			wave64::lds_fence();
 
-			// 4. cut the elements out
-			group<U, E> values;
-			offset += head;
+			// 4. cut the elements out, 5. store
 			#pragma unroll
-			for (unsigned j = 0; j < E; j++) {
-				const unsigned word = offset >> 2, shift = (offset & 3) * 8, size = sizes[j];
-				uint64_t v = 0;
-				if (size != 0) {
-					uint64_t low = (uint64_t) stage[word] | ((uint64_t) stage[word + 1] << 32);
-					v = low >> shift;
-					if (UncompressedSize == 8 && shift != 0) { v |= (uint64_t) stage[word + 2] << (64 - shift); }
-					if (size < 8) { v &= (((uint64_t) 1) << (8 * size)) - 1; }
-				}
-				values[j] = (U) v;
-				offset += size;
-			}
-			wave64::lds_fence();   // the staging area is rewritten by the next row
-
-			// 5. store
-			if (i0 + E <= segment_end && is_aligned(decompressed + i0, 16)) { store_group(decompressed + i0, values); }
-			else {
+			for (unsigned k = 0; k < R; k++) {
+				const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
+				const uint32_t* row_stage = stage + k * detail::staging_words;
+				group<U, E> values;
+				unsigned at = offset[k];
 				#pragma unroll
-				for (unsigned j = 0; j < E; j++) { if (i0 + j < segment_end) { decompressed[i0 + j] = values[j]; } }
+				for (unsigned j = 0; j < E; j++) {
+					const unsigned word = at >> 2, shift = (at & 3) * 8, size = sizes[k][j];
+					uint64_t v = 0;
+					if (size != 0) {
+						uint64_t low = (uint64_t) row_stage[word] | ((uint64_t) row_stage[word + 1] << 32);
+						v = low >> shift;
+						if (UncompressedSize == 8 && shift != 0) { v |= (uint64_t) row_stage[word + 2] << (64 - shift); }
+						if (size < 8) { v &= (((uint64_t) 1) << (8 * size)) - 1; }
+					}
+					values[j] = (U) v;
+					at += size;
+				}
+				if (i0 + E <= segment_end && is_aligned(decompressed + i0, 16)) { store_group(decompressed + i0, values); }
+				else {
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { if (i0 + j < segment_end) { decompressed[i0 + j] = values[j]; } }
+				}
 			}
-			row_bytes_start += row_bytes;
+			wave64::lds_fence();   // the staging area is rewritten by the next iteration
 		}
 	}
 }
@@ -167,7 +191,7 @@ public:
 		serialization_option          = auto_maximized;    // segments at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 8;
+		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_in_elements, size_t segment_length)

@@ -135,7 +135,7 @@ public:
 		serialization_option          = auto_maximized;   // tiles at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 8;               // 256 CUs x 4 SIMDs x 8 / 4 waves = 2048 workgroups
+		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t data_length, size_t segment_length)

@@ -116,7 +116,7 @@ public:
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 8;
+		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 	}
 
 	launch_config_resolution_params_t(

@@ -7,7 +7,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libgiddy_amd.so")
+# GIDDY_LIBRARY_PATH selects another build of the same library (e.g. a tuning variant); there is still no fallback
+LIBRARY_PATH = os.environ.get("GIDDY_LIBRARY_PATH") or os.path.join(_HERE, "libgiddy_amd.so")
 
 
 class giddy_value(ctypes.Union):

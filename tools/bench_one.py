@@ -1,0 +1,16 @@
+"""python tools/bench_one.py WORKLOAD [log2n] [steps] — time one workload with the library selected by GIDDY_LIBRARY_PATH"""
+import os, sys, json
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
+import torch
+import bench
+name = sys.argv[1]; log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 30; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
+w = bench.make_workload(name, 1 << log2n, torch.device("cuda", 0))
+w.run(torch.cuda.current_stream().cuda_stream)
+if os.environ.get("VERIFY", "1") == "1":
+    from oracle import oracle
+    w.verify(oracle)
+el, ms = bench.timed_steps(w, steps, 2, lambda: None)
+print("%-34s %-28s %8.4f ms  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  cfg=%s" % (
+    os.path.basename(os.environ.get("GIDDY_LIBRARY_PATH", "default")), name, ms, w.algorithmic_bytes / ms / 1e6,
+    w.algorithmic_bytes / ms / 1e6 / 80.0, w.config))
