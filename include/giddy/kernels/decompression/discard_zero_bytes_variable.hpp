@@ -22,8 +22,8 @@
 //      kernel never touches a chunk holding no valid byte: nothing is read past the buffer's end);
 //   4. each element is cut out of LDS with aligned 32-bit reads + a funnel shift and masked to n_i bytes;
 //   5. one 16-byte store per lane, contiguous across the wavefront.
-// Rows are processed four at a time so that four rows' requests are in flight behind each dependent
-// step (size words -> byte ranges -> elements).  No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +
+// Rows are processed four at a time and software-pipelined two groups deep (see the kernel body), so
+// HBM round trips overlap instead of adding up.  No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +
 // UncompressedSize + anchor/segment_length  (10.76 B for 1..4-byte sizes into 64 bits, config C5).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -41,19 +41,246 @@ namespace variable_width {
 
 using element_size_t = native_word_t;
 
+// build-time tuning knob (default measured on MI355X)
+#ifndef GIDDY_DZBV_ROWS_IN_FLIGHT
+#define GIDDY_DZBV_ROWS_IN_FLIGHT 2
+#endif
+
 namespace detail {
 
 enum : unsigned {
 	max_waves_per_block = 4,          // the launch parameters cap the workgroup at 256 threads
-	rows_in_flight = 4,
+	rows_in_flight = GIDDY_DZBV_ROWS_IN_FLIGHT,
 	staging_bytes = 1024 + 16 + 16,   // a row's bytes + head misalignment + over-read slack for the aligned dword reads
 	staging_words = staging_bytes / 4,
 };
 
 } // namespace detail
 
+namespace detail {
+
+/// low `size` bytes of the 8 bytes starting `shift_bytes` into the three aligned words (w0, w1, w2)
+template <unsigned UncompressedSize>
+__device__ __forceinline__ uint64_t cut(uint32_t w0, uint32_t w1, uint32_t w2, unsigned shift_bytes, unsigned size)
+{
+	// v_alignbyte_b32: bytes [shift, shift+4) of the 8-byte pair {hi, lo}
+	uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, shift_bytes);
+	uint32_t lo_mask = size >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * size));
+	if (UncompressedSize <= 4) { return lo & lo_mask; }
+	uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, shift_bytes);
+	uint32_t hi_mask = size <= 4 ? 0u : (size >= 8 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * (size - 4))));
+	return ((uint64_t) (hi & hi_mask) << 32) | (lo & lo_mask);
+}
+
+/// Fast path (all R rows inside the segment, 16-byte aligned output, a lane's E size fields share a
+/// container): the lane's E fields of row k, already shifted down to bit 0.  The group's first element
+/// is field `field_base` (< per) of container `container_base` — both wave-uniform, so the only
+/// per-lane division is a 32-bit one by `per`.
+template <unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+__device__ __forceinline__ void load_size_fields(
+	uint_t<ElementSizesContainerSize> (&fields)[rows_in_flight],
+	const uint_t<ElementSizesContainerSize>* __restrict__ packed_element_sizes,
+	unsigned lane, uint64_t container_base, unsigned field_base, unsigned bits, unsigned per)
+{
+	constexpr unsigned E = 16 / UncompressedSize;
+	#pragma unroll
+	for (unsigned k = 0; k < rows_in_flight; k++) {
+		const unsigned index = field_base + k * 64 * E + lane * E;
+		const unsigned q = index / per, field = index - q * per;
+		fields[k] = packed_element_sizes[container_base + q] >> (field * bits);
+	}
+}
+
+template <unsigned UncompressedSize, typename Container>
+__device__ __forceinline__ unsigned size_of(Container fields, unsigned j, unsigned min_size, unsigned bits, Container field_mask)
+{
+	unsigned size = min_size + (unsigned) ((fields >> (j * bits)) & field_mask);
+	return size > UncompressedSize ? UncompressedSize : size;   // precondition n_i <= sizeof(element); never read more
+}
+
+/// Everything the fast path knows about a group of R full rows
+template <unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+struct row_group {
+	using container_type = uint_t<ElementSizesContainerSize>;
+	using chunk_t = typename memory_access::chunk<16>::type;
+	enum : unsigned { E = 16 / UncompressedSize, R = rows_in_flight };
+	container_type fields[R];     // the lane's E size fields of each row, shifted down to bit 0
+	unsigned       offset[R];     // byte offset of the lane's first element within the row's staging area
+	unsigned       num_chunks[R]; // 16-byte chunks overlapping the row's byte range (<= 65)
+	uintptr_t      first_chunk[R];
+	chunk_t        chunks[R];     // this lane's chunk of each row, in flight from HBM
+
+	/// byte offsets (DPP prefix sums) and chunk ranges; returns the byte position after the group
+	__device__ __forceinline__ uint64_t locate(const uint8_t* __restrict__ compressed_data, uint64_t bytes_start, unsigned min_size, unsigned bits)
+	{
+		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) {
+			unsigned lane_bytes = 0;
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { lane_bytes += size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask); }
+			const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
+			const unsigned row_bytes = wave64::read_last_lane(inclusive);
+			const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
+			first_chunk[k] = address & ~(uintptr_t) 15;
+			const unsigned head = (unsigned) (address - first_chunk[k]);
+			num_chunks[k] = row_bytes == 0 ? 0 : (head + row_bytes + 15) / 16;
+			offset[k] = inclusive - lane_bytes + head;
+			bytes_start += row_bytes;
+		}
+		return bytes_start;
+	}
+	/// request the rows' bytes: exactly the 16-byte chunks that overlap them.  Every lane loads — lanes past
+	/// the last chunk re-read it (same cache line) — so there is no divergent branch around the loads.
+	__device__ __forceinline__ void request(unsigned lane, const void* any_valid_address)
+	{
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) {
+			const unsigned last = num_chunks[k] == 0 ? 0 : num_chunks[k] - 1;
+			const unsigned mine = lane < last ? lane : (last < 64 ? last : 63);
+			const uintptr_t base = num_chunks[k] == 0 ? (reinterpret_cast<uintptr_t>(any_valid_address) & ~(uintptr_t) 15) : first_chunk[k];
+			chunks[k] = *reinterpret_cast<const chunk_t*>(base + 16 * (uintptr_t) mine);
+		}
+	}
+	__device__ __forceinline__ void stage_into(uint32_t* stage, unsigned lane) const
+	{
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) {
+			chunk_t* row_stage = reinterpret_cast<chunk_t*>(stage + k * staging_words);
+			row_stage[lane] = chunks[k];   // lanes past the last chunk write bytes nobody reads
+			if (num_chunks[k] > 64) {      // a 1024-byte row that starts unaligned: one more chunk (rare)
+				if (lane == 0) { row_stage[64] = *reinterpret_cast<const chunk_t*>(first_chunk[k] + 16 * (uintptr_t) 64); }
+			}
+		}
+		wave64::lds_fence();
+	}
+	__device__ __forceinline__ void extract_and_store(uint_t<UncompressedSize>* __restrict__ decompressed, const uint32_t* stage,
+		unsigned lane, uint64_t rows_start, unsigned min_size, unsigned bits) const
+	{
+		using U = uint_t<UncompressedSize>;
+		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) {
+			const uint64_t i0 = rows_start + (uint64_t) k * 64 * E + (uint64_t) lane * E;
+			const uint32_t* row_stage = stage + k * staging_words;
+			memory_access::group<U, E> values;
+			unsigned at = offset[k];
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				const unsigned word = at >> 2, size = size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask);
+				// unconditional aligned reads: the staging area has slack, bytes beyond the element are masked off
+				values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size);
+				at += size;
+			}
+			memory_access::store_group(decompressed + i0, values);
+		}
+		wave64::lds_fence();   // the staging area may be rewritten after this
+	}
+};
+
+/// R rows of one segment, starting at element rows_start.  Full: all R rows lie inside the segment and
+/// the output is 16-byte aligned.  Packed: a lane's E size fields never straddle a container.
+template <bool Full, bool Packed, unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+__device__ __forceinline__ uint64_t decompress_rows(
+	uint_t<UncompressedSize>*  __restrict__  decompressed,
+	const uint8_t*             __restrict__  compressed_data,
+	const uint_t<ElementSizesContainerSize>* __restrict__ packed_element_sizes,
+	uint32_t* stage, unsigned lane, uint64_t rows_start, uint64_t segment_end, uint64_t bytes_start,
+	unsigned min_size, unsigned bits, unsigned per)
+{
+	using namespace memory_access;
+	using U = uint_t<UncompressedSize>;
+	using container_type = uint_t<ElementSizesContainerSize>;
+	using chunk_t = typename chunk<16>::type;
+	constexpr unsigned E = 16 / UncompressedSize;
+	constexpr unsigned row = 64 * E;
+	constexpr unsigned R = rows_in_flight;
+	const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
+
+	unsigned sizes[R][E]; unsigned offset[R]; unsigned row_bytes[R];
+	// 1. element sizes of R rows
+	#pragma unroll
+	for (unsigned k = 0; k < R; k++) {
+		const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
+		uint64_t container_index; unsigned field;
+		if (IndexSize <= 4 || (i0 >> 32) == 0) { uint32_t q = (uint32_t) i0 / per; container_index = q; field = (uint32_t) i0 - q * per; }
+		else { container_index = i0 / per; field = (unsigned) (i0 - container_index * per); }
+		unsigned lane_bytes = 0;
+		if (Full && Packed) {
+			container_type fields = packed_element_sizes[container_index] >> (field * bits);
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				unsigned size = min_size + (unsigned) ((fields >> (j * bits)) & field_mask);
+				if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+				sizes[k][j] = size; lane_bytes += size;
+			}
+		}
+		else {
+			container_type container = (i0 < segment_end) ? packed_element_sizes[container_index] : (container_type) 0;
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				unsigned size = 0;
+				if (i0 + j < segment_end) {
+					size = min_size + (unsigned) ((container >> (field * bits)) & field_mask);
+					if (size > UncompressedSize) { size = UncompressedSize; }
+				}
+				sizes[k][j] = size; lane_bytes += size;
+				if (++field == per) { field = 0; container_index++; if (j + 1 < E && i0 + j + 1 < segment_end) { container = packed_element_sizes[container_index]; } }
+			}
+		}
+		offset[k] = lane_bytes;
+	}
+	// 2. byte offsets within each row (one DPP prefix sum per row; row byte counts < 2^11)
+	#pragma unroll
+	for (unsigned k = 0; k < R; k++) {
+		const unsigned inclusive = wave64::inclusive_sum(offset[k]);
+		row_bytes[k] = wave64::read_last_lane(inclusive);
+		offset[k] = inclusive - offset[k];
+	}
+	// 3. stage each row's bytes: the 16-byte chunks overlapping [address, address + row_bytes)
+	#pragma unroll
+	for (unsigned k = 0; k < R; k++) {
+		const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
+		const uintptr_t first_chunk = address & ~(uintptr_t) 15;
+		const unsigned head = (unsigned) (address - first_chunk);
+		const unsigned num_chunks = row_bytes[k] == 0 ? 0 : (head + row_bytes[k] + 15) / 16;   // <= 65
+		chunk_t* row_stage = reinterpret_cast<chunk_t*>(stage + k * staging_words);
+		if (lane < num_chunks) { row_stage[lane] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) lane); }
+		if (num_chunks > 64 && lane == 0) { row_stage[64] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) 64); }
+		offset[k] += head;
+		bytes_start += row_bytes[k];
+	}
+	wave64::lds_fence();
+
+	// 4. cut the elements out, 5. store
+	#pragma unroll
+	for (unsigned k = 0; k < R; k++) {
+		const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
+		const uint32_t* row_stage = stage + k * staging_words;
+		group<U, E> values;
+		unsigned at = offset[k];
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) {
+			const unsigned word = at >> 2, size = sizes[k][j];
+			// unconditional aligned reads: the staging area has slack, bytes beyond the element are masked off
+			values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size);
+			at += size;
+		}
+		if (Full) { store_group(decompressed + i0, values); }
+		else if (i0 + E <= segment_end && is_aligned(decompressed + i0, 16)) { store_group(decompressed + i0, values); }
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { if (i0 + j < segment_end) { decompressed[i0 + j] = values[j]; } }
+		}
+	}
+	wave64::lds_fence();   // the staging area is rewritten by the next call
+	return bytes_start;
+}
+
+} // namespace detail
+
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-__global__ void decompress(
+__global__ void __launch_bounds__(256) decompress(
 	uint_t<UncompressedSize>*  __restrict__  decompressed,
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>*
@@ -64,17 +291,14 @@ __global__ void decompress(
 	element_size_t                           min_represented_element_size,
 	native_word_t                            bits_per_element_size)
 {
-	using namespace memory_access;
-	using U = uint_t<UncompressedSize>;
-	using container_type = uint_t<ElementSizesContainerSize>;
 	static_assert(ElementSizesContainerSize == 4 || ElementSizesContainerSize == 8,
 		"Only container types with 32 or 64 bits are currently supported");
 	constexpr unsigned E = 16 / UncompressedSize;
 	constexpr unsigned row = 64 * E;
-	using chunk_t = typename chunk<16>::type;
-
 	constexpr unsigned R = detail::rows_in_flight;
+	using container_type = uint_t<ElementSizesContainerSize>;
 	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][R * detail::staging_words];
+
 	// staging exists for max_waves_per_block wavefronts; in a larger workgroup the extra wavefronts sit idle
 	const unsigned working_waves = wave64::per_block() < detail::max_waves_per_block ? wave64::per_block() : detail::max_waves_per_block;
 	if (wave64::index_in_block() >= working_waves) { return; }
@@ -88,89 +312,63 @@ __global__ void decompress(
 	const uint64_t num_segments = (n + L - 1) / L;
 	const unsigned bits = bits_per_element_size;
 	const unsigned per = (8 * ElementSizesContainerSize) / bits;
-	const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
+	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
+	const bool aligned_output = memory_access::is_aligned(decompressed, 16) && (L % E == 0);
 
 	for (uint64_t s = wave; s < num_segments; s += num_waves) {
 		const uint64_t segment_start = s * L;
 		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
-		uint64_t bytes_start = position_anchors[s];   // byte offset of the next row's first element
+		uint64_t bytes_start = wave64::read_first_lane((uint64_t) position_anchors[s]);   // byte offset of the next row's first element (wave-uniform)
 
-		// R rows per iteration: all size words first, then all byte ranges, then all extractions, so that
-		// R rows' worth of HBM requests are in flight behind each dependent step
-		for (uint64_t rows_start = segment_start; rows_start < segment_end; rows_start += (uint64_t) R * row) {
-			unsigned sizes[R][E]; unsigned offset[R]; unsigned row_bytes[R];
-			// 1. element sizes of R rows
-			#pragma unroll
-			for (unsigned k = 0; k < R; k++) {
-				const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
-				uint64_t container_index; unsigned field;
-				if (IndexSize <= 4 || (i0 >> 32) == 0) { uint32_t q = (uint32_t) i0 / per; container_index = q; field = (uint32_t) i0 - q * per; }
-				else { container_index = i0 / per; field = (unsigned) (i0 - container_index * per); }
-				unsigned lane_bytes = 0;
-				container_type container = (i0 < segment_end) ? packed_element_sizes[container_index] : (container_type) 0;
-				#pragma unroll
-				for (unsigned j = 0; j < E; j++) {
-					unsigned size = 0;
-					if (i0 + j < segment_end) {
-						size = min_represented_element_size + (unsigned) ((container >> (field * bits)) & field_mask);
-						if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+		uint64_t rows_start = segment_start;
+		if (packed && aligned_output) {
+			// Full groups of R rows, software-pipelined two deep so that a wavefront never waits for two HBM
+			// round trips in a row (CDNA4 retires vector-memory operations in order — loads queue behind
+			// earlier stores): while group g is cut out of LDS and stored, group g+1's bytes and group g+2's
+			// size words are already in flight.
+			using group_t = detail::row_group<UncompressedSize, ElementSizesContainerSize>;
+			const uint64_t group_elements = (uint64_t) R * row;
+			const uint64_t num_groups = (segment_end - segment_start) / group_elements;
+			if (num_groups > 0) {
+				group_t current, next;
+				container_type after_next[R];
+				// wave-uniform position of the next group's first size field
+				uint64_t container_base = segment_start / per;
+				unsigned field_base = (unsigned) (segment_start - container_base * per);
+				auto fetch_fields = [&](container_type (&fields)[R]) {
+					detail::load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per);
+					field_base += (unsigned) group_elements;
+					container_base += field_base / per;
+					field_base %= per;
+				};
+				fetch_fields(current.fields);
+				if (num_groups > 1) { fetch_fields(next.fields); }
+				bytes_start = current.locate(compressed_data, bytes_start, min_represented_element_size, bits);
+				current.request(lane, packed_element_sizes);
+				current.stage_into(stage, lane);
+				for (uint64_t g = 0; g < num_groups; g++) {
+					const bool has_next = g + 1 < num_groups;
+					if (has_next) {
+						bytes_start = next.locate(compressed_data, bytes_start, min_represented_element_size, bits);
+						next.request(lane, packed_element_sizes);
 					}
-					sizes[k][j] = size; lane_bytes += size;
-					if (++field == per) { field = 0; container_index++; if (j + 1 < E && i0 + j + 1 < segment_end) { container = packed_element_sizes[container_index]; } }
-				}
-				offset[k] = lane_bytes;
-			}
-			// 2. byte offsets within each row (one DPP prefix sum per row; row byte counts < 2^11)
-			#pragma unroll
-			for (unsigned k = 0; k < R; k++) {
-				const unsigned inclusive = wave64::inclusive_sum(offset[k]);
-				row_bytes[k] = wave64::read_last_lane(inclusive);
-				offset[k] = inclusive - offset[k];
-			}
-			// 3. stage each row's bytes: the 16-byte chunks overlapping [address, address + row_bytes)
-			uint64_t row_bytes_start = bytes_start;
-			#pragma unroll
-			for (unsigned k = 0; k < R; k++) {
-				const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + row_bytes_start;
-				const uintptr_t first_chunk = address & ~(uintptr_t) 15;
-				const unsigned head = (unsigned) (address - first_chunk);
-				const unsigned num_chunks = row_bytes[k] == 0 ? 0 : (head + row_bytes[k] + 15) / 16;
-				for (unsigned c = lane; c < num_chunks; c += 64) {
-					reinterpret_cast<chunk_t*>(stage + k * detail::staging_words)[c] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) c);
-				}
-				offset[k] += head;
-				row_bytes_start += row_bytes[k];
-			}
-			bytes_start = row_bytes_start;
-			wave64::lds_fence();
-
-			// 4. cut the elements out, 5. store
-			#pragma unroll
-			for (unsigned k = 0; k < R; k++) {
-				const uint64_t i0 = rows_start + (uint64_t) k * row + (uint64_t) lane * E;
-				const uint32_t* row_stage = stage + k * detail::staging_words;
-				group<U, E> values;
-				unsigned at = offset[k];
-				#pragma unroll
-				for (unsigned j = 0; j < E; j++) {
-					const unsigned word = at >> 2, shift = (at & 3) * 8, size = sizes[k][j];
-					uint64_t v = 0;
-					if (size != 0) {
-						uint64_t low = (uint64_t) row_stage[word] | ((uint64_t) row_stage[word + 1] << 32);
-						v = low >> shift;
-						if (UncompressedSize == 8 && shift != 0) { v |= (uint64_t) row_stage[word + 2] << (64 - shift); }
-						if (size < 8) { v &= (((uint64_t) 1) << (8 * size)) - 1; }
+					if (g + 2 < num_groups) { fetch_fields(after_next); }
+					current.extract_and_store(decompressed, stage, lane, rows_start, min_represented_element_size, bits);
+					rows_start += group_elements;
+					if (has_next) {
+						next.stage_into(stage, lane);
+						current = next;
+						#pragma unroll
+						for (unsigned k = 0; k < R; k++) { next.fields[k] = after_next[k]; }
 					}
-					values[j] = (U) v;
-					at += size;
-				}
-				if (i0 + E <= segment_end && is_aligned(decompressed + i0, 16)) { store_group(decompressed + i0, values); }
-				else {
-					#pragma unroll
-					for (unsigned j = 0; j < E; j++) { if (i0 + j < segment_end) { decompressed[i0 + j] = values[j]; } }
 				}
 			}
-			wave64::lds_fence();   // the staging area is rewritten by the next iteration
+		}
+		// whatever is left: ragged tails, unaligned outputs, size fields straddling containers
+		for (; rows_start < segment_end; rows_start += (uint64_t) R * row) {
+			bytes_start = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, segment_end, bytes_start,
+				min_represented_element_size, bits, per);
 		}
 	}
 }

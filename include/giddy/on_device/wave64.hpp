@@ -19,8 +19,10 @@ __device__ __forceinline__ unsigned lane_id()
 	return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 }
 
-/// index of this wavefront within its workgroup / number of wavefronts in the workgroup (1-D blocks)
-__device__ __forceinline__ unsigned index_in_block() { return threadIdx.x >> log_size; }
+/// index of this wavefront within its workgroup / number of wavefronts in the workgroup (1-D blocks).
+/// readfirstlane tells the compiler the value is wave-uniform, so everything derived from it (segment
+/// numbers, loop bounds, base addresses) lives in scalar registers and branches on it are real branches.
+__device__ __forceinline__ unsigned index_in_block() { return (unsigned) __builtin_amdgcn_readfirstlane((int) (threadIdx.x >> log_size)); }
 __device__ __forceinline__ unsigned per_block() { return (blockDim.x + size - 1) >> log_size; }
 
 // DPP controls (LLVM AMDGPU: row_shr:n = 0x110+n, row_bcast:15 = 0x142, row_bcast:31 = 0x143)
