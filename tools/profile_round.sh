@@ -1,0 +1,21 @@
+#!/bin/bash
+# Runs ON THE GPU BOX (through gpurun): rocprofv3 kernel-trace/stats of the default bench command, then
+# separate --pmc passes (FETCH_SIZE, WRITE_SIZE — they do not fit one pass) over every workload and the
+# calibration kernels.  Raw outputs go to gpurun_out/prof/; tools/summarize_profiles.py turns them into
+# the committed summaries under profiles/.
+set -u
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+OUT=gpurun_out/prof
+rm -rf $OUT; mkdir -p $OUT
+hipcc --offload-arch=gfx950 -O3 tools/pmc_calibrate.hip -o /tmp/pmc_calibrate
+# 1. kernel trace + stats of the bench command itself
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+# 2. PMC passes (separate runs)
+for counter in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $counter -d $OUT/pmc_$counter/calibrate -o cal --output-format csv -- /tmp/pmc_calibrate > $OUT/cal_$counter.log 2>&1
+  for w in dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable; do
+    VERIFY=0 rocprofv3 --pmc $counter -d $OUT/pmc_$counter/$w -o pmc --output-format csv -- python3 tools/bench_one.py $w 30 3 > $OUT/pmc_${counter}_$w.log 2>&1
+  done
+done
+find $OUT -name "*.csv" | head -50

@@ -1,0 +1,111 @@
+"""Turns the raw rocprofv3 outputs of tools/profile_round.sh (gpurun_out/prof/) into the committed
+summaries under profiles/:  <round>_kernel_stats.csv (rocprofv3 --kernel-trace --stats of the default
+bench command, our kernels only), <round>_pmc_hbm.md / hbm_traffic.json (HBM bytes per launch from
+separate --pmc FETCH_SIZE / WRITE_SIZE passes, corrected with the calibration kernels as
+MI355X_MICROARCH.md §HBM prescribes: units are KiB; FETCH_SIZE counts half of a streaming read on gfx950)."""
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RAW = os.path.join(ROOT, "gpurun_out", "prof")
+OUT = os.path.join(ROOT, "profiles")
+ROUND = sys.argv[1] if len(sys.argv) > 1 else "r01"
+
+KERNELS = {  # workload -> (substring of the kernel name, algorithmic bytes per launch at 2^30 (2^28 for DZB-V))
+    "dictionary": "dictionary::decompress",
+    "frame_of_reference": "frame_of_reference::decompress",
+    "delta_patched": "delta::decompress",
+    "run_length_encoding": "run_length_encoding::decompress",
+    "run_position_encoding_relative": "run_position_encoding::decompress",
+    "run_position_encoding_absolute": "run_position_encoding::decompress",
+    "discard_zero_bytes_variable": "variable_width::decompress",
+}
+
+
+def mean_counter(path, kernel_substring):
+    values = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substring in r["Kernel_Name"]]
+    return (sum(values) / len(values), len(values)) if values else (None, 0)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # ---- kernel stats ------------------------------------------------------------------------------
+    stats = list(csv.DictReader(open(os.path.join(RAW, "trace", "bench_kernel_stats.csv"))))
+    ours = [r for r in stats if "cuda::kernels::" in r["Name"]]
+    # the stats average includes the cold first launches (verification + warm-up); the timed region is the
+    # last `steps` dispatches of each kernel — average those from the kernel trace as well
+    trace = list(csv.DictReader(open(os.path.join(RAW, "trace", "bench_kernel_trace.csv"))))
+    durations_by_kernel = {}
+    for r in trace:
+        durations_by_kernel.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    with open(os.path.join(OUT, ROUND + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "TimedRegionCalls", "TimedRegionAverageNs"])
+        for r in ours:
+            d = durations_by_kernel.get(r["Name"], [])
+            timed = d[-20:] if "dictionary" in r["Name"] else d[-10:]
+            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
+                        len(timed), "%.1f" % (sum(timed) / max(len(timed), 1))])
+    bench_line = open(os.path.join(RAW, "bench_under_rocprof.json")).read().strip().splitlines()[-1]
+    with open(os.path.join(OUT, ROUND + "_bench_under_rocprof.json"), "w") as f:
+        f.write(bench_line + "\n")
+
+    # ---- calibration ---------------------------------------------------------------------------------
+    known_kib = (1 << 30) / 1024.0
+    cal = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for r in csv.DictReader(open(os.path.join(RAW, "pmc_" + counter, "calibrate", "cal_counter_collection.csv"))):
+            if "calibrate_" in r["Kernel_Name"]:
+                name = r["Kernel_Name"].replace("void ", "")
+                name = name[: name.index(">(") + 1] if ">(" in name else name
+                cal.setdefault(counter, {})[name] = float(r["Counter_Value"])
+    read_factor = known_kib / [v for k, v in cal["FETCH_SIZE"].items() if "calibrate_read" in k and "(4)" in k][0]
+    write_factor = known_kib / [v for k, v in cal["WRITE_SIZE"].items() if "calibrate_write" in k and "(4)" in k][0]
+
+    # ---- per-kernel traffic -----------------------------------------------------------------------------
+    bench = json.loads(bench_line)
+    algorithmic = {"dictionary": bench["roofline"]["algorithmic_bytes_per_launch"]}
+    durations = {"dictionary": bench["roofline"]["mean_launch_ms"]}
+    for name, entry in bench.get("schemes", {}).items():
+        algorithmic[name] = entry["roofline"]["algorithmic_bytes_per_launch"]
+        durations[name] = entry["roofline"]["mean_launch_ms"]
+    traffic, lines = {}, []
+    for workload, kernel in KERNELS.items():
+        fetch, nf = mean_counter(os.path.join(RAW, "pmc_FETCH_SIZE", workload, "pmc_counter_collection.csv"), kernel)
+        write, nw = mean_counter(os.path.join(RAW, "pmc_WRITE_SIZE", workload, "pmc_counter_collection.csv"), kernel)
+        if fetch is None or write is None:
+            continue
+        read_bytes = fetch * 1024 * read_factor
+        write_bytes = write * 1024 * write_factor
+        total = read_bytes + write_bytes
+        traffic[workload] = {"kernel": kernel, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
+                             "hbm_read_bytes": int(read_bytes), "hbm_write_bytes": int(write_bytes),
+                             "hbm_bytes_per_launch": int(total), "algorithmic_bytes_per_launch": algorithmic.get(workload),
+                             "dispatches_averaged": min(nf, nw)}
+        ratio = total / algorithmic[workload] if algorithmic.get(workload) else float("nan")
+        lines.append("| %s | %s | %.0f | %.0f | %.3f | %.3f | %.3f | %.3f |" % (
+            workload, kernel, fetch, write, read_bytes / 1e9, write_bytes / 1e9, (algorithmic.get(workload) or 0) / 1e9, ratio))
+    by_kernel = {}
+    for workload, t in traffic.items():
+        by_kernel.setdefault(t["kernel"], t)   # bench.py looks traffic up by kernel name (first workload wins)
+    with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
+        json.dump({"round": ROUND, "read_correction": read_factor, "write_correction": write_factor,
+                   "by_workload": traffic, **by_kernel}, f, indent=1)
+    with open(os.path.join(OUT, ROUND + "_pmc_hbm.md"), "w") as f:
+        f.write("# HBM traffic per launch from rocprofv3 PMC passes (%s)\n\n" % ROUND)
+        f.write("Separate `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` runs of `tools/bench_one.py <workload> 30 3` "
+                "(DZB-V: 2^28 elements), mean over the profiled dispatches of the decoder kernel.\n\n"
+                "Calibration (tools/pmc_calibrate.hip, each kernel moves exactly 1 GiB): raw counters are KiB; "
+                "FETCH_SIZE read %.4f of the true bytes for 4-, 8- and 16-byte-per-lane streaming loads alike "
+                "(%s) -> reads are multiplied by %.4f; WRITE_SIZE read %.4f of the true bytes -> x %.4f.\n\n" % (
+                    1 / read_factor, ", ".join("%s=%.0f" % kv for kv in sorted(cal["FETCH_SIZE"].items()) if "read" in kv[0]),
+                    read_factor, 1 / write_factor, write_factor))
+        f.write("| workload | kernel | FETCH_SIZE raw KiB | WRITE_SIZE raw KiB | HBM read GB | HBM write GB | algorithmic GB | HBM / algorithmic |\n|---|---|---|---|---|---|---|---|\n")
+        f.write("\n".join(lines) + "\n")
+    print(open(os.path.join(OUT, ROUND + "_pmc_hbm.md")).read())
+
+
+if __name__ == "__main__":
+    main()
