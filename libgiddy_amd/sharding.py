@@ -1,0 +1,170 @@
+"""Segment-range sharding of compressed columns across the GPUs of a node.
+
+Every variable-rate scheme carries per-segment anchors so that any anchored segment decodes
+independently (reference: delta.cuh:5-19, discard_zero_bytes_variable.cuh:355-370,
+run_length_encoding.cuh:285-288, run_position_encoding.cuh:255-308,
+compressed_indices_scatter.cuh:202-212) and fixed-rate schemes are elementwise — so rank g of W
+decodes output elements [start_g, end_g), a whole number of segments, from:
+  * the same slice of the fixed-rate inputs,
+  * the anchor slice, with anchors REBASED to the shard (run indices / byte offsets start at 0),
+  * for RLE/RPE the run slice [anchor[s0], anchor[s1]] (the run straddling the shard's end included),
+  * for DZB-variable the byte slice [anchor[s0], anchor[s1]) and the size-container slice — shard
+    boundaries are kept multiples of lcm(segment_length, sizes-per-container) so that a shard's
+    first size field is field 0 of a container,
+  * a replica of small side tables (dictionary, model record).
+There is NO exchange step during decode; the only collective is the optional gather of the decoded
+shards into one contiguous buffer (libgiddy_amd.distributed.gather_decoded).
+
+Everything here is host-side index arithmetic on numpy arrays (or anything sliceable): it returns
+`Shard(fields, start, stop)` where `fields` has the same keys as libgiddy_amd.formats' writers.
+"""
+import math
+from collections import namedtuple
+
+import numpy as np
+
+Shard = namedtuple("Shard", ["fields", "start", "stop"])   # decodes output elements [start, stop)
+
+
+def segment_range(num_segments, rank, world_size, granule=1):
+    """Contiguous, balanced split of `num_segments` segments into `world_size` ranges whose boundaries
+    are multiples of `granule` segments (the last range takes the remainder)."""
+    units = -(-num_segments // granule)
+    lo = (units * rank // world_size) * granule
+    hi = (units * (rank + 1) // world_size) * granule
+    return min(lo, num_segments), min(hi, num_segments)
+
+
+def _element_range(length, segment_length, rank, world_size, granule=1):
+    num_segments = -(-length // segment_length)
+    s0, s1 = segment_range(num_segments, rank, world_size, granule)
+    return s0, s1, min(s0 * segment_length, length), min(s1 * segment_length, length)
+
+
+def elementwise(fields, rank, world_size, array_keys=("compressed_input",), granule=4096):
+    """Dictionary / DZB-fixed: split on multiples of `granule` elements; side tables are replicated."""
+    n = int(fields["length"])
+    s0, s1, lo, hi = _element_range(n, granule, rank, world_size)
+    out = dict(fields)
+    for k in array_keys:
+        out[k] = fields[k][lo:hi]
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def frame_of_reference(fields, rank, world_size):
+    n, L = int(fields["length"]), int(fields["segment_length"])
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    out = dict(fields)
+    out["compressed_input"] = fields["compressed_input"][lo:hi]
+    out["segment_model_coefficients"] = fields["segment_model_coefficients"][s0:s1]
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def model(fields, rank, world_size, model="linear", granule=4096):
+    """out[p] = model(p): a shard starting at element `lo` uses c0' = c0 + c1*lo (wrapping), c1' = c1."""
+    n = int(fields["length"])
+    s0, s1, lo, hi = _element_range(n, granule, rank, world_size)
+    c = np.array(fields["model_coefficients"]).copy()
+    if model == "linear":
+        bits = 8 * c.dtype.itemsize
+        c0 = (int(c[0]) + int(c[1]) * lo) % (1 << bits)
+        c[0] = np.array(c0, dtype=np.dtype("u%d" % c.dtype.itemsize)).view(c.dtype) if c.dtype.kind == "i" else c0
+    out = dict(fields, model_coefficients=c, length=hi - lo)
+    return Shard(out, lo, hi)
+
+
+def delta(fields, rank, world_size):
+    n, L = int(fields["length"]), int(fields["segment_length"])
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    out = dict(fields)
+    out["compressed_input"] = fields["compressed_input"][lo:hi]
+    out["anchor_values"] = fields["anchor_values"][s0:s1]
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def discard_zero_bytes_variable(fields, rank, world_size):
+    n, L = int(fields["length"]), int(fields["segment_length"])
+    bits = int(fields["bits_per_element_size"])
+    per = (8 * fields["packed_element_sizes"].dtype.itemsize) // bits
+    granule = (L * per // math.gcd(L, per)) // L          # segments per lcm(L, per) elements
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size, granule)
+    anchors = fields["position_anchors"]
+    total_bytes = len(fields["compressed_data"])
+    b0 = int(anchors[s0]) if s0 < len(anchors) else total_bytes
+    b1 = int(anchors[s1]) if s1 < len(anchors) else total_bytes
+    out = dict(fields)
+    out["compressed_data"] = fields["compressed_data"][b0:b1]
+    out["packed_element_sizes"] = fields["packed_element_sizes"][lo // per: -(-hi // per)]
+    out["position_anchors"] = (anchors[s0:s1] - anchors.dtype.type(b0)) if s1 > s0 else anchors[s0:s1]
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def incidence_bitmaps(fields, rank, world_size, alignment_in_ints=2, granule_words=128):
+    """Split on whole bitmap words; every bitmap is sliced and re-laid out at the shard's aligned stride."""
+    words, nb = int(fields["bitmap_length"]), int(fields["num_bitmaps"])
+    aligned = -(-words // alignment_in_ints) * alignment_in_ints
+    s0, s1, w0, w1 = _element_range(words, granule_words, rank, world_size)
+    bm = np.asarray(fields["incidence_bitmaps"]).reshape(nb, aligned)[:, w0:w1]
+    shard_aligned = -(-(w1 - w0) // alignment_in_ints) * alignment_in_ints
+    laid_out = np.zeros((nb, max(shard_aligned, 0)), dtype=bm.dtype)
+    laid_out[:, : w1 - w0] = bm
+    out = dict(fields, incidence_bitmaps=laid_out.reshape(-1), bitmap_length=w1 - w0)
+    return Shard(out, 32 * w0, 32 * w1)
+
+
+def run_length_encoding(fields, rank, world_size):
+    n, L = int(fields["length"]), int(fields["segment_length"])
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    anchors = fields["position_anchors"]
+    num_runs = int(fields["num_element_runs"])
+    if s1 <= s0:
+        empty = {k: (v[:0] if hasattr(v, "__len__") else v) for k, v in fields.items()}
+        return Shard(dict(empty, length=0, num_segments=0, num_element_runs=0), lo, hi)
+    r0 = int(anchors[s0])
+    r1 = int(anchors[s1]) + 1 if s1 < len(anchors) else num_runs     # the run straddling the end is included
+    out = dict(fields)
+    out["run_data"] = fields["run_data"][r0:r1]
+    out["run_lengths"] = fields["run_lengths"][r0:r1]
+    out["position_anchors"] = anchors[s0:s1] - anchors.dtype.type(r0)
+    out["intra_run_anchor_offsets"] = fields["intra_run_anchor_offsets"][s0:s1]
+    out["num_segments"] = s1 - s0
+    out["num_element_runs"] = r1 - r0
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def run_position_encoding(fields, rank, world_size, relative=True):
+    n, L = int(fields["length"]), int(fields["segment_length"])
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    anchors = fields["position_anchors"]
+    num_runs = int(fields["num_element_runs"])
+    if s1 <= s0:
+        empty = {k: (v[:0] if hasattr(v, "__len__") else v) for k, v in fields.items()}
+        return Shard(dict(empty, length=0, num_anchors=0, num_element_runs=0), lo, hi)
+    r0 = int(anchors[s0])
+    r1 = int(anchors[s1]) + 1 if s1 < len(anchors) else num_runs
+    positions = fields["run_start_positions"][r0:r1]
+    if not relative:
+        # absolute positions are rebased to the shard; the first run may have started before the shard —
+        # its (wrapped) position is never read (run_position_encoding.cuh:122,221)
+        positions = positions - positions.dtype.type(lo)
+    out = dict(fields)
+    out["run_data"] = fields["run_data"][r0:r1]
+    out["run_start_positions"] = positions
+    out["position_anchors"] = anchors[s0:s1] - anchors.dtype.type(r0)
+    out["num_anchors"] = s1 - s0
+    out["num_element_runs"] = r1 - r0
+    out["length"] = hi - lo
+    return Shard(out, lo, hi)
+
+
+def patches(fields, start, stop):
+    """Naive patches whose target lies in the shard [start, stop), positions rebased to the shard."""
+    idx = np.asarray(fields["indices"])
+    inside = (idx >= start) & (idx < stop)
+    return {"indices": (idx[inside] - idx.dtype.type(start)), "data": np.asarray(fields["data"])[inside],
+            "data_length": int(inside.sum())}

@@ -1,0 +1,119 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/giddy.h
+declares, the factory holds the reference's 163 registrations under the reference's key strings, the
+launch-configuration resolver behaves (and fails) like the reference's, and argument maps are
+type-checked.  No kernel is launched here."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from libgiddy_amd import _native, registered as r, schemes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = r.NOMINAL_MI355X
+
+
+def test_every_declared_symbol_is_exported():
+    header = open(os.path.join(ROOT, "include", "giddy.h")).read()
+    declared = set(re.findall(r"\b(giddy_[a-z_]+)\s*\(", header))
+    assert declared == set(_native.EXPORTED_SYMBOLS)
+    lib = ctypes.CDLL(_native.LIBRARY_PATH)
+    for symbol in declared:
+        assert hasattr(lib, symbol), symbol
+    assert _native.lib.giddy_version().decode().startswith("libgiddy_amd")
+
+
+def test_factory_has_the_163_reference_registrations():
+    keys = r.kernel_t.registered_keys()
+    assert len(keys) == 163 and len(set(keys)) == 163
+    counts = {}
+    for k in keys:
+        counts[k.split("::kernel_t")[0]] = counts.get(k.split("::kernel_t")[0], 0) + 1
+    # SURVEY.md Appendix B
+    assert counts == {"decompression::delta": 12, "decompression::dictionary": 20,
+                      "decompression::discard_zero_bytes::fixed_width": 12, "decompression::discard_zero_bytes::variable_width": 9,
+                      "decompression::frame_of_reference": 8, "decompression::incidence_bitmaps": 5, "decompression::model": 5,
+                      "decompression::run_length_encoding": 18, "decompression::run_position_encoding": 10,
+                      "scatter": 32, "scatter::compressed_indices": 32}
+    # the key the reference's own example uses (factory_provided_type_erased_wrapper.cu:14-15)
+    assert r.kernel_t.canProduce("decompression::frame_of_reference::kernel_t<4u, int, short, "
+                                 "cuda::functors::unary::parametric_model::constant<4u, int> >")
+    # every key builder in schemes.py produces registered keys
+    for key in [schemes.key_dictionary(4, 4, 1), schemes.key_delta(8, 8, 4), schemes.key_discard_zero_bytes_fixed(4, 8, 2),
+                schemes.key_discard_zero_bytes_variable(8, 8, 4), schemes.key_incidence_bitmaps(4, 1, 2, False),
+                schemes.key_model(8, 4, "linear"), schemes.key_model(4, 2, "constant"), schemes.key_run_length_encoding(8, 1, 8),
+                schemes.key_run_position_encoding(4, 8, 2, True), schemes.key_run_position_encoding(8, 4, 8, False),
+                schemes.key_scatter(8, 1, 2), schemes.key_compressed_indices_scatter(4, 8, 1),
+                schemes.key_frame_of_reference(8, 4, 2, "linear", 8)]:
+        assert r.kernel_t.canProduce(key), key
+
+
+def test_unknown_key_is_invalid_argument():
+    with pytest.raises(r.InvalidArgument, match="No subclass of the base type cuda::registered::kernel_t is registered with key"):
+        r.kernel_t.produceSubclass("decompression::nope::kernel_t<4u>")
+
+
+def test_resolver_shapes():
+    k = schemes.kernel(schemes.key_dictionary(4, 4, 1))
+    c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 30)})
+    assert c.block_dimensions == (256, 1, 1) and c.grid_dimensions[0] == (1 << 30) // (256 * 16) and c.dynamic_shared_memory_size == 1024
+    # a dictionary too large for LDS falls back to look-ups through the caches
+    c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(1 << 20), "data_length": r.size_t(1 << 20)})
+    assert c.dynamic_shared_memory_size == 0
+    # explicit opt-out
+    c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 20),
+                                           "cache_input_data_in_shared_mem": r.boolean(False)})
+    assert c.dynamic_shared_memory_size == 0
+    # small inputs: no more threads than the input can occupy, rounded to whole wavefronts
+    c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(4), "data_length": r.size_t(100)})
+    assert c.block_dimensions[0] == 64 and c.grid_dimensions[0] == 1
+    # empty input: an empty grid, which enqueue treats as a no-op
+    c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(4), "data_length": r.size_t(0)})
+    assert c.grid_dimensions[0] == 0
+
+    d = schemes.kernel(schemes.key_delta(4, 8, 2))
+    c = d.resolve_launch_configuration(N, {"length": r.size_t(1 << 30), "segment_length": r.size_t(4096)})
+    assert c.block_dimensions[0] == 256 and c.grid_dimensions[0] == (1 << 30) // 4096 // 4          # one wavefront per segment
+    c = d.resolve_launch_configuration(N, {"length": r.size_t(1 << 30), "segment_length": r.size_t(1 << 20)})
+    assert c.block_dimensions[0] == 1024 and c.grid_dimensions[0] == 1024                            # one workgroup per long segment
+
+
+def test_one_time_limits():
+    k = schemes.kernel(schemes.key_frame_of_reference(4, 4, 2))
+    args = {"length": r.size_t(1 << 24), "segment_length": r.size_t(4096)}
+    c = k.resolve_launch_configuration(N, args, r.launch_configuration_limits_t(block_size=128))
+    assert c.block_dimensions[0] == 128
+    c = k.resolve_launch_configuration(N, args, r.launch_configuration_limits_t(grid_size=7))
+    assert c.grid_dimensions[0] == 7
+    with pytest.raises(r.InvalidArgument, match="do not allow any threads in a block"):
+        k.resolve_launch_configuration(N, args, r.launch_configuration_limits_t(block_size=32))   # less than a wavefront
+
+
+def test_reference_error_behaviour():
+    k = schemes.kernel(schemes.key_frame_of_reference(4, 4, 2))
+    with pytest.raises(r.InvalidArgument, match="segment length must be a positive number"):
+        k.resolve_launch_configuration(N, {"length": r.size_t(100), "segment_length": r.size_t(0)})
+    with pytest.raises(r.InvalidArgument, match="aligned with the GPU's native word size"):
+        k.resolve_launch_configuration(N, {"length": r.size_t(100), "segment_length": r.size_t(6)})
+    # the reference cannot launch a single segment longer than a block (frame_of_reference.cuh:111-113); here it resolves
+    c = k.resolve_launch_configuration(N, {"length": r.size_t(1 << 20), "segment_length": r.size_t(1 << 20)})
+    assert c.grid_dimensions[0] == (1 << 20) // (256 * 16)
+    cis = schemes.kernel(schemes.key_compressed_indices_scatter(4, 4, 4))
+    with pytest.raises(r.InvalidArgument, match="Zero-length scatters not currently supported"):
+        cis.resolve_launch_configuration(N, {"input_data_length": r.size_t(0), "anchoring_period": r.size_t(1024)})
+    # missing key -> out_of_range, wrong C++ type -> bad_any_cast (kernel_wrapper.cuh:47-49)
+    with pytest.raises(r.OutOfRange):
+        k.resolve_launch_configuration(N, {"length": r.size_t(100)})
+    with pytest.raises(r.BadAnyCast):
+        k.resolve_launch_configuration(N, {"length": r.uint32(100), "segment_length": r.size_t(4)})
+    # a serialization factor on a kernel that does not serialize per request is accepted only for Dictionary
+    d = schemes.kernel(schemes.key_dictionary(4, 4, 1))
+    d.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(4), "data_length": r.size_t(100),
+                                       "serialization_factor": r.serialization_factor_t(16)})
+
+
+def test_untyped_arguments_are_rejected_before_reaching_c():
+    k = schemes.kernel(schemes.key_delta(4, 8, 2))
+    with pytest.raises(TypeError, match="typed constructors"):
+        k.resolve_launch_configuration(N, {"length": 100, "segment_length": 4096})

@@ -1,0 +1,24 @@
+"""-m gpu: the three C++ "modes of use" programs (examples/) — factory-produced type-erased wrapper,
+instantiated wrapper, direct kernel launch — each decodes the reference's known-answer test through the
+C++ API and checks every element itself."""
+import os
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROGRAMS = ["factory_provided_type_erased_wrapper", "instantiation_of_wrapper", "direct_use_of_kernel"]
+
+
+@pytest.mark.parametrize("program", PROGRAMS)
+def test_mode_of_use(program):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(ROOT, "examples", "bin", program)
+    if not os.path.exists(path):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    result = subprocess.run([path], capture_output=True, text=True, timeout=120)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "OK" in result.stdout

@@ -1,0 +1,62 @@
+"""-m gpu: every shard of a sharded column decoded by the HIP kernels (one GPU plays each rank in turn),
+concatenation == the column.  Shard inputs are fresh device buffers, as they would be on their own GPU."""
+import numpy as np
+import pytest
+
+import cases
+from libgiddy_amd import formats, sharding
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_decode_on_gpu(world):
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    n = 300000
+
+    def run(shard_fn, fields, truth, launch, dtype):
+        pieces = []
+        for rank in range(world):
+            sh = shard_fn(fields, rank, world)
+            count = sh.stop - sh.start
+            out = g.dev_empty(count, dtype)
+            if count:
+                launch(out, sh.fields)
+            pieces.append(g.host(out, dtype, count))
+        got = np.concatenate(pieces)
+        assert (got == truth).all(), np.flatnonzero(got != truth)[:5]
+
+    f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=3)
+    run(sharding.delta, f, truth, lambda out, s: schemes.delta(out, g.dev(s["compressed_input"]), g.dev(s["anchor_values"]), s["length"], 4096, stream=st), np.uint64)
+
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 3, seed=4)
+    f = formats.discard_zero_bytes_variable(col, 1024, 1, 3, np.uint32, 8, element_sizes=sizes)
+    run(sharding.discard_zero_bytes_variable, f, col,
+        lambda out, s: schemes.discard_zero_bytes_variable(out, g.dev(s["compressed_data"]), g.dev(s["packed_element_sizes"]), g.dev(s["position_anchors"]),
+                                                           1024, s["length"], 1, 3, stream=st), np.uint64)
+
+    col = cases.runs_column(n, 32, np.uint32, seed=5)
+    f = formats.run_length_encoding(col, 4096, np.uint16)
+    run(sharding.run_length_encoding, f, col,
+        lambda out, s: schemes.run_length_encoding(out, g.dev(s["run_data"]), g.dev(s["run_lengths"]), g.dev(s["position_anchors"]),
+                                                   g.dev(s["intra_run_anchor_offsets"]), 4096, s["num_segments"], s["num_element_runs"], s["length"], stream=st), np.uint32)
+    for relative, pd in ((True, np.uint16), (False, np.uint32)):
+        f = formats.run_position_encoding(col, 4096, pd, relative)
+        run(lambda ff, r_, w: sharding.run_position_encoding(ff, r_, w, relative=relative), f, col,
+            lambda out, s: schemes.run_position_encoding(out, g.dev(s["run_data"]), g.dev(s["run_start_positions"]), g.dev(s["position_anchors"]), 4096,
+                                                         s["num_anchors"], s["num_element_runs"], s["length"], position_size=np.dtype(pd).itemsize,
+                                                         relative=relative, stream=st), np.uint32)
+
+    f = cases.dictionary_case(n, 256, np.uint32, np.uint8, seed=2)
+    truth = f["dictionary_entries"][f["compressed_input"].astype(np.int64)]
+    run(sharding.elementwise, f, truth,
+        lambda out, s: schemes.dictionary(out, g.dev(s["compressed_input"]), g.dev(s["dictionary_entries"]), s["length"], 256, stream=st), np.uint32)
