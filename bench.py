@@ -41,7 +41,8 @@ def parse():
     p.add_argument("--warmup", type=int, default=3)
     p.add_argument("--log2n", type=int, default=30)
     p.add_argument("--workload", default="dictionary")
-    p.add_argument("--schemes", default="all", help="extra per-scheme measurements at N=1: all | none | comma list")
+    p.add_argument("--schemes", default="all", help="extra per-scheme measurements at N=1: all (the BASELINE configs) | "
+                   "coverage (all + DZB-fixed, Model, incidence bitmaps) | none | comma list")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-sample-log2", type=int, default=27)
     return p.parse_args()
@@ -58,6 +59,9 @@ def make_workload(name, n, device):
         "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
         "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),
         "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device),
+        "discard_zero_bytes_fixed": lambda: w.DiscardZeroBytesFixed(n, device),
+        "model": lambda: w.Model(n, device),
+        "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, 1 << 28), device),
     }
     return table[name]()
 
@@ -180,7 +184,9 @@ def main():
     if world == 1 and args.schemes != "none":
         names = ["frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
                  "run_position_encoding_absolute", "discard_zero_bytes_variable"]
-        if args.schemes != "all":
+        if args.schemes == "coverage":
+            names += ["discard_zero_bytes_fixed", "model", "incidence_bitmaps"]
+        elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
         del work
         torch.cuda.empty_cache()

@@ -22,6 +22,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -38,7 +39,7 @@ constexpr serialization_factor_t get_default_serialization_factor(bool cache_all
 
 namespace detail {
 
-enum : unsigned { steps_per_tile = 4 };
+enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
 
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 struct tiling {
@@ -150,7 +151,7 @@ public:
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // persistent workgroups: stage once, walk tiles at grid stride
 		quanta.threads_in_block       = warp_size;
-		upper_limits.threads_in_block = 256;
+		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) (num_dictionary_entries * UncompressedSize); }
 		default_serialization_factor  = get_default_serialization_factor(cache);

@@ -10,6 +10,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -21,7 +22,7 @@ namespace fixed_width {
 
 enum : serialization_factor_t { DefaultSerializationFactor = 32 };
 
-namespace detail { enum : unsigned { steps_per_tile = 4 }; }
+namespace detail { enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE }; }
 
 template <unsigned UncompressedSize, unsigned CompressedSize, cuda::endianness_t OutputEndianness>
 struct pad_high_bytes {
@@ -91,7 +92,7 @@ public:
 		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
-		upper_limits.threads_in_block = 256;
+		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		default_serialization_factor  = DefaultSerializationFactor;
 	}

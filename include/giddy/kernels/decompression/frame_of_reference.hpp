@@ -25,6 +25,7 @@
 #include "giddy/common.hpp"
 #include "giddy/functors/model_functors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -37,7 +38,7 @@ enum : serialization_factor_t { DefaultSerializationFactor = 16 };
 
 namespace detail {
 
-enum : unsigned { steps_per_tile = 4 };
+enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
 
 template <unsigned IndexSize>
 __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotient, uint64_t& remainder)
@@ -134,7 +135,7 @@ public:
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride
 		quanta.threads_in_block       = warp_size;
-		upper_limits.threads_in_block = 256;
+		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 	}
 

@@ -9,14 +9,18 @@
 //
 // The reference ties the data layout to a 32-lane warp (static_assert warp_size == 32 == bits per
 // container, :83-84): each thread peels one container bit by bit into a per-thread 32-byte shared
-// memory strip, then the warp copies the strip out through the dictionary.  Here a lane owns
-// E = 16/UncompressedSize consecutive OUTPUT elements (E divides 32, so they live in one container):
-// it walks the bitmaps in ascending order — 4 independent loads in flight — keeping, per element,
-// the index of the last bitmap whose bit was set, translates through an LDS copy of the (<= 256
-// entry) dictionary and issues one 16-byte store, contiguous across the wavefront.  The 32/E lanes
-// sharing a container read the same address, which the memory pipeline serves as one request.
-// Elements covered by no bitmap are undefined in the reference (stale shared memory); here they
-// decode as bitmap 0.
+// memory strip, then the warp copies the strip out through the dictionary.  Here, per wavefront and
+// per 64 consecutive containers (2048 outputs):
+//   1. lane l owns container l: it loads its word of EVERY bitmap (coalesced 256-byte wave loads, 16 in
+//      flight) and folds them, in ascending bitmap order, into 8 bit-planes of the winning bitmap index
+//      with one v_bfi_b32 per plane per bitmap ("highest index wins" falls out of the order);
+//   2. the planes go through wave-private LDS (2 KiB) so that outputs can be written in order:
+//      a lane owning E = 16/UncompressedSize consecutive outputs reads the 8 planes of their container
+//      (two 16-byte LDS reads), turns each 4-bit slice of the planes into four byte indices with a
+//      multiply-and-mask bit spread (3 VALU ops per plane), translates them through an LDS copy of the
+//      (<= 256 entry) dictionary and issues 16-byte stores, contiguous across the wavefront.
+// No __syncthreads after the dictionary is staged.  Elements covered by no bitmap are undefined in the
+// reference (stale shared memory); here they decode as bitmap 0.
 //
 // HBM bytes per element: UncompressedSize + num_bitmaps/8.
 #pragma once
@@ -35,7 +39,13 @@ namespace incidence_bitmaps {
 using bitmap_index_t   = uint8_t;
 using bitmap_size_type = size_type_by_index_size<sizeof(bitmap_index_t)>;
 
-namespace detail { enum : unsigned { max_bitmaps = 256, bitmaps_in_flight = 4 }; }
+namespace detail {
+
+enum : unsigned { max_bitmaps = 256, bitmaps_in_flight = 16, planes = 8, containers_per_wave = 64, max_waves_per_block = 16 };
+
+struct alignas(16) plane_set { uint32_t plane[planes]; };   // bit j of plane[k] = bit k of the bitmap index of the container's element j
+
+} // namespace detail
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned BitmapAlignmentInInts, bool UseDictionary = true>
 __global__ void decompress(
@@ -49,54 +59,82 @@ __global__ void decompress(
 	using U = uint_t<UncompressedSize>;
 	constexpr unsigned E = 16 / UncompressedSize;
 	constexpr unsigned B = detail::bitmaps_in_flight;
+	constexpr unsigned W = detail::containers_per_wave;
 	static_assert(32 % E == 0, "a lane's elements must share a container");
 
 	__shared__ U dictionary[detail::max_bitmaps];
+	__shared__ detail::plane_set plane_sets[detail::max_waves_per_block][W];
 	if (UseDictionary) {
 		for (unsigned i = threadIdx.x; i < num_bitmaps && i < detail::max_bitmaps; i += blockDim.x) { dictionary[i] = dictionary_entries[i]; }
 		__syncthreads();
 	}
 
+	const unsigned lane = wave64::lane_id();
+	detail::plane_set* mine = plane_sets[wave64::index_in_block() % detail::max_waves_per_block];
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
 	const uint64_t words = bitmap_length;
 	const uint64_t aligned_words = (words + BitmapAlignmentInInts - 1) / BitmapAlignmentInInts * BitmapAlignmentInInts;
-	const uint64_t n = words * 32;
-	const uint64_t num_groups = n / E;   // n is a multiple of 32, hence of E
+	const uint64_t num_chunks = (words + W - 1) / W;
 	const bool aligned = is_aligned(decompressed, 16);
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
 
-	for (uint64_t g = global_thread; g < num_groups; g += num_threads) {
-		const uint64_t p = g * E;
-		const uint64_t w = p >> 5;
-		const unsigned shift = (unsigned) (p & 31);
-		unsigned index[E];
+	for (uint64_t chunk = wave; chunk < num_chunks; chunk += num_waves) {
+		// 1. fold this lane's container of every bitmap into index bit-planes
+		const uint64_t w = chunk * W + lane;
+		const bool have = w < words;
+		detail::plane_set folded;
 		#pragma unroll
-		for (unsigned j = 0; j < E; j++) { index[j] = 0; }
-		unsigned b = 0;
-		for (; b + B <= num_bitmaps; b += B) {
+		for (unsigned k = 0; k < detail::planes; k++) { folded.plane[k] = 0; }
+		for (unsigned b0 = 0; b0 < num_bitmaps; b0 += B) {
 			standard_bit_container_t word[B];
 			#pragma unroll
-			for (unsigned i = 0; i < B; i++) { word[i] = bitmaps[(uint64_t) (b + i) * aligned_words + w]; }
+			for (unsigned i = 0; i < B; i++) { word[i] = (have && b0 + i < num_bitmaps) ? bitmaps[(uint64_t) (b0 + i) * aligned_words + w] : 0u; }
 			#pragma unroll
 			for (unsigned i = 0; i < B; i++) {
-				unsigned mine = word[i] >> shift;
+				const unsigned b = b0 + i;   // wave-uniform
 				#pragma unroll
-				for (unsigned j = 0; j < E; j++) { if ((mine >> j) & 1u) { index[j] = b + i; } }
+				for (unsigned k = 0; k < detail::planes; k++) {
+					const uint32_t select = ((b >> k) & 1u) ? 0xFFFFFFFFu : 0u;
+					folded.plane[k] = (word[i] & select) | (~word[i] & folded.plane[k]);   // v_bfi_b32
+				}
 			}
 		}
-		for (; b < num_bitmaps; b++) {
-			unsigned mine = bitmaps[(uint64_t) b * aligned_words + w] >> shift;
-			#pragma unroll
-			for (unsigned j = 0; j < E; j++) { if ((mine >> j) & 1u) { index[j] = b; } }
+		mine[lane] = folded;
+		wave64::lds_fence();
+
+		// 2. outputs in order: E consecutive elements per lane per step
+		const uint64_t chunk_first_element = chunk * W * 32;
+		const uint64_t chunk_elements = (words - chunk * W < W ? words - chunk * W : W) * 32;
+		#pragma unroll 2
+		for (unsigned step = 0; step < (W * 32) / (64 * E); step++) {
+			const unsigned e0 = step * 64 * E + lane * E;
+			if (e0 < chunk_elements) {
+				const detail::plane_set p = mine[e0 >> 5];
+				const unsigned shift = e0 & 31;
+				group<U, E> values;
+				#pragma unroll
+				for (unsigned c = 0; c < (E + 3) / 4; c++) {
+					uint32_t indices = 0;   // byte j = bitmap index of element 4c + j
+					#pragma unroll
+					for (unsigned k = 0; k < detail::planes; k++) {
+						const uint32_t nibble = (p.plane[k] >> (shift + 4 * c)) & 0xFu;
+						indices |= ((nibble * 0x00204081u) & 0x01010101u) << k;   // bit j of the nibble -> bit k of byte j
+					}
+					#pragma unroll
+					for (unsigned j = 0; j < 4 && 4 * c + j < E; j++) {
+						const unsigned index = (indices >> (8 * j)) & 0xFFu;
+						values[4 * c + j] = UseDictionary ? dictionary[index] : (U) index;
+					}
+				}
+				U* where = decompressed + chunk_first_element + e0;
+				if (aligned) { store_group(where, values); }
+				else {
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { where[j] = values[j]; }
+				}
+			}
 		}
-		group<U, E> values;
-		#pragma unroll
-		for (unsigned j = 0; j < E; j++) { values[j] = UseDictionary ? dictionary[index[j]] : (U) index[j]; }
-		if (aligned) { store_group(decompressed + p, values); }
-		else {
-			#pragma unroll
-			for (unsigned j = 0; j < E; j++) { decompressed[p + j] = values[j]; }
-		}
+		wave64::lds_fence();   // the planes are overwritten by the next chunk
 	}
 }
 
@@ -111,12 +149,12 @@ public:
 		size_t uncompressed_length, optional<shared_memory_size_t> dynamic_shared_mem_limit = nullopt)
 	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
 	{
-		grid_construction_resolution  = thread;
-		length                        = util::div_rounding_up(uncompressed_length, (size_t) (16 / UncompressedSize));
+		grid_construction_resolution  = warp;   // one wavefront per 64 containers (2048 elements)
+		length                        = util::div_rounding_up(uncompressed_length, (size_t) (32 * detail::containers_per_wave));
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
+		keep_gpu_busy_factor          = 1024;
 	}
 
 	launch_config_resolution_params_t(

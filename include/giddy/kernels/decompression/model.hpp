@@ -12,6 +12,7 @@
 #include "giddy/common.hpp"
 #include "giddy/functors/model_functors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -20,7 +21,7 @@ namespace kernels {
 namespace decompression {
 namespace model {
 
-namespace detail { enum : unsigned { steps_per_tile = 4 }; }
+namespace detail { enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE }; }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
 __global__ void decompress(
@@ -70,7 +71,7 @@ public:
 		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
-		upper_limits.threads_in_block = 256;
+		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		default_serialization_factor  = warp_size / sizeof(Uncompressed);
 	}

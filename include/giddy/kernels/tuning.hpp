@@ -1,0 +1,10 @@
+// Build-time tuning knobs shared by the streaming kernels (FOR, Dictionary, DZB-fixed, Model).
+// Defaults were measured on MI355X; override with -D for experiments (tools/build_variant.sh).
+#pragma once
+
+#ifndef GIDDY_STREAM_STEPS_PER_TILE
+#define GIDDY_STREAM_STEPS_PER_TILE 4      // 16-byte stores per lane per tile
+#endif
+#ifndef GIDDY_STREAM_THREADS_PER_BLOCK
+#define GIDDY_STREAM_THREADS_PER_BLOCK 256 // workgroup size cap for streaming kernels
+#endif

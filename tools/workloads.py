@@ -376,3 +376,102 @@ class DiscardZeroBytesVariable:
         an = _np(self.anchors[: sample // L], np.uint64).copy()
         out = np.empty(sample, dtype=np.uint64)
         return (lambda: oracle.dzb_variable(data, packed, an, L, sample, self.min_size, self.bits, np.uint64, threads=threads, out=out)), 8 * sample
+
+
+class DiscardZeroBytesFixed:
+    """DZB-fixed uint64 <- uint16 (coverage sweep, not a BASELINE config)."""
+    name = "discard_zero_bytes::fixed_width<4,8,2>"
+    kernel = "fixed_width::decompress"
+
+    def __init__(self, n, device, seed=9):
+        self.n = n
+        self.comp = torch.randint(-32768, 32768, (n,), dtype=torch.int16, generator=_gen(seed, device), device=device)
+        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.algorithmic_bytes = 10 * n
+        self.decompressed_bytes = 8 * n
+        self.config = schemes.discard_zero_bytes_fixed(self.output, self.comp, n, uncompressed_size=8, compressed_size=2,
+                                                       stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.discard_zero_bytes_fixed(self.output, self.comp, self.n, uncompressed_size=8, compressed_size=2, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        s = min(sample, self.n)
+        assert (oracle.dzb_fixed(_np(self.comp[:s], np.uint16), np.uint64) == _np(self.output[:s], np.uint64)).all()
+        assert bool((self.output == (self.comp.to(torch.int64) & 0xFFFF)).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        c = _np(self.comp[:sample], np.uint16).copy()
+        return (lambda: oracle.dzb_fixed(c, np.uint64, threads=threads)), 8 * sample
+
+
+class Model:
+    """Model int32, linear (coverage sweep): a pure store stream."""
+    name = "model<4,int,linear>"
+    kernel = "model::decompress"
+
+    def __init__(self, n, device, seed=10):
+        self.n = n
+        self.coefs = np.array([-12345, 37], dtype=np.int32)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 4 * n
+        self.decompressed_bytes = 4 * n
+        self.config = schemes.model(self.output, self.coefs, n, stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.model(self.output, self.coefs, self.n, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        s = min(sample, self.n)
+        assert (oracle.model(self.coefs, s, np.int32, "linear") == _np(self.output[:s])).all()
+        expect = (torch.arange(self.n, device=self.output.device, dtype=torch.int64) * 37 - 12345).to(torch.int32)
+        assert bool((self.output == expect).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        return (lambda: oracle.model(self.coefs, sample, np.int32, "linear", threads=threads)), 4 * sample
+
+
+class IncidenceBitmaps:
+    """Incidence bitmaps, 16 distinct uint32 values (coverage sweep)."""
+    name = "incidence_bitmaps<4,4,2,true>"
+    kernel = "incidence_bitmaps::decompress"
+
+    def __init__(self, n, device, seed=11, num_values=16):
+        g = _gen(seed, device)
+        self.n, self.nb = n, num_values
+        words = n // 32
+        self.words = words
+        self.keys = torch.randint(0, num_values, (n,), dtype=torch.int64, generator=g, device=device)
+        self.entries = (torch.randperm(1 << 20, generator=g, device=device)[:num_values] * 1009 + 3).to(torch.int32)
+        aligned = (words + 1) // 2 * 2
+        bitmaps = torch.zeros((num_values, aligned), dtype=torch.int32, device=device)
+        shifts = torch.arange(32, device=device, dtype=torch.int64)
+        for b in range(num_values):
+            bits = (self.keys == b).view(words, 32).to(torch.int64)
+            word = (bits << shifts).sum(dim=1)
+            bitmaps[b, :words] = torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)
+        self.bitmaps = bitmaps.view(-1)
+        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 4 * n + num_values * 4 * words
+        self.decompressed_bytes = 4 * n
+        self.config = schemes.incidence_bitmaps(self.output, self.bitmaps, self.entries, words, num_values,
+                                                stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.incidence_bitmaps(self.output, self.bitmaps, self.entries, self.words, self.nb, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 20):
+        torch.cuda.synchronize()
+        assert bool((self.output == self.entries[self.keys]).all())
+
+    def cpu_run(self, oracle, sample, threads):
+        words = min(sample // 32, self.words)
+        aligned = (self.words + 1) // 2 * 2
+        bm = _np(self.bitmaps, np.uint32).reshape(self.nb, aligned)[:, :words]
+        al = (words + 1) // 2 * 2
+        laid = np.zeros((self.nb, al), dtype=np.uint32); laid[:, :words] = bm
+        ent = _np(self.entries, np.uint32).copy()
+        flat = laid.reshape(-1)
+        return (lambda: oracle.incidence_bitmaps(flat, ent, words, self.nb, 2, np.uint32, threads=threads)), 4 * 32 * words
