@@ -50,6 +50,7 @@ def parse():
 
 def make_workload(name, n, device):
     import workloads as w
+    w.SEED_OFFSET = 1000 * int(os.environ.get("RANK", "0"))
     table = {
         "dictionary": lambda: w.Dictionary(n, device),
         "dictionary_zipf": lambda: w.Dictionary(n, device, zipf=True),

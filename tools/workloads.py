@@ -16,9 +16,12 @@ import torch
 from libgiddy_amd import schemes
 
 
+SEED_OFFSET = 0   # bench.py sets this to 1000 * rank so that every GPU decodes different data
+
+
 def _gen(seed, device):
     g = torch.Generator(device=device)
-    g.manual_seed(seed)
+    g.manual_seed(seed + SEED_OFFSET)
     return g
 
 
