@@ -183,7 +183,7 @@ def main():
 
     # ---- the other single-GPU configs, same treatment (rank 0 of a 1-GPU run only) ----------------
     if world == 1 and args.schemes != "none":
-        names = ["frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
+        names = ["dictionary_zipf", "frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
                  "run_position_encoding_absolute", "discard_zero_bytes_variable"]
         if args.schemes == "coverage":
             names += ["discard_zero_bytes_fixed", "model", "incidence_bitmaps"]

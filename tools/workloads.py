@@ -129,6 +129,7 @@ class DeltaPatched:
         g = _gen(seed, device)
         self.n, self.L = n, segment_length
         self.deltas = torch.randint(0, 65536, (n,), dtype=torch.int32, generator=g, device=device).to(torch.int16)  # bit pattern of uint16
+        self.csize = 2
         nseg = (n + segment_length - 1) // segment_length
         seg_sums = (self.deltas.view(-1)[: nseg * segment_length if n % segment_length == 0 else n].to(torch.int32) & 0xFFFF)
         if n % segment_length == 0:
