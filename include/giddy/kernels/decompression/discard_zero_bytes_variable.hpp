@@ -59,34 +59,43 @@ enum : unsigned {
 
 namespace detail {
 
+/// byte masks by element size, 0..8 bytes — kept in LDS so that masking costs one LDS read instead of ~8 VALU ops
+struct size_masks { uint64_t mask[9]; };
+
+__device__ __forceinline__ void fill(size_masks& table)
+{
+	if (threadIdx.x < 9) { table.mask[threadIdx.x] = threadIdx.x == 8 ? ~(uint64_t) 0 : ((((uint64_t) 1) << (8 * threadIdx.x)) - 1); }
+	__syncthreads();
+}
+
 /// low `size` bytes of the 8 bytes starting `shift_bytes` into the three aligned words (w0, w1, w2)
 template <unsigned UncompressedSize>
-__device__ __forceinline__ uint64_t cut(uint32_t w0, uint32_t w1, uint32_t w2, unsigned shift_bytes, unsigned size)
+__device__ __forceinline__ uint64_t cut(uint32_t w0, uint32_t w1, uint32_t w2, unsigned shift_bytes, unsigned size, const size_masks& masks)
 {
 	// v_alignbyte_b32: bytes [shift, shift+4) of the 8-byte pair {hi, lo}
+	const uint64_t mask = masks.mask[size];
 	uint32_t lo = __builtin_amdgcn_alignbyte(w1, w0, shift_bytes);
-	uint32_t lo_mask = size >= 4 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * size));
-	if (UncompressedSize <= 4) { return lo & lo_mask; }
+	if (UncompressedSize <= 4) { return lo & (uint32_t) mask; }
 	uint32_t hi = __builtin_amdgcn_alignbyte(w2, w1, shift_bytes);
-	uint32_t hi_mask = size <= 4 ? 0u : (size >= 8 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu << (8 * (size - 4))));
-	return ((uint64_t) (hi & hi_mask) << 32) | (lo & lo_mask);
+	return (((uint64_t) hi << 32) | lo) & mask;
 }
 
 /// Fast path (all R rows inside the segment, 16-byte aligned output, a lane's E size fields share a
 /// container): the lane's E fields of row k, already shifted down to bit 0.  The group's first element
-/// is field `field_base` (< per) of container `container_base` — both wave-uniform, so the only
-/// per-lane division is a 32-bit one by `per`.
+/// is field `field_base` (< per) of container `container_base` — both wave-uniform; the per-lane
+/// division by `per` is a multiplication by its precomputed reciprocal.
 template <unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 __device__ __forceinline__ void load_size_fields(
 	uint_t<ElementSizesContainerSize> (&fields)[rows_in_flight],
 	const uint_t<ElementSizesContainerSize>* __restrict__ packed_element_sizes,
-	unsigned lane, uint64_t container_base, unsigned field_base, unsigned bits, unsigned per)
+	unsigned lane, uint64_t container_base, unsigned field_base, unsigned bits, unsigned per, unsigned per_reciprocal)
 {
 	constexpr unsigned E = 16 / UncompressedSize;
 	#pragma unroll
 	for (unsigned k = 0; k < rows_in_flight; k++) {
+		// floor(index / per) == mulhi(index, ceil(2^32 / per)) exactly while index * per < 2^32 (index < 2^13, per <= 64)
 		const unsigned index = field_base + k * 64 * E + lane * E;
-		const unsigned q = index / per, field = index - q * per;
+		const unsigned q = per == 1 ? index : __umulhi(index, per_reciprocal), field = index - q * per;
 		fields[k] = packed_element_sizes[container_base + q] >> (field * bits);
 	}
 }
@@ -155,7 +164,7 @@ struct row_group {
 		wave64::lds_fence();
 	}
 	__device__ __forceinline__ void extract_and_store(uint_t<UncompressedSize>* __restrict__ decompressed, const uint32_t* stage,
-		unsigned lane, uint64_t rows_start, unsigned min_size, unsigned bits) const
+		unsigned lane, uint64_t rows_start, unsigned min_size, unsigned bits, const size_masks& masks) const
 	{
 		using U = uint_t<UncompressedSize>;
 		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
@@ -169,7 +178,7 @@ struct row_group {
 			for (unsigned j = 0; j < E; j++) {
 				const unsigned word = at >> 2, size = size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask);
 				// unconditional aligned reads: the staging area has slack, bytes beyond the element are masked off
-				values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size);
+				values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size, masks);
 				at += size;
 			}
 			memory_access::store_group(decompressed + i0, values);
@@ -186,7 +195,7 @@ __device__ __forceinline__ uint64_t decompress_rows(
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>* __restrict__ packed_element_sizes,
 	uint32_t* stage, unsigned lane, uint64_t rows_start, uint64_t segment_end, uint64_t bytes_start,
-	unsigned min_size, unsigned bits, unsigned per)
+	unsigned min_size, unsigned bits, unsigned per, const size_masks& masks)
 {
 	using namespace memory_access;
 	using U = uint_t<UncompressedSize>;
@@ -263,7 +272,7 @@ __device__ __forceinline__ uint64_t decompress_rows(
 		for (unsigned j = 0; j < E; j++) {
 			const unsigned word = at >> 2, size = sizes[k][j];
 			// unconditional aligned reads: the staging area has slack, bytes beyond the element are masked off
-			values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size);
+			values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size, masks);
 			at += size;
 		}
 		if (Full) { store_group(decompressed + i0, values); }
@@ -299,6 +308,8 @@ __global__ void __launch_bounds__(256) decompress(
 	using container_type = uint_t<ElementSizesContainerSize>;
 	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][R * detail::staging_words];
 
+	__shared__ detail::size_masks masks;
+	detail::fill(masks);
 	// staging exists for max_waves_per_block wavefronts; in a larger workgroup the extra wavefronts sit idle
 	const unsigned working_waves = wave64::per_block() < detail::max_waves_per_block ? wave64::per_block() : detail::max_waves_per_block;
 	if (wave64::index_in_block() >= working_waves) { return; }
@@ -312,6 +323,7 @@ __global__ void __launch_bounds__(256) decompress(
 	const uint64_t num_segments = (n + L - 1) / L;
 	const unsigned bits = bits_per_element_size;
 	const unsigned per = (8 * ElementSizesContainerSize) / bits;
+	const unsigned per_reciprocal = per == 1 ? 0u : (unsigned) ((((uint64_t) 1 << 32) + per - 1) / per);
 	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
 	const bool aligned_output = memory_access::is_aligned(decompressed, 16) && (L % E == 0);
 
@@ -336,7 +348,7 @@ __global__ void __launch_bounds__(256) decompress(
 				uint64_t container_base = segment_start / per;
 				unsigned field_base = (unsigned) (segment_start - container_base * per);
 				auto fetch_fields = [&](container_type (&fields)[R]) {
-					detail::load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per);
+					detail::load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per, per_reciprocal);
 					field_base += (unsigned) group_elements;
 					container_base += field_base / per;
 					field_base %= per;
@@ -353,7 +365,7 @@ __global__ void __launch_bounds__(256) decompress(
 						next.request(lane, packed_element_sizes);
 					}
 					if (g + 2 < num_groups) { fetch_fields(after_next); }
-					current.extract_and_store(decompressed, stage, lane, rows_start, min_represented_element_size, bits);
+					current.extract_and_store(decompressed, stage, lane, rows_start, min_represented_element_size, bits, masks);
 					rows_start += group_elements;
 					if (has_next) {
 						next.stage_into(stage, lane);
@@ -368,7 +380,7 @@ __global__ void __launch_bounds__(256) decompress(
 		for (; rows_start < segment_end; rows_start += (uint64_t) R * row) {
 			bytes_start = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, segment_end, bytes_start,
-				min_represented_element_size, bits, per);
+				min_represented_element_size, bits, per, masks);
 		}
 	}
 }
