@@ -1,33 +1,39 @@
-// Mode of use A: a type-erased wrapper produced by the factory from its key string; nothing about the
-// kernel is known at compile time (cf. the reference's README.md:117-126).
+// Mode of use A: the kernel is known only by its factory key — a string — at run time.  The factory
+// produces a type-erased wrapper; sizes go in as a name -> value map to resolve the launch
+// configuration, buffers go in the same way to enqueue the launch (cf. the reference's README.md:117-126).
 #include "common.hpp"
 
 #include "kernel_wrappers/registered_wrapper.h"
 
+namespace {
+
+const char* const frame_of_reference_int32_from_int16 =
+	"decompression::frame_of_reference::kernel_t<4u, int, short, "
+	"cuda::functors::unary::parametric_model::constant<4u, int> >";
+
+} // namespace
+
 void decompress_on_device(
-	uncompressed_type* decompressed, const compressed_type* compressed,
+	uncompressed_type* decompressed, const compressed_type* compressed_input,
 	const model_coefficients_type* segment_model_coefficients, size_type length, size_type segment_length)
 {
-	auto kernel_name =
-		"decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
-	auto type_erased_kernel = cuda::registered::kernel_t::produceSubclass(kernel_name);
+	using wrapper = cuda::registered::kernel_t;
+	if (!wrapper::canProduce(frame_of_reference_int32_from_int16)) {
+		std::cerr << "the library does not register " << frame_of_reference_int32_from_int16 << "\n";
+		std::exit(EXIT_FAILURE);
+	}
+	std::unique_ptr<wrapper> kernel = wrapper::produceSubclass(frame_of_reference_int32_from_int16);
 
-	auto device_properties = cuda::device::current::get().properties();
-	auto kernel_function_attributes = type_erased_kernel->get_device_function().attributes();
+	// launch-configuration resolution takes plain size_t's
+	wrapper::arguments_type sizes;
+	sizes["length"] = (size_t) length;
+	sizes["segment_length"] = (size_t) segment_length;
+	cuda::launch_configuration_t configuration = kernel->resolve_launch_configuration(
+		cuda::device::current::get().properties(), kernel->get_device_function().attributes(), sizes);
 
-	cuda::registered::kernel_t::arguments_type config_resolution_arguments = {
-		{ "length",         (size_t) length         },
-		{ "segment_length", (size_t) segment_length },
-	};
-	auto launch_config = type_erased_kernel->resolve_launch_configuration(
-		device_properties, kernel_function_attributes, config_resolution_arguments);
-
-	cuda::registered::kernel_t::arguments_type launch_arguments = {
-		{ "decompressed",               decompressed                },
-		{ "compressed_input",           compressed                  },
-		{ "segment_model_coefficients", segment_model_coefficients  },
-		{ "length",                     length                      },
-		{ "segment_length",             segment_length              },
-	};
-	type_erased_kernel->enqueue_launch(cuda::stream::default_stream_id, launch_config, launch_arguments);
+	// the launch takes every argument in exactly the type the kernel declares; the macro names each
+	// map entry after the variable it is built from
+	wrapper::arguments_type launch_arguments =
+		MAKE_KERNEL_ARGUMENTS(decompressed, compressed_input, segment_model_coefficients, length, segment_length);
+	kernel->enqueue_launch(cuda::stream::default_stream_id, configuration, launch_arguments);
 }

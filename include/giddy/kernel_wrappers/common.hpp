@@ -7,6 +7,18 @@
 #include "giddy/util/math.hpp"
 #include "giddy/util/static_block.hpp"
 
+namespace cuda {
+
+/// the value stored under `name`, which must hold exactly a T (std::out_of_range / bad_any_cast otherwise)
+template <typename T>
+inline T argument(const kernel_t::arguments_type& arguments, const char* name) { return cuda::any_cast<T>(arguments.at(name)); }
+
+/// the value stored under `name` if there is one
+template <typename T>
+inline optional<T> optional_argument(const kernel_t::arguments_type& arguments, const char* name) { return cuda::any_cast<T>(cuda::maybe_at(arguments, name)); }
+
+} // namespace cuda
+
 /// util::endianness_t <-> cuda::endianness_t (kernel_wrappers/common.h:38-43)
 inline constexpr cuda::endianness_t translate(util::endianness_t endianness)
 {

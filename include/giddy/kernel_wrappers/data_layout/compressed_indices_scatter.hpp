@@ -40,8 +40,8 @@ launch_configuration_t GIDDY_CIS_KERNEL::resolve_launch_configuration(
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto input_data_length = any_cast<size_t>(extra_arguments.at("input_data_length"));
-	auto anchoring_period  = any_cast<size_t>(extra_arguments.at("anchoring_period"));
+	auto input_data_length = argument<size_t>(extra_arguments, "input_data_length");
+	auto anchoring_period  = argument<size_t>(extra_arguments, "anchoring_period");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, input_data_length, anchoring_period, limits);
 }
 
@@ -50,17 +50,17 @@ void GIDDY_CIS_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 {
 	if (launch_config.grid_dimensions == 0) { return; }   // no patches, nothing to do
 
-	auto target                                       = any_cast<element_type*            >(arguments.at("target"));
-	auto data_to_scatter                              = any_cast<const element_type*      >(arguments.at("data_to_scatter"));
-	auto scatter_position_run_lengths                 = any_cast<const run_length_type*   >(arguments.at("scatter_position_run_lengths"));
-	auto scatter_position_run_individual_offset_sizes = any_cast<const unsigned char*     >(arguments.at("scatter_position_run_individual_offset_sizes"));
-	auto scatter_position_run_baseline_values         = any_cast<const output_index_type* >(arguments.at("scatter_position_run_baseline_values"));
-	auto scatter_position_run_offsets_start_pos       = any_cast<const input_index_type*  >(arguments.at("scatter_position_run_offsets_start_pos"));
-	auto scatter_position_offset_bytes                = any_cast<const unsigned char*     >(arguments.at("scatter_position_offset_bytes"));
-	auto scatter_position_anchors                     = any_cast<const input_index_type*  >(arguments.at("scatter_position_anchors"));
-	auto anchoring_period                             = any_cast<input_index_type         >(arguments.at("anchoring_period"));
-	auto num_scatter_position_runs                    = any_cast<input_index_type         >(arguments.at("num_scatter_position_runs"));
-	auto input_data_length                            = any_cast<input_size_type          >(arguments.at("input_data_length"));
+	auto target                                       = argument<element_type*>(arguments, "target");
+	auto data_to_scatter                              = argument<const element_type*>(arguments, "data_to_scatter");
+	auto scatter_position_run_lengths                 = argument<const run_length_type*>(arguments, "scatter_position_run_lengths");
+	auto scatter_position_run_individual_offset_sizes = argument<const unsigned char*>(arguments, "scatter_position_run_individual_offset_sizes");
+	auto scatter_position_run_baseline_values         = argument<const output_index_type*>(arguments, "scatter_position_run_baseline_values");
+	auto scatter_position_run_offsets_start_pos       = argument<const input_index_type*>(arguments, "scatter_position_run_offsets_start_pos");
+	auto scatter_position_offset_bytes                = argument<const unsigned char*>(arguments, "scatter_position_offset_bytes");
+	auto scatter_position_anchors                     = argument<const input_index_type*>(arguments, "scatter_position_anchors");
+	auto anchoring_period                             = argument<input_index_type>(arguments, "anchoring_period");
+	auto num_scatter_position_runs                    = argument<input_index_type>(arguments, "num_scatter_position_runs");
+	auto input_data_length                            = argument<input_size_type>(arguments, "input_data_length");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		target, data_to_scatter, scatter_position_run_lengths, scatter_position_run_individual_offset_sizes,

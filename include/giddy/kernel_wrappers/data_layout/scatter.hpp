@@ -39,7 +39,7 @@ launch_configuration_t kernel_t<OutputIndexSize, ElementSize, InputIndexSize, Se
 	arguments_type                  extra_arguments,
 	launch_configuration_limits_t   limits) const
 {
-	auto data_length = any_cast<size_t>(extra_arguments.at("data_length"));
+	auto data_length = argument<size_t>(extra_arguments, "data_length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, data_length, limits);
 }
 
@@ -49,10 +49,10 @@ void kernel_t<OutputIndexSize, ElementSize, InputIndexSize, SerializationFactor>
 	const launch_configuration_t&  launch_config,
 	arguments_type                 arguments) const
 {
-	auto target       = any_cast<element_type*            >(arguments.at("target"));
-	auto data         = any_cast<const element_type*      >(arguments.at("data"));
-	auto indices      = any_cast<const output_index_type* >(arguments.at("indices"));
-	auto data_length  = any_cast<input_size_type          >(arguments.at("data_length"));
+	auto target       = argument<element_type*>(arguments, "target");
+	auto data         = argument<const element_type*>(arguments, "data");
+	auto indices      = argument<const output_index_type*>(arguments, "indices");
+	auto data_length  = argument<input_size_type>(arguments, "data_length");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config, target, data, indices, data_length);
 }

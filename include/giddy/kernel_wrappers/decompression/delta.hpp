@@ -38,8 +38,8 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::re
 	arguments_type                 extra_arguments,
 	launch_configuration_limits_t  limits) const
 {
-	auto length         = any_cast<size_t>(extra_arguments.at("length"));
-	auto segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));
+	auto length         = argument<size_t>(extra_arguments, "length");
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
 }
 
@@ -49,11 +49,11 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 	const launch_configuration_t&  launch_config,
 	arguments_type                 arguments) const
 {
-	auto decompressed      = any_cast<uncompressed_type*       >(arguments.at("decompressed"));
-	auto compressed_input  = any_cast<const compressed_type*   >(arguments.at("compressed_input"));
-	auto anchor_values     = any_cast<const uncompressed_type* >(arguments.at("anchor_values"));
-	auto length            = any_cast<uint_t<IndexSize>        >(arguments.at("length"));
-	auto segment_length    = any_cast<uint_t<IndexSize>        >(arguments.at("segment_length"));
+	auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
+	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
+	auto length            = argument<uint_t<IndexSize>>(arguments, "length");
+	auto segment_length    = argument<uint_t<IndexSize>>(arguments, "segment_length");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length);

@@ -45,10 +45,10 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize
 	arguments_type                 extra_arguments,
 	launch_configuration_limits_t  limits) const
 {
-	auto num_dictionary_entries = any_cast<size_t>(extra_arguments.at("num_dictionary_entries"));
-	auto data_length            = any_cast<size_t>(extra_arguments.at("data_length"));
-	auto cache_input_data_in_shared_mem = any_cast<bool>(maybe_at(extra_arguments, "cache_input_data_in_shared_mem"));
-	auto serialization_factor   = any_cast<serialization_factor_t>(maybe_at(extra_arguments, "serialization_factor"));
+	auto num_dictionary_entries = argument<size_t>(extra_arguments, "num_dictionary_entries");
+	auto data_length            = argument<size_t>(extra_arguments, "data_length");
+	auto cache_input_data_in_shared_mem = optional_argument<bool>(extra_arguments, "cache_input_data_in_shared_mem");
+	auto serialization_factor   = optional_argument<serialization_factor_t>(extra_arguments, "serialization_factor");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes,
 		num_dictionary_entries, data_length, cache_input_data_in_shared_mem, serialization_factor, limits);
 }
@@ -59,14 +59,14 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch(
 	const launch_configuration_t&  launch_config,
 	arguments_type                 arguments) const
 {
-	auto maybe_cache = any_cast<bool>(maybe_at(arguments, "cache_dictionary_in_shared_mem"));
-	auto maybe_serialization_factor = any_cast<serialization_factor_t>(maybe_at(arguments, "serialization_factor"));
+	auto maybe_cache = optional_argument<bool>(arguments, "cache_dictionary_in_shared_mem");
+	auto maybe_serialization_factor = optional_argument<serialization_factor_t>(arguments, "serialization_factor");
 
-	auto decompressed            = any_cast<uncompressed_type*           >(arguments.at("decompressed"));
-	auto compressed_input        = any_cast<const dictionary_index_type* >(arguments.at("compressed_input"));
-	auto dictionary_entries      = any_cast<const uncompressed_type*     >(arguments.at("dictionary_entries"));
-	auto length                  = any_cast<size_type                    >(arguments.at("length"));
-	auto num_dictionary_entries  = any_cast<dictionary_size_type         >(arguments.at("num_dictionary_entries"));
+	auto decompressed            = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input        = argument<const dictionary_index_type*>(arguments, "compressed_input");
+	auto dictionary_entries      = argument<const uncompressed_type*>(arguments, "dictionary_entries");
+	auto length                  = argument<size_type>(arguments, "length");
+	auto num_dictionary_entries  = argument<dictionary_size_type>(arguments, "num_dictionary_entries");
 
 	// The dictionary is staged in LDS iff the resolved configuration reserved room for it.
 	bool fits = (size_t) num_dictionary_entries * UncompressedSize <= launch_config.dynamic_shared_memory_size;

@@ -42,16 +42,16 @@ launch_configuration_t GIDDY_DZBF_KERNEL::resolve_launch_configuration(
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto length = any_cast<size_t>(extra_arguments.at("length"));
+	auto length = argument<size_t>(extra_arguments, "length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
 }
 
 GIDDY_DZBF_TEMPLATE
 void GIDDY_DZBF_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
-	auto decompressed     = any_cast<uncompressed_type*     >(arguments.at("decompressed"));
-	auto compressed_input = any_cast<const compressed_type* >(arguments.at("compressed_input"));
-	auto length           = any_cast<uint_t<IndexSize>      >(arguments.at("length"));
+	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
+	auto length           = argument<uint_t<IndexSize>>(arguments, "length");
 	cuda::kernel::enqueue_launch(*this, stream, launch_config, decompressed, compressed_input, (size_type) length);
 }
 

@@ -35,8 +35,8 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, ElementSizesContain
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto length         = any_cast<size_t>(extra_arguments.at("length"));          // overall, in elements
-	auto segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));  // elements per anchored segment
+	auto length         = argument<size_t>(extra_arguments, "length");          // overall, in elements
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");  // elements per anchored segment
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
 }
 
@@ -45,14 +45,14 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
 	using index_type = uint_t<IndexSize>;
-	auto decompressed                 = any_cast<uncompressed_type*   >(arguments.at("decompressed"));
-	auto compressed_data              = any_cast<const unsigned char* >(arguments.at("compressed_data"));
-	auto packed_element_sizes         = any_cast<const element_sizes_container_size_type*>(arguments.at("packed_element_sizes"));
-	auto position_anchors             = any_cast<const index_type*    >(arguments.at("position_anchors"));
-	auto segment_length               = any_cast<index_type           >(arguments.at("segment_length"));
-	auto length                       = any_cast<index_type           >(arguments.at("length"));
-	auto min_represented_element_size = any_cast<element_size_t       >(arguments.at("min_represented_element_size"));
-	auto bits_per_element_size        = any_cast<unsigned             >(arguments.at("bits_per_element_size"));
+	auto decompressed                 = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_data              = argument<const unsigned char*>(arguments, "compressed_data");
+	auto packed_element_sizes         = argument<const element_sizes_container_size_type*>(arguments, "packed_element_sizes");
+	auto position_anchors             = argument<const index_type*>(arguments, "position_anchors");
+	auto segment_length               = argument<index_type>(arguments, "segment_length");
+	auto length                       = argument<index_type>(arguments, "length");
+	auto min_represented_element_size = argument<element_size_t>(arguments, "min_represented_element_size");
+	auto bits_per_element_size        = argument<unsigned>(arguments, "bits_per_element_size");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_data, packed_element_sizes, position_anchors,

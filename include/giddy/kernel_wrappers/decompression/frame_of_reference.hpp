@@ -38,8 +38,8 @@ launch_configuration_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelF
 	arguments_type                 extra_arguments,
 	launch_configuration_limits_t  limits) const
 {
-	auto length         = any_cast<size_t>(extra_arguments.at("length"));
-	auto segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));
+	auto length         = argument<size_t>(extra_arguments, "length");
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
 }
 
@@ -51,11 +51,11 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 {
 	using index_type = uint_t<IndexSize>;
 
-	auto decompressed               = any_cast<Uncompressed*                  >(arguments.at("decompressed"));
-	auto compressed_input           = any_cast<const Compressed*              >(arguments.at("compressed_input"));
-	auto segment_model_coefficients = any_cast<const model_coefficients_type* >(arguments.at("segment_model_coefficients"));
-	auto length                     = any_cast<index_type                     >(arguments.at("length"));
-	auto segment_length             = any_cast<index_type                     >(arguments.at("segment_length"));
+	auto decompressed               = argument<Uncompressed*>(arguments, "decompressed");
+	auto compressed_input           = argument<const Compressed*>(arguments, "compressed_input");
+	auto segment_model_coefficients = argument<const model_coefficients_type*>(arguments, "segment_model_coefficients");
+	auto length                     = argument<index_type>(arguments, "length");
+	auto segment_length             = argument<index_type>(arguments, "segment_length");
 
 	// One model record per segment.  The kernel's last parameter exists for signature parity
 	// with the reference (frame_of_reference.cu:93-100 computes it the same way).

@@ -38,18 +38,18 @@ launch_configuration_t GIDDY_IB_KERNEL::resolve_launch_configuration(
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto length = any_cast<size_t>(extra_arguments.at("length"));
+	auto length = argument<size_t>(extra_arguments, "length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
 }
 
 GIDDY_IB_TEMPLATE
 void GIDDY_IB_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
-	auto decompressed       = any_cast<uncompressed_type*       >(arguments.at("decompressed"));
-	auto incidence_bitmaps  = any_cast<const bit_container_t*   >(arguments.at("incidence_bitmaps"));
-	auto dictionary_entries = any_cast<const uncompressed_type* >(arguments.at("dictionary_entries"));
-	auto bitmap_length      = any_cast<size_type                >(arguments.at("bitmap_length"));
-	auto num_bitmaps        = any_cast<num_bitmaps_type         >(arguments.at("num_bitmaps"));
+	auto decompressed       = argument<uncompressed_type*>(arguments, "decompressed");
+	auto incidence_bitmaps  = argument<const bit_container_t*>(arguments, "incidence_bitmaps");
+	auto dictionary_entries = argument<const uncompressed_type*>(arguments, "dictionary_entries");
+	auto bitmap_length      = argument<size_type>(arguments, "bitmap_length");
+	auto num_bitmaps        = argument<num_bitmaps_type>(arguments, "num_bitmaps");
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, incidence_bitmaps, dictionary_entries, bitmap_length, num_bitmaps);
 }

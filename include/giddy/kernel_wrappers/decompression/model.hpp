@@ -32,7 +32,7 @@ launch_configuration_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::re
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto length = any_cast<size_t>(extra_arguments.at("length"));
+	auto length = argument<size_t>(extra_arguments, "length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
 }
 
@@ -41,9 +41,9 @@ void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch(
 	stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
 	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
-	auto length             = any_cast<uint_t<IndexSize>       >(arguments.at("length"));
-	auto decompressed       = any_cast<Uncompressed*           >(arguments.at("decompressed"));
-	auto model_coefficients = any_cast<model_coefficients_type >(arguments.at("model_coefficients"));
+	auto length             = argument<uint_t<IndexSize>>(arguments, "length");
+	auto decompressed       = argument<Uncompressed*>(arguments, "decompressed");
+	auto model_coefficients = argument<model_coefficients_type>(arguments, "model_coefficients");
 	cuda::kernel::enqueue_launch(*this, stream, launch_config, decompressed, model_coefficients, (size_type) length);
 }
 

@@ -44,23 +44,23 @@ launch_configuration_t GIDDY_RLE_KERNEL::resolve_launch_configuration(
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto uncompressed_length = any_cast<size_t>(extra_arguments.at("length"));
-	auto segment_length      = any_cast<size_t>(extra_arguments.at("segment_length"));
+	auto uncompressed_length = argument<size_t>(extra_arguments, "length");
+	auto segment_length      = argument<size_t>(extra_arguments, "segment_length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes, uncompressed_length, segment_length, limits);
 }
 
 GIDDY_RLE_TEMPLATE
 void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
-	auto decompressed             = any_cast<uncompressed_type*       >(arguments.at("decompressed"));
-	auto run_data                 = any_cast<const uncompressed_type* >(arguments.at("run_data"));
-	auto run_lengths              = any_cast<const run_length_type*   >(arguments.at("run_lengths"));
-	auto position_anchors         = any_cast<const run_index_type*    >(arguments.at("position_anchors"));
-	auto intra_run_anchor_offsets = any_cast<const run_length_type*   >(arguments.at("intra_run_anchor_offsets"));
-	auto segment_length           = any_cast<size_type                >(arguments.at("segment_length"));
-	auto num_segments             = any_cast<size_type                >(arguments.at("num_segments"));
-	auto num_element_runs         = any_cast<run_index_size_type      >(arguments.at("num_element_runs"));
-	auto uncompressed_length      = any_cast<size_type                >(arguments.at("length"));
+	auto decompressed             = argument<uncompressed_type*>(arguments, "decompressed");
+	auto run_data                 = argument<const uncompressed_type*>(arguments, "run_data");
+	auto run_lengths              = argument<const run_length_type*>(arguments, "run_lengths");
+	auto position_anchors         = argument<const run_index_type*>(arguments, "position_anchors");
+	auto intra_run_anchor_offsets = argument<const run_length_type*>(arguments, "intra_run_anchor_offsets");
+	auto segment_length           = argument<size_type>(arguments, "segment_length");
+	auto num_segments             = argument<size_type>(arguments, "num_segments");
+	auto num_element_runs         = argument<run_index_size_type>(arguments, "num_element_runs");
+	auto uncompressed_length      = argument<size_type>(arguments, "length");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,

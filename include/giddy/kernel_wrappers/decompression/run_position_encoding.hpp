@@ -43,8 +43,8 @@ launch_configuration_t GIDDY_RPE_KERNEL::resolve_launch_configuration(
 	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
-	auto uncompressed_length         = any_cast<size_t>(extra_arguments.at("length"));
-	auto uncompressed_segment_length = any_cast<size_t>(extra_arguments.at("segment_length"));
+	auto uncompressed_length         = argument<size_t>(extra_arguments, "length");
+	auto uncompressed_segment_length = argument<size_t>(extra_arguments, "segment_length");
 	return resolve_launch_configuration(device_properties, kernel_function_attributes,
 		uncompressed_length, uncompressed_segment_length, limits);
 }
@@ -52,14 +52,14 @@ launch_configuration_t GIDDY_RPE_KERNEL::resolve_launch_configuration(
 GIDDY_RPE_TEMPLATE
 void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
 {
-	auto decompressed                = any_cast<uncompressed_type*           >(arguments.at("decompressed"));
-	auto run_data                    = any_cast<const uncompressed_type*     >(arguments.at("run_data"));
-	auto run_start_positions         = any_cast<const position_offset_type*  >(arguments.at("run_start_positions"));
-	auto position_anchors            = any_cast<const run_index_type*        >(arguments.at("position_anchors"));
-	auto uncompressed_segment_length = any_cast<position_offset_size_type    >(arguments.at("segment_length"));
-	auto num_anchors                 = any_cast<uncompressed_index_size_type >(arguments.at("num_anchors"));
-	auto num_element_runs            = any_cast<run_index_size_type          >(arguments.at("num_element_runs"));
-	auto uncompressed_length         = any_cast<uncompressed_index_size_type >(arguments.at("length"));
+	auto decompressed                = argument<uncompressed_type*>(arguments, "decompressed");
+	auto run_data                    = argument<const uncompressed_type*>(arguments, "run_data");
+	auto run_start_positions         = argument<const position_offset_type*>(arguments, "run_start_positions");
+	auto position_anchors            = argument<const run_index_type*>(arguments, "position_anchors");
+	auto uncompressed_segment_length = argument<position_offset_size_type>(arguments, "segment_length");
+	auto num_anchors                 = argument<uncompressed_index_size_type>(arguments, "num_anchors");
+	auto num_element_runs            = argument<run_index_size_type>(arguments, "num_element_runs");
+	auto uncompressed_length         = argument<uncompressed_index_size_type>(arguments, "length");
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, run_data, run_start_positions, position_anchors,

@@ -34,25 +34,22 @@ inline std::string factory_key_of(const std::string& type_name)
 } // namespace registered
 } // namespace cuda
 
+// What every wrapper class declares: its own factory registration (keyed by its demangled type name)
+// and the three virtual overrides.  The member signatures are the API of cuda::kernel_t.
 #define REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(subclass_name) \
-	using parent          = cuda::registered::kernel_t; \
-	using arguments_type  = parent::arguments_type; \
+	using parent = cuda::registered::kernel_t; \
+	using arguments_type = parent::arguments_type; \
 	using parent::resolve_launch_configuration; \
-	static void registerInSubclassFactory() { \
-		FactoryProducible::registerInSubclassFactory<subclass_name>( \
-			cuda::registered::detail::factory_key_of(util::type_name<subclass_name>())); \
+	static void registerInSubclassFactory() \
+	{ \
+		const std::string key = cuda::registered::detail::factory_key_of(util::type_name<subclass_name>()); \
+		FactoryProducible::registerInSubclassFactory<subclass_name>(key); \
 	} \
 public: \
-	launch_configuration_t resolve_launch_configuration( \
-		device::properties_t           device_properties, \
-		device_function::attributes_t  kernel_function_attributes, \
-		arguments_type                 extra_arguments, \
-		launch_configuration_limits_t  limits = { nullopt, nullopt, nullopt }) const override final; \
-	\
-	/* Note: the stream is assumed to be on the current device */ \
-	void enqueue_launch( \
-		stream::id_t                   stream, \
-		const launch_configuration_t&  launch_config, \
-		arguments_type                 arguments) const override final; \
-	\
+	launch_configuration_t resolve_launch_configuration(device::properties_t device_properties, \
+		device_function::attributes_t kernel_function_attributes, arguments_type extra_arguments, \
+		launch_configuration_limits_t limits = { nullopt, nullopt, nullopt }) const override final; \
+	/* the stream is assumed to belong to the current device */ \
+	void enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, \
+		arguments_type arguments) const override final; \
 	const device_function_t get_device_function() const override final
