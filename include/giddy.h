@@ -96,6 +96,7 @@ typedef struct giddy_launch_configuration_limits {
 } giddy_launch_configuration_limits_t;
 
 #define GIDDY_NOMINAL_MI355X_DEVICE (-1)
+#define GIDDY_CURRENT_DEVICE        (-2)
 
 /* ---- factory ---------------------------------------------------------------------------- */
 int          giddy_kernel_count(void);                 /* number of registered wrapper instantiations (163) */
@@ -105,7 +106,8 @@ int          giddy_produce(const char* key, giddy_kernel_t** kernel);
 void         giddy_release(giddy_kernel_t* kernel);
 
 /* ---- per-kernel --------------------------------------------------------------------------- */
-/* device_id >= 0: properties and function attributes are queried from that HIP device.
+/* device_id >= 0: properties and function attributes are queried from that HIP device;
+ * device_id == GIDDY_CURRENT_DEVICE: from the calling thread's current HIP device.
  * device_id == GIDDY_NOMINAL_MI355X_DEVICE: nominal MI355X properties, no device is touched
  * (host-only resolution, usable where no GPU is present). */
 int          giddy_resolve_launch_configuration(

@@ -158,6 +158,7 @@ int giddy_resolve_launch_configuration(
 				cuda::device::properties_t::nominal_mi355x(), cuda::device_function::attributes_t(), map, l);
 		}
 		else {
+			if (device_id == GIDDY_CURRENT_DEVICE) { device_id = cuda::device::current::get().id(); }
 			auto properties = cuda::device::get(device_id).properties();
 			cuda::device::current::scoped_override_t<> use(device_id);
 			config = k.wrapper->resolve_launch_configuration(properties, k.wrapper->get_device_function().attributes(), map, l);

@@ -19,6 +19,7 @@ from . import _native
 from ._native import giddy_argument, giddy_launch_configuration, giddy_launch_configuration_limits
 
 NOMINAL_MI355X = -1  # GIDDY_NOMINAL_MI355X_DEVICE: resolve without touching a device
+CURRENT_DEVICE = -2  # GIDDY_CURRENT_DEVICE: the calling thread's current HIP device
 
 # giddy_type_t
 _TAGS = {name: i + 1 for i, name in enumerate([
@@ -216,7 +217,7 @@ class kernel_t:
 
     # ---- cuda::kernel_t -------------------------------------------------------------------------
     def resolve_launch_configuration(self, device, extra_arguments, limits=None):
-        """`device`: a HIP device ordinal, or NOMINAL_MI355X to resolve on the host alone"""
+        """`device`: a HIP device ordinal, CURRENT_DEVICE, or NOMINAL_MI355X to resolve on the host alone"""
         array, keep = _marshal(extra_arguments)
         out = giddy_launch_configuration()
         c_limits = limits._c() if limits is not None else None

@@ -93,7 +93,7 @@ def key_compressed_indices_scatter(output_index_size, element_size, input_index_
 
 def frame_of_reference(decompressed, compressed_input, segment_model_coefficients, length, segment_length, *,
                        uncompressed_size=4, compressed_size=2, model="constant", index_size=4, model_index_size=4,
-                       stream=0, device=0, limits=None, launch_config=None):
+                       stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     dim = 1 if model == "constant" else 2
     return _run(
         key_frame_of_reference(index_size, uncompressed_size, compressed_size, model, model_index_size, 4),
@@ -106,7 +106,7 @@ def frame_of_reference(decompressed, compressed_input, segment_model_coefficient
 
 
 def model(decompressed, model_coefficients, length, *, uncompressed_size=4, model="linear", index_size=4,
-          stream=0, device=0, limits=None, launch_config=None):
+          stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_model(index_size, uncompressed_size, model),
         {"length": r.size_t(length)},
@@ -118,7 +118,7 @@ def model(decompressed, model_coefficients, length, *, uncompressed_size=4, mode
 
 def dictionary(decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, *,
                uncompressed_size=4, dictionary_index_size=1, index_size=4, cache_dictionary_in_shared_mem=None,
-               stream=0, device=0, limits=None, launch_config=None):
+               stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     resolve = {"num_dictionary_entries": r.size_t(num_dictionary_entries), "data_length": r.size_t(length)}
     launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
               "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * dictionary_index_size)),
@@ -134,7 +134,7 @@ def dictionary(decompressed, compressed_input, dictionary_entries, length, num_d
 
 
 def delta(decompressed, compressed_input, anchor_values, length, segment_length, *,
-          uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=0, limits=None, launch_config=None):
+          uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_delta(index_size, uncompressed_size, compressed_size),
         {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
@@ -146,7 +146,7 @@ def delta(decompressed, compressed_input, anchor_values, length, segment_length,
 
 
 def discard_zero_bytes_fixed(decompressed, compressed_input, length, *, uncompressed_size=8, compressed_size=4,
-                             index_size=4, stream=0, device=0, limits=None, launch_config=None):
+                             index_size=4, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size),
         {"length": r.size_t(length)},
@@ -159,7 +159,7 @@ def discard_zero_bytes_fixed(decompressed, compressed_input, length, *, uncompre
 def discard_zero_bytes_variable(decompressed, compressed_data, packed_element_sizes, position_anchors,
                                 segment_length, length, min_represented_element_size, bits_per_element_size, *,
                                 uncompressed_size=8, container_size=4, index_size=8,
-                                stream=0, device=0, limits=None, launch_config=None):
+                                stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_discard_zero_bytes_variable(index_size, uncompressed_size, container_size),
         {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
@@ -175,7 +175,7 @@ def discard_zero_bytes_variable(decompressed, compressed_data, packed_element_si
 
 def incidence_bitmaps(decompressed, bitmaps, dictionary_entries, bitmap_length, num_bitmaps, *,
                       uncompressed_size=4, alignment_in_ints=2, use_dictionary=True, index_size=4,
-                      stream=0, device=0, limits=None, launch_config=None):
+                      stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_incidence_bitmaps(index_size, uncompressed_size, alignment_in_ints, use_dictionary),
         {"length": r.size_t(32 * bitmap_length)},
@@ -190,7 +190,7 @@ def incidence_bitmaps(decompressed, bitmaps, dictionary_entries, bitmap_length, 
 def run_length_encoding(decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
                         segment_length, num_segments, num_element_runs, length, *,
                         uncompressed_size=4, run_length_size=2, index_size=4, run_index_size=None,
-                        stream=0, device=0, limits=None, launch_config=None):
+                        stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     run_index_size = run_index_size or index_size
     return _run(
         key_run_length_encoding(index_size, uncompressed_size, run_length_size, run_index_size),
@@ -210,7 +210,7 @@ def run_length_encoding(decompressed, run_data, run_lengths, position_anchors, i
 def run_position_encoding(decompressed, run_data, run_start_positions, position_anchors, segment_length,
                           num_anchors, num_element_runs, length, *, uncompressed_size=4, position_size=2,
                           relative=True, index_size=4, run_index_size=None,
-                          stream=0, device=0, limits=None, launch_config=None):
+                          stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     run_index_size = run_index_size or index_size
     return _run(
         key_run_position_encoding(index_size, uncompressed_size, position_size, relative, run_index_size),
@@ -227,7 +227,7 @@ def run_position_encoding(decompressed, run_data, run_start_positions, position_
 
 
 def scatter(target, data, indices, data_length, *, output_index_size=4, element_size=8, input_index_size=4,
-            stream=0, device=0, limits=None, launch_config=None):
+            stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     return _run(
         key_scatter(output_index_size, element_size, input_index_size),
         {"data_length": r.size_t(data_length)},
@@ -243,7 +243,7 @@ def compressed_indices_scatter(target, data_to_scatter, scatter_position_run_len
                                scatter_position_run_offsets_start_pos, scatter_position_offset_bytes,
                                scatter_position_anchors, anchoring_period, num_scatter_position_runs,
                                input_data_length, *, output_index_size=4, element_size=4, input_index_size=4,
-                               run_length_size=None, stream=0, device=0, limits=None, launch_config=None):
+                               run_length_size=None, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     run_length_size = run_length_size or input_index_size
     return _run(
         key_compressed_indices_scatter(output_index_size, element_size, input_index_size, run_length_size),
