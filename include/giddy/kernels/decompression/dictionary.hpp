@@ -8,9 +8,9 @@
 //    entry; its shared-memory dictionary cache is commented out and force-disabled
 //    (gather.cuh:33-90, :202-205);
 //  * here the dictionary is staged ONCE per workgroup into LDS (the launch configuration asks for
-//    num_entries * sizeof(entry) bytes of dynamic LDS whenever that fits) and workgroups are
-//    persistent — they walk tiles at grid stride, so the staging cost is amortised over the whole
-//    column.  A lane loads G keys as a single 4/8/16-byte load, performs G LDS look-ups
+//    num_entries * sizeof(entry) bytes of dynamic LDS whenever that fits); with a small dictionary
+//    every workgroup takes one tile, with a large one workgroups walk enough tiles at grid stride to
+//    amortise the staging (see the launch parameters below).  A lane loads G keys as a single 4/8/16-byte load, performs G LDS look-ups
 //    (ds_read; random keys cost a few bank-conflict cycles, far below the HBM budget of ~10 B/clk/CU)
 //    and writes 16-byte stores that are contiguous across the wavefront.
 //  * dictionaries that do not fit in LDS fall back to look-ups through L1/L2.
@@ -19,6 +19,8 @@
 // workgroup, L2-resident) — 5 B for 8-bit keys -> 32-bit values.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#include <algorithm>
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
@@ -43,11 +45,10 @@ enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
 
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 struct tiling {
-	enum : unsigned {
-		by_store = 16 / UncompressedSize,        // one 16-byte store
-		by_load  = 4 / DictionaryIndexSize,      // at least a 4-byte key load
-		elements_per_step = by_store > by_load ? by_store : (by_load > 0 ? by_load : 1),
-	};
+	// one 16-byte store per lane per step — contiguous across the wavefront; the keys of those elements
+	// arrive as one 1..16-byte load (measured: two 16-byte stores per lane, i.e. a 32-byte lane stride,
+	// costs more than the narrower key load saves)
+	enum : unsigned { elements_per_step = 16 / UncompressedSize };
 };
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup>
@@ -149,11 +150,26 @@ public:
 			should_cache_dictionary_in_shared_memory(num_dictionary_entries));
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
-		serialization_option          = auto_maximized;   // persistent workgroups: stage once, walk tiles at grid stride
+		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
-		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
-		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) (num_dictionary_entries * UncompressedSize); }
+		// Small dictionaries: one tile per workgroup (tiles handed out in address order, which HBM likes best —
+		// DESIGN.md §4); re-staging <= 2 KiB per 20 KiB of traffic is noise.  A large staged dictionary must be
+		// amortised instead: a persistent grid of exactly as many workgroups as fit on the chip with that much
+		// LDS each (at most 8 per CU), every one staging once and walking tiles at grid stride.
+		keep_gpu_busy_factor          = 1024;
+		size_t dictionary_bytes = num_dictionary_entries * UncompressedSize;
+		if (cache && dictionary_bytes > 2048) {
+			size_t lds_per_cu = device_properties.maxSharedMemoryPerMultiProcessor ? device_properties.maxSharedMemoryPerMultiProcessor : 65536;
+			// (measured: five 32 KiB workgroups do NOT fit a 160 KiB CU — leave a 1 KiB margin)
+			size_t workgroups_per_cu = std::min<size_t>(8, std::max<size_t>(1, (lds_per_cu - 1024) / dictionary_bytes));
+			// fewer workgroups per CU -> larger workgroups, to keep ~32 wavefronts per CU in flight
+			grid_block_dimension_t threads = workgroups_per_cu >= 8 ? 256 : (workgroups_per_cu >= 4 ? 512 : 1024);
+			upper_limits.threads_in_block = threads;
+			// the cap the resolver applies is CUs x 4 x factor / wavefronts-per-workgroup
+			keep_gpu_busy_factor = (unsigned) std::max<size_t>(1, workgroups_per_cu * (threads / warp_size) / 4);
+		}
+		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) dictionary_bytes; }
 		default_serialization_factor  = get_default_serialization_factor(cache);
 	}
 
