@@ -33,7 +33,7 @@ enum : unsigned {
 	tile_length         = 32 * tile_words,         // 4096 outputs per tile
 	runs_per_lane       = 4,                       // run descriptors examined per lane per batch
 	runs_per_batch      = 64 * runs_per_lane,
-	max_waves_per_block = 16,
+	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
 };
 
 struct tile_entry {
@@ -53,7 +53,8 @@ __device__ __forceinline__ void mark(tile_entry* table, uint32_t position_in_til
 	atomicOr(&table[position_in_tile >> 5].bits, 1u << (position_in_tile & 31));
 }
 
-__device__ __forceinline__ void rank(tile_entry* table, unsigned lane)
+/// fills rank_before; returns the number of run starts marked in the tile (wave-uniform)
+__device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 {
 	wave64::lds_fence();
 	uint32_t a = __builtin_popcount(table[words_per_lane * lane].bits);
@@ -63,18 +64,35 @@ __device__ __forceinline__ void rank(tile_entry* table, unsigned lane)
 	table[words_per_lane * lane].rank_before = exclusive;
 	table[words_per_lane * lane + 1].rank_before = exclusive + a;
 	wave64::lds_fence();
+	return wave64::read_last_lane(inclusive);
 }
 
+/// Narrow elements (1-2 bytes) are looked up E = 8..16 times per lane: through the vector memory pipeline
+/// that is 64 byte-sized gathers per instruction and it, not HBM, becomes the limit.  Their run values are
+/// therefore staged into wave-private LDS first (one coalesced sweep) and looked up there.
+template <unsigned ElementSize>
+struct value_staging {
+	enum : unsigned { enabled = ElementSize <= 2, bytes = 2048, capacity = bytes / ElementSize };
+};
+
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
+/// `staged` (may be null) is a wave-private LDS area of value_staging<ElementSize>::capacity elements;
+/// `num_runs_in_tile` = marks + 1.
 template <unsigned ElementSize>
 __device__ __forceinline__ void expand(
 	uint_t<ElementSize>* __restrict__ out, uint32_t tile_len, const tile_entry* table,
-	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane)
+	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane,
+	uint_t<ElementSize>* staged = nullptr, uint32_t num_runs_in_tile = 0)
 {
 	using namespace memory_access;
 	using element_type = uint_t<ElementSize>;
 	constexpr unsigned E = 16 / ElementSize;
 	const bool aligned = is_aligned(out, 16);
+	const bool use_staged = value_staging<ElementSize>::enabled && staged != nullptr && num_runs_in_tile <= value_staging<ElementSize>::capacity;
+	if (use_staged) {
+		for (uint32_t i = lane; i < num_runs_in_tile; i += 64) { staged[i] = first_run_data[i]; }
+		wave64::lds_fence();
+	}
 
 	for (uint32_t row_start = 0; row_start < tile_len; row_start += 64 * E) {
 		const uint32_t p = row_start + lane * E;
@@ -87,15 +105,21 @@ __device__ __forceinline__ void expand(
 			ranks[j] = entry.rank_before + __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - bit)));
 		}
 		group<element_type, E> values;
-		element_type first = first_run_data[ranks[0]];
-		if (ranks[E - 1] == ranks[0]) {
+		if (use_staged) {
 			#pragma unroll
-			for (unsigned j = 0; j < E; j++) { values[j] = first; }
+			for (unsigned j = 0; j < E; j++) { values[j] = staged[ranks[j]]; }
 		}
 		else {
-			values[0] = first;
-			#pragma unroll
-			for (unsigned j = 1; j < E; j++) { values[j] = first_run_data[ranks[j]]; }
+			element_type first = first_run_data[ranks[0]];
+			if (ranks[E - 1] == ranks[0]) {
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) { values[j] = first; }
+			}
+			else {
+				values[0] = first;
+				#pragma unroll
+				for (unsigned j = 1; j < E; j++) { values[j] = first_run_data[ranks[j]]; }
+			}
 		}
 		if (aligned && p + E <= tile_len) { store_group(out + p, values); }
 		else {
@@ -103,7 +127,7 @@ __device__ __forceinline__ void expand(
 			for (unsigned j = 0; j < E; j++) { if (p + j < tile_len) { out[p + j] = values[j]; } }
 		}
 	}
-	wave64::lds_fence();   // the table may be cleared for the next tile after this
+	wave64::lds_fence();   // the table (and the staged values) may be rewritten for the next tile after this
 }
 
 } // namespace run_expansion

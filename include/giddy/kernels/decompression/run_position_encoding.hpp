@@ -44,11 +44,18 @@ __global__ void decompress(
 		"If run positions are in absolute values, their type must be able to cover the entire potential range of data");
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
+	using staging = value_staging<UncompressedSize>;
+	__shared__ uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::capacity : 1];
+	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
 
+	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256
+	// threads); in a larger workgroup the extra wavefronts sit idle — there is no barrier they could miss
+	const unsigned working_waves = wave64::per_block() < max_waves_per_block ? wave64::per_block() : max_waves_per_block;
+	if (wave64::index_in_block() >= working_waves) { return; }
 	const unsigned lane = wave64::lane_id();
-	tile_entry* table = tables[wave64::index_in_block() % max_waves_per_block];
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	tile_entry* table = tables[wave64::index_in_block()];
+	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
 
 	for (uint64_t s = wave; s < num_anchors; s += num_waves) {
@@ -86,8 +93,8 @@ __global__ void decompress(
 				batch_base += runs_per_batch;
 			} while (!reached_past_tile);
 
-			rank(table, lane);
-			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+			const uint32_t marks = rank(table, lane);
+			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
