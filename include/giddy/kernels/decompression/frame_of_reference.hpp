@@ -69,8 +69,9 @@ __global__ void decompress(
 	(void) num_segments_to_decompress_per_block;
 
 	const uint64_t n = length, L = segment_length;
-	auto element = [&](uint64_t segment, uint64_t within, Compressed offset) -> Uncompressed {
-		UnaryModelFunction segment_model(segment_model_coefficients[segment]);
+	using coefficients_type = typename UnaryModelFunction::coefficients_type;
+	auto predict = [](const coefficients_type& record, uint64_t within, Compressed offset) -> Uncompressed {
+		UnaryModelFunction segment_model(record);
 		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
 		return (Uncompressed) (predicted_value + offset);
 	};
@@ -93,11 +94,17 @@ __global__ void decompress(
 			if (g >= num_groups) { continue; }
 			uint64_t segment, within;
 			detail::divide<IndexSize>(g * G, L, segment, within);
+			// the segment's record is fetched once per group (neighbouring lanes hit the same address) and
+			// again only if the group crosses into the next segment
+			coefficients_type record = segment_model_coefficients[segment];
 			group<Uncompressed, G> out;
 			#pragma unroll
 			for (unsigned j = 0; j < G; j++) {
-				out[j] = element(segment, within, in[k][j]);
-				if (++within == L) { within = 0; segment++; }
+				out[j] = predict(record, within, in[k][j]);
+				if (++within == L) {
+					within = 0; segment++;
+					if (j + 1 < G) { record = segment_model_coefficients[segment]; }
+				}
 			}
 			store_group(decompressed + g * G, out);
 		}
@@ -109,7 +116,7 @@ __global__ void decompress(
 	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
 		uint64_t segment, within;
 		detail::divide<IndexSize>(p, L, segment, within);
-		decompressed[p] = element(segment, within, compressed_input[p]);
+		decompressed[p] = predict(segment_model_coefficients[segment], within, compressed_input[p]);
 	}
 }
 
