@@ -60,3 +60,16 @@ def test_sharded_decode_on_gpu(world):
     truth = f["dictionary_entries"][f["compressed_input"].astype(np.int64)]
     run(sharding.elementwise, f, truth,
         lambda out, s: schemes.dictionary(out, g.dev(s["compressed_input"]), g.dev(s["dictionary_entries"]), s["length"], 256, stream=st), np.uint32)
+
+
+def test_pipelined_decode_from_pinned_host_memory():
+    """libgiddy_amd.pipeline: chunks copied H2D on several streams while earlier chunks decode."""
+    from libgiddy_amd import pipeline
+    n = (1 << 22) + 12345
+    gen = torch.Generator(); gen.manual_seed(3)
+    keys_host = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=gen).pin_memory()
+    entries = (torch.arange(256, device="cuda") * 16777259 + 5).to(torch.int32)
+    out = torch.full((n,), -1, dtype=torch.int32, device="cuda")
+    for s in pipeline.dictionary_from_host(keys_host, entries, out, chunk_elements=1 << 20, depth=3):
+        s.synchronize()
+    assert bool((out == entries[keys_host.cuda().long()]).all())
