@@ -68,10 +68,14 @@ def make_workload(name, n, device):
 
 
 def timed_steps(work, steps, warmup, barrier):
-    """EXACTLY `steps` timed passes between barrier+synchronize brackets; per-launch durations from
-    HIP events recorded on the launch stream (torch's current stream, the one the kernels are enqueued on)."""
+    """EXACTLY `steps` timed passes between barrier+synchronize brackets.  The dominant kernel's launch
+    duration comes from a HIP event pair recorded around THAT launch on the launch stream (torch's current
+    stream, the one the kernels are enqueued on); a step with a second small kernel (Delta + patches) passes
+    the pair down so that only the decoder is bracketed."""
+    import inspect
     import torch
     stream = torch.cuda.current_stream().cuda_stream
+    brackets_itself = "around_dominant_kernel" in inspect.signature(work.run).parameters
     for _ in range(warmup):
         work.run(stream)
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
@@ -79,9 +83,12 @@ def timed_steps(work, steps, warmup, barrier):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for begin, end in events:
-        begin.record()
-        work.run(stream)
-        end.record()
+        if brackets_itself:
+            work.run(stream, around_dominant_kernel=(begin.record, end.record))
+        else:
+            begin.record()
+            work.run(stream)
+            end.record()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -143,10 +143,18 @@ __device__ __forceinline__ void wave_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
+		// Software-pipelined: the NEXT group's loads are issued before this group's stores.  CDNA4 retires
+		// vector-memory operations in order, so a load issued after a store cannot be waited for without
+		// waiting for the store too; this way a wavefront waits for one HBM round trip per group, not two.
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { rows[k].load(in, start + (uint64_t) k * traits::row, end, lane); }
 		for (uint64_t row_start = start; row_start < end; row_start += (uint64_t) R * traits::row) {
-			row_t<UncompressedSize, CompressedSize> rows[R];
-			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { rows[k].load(in, row_start + (uint64_t) k * traits::row, end, lane); }
+			const uint64_t next_start = row_start + (uint64_t) R * traits::row;
+			if (next_start < end) {
+				#pragma unroll
+				for (unsigned k = 0; k < R; k++) { next[k].load(in, next_start + (uint64_t) k * traits::row, end, lane); }
+			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
 			#pragma unroll
@@ -154,6 +162,8 @@ __device__ __forceinline__ void wave_per_segment(
 				rows[k].store(out, row_start + (uint64_t) k * traits::row, end, lane, base);
 				base += (U) rows[k].total;
 			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; }
 		}
 	}
 }

@@ -142,14 +142,21 @@ class DeltaPatched:
         self.patch_idx = torch.sort(torch.randperm(n, generator=_gen(seed + 1, device), device=device)[: self.p])[0].to(torch.int32)
         self.patch_val = torch.randint(0, 1 << 62, (self.p,), dtype=torch.int64, generator=_gen(seed + 2, device), device=device)
         self.output = torch.empty(n, dtype=torch.int64, device=device)
-        self.algorithmic_bytes = 10 * n + 8 * nseg + self.p * 20
+        self.algorithmic_bytes = 10 * n + 8 * nseg             # the dominant kernel (Delta) alone
+        self.step_algorithmic_bytes = self.algorithmic_bytes + self.p * 20   # + patches: index, value, scattered store
         self.decompressed_bytes = 8 * n
         st = torch.cuda.current_stream().cuda_stream
         self.config = schemes.delta(self.output, self.deltas, self.anchors, n, segment_length, stream=st)
         self.patch_config = schemes.scatter(self.output, self.patch_val, self.patch_idx, self.p, stream=st)
 
-    def run(self, stream):
+    def run(self, stream, around_dominant_kernel=None):
+        """one step = the Delta decode, then the naive patches on the same stream; `around_dominant_kernel`
+        (begin, end) callables bracket the Delta launch alone, for the per-kernel roofline"""
+        if around_dominant_kernel:
+            around_dominant_kernel[0]()
         schemes.delta(self.output, self.deltas, self.anchors, self.n, self.L, stream=stream, launch_config=self.config)
+        if around_dominant_kernel:
+            around_dominant_kernel[1]()
         schemes.scatter(self.output, self.patch_val, self.patch_idx, self.p, stream=stream, launch_config=self.patch_config)
 
     def verify(self, oracle, sample=1 << 22):
