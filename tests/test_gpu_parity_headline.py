@@ -192,3 +192,15 @@ def test_launches_are_graph_capturable():
     out.fill_(0xCD)
     graph.replay()
     assert (g.host(out, np.uint64, n) == expect).all()
+
+
+def test_dictionary_128_kib_staged_in_lds():
+    """a full 16-bit-key dictionary of 16-bit values (128 KiB) is staged in LDS by one 1024-thread workgroup per CU"""
+    schemes, r, g = _imports()
+    n, entries = 3000001, 1 << 16
+    f = cases.dictionary_case(n, entries, np.uint16, np.uint16, seed=31)
+    out = g.dev_empty(n, np.uint16)
+    cfg = schemes.dictionary(out, g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"]), n, entries,
+                             uncompressed_size=2, dictionary_index_size=2, stream=g.stream())
+    assert cfg.dynamic_shared_memory_size == 2 * entries and cfg.block_dimensions[0] == 1024
+    assert (g.host(out, np.uint16, n) == oracle.dictionary(f["compressed_input"], f["dictionary_entries"])).all()
