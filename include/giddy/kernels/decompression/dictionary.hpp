@@ -25,6 +25,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -41,57 +42,23 @@ constexpr serialization_factor_t get_default_serialization_factor(bool cache_all
 
 namespace detail {
 
-enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
-
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
-struct tiling {
-	// one 16-byte store per lane per step — contiguous across the wavefront; the keys of those elements
-	// arrive as one 1..16-byte load (measured: two 16-byte stores per lane, i.e. a 32-byte lane stride,
-	// costs more than the narrower key load saves)
-	enum : unsigned { elements_per_step = 16 / UncompressedSize };
-};
-
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup>
+/// out[p] = lookup(keys[p]) over the shared streaming tile loop
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
 	uint64_t                                          n,
 	Lookup                                            lookup)
 {
-	using namespace memory_access;
 	using key_type = uint_t<DictionaryIndexSize>;
 	using value_type = uint_t<UncompressedSize>;
-	constexpr unsigned G = tiling<UncompressedSize, DictionaryIndexSize>::elements_per_step;
-	constexpr unsigned K = steps_per_tile;
-
-	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * sizeof(key_type) >= 16 ? 16 : G * sizeof(key_type));
-	const uint64_t num_groups = vectorizable ? n / G : 0;
-	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
-
-	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
-		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
-		group<key_type, G> keys[K];
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g < num_groups) { keys[k] = load_group<key_type, G>(compressed_input + g * G); }
-		}
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g >= num_groups) { continue; }
-			group<value_type, G> out;
+	constexpr unsigned G = stream_tiles::group_size<value_type>::value;
+	stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n,
+		[&](uint64_t, const memory_access::group<key_type, G>& keys, memory_access::group<value_type, G>& out) {
 			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[k][j]); }
-			store_group(decompressed + g * G, out);
-		}
-	}
-
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
-	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
-		decompressed[p] = lookup(compressed_input[p]);
-	}
+			for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
+		},
+		[&](uint64_t, key_type key) { return lookup(key); });
 }
 
 } // namespace detail
@@ -115,11 +82,11 @@ __global__ void decompress(
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();
-		detail::translate<IndexSize, UncompressedSize, DictionaryIndexSize>(
+		detail::translate<UncompressedSize, DictionaryIndexSize>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; });
 	}
 	else {
-		detail::translate<IndexSize, UncompressedSize, DictionaryIndexSize>(
+		detail::translate<UncompressedSize, DictionaryIndexSize>(
 			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; });
 	}
 }
@@ -144,8 +111,7 @@ public:
 		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
 	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
 	{
-		constexpr unsigned elements_per_thread_per_tile =
-			detail::tiling<UncompressedSize, DictionaryIndexSize>::elements_per_step * detail::steps_per_tile;
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		bool cache = cache_dictionary_in_shared_memory_override.value_or(
 			should_cache_dictionary_in_shared_memory(num_dictionary_entries));
 		grid_construction_resolution  = thread;

@@ -11,6 +11,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -21,8 +22,6 @@ namespace discard_zero_bytes {
 namespace fixed_width {
 
 enum : serialization_factor_t { DefaultSerializationFactor = 32 };
-
-namespace detail { enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE }; }
 
 template <unsigned UncompressedSize, unsigned CompressedSize, cuda::endianness_t OutputEndianness>
 struct pad_high_bytes {
@@ -41,39 +40,16 @@ __global__ void decompress(
 	const uint_t<CompressedSize>*  __restrict__  compressed_input,
 	size_type_by_index_size<IndexSize>           length)
 {
-	using namespace memory_access;
 	using U = uint_t<UncompressedSize>;
 	using C = uint_t<CompressedSize>;
-	constexpr unsigned G = 16 / UncompressedSize;
-	constexpr unsigned K = detail::steps_per_tile;
+	constexpr unsigned G = stream_tiles::group_size<U>::value;
 	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
-
-	const uint64_t n = length;
-	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * CompressedSize);
-	const uint64_t num_groups = vectorizable ? n / G : 0;
-	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
-
-	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
-		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
-		group<C, G> in[K];
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g < num_groups) { in[k] = load_group<C, G>(compressed_input + g * G); }
-		}
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g >= num_groups) { continue; }
-			group<U, G> out;
+	stream_tiles::transform<C, U>(decompressed, compressed_input, length,
+		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
 			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[k][j]); }
-			store_group(decompressed + g * G, out);
-		}
-	}
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
-	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) { decompressed[p] = widen(compressed_input[p]); }
+			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
+		},
+		[&](uint64_t, C x) { return widen(x); });
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
@@ -87,7 +63,7 @@ public:
 		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_, size_t length_)
 	: parent(device_properties_, kernel_function_attributes_)
 	{
-		constexpr unsigned elements_per_thread_per_tile = (16 / UncompressedSize) * detail::steps_per_tile;
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;

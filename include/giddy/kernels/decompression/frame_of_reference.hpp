@@ -26,6 +26,7 @@
 #include "giddy/functors/model_functors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -37,8 +38,6 @@ namespace frame_of_reference {
 enum : serialization_factor_t { DefaultSerializationFactor = 16 };
 
 namespace detail {
-
-enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
 
 template <unsigned IndexSize>
 __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotient, uint64_t& remainder)
@@ -62,62 +61,38 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>  segment_length,
 	uint_t<IndexSize>                   num_segments_to_decompress_per_block) // kept for signature parity; the tiling here does not depend on it
 {
-	using namespace memory_access;
 	using model_index_type = typename UnaryModelFunction::index_type;
-	constexpr unsigned G = 16 / sizeof(Uncompressed);
-	constexpr unsigned K = detail::steps_per_tile;
-	(void) num_segments_to_decompress_per_block;
-
-	const uint64_t n = length, L = segment_length;
 	using coefficients_type = typename UnaryModelFunction::coefficients_type;
+	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
+	(void) num_segments_to_decompress_per_block;
+	const uint64_t L = segment_length;
+
 	auto predict = [](const coefficients_type& record, uint64_t within, Compressed offset) -> Uncompressed {
 		UnaryModelFunction segment_model(record);
 		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
 		return (Uncompressed) (predicted_value + offset);
 	};
-
-	const bool vectorizable = is_aligned(decompressed, 16) && is_aligned(compressed_input, G * sizeof(Compressed));
-	const uint64_t num_groups = vectorizable ? n / G : 0;
-	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
-
-	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
-		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
-		group<Compressed, G> in[K];
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g < num_groups) { in[k] = load_group<Compressed, G>(compressed_input + g * G); }
-		}
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g >= num_groups) { continue; }
+	stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length,
+		[&](uint64_t first_position, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out) {
 			uint64_t segment, within;
-			detail::divide<IndexSize>(g * G, L, segment, within);
+			detail::divide<IndexSize>(first_position, L, segment, within);
 			// the segment's record is fetched once per group (neighbouring lanes hit the same address) and
 			// again only if the group crosses into the next segment
 			coefficients_type record = segment_model_coefficients[segment];
-			group<Uncompressed, G> out;
 			#pragma unroll
 			for (unsigned j = 0; j < G; j++) {
-				out[j] = predict(record, within, in[k][j]);
+				out[j] = predict(record, within, in[j]);
 				if (++within == L) {
 					within = 0; segment++;
 					if (j + 1 < G) { record = segment_model_coefficients[segment]; }
 				}
 			}
-			store_group(decompressed + g * G, out);
-		}
-	}
-
-	// whatever the vector path did not cover: the ragged tail, or everything if a base pointer is unaligned
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
-	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
-		uint64_t segment, within;
-		detail::divide<IndexSize>(p, L, segment, within);
-		decompressed[p] = predict(segment_model_coefficients[segment], within, compressed_input[p]);
-	}
+		},
+		[&](uint64_t position, Compressed offset) {
+			uint64_t segment, within;
+			detail::divide<IndexSize>(position, L, segment, within);
+			return predict(segment_model_coefficients[segment], within, offset);
+		});
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
@@ -137,7 +112,7 @@ public:
 		if (segment_length % sizeof(native_word_t) != 0) {
 			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
 		}
-		constexpr unsigned elements_per_thread_per_tile = (16 / sizeof(Uncompressed)) * detail::steps_per_tile;
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride

@@ -13,6 +13,7 @@
 #include "giddy/functors/model_functors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -21,40 +22,21 @@ namespace kernels {
 namespace decompression {
 namespace model {
 
-namespace detail { enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE }; }
-
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
 __global__ void decompress(
 	Uncompressed* __restrict__                      decompressed,
 	typename UnaryModelFunction::coefficients_type  model_coefficients,
 	size_type_by_index_size<IndexSize>              length)
 {
-	using namespace memory_access;
 	using model_index_type = typename UnaryModelFunction::index_type;
-	constexpr unsigned G = 16 / sizeof(Uncompressed);
-	constexpr unsigned K = detail::steps_per_tile;
+	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	UnaryModelFunction model(model_coefficients);
-
-	const uint64_t n = length;
-	const uint64_t num_groups = is_aligned(decompressed, 16) ? n / G : 0;
-	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
-	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
-		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
-		#pragma unroll
-		for (unsigned k = 0; k < K; k++) {
-			uint64_t g = first_group + (uint64_t) k * blockDim.x;
-			if (g >= num_groups) { continue; }
-			group<Uncompressed, G> out;
+	stream_tiles::generate<Uncompressed>(decompressed, length,
+		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (g * G + j))); }
-			store_group(decompressed + g * G, out);
-		}
-	}
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
-	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) {
-		decompressed[p] = static_cast<Uncompressed>(model((model_index_type) p));
-	}
+			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
+		},
+		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); });
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
@@ -66,7 +48,7 @@ public:
 		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_, size_t length_)
 	: parent(device_properties_, kernel_function_attributes_)
 	{
-		constexpr unsigned elements_per_thread_per_tile = (16 / sizeof(Uncompressed)) * detail::steps_per_tile;
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;
