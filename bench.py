@@ -60,6 +60,7 @@ def make_workload(name, n, device):
         "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
         "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),
         "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device),
+        "discard_zero_bytes_variable_3bit": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device, bits=3),
         "discard_zero_bytes_fixed": lambda: w.DiscardZeroBytesFixed(n, device),
         "model": lambda: w.Model(n, device),
         "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, 1 << 28), device),
@@ -193,7 +194,7 @@ def main():
         names = ["dictionary_zipf", "frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
                  "run_position_encoding_absolute", "discard_zero_bytes_variable"]
         if args.schemes == "coverage":
-            names += ["discard_zero_bytes_fixed", "model", "incidence_bitmaps"]
+            names += ["discard_zero_bytes_variable_3bit", "discard_zero_bytes_fixed", "model", "incidence_bitmaps"]
         elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
         del work

@@ -334,6 +334,7 @@ class DiscardZeroBytesVariable:
     def __init__(self, n, device, seed=8, segment_length=1024, bits=2, min_size=1):
         g = _gen(seed, device)
         self.n, self.L, self.bits, self.min_size = n, segment_length, bits, min_size
+        self.name = "discard_zero_bytes::variable_width<8,8,4> (%d-bit sizes, %d..%d bytes)" % (bits, min_size, min(8, min_size + (1 << bits) - 1))
         per = 32 // bits
         sizes = torch.randint(min_size, min_size + (1 << bits), (n,), dtype=torch.int64, generator=g, device=device).clamp_(max=8)
         offsets = torch.cumsum(sizes, 0) - sizes
@@ -374,7 +375,7 @@ class DiscardZeroBytesVariable:
         n, L = self.n, self.L
         sample = min((sample // L) * L, n)
         nbytes = int(self.anchors[sample // L]) if sample < n else self.total_bytes
-        expect = oracle.dzb_variable(_np(self.data[:nbytes]), _np(self.packed[: (sample * self.bits + 31) // 32 + 1], np.uint32),
+        expect = oracle.dzb_variable(_np(self.data[:nbytes]), _np(self.packed[: -(-sample // (32 // self.bits)) + 1], np.uint32),
                                      _np(self.anchors[: (sample + L - 1) // L], np.uint64), L, sample, self.min_size, self.bits, np.uint64)
         assert (expect == _np(self.output[:sample], np.uint64)).all(), "DZB-V: sample mismatch vs oracle"
         assert bool((self.output == self.values).all())
@@ -383,7 +384,7 @@ class DiscardZeroBytesVariable:
         L = self.L
         sample = min((sample // L) * L, self.n)
         nbytes = int(self.anchors[sample // L]) if sample < self.n else self.total_bytes
-        data = _np(self.data[:nbytes]).copy(); packed = _np(self.packed[: (sample * self.bits + 31) // 32 + 1], np.uint32).copy()
+        data = _np(self.data[:nbytes]).copy(); packed = _np(self.packed[: -(-sample // (32 // self.bits)) + 1], np.uint32).copy()
         an = _np(self.anchors[: sample // L], np.uint64).copy()
         out = np.empty(sample, dtype=np.uint64)
         return (lambda: oracle.dzb_variable(data, packed, an, L, sample, self.min_size, self.bits, np.uint64, threads=threads, out=out)), 8 * sample
