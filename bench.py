@@ -105,6 +105,33 @@ def roofline(work, mean_launch_ms, traffic):
             "mean_launch_ms": round(mean_launch_ms, 4)}
 
 
+def measured_copy_ceiling():
+    """what this box sustains on a plain device-to-device copy of 4 GiB (hipMemcpy D2D via torch), read + write GB/s"""
+    import torch
+    a = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
+    b = torch.empty_like(a)
+    b.copy_(a); torch.cuda.synchronize()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for begin, end in events:
+        begin.record(); b.copy_(a); end.record()
+    torch.cuda.synchronize()
+    ms = sorted(x.elapsed_time(y) for x, y in events)[2]
+    del a, b
+    torch.cuda.empty_cache()
+    return round(2 * 4 * (1 << 30) / ms / 1e6, 1)
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def committed_traffic(kernel):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json), or None."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -130,7 +157,7 @@ def cpu_baseline(work, sample, unit_bytes_label="decompressed GB/s"):
         results[threads] = out_bytes / best / 1e9
     return {"value": round(results[cores], 3), "unit": unit_bytes_label, "cores": cores, "kind": "port",
             "sample": "first %d elements of the same workload, CPU oracle (oracle/giddy_oracle.c, gcc -O3 -fopenmp), best of >=3" % sample,
-            "single_thread_value": round(results[1], 3)}
+            "single_thread_value": round(results[1], 3), "cpu": cpu_model()}
 
 
 def main():
@@ -186,6 +213,10 @@ def main():
         "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel)),
     }
 
+    if rank == 0 and world == 1:
+        ceiling = measured_copy_ceiling()
+        line["roofline"]["measured_d2d_copy_GBps"] = ceiling
+        line["roofline"]["frac_of_measured_copy"] = round(line["roofline"]["achieved"] / ceiling, 4)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(work, min(n, 1 << args.cpu_sample_log2))
 

@@ -15,12 +15,13 @@
 // iteration: integer div+mod, a 5-step shuffle scan, a byte-wise unaligned memcpy from global
 // memory and a broadcast, per 32 elements.  Here a WAVEFRONT owns a segment (segments at grid
 // stride) and works in rows of 64*E elements, E = 16/UncompressedSize consecutive elements per lane:
-//   1. size fields: one division per lane per row, then E shifts/masks;
+//   1. size fields: the lane's position within its container by a reciprocal multiply, then E shifts/masks;
 //   2. byte offsets: in-lane running sum + one 64-lane DPP prefix sum (row byte counts < 2^11);
 //   3. the row's compressed bytes — one contiguous range of <= 1 KiB — are staged into LDS with
 //      16-byte-per-lane COALESCED loads of exactly the 16-byte chunks that overlap the range (so the
 //      kernel never touches a chunk holding no valid byte: nothing is read past the buffer's end);
-//   4. each element is cut out of LDS with aligned 32-bit reads + a funnel shift and masked to n_i bytes;
+//   4. each element is cut out of LDS with aligned 32-bit reads + v_alignbyte and masked to n_i bytes through
+//      a 9-entry mask table kept in LDS;
 //   5. one 16-byte store per lane, contiguous across the wavefront.
 // Rows are processed four at a time and software-pipelined two groups deep (see the kernel body), so
 // HBM round trips overlap instead of adding up.  No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +

@@ -11,9 +11,9 @@
 //    >1024-element column un-launchable, frame_of_reference.cuh:111-113);
 //  * here the kernel is a plain HBM stream: a lane owns G = 16/sizeof(Uncompressed) consecutive
 //    elements per step, reads them as one 4/8-byte load, writes them as one 16-byte store, and
-//    every workgroup walks tiles of K steps at grid stride.  Segments only matter for picking the
-//    coefficient record: one integer division per G elements, record fetched through L1/L2
-//    (neighbouring lanes hit the same record).  Any grid/block shape is correct.
+//    the tile loop is the one all streaming decoders share (on_device/stream_tiles.hpp).  Segments only
+//    matter for picking the coefficient record: one integer division and one record fetch (through
+//    L1/L2; neighbouring lanes hit the same record) per G elements.  Any grid/block shape is correct.
 //
 // HBM traffic per element: sizeof(Compressed) read + sizeof(Uncompressed) written (+ one record per
 // segment) — the algorithmic minimum (6 B for int32 <- int16).
