@@ -204,3 +204,16 @@ def test_scatter_and_compressed_indices(esize, osize, isize):
             c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"],
             c["scatter_position_anchors"], period, osize)
         assert (got2 == expect).all()
+
+
+def test_config_c1_frame_of_reference_single_segment_1m():
+    """BASELINE.json configs[0]: FOR, int32 <- int16, ONE segment of 2^20 elements, reference value 1 000 000,
+    offsets uniform over the int16 range (seed 1) — the CPU plumbing case: C oracle (1 and 8 threads) == numpy."""
+    n = 1 << 20
+    r = cases.rng(1)
+    comp = r.integers(-32768, 32767, size=n, endpoint=True).astype(np.int16)
+    coefs = np.array([[1000000]], dtype=np.int32)
+    a = oracle.frame_of_reference(comp, coefs, n, n, np.int32, "constant")
+    assert (a == (1000000 + comp.astype(np.int64)).astype(np.int32)).all()
+    assert (a == oracle.frame_of_reference(comp, coefs, n, n, np.int32, "constant", threads=8)).all()
+    assert (a[:5000] == naive.frame_of_reference(comp[:5000], coefs, 5000, n, np.int32, "constant")).all()
