@@ -42,6 +42,20 @@ __device__ __forceinline__ void transform(
 	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
 		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 		group<In, G> inputs[K];
+		if ((tile + 1) * groups_per_tile <= num_groups) {
+			// a whole tile (every tile but possibly the last): no per-step bounds checks, so the K loads and the
+			// K stores form straight-line code the compiler can schedule with counted waits
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { inputs[k] = load_group<In, G>(in + (first_group + (uint64_t) k * blockDim.x) * G); }
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				group<Out, G> outputs;
+				produce_group(g * G, inputs[k], outputs);
+				store_group(out + g * G, outputs);
+			}
+			continue;
+		}
 		#pragma unroll
 		for (unsigned k = 0; k < K; k++) {
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
