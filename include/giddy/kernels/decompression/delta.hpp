@@ -17,9 +17,11 @@
 //    that is contiguous across the wavefront.  R rows are in flight per wavefront; their scans are
 //    independent and only the R row totals chain.  When the deltas are <= 2 bytes wide the
 //    in-row scan runs in 32 bits even for 64-bit outputs (a row's prefix cannot overflow).
-//  * wave path (segment_length % row == 0, segment_length <= 16384): one wavefront per anchored
-//    segment, carry in a register, NO barriers and no LDS at all.  (Measured on MI355X: 2 rows in
-//    flight per wavefront is the best setting; the block path is no faster at 4096-element segments.)
+//  * wave path (segment_length % row == 0, at most 32 rows = 32 KiB of output per segment): one
+//    wavefront per anchored segment — or per batch of short segments adding up to 32 rows — carry in
+//    a register, NO barriers and no LDS at all; the next group's loads are issued before this group's
+//    stores.  (Measured on MI355X: 2 rows in flight is the best setting; at 4096-element segments of
+//    64-bit values the block path is no faster, from 8192 elements on it is.)
 //  * block path (longer segments): a workgroup of ceil(rows per segment / 8) wavefronts (at most 16)
 //    owns a segment; wavefront w takes 8 consecutive rows of each sweep, all its loads are issued
 //    before the single barrier of the sweep, carries cross wavefronts through a double-buffered
@@ -55,9 +57,6 @@ namespace detail {
 #ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
 #define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
 #endif
-#ifndef GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH
-#define GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH 16384
-#endif
 #ifndef GIDDY_DELTA_WAVE_PATH_THREADS
 #define GIDDY_DELTA_WAVE_PATH_THREADS 256
 #endif
@@ -65,8 +64,9 @@ namespace detail {
 enum : unsigned {
 	rows_in_flight = GIDDY_DELTA_ROWS_IN_FLIGHT,                                  // wave path
 	rows_per_wave_per_sweep = GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP,                // block path
-	longest_segment_for_wave_path = GIDDY_DELTA_LONGEST_SEGMENT_FOR_WAVE_PATH,    // longer segments are swept by a whole workgroup
 	wave_path_threads = GIDDY_DELTA_WAVE_PATH_THREADS,
+	rows_per_chunk = 32,                                                          // wave path: rows a wavefront takes per outer-loop trip;
+	                                                                              // segments of more rows are swept by a whole workgroup
 	max_waves_per_block = 16,
 };
 
@@ -125,7 +125,14 @@ struct row_t {
 	}
 };
 
-/// wave path: this wavefront decompresses whole segments on its own
+/// Segments per wavefront chunk on the wave path: short segments are batched so that a wavefront always has
+/// about `rows_per_chunk` rows of work between two trips around its outer loop (kernel and launch parameters agree).
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_segment)
+{
+	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / rows_per_segment;
+}
+
+/// wave path: this wavefront decompresses whole segments on its own (several short ones per chunk)
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __device__ __forceinline__ void wave_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
@@ -137,12 +144,14 @@ __device__ __forceinline__ void wave_per_segment(
 	const unsigned lane = wave64::lane_id();
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
-	const uint64_t num_segments = (n + L - 1) / L;
+	const uint64_t chunk_length = segments_per_wave_chunk(L / traits::row) * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
 
-	for (uint64_t s = wave; s < num_segments; s += num_waves) {
-		const uint64_t start = s * L;
-		const uint64_t end = (start + L < n) ? start + L : n;
-		U base = anchors[s];
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t start = c * chunk_length;
+		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
+		uint64_t segment = start / L, next_segment_start = start;   // the chunk starts on a segment boundary
+		U base = 0;
 		// Software-pipelined: the NEXT group's loads are issued before this group's stores.  CDNA4 retires
 		// vector-memory operations in order, so a load issued after a store cannot be waited for without
 		// waiting for the store too; this way a wavefront waits for one HBM round trip per group, not two.
@@ -159,7 +168,9 @@ __device__ __forceinline__ void wave_per_segment(
 			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
-				rows[k].store(out, row_start + (uint64_t) k * traits::row, end, lane, base);
+				const uint64_t this_row = row_start + (uint64_t) k * traits::row;
+				if (this_row == next_segment_start && this_row < end) { base = anchors[segment++]; next_segment_start += L; }   // wave-uniform
+				rows[k].store(out, this_row, end, lane, base);
 				base += (U) rows[k].total;
 			}
 			#pragma unroll
@@ -293,7 +304,7 @@ __global__ void decompress(
 	const bool rows_fit_segments = (L % traits::row == 0)
 		&& memory_access::is_aligned(decompressed, 16)
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
-	if (rows_fit_segments && L <= detail::longest_segment_for_wave_path) {
+	if (rows_fit_segments && L / traits::row <= detail::rows_per_chunk) {
 		detail::wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
 	}
 	else if (rows_fit_segments && wave64::per_block() <= detail::max_waves_per_block) {
@@ -320,7 +331,7 @@ public:
 		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		auto num_segments = util::div_rounding_up(data_length, segment_length);
-		bool wave_path = segment_length % traits::row == 0 && segment_length <= detail::longest_segment_for_wave_path;
+		bool wave_path = segment_length % traits::row == 0 && segment_length / traits::row <= detail::rows_per_chunk;
 		bool block_path = segment_length % traits::row == 0 && !wave_path;
 		if (block_path) {
 			// one workgroup per segment (segments at grid stride), as many wavefronts as one sweep needs
@@ -336,7 +347,8 @@ public:
 			// one wavefront per segment (or per row-sized run of short segments), at grid stride
 			grid_construction_resolution = warp;
 			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
-			length = wave_path ? num_segments : util::div_rounding_up(num_segments, per_chunk);
+			length = wave_path ? util::div_rounding_up(num_segments, (size_t) detail::segments_per_wave_chunk(segment_length / traits::row))
+			                   : util::div_rounding_up(num_segments, per_chunk);
 			upper_limits.threads_in_block = detail::wave_path_threads;
 		}
 		serialization_option = auto_maximized;

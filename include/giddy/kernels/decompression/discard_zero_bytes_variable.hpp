@@ -52,6 +52,7 @@ namespace detail {
 enum : unsigned {
 	max_waves_per_block = 4,          // the launch parameters cap the workgroup at 256 threads
 	rows_in_flight = GIDDY_DZBV_ROWS_IN_FLIGHT,
+	rows_per_chunk = 8,               // a wavefront batches short segments up to this many rows per outer-loop trip
 	staging_bytes = 1024 + 16 + 16,   // a row's bytes + head misalignment + over-read slack for the aligned dword reads
 	staging_words = staging_bytes / 4,
 };
@@ -108,6 +109,45 @@ __device__ __forceinline__ unsigned size_of(Container fields, unsigned j, unsign
 	return size > UncompressedSize ? UncompressedSize : size;   // precondition n_i <= sizeof(element); never read more
 }
 
+/// where a wavefront is in the compressed byte stream (all wave-uniform)
+template <unsigned IndexSize>
+struct segment_cursor {
+	uint64_t bytes_start;                  // byte offset of the next row's first element
+	uint64_t next_anchor;                  // the next segment's anchor, fetched a segment ahead so that nobody waits for it
+	const uint_t<IndexSize>* following;    // where the anchor after that one lives ...
+	uint32_t anchors_left;                 // ... if the column has one
+	uint32_t rows_left_in_segment;
+
+	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t num_segments)
+	{
+		const uint64_t left = num_segments - segment - 1;
+		next_anchor = wave64::read_first_lane((uint64_t) position_anchors[segment]);
+		following = position_anchors + segment + 1;
+		anchors_left = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) left;
+		rows_left_in_segment = 0; bytes_start = 0;
+	}
+	__device__ __forceinline__ void begin_segment(uint32_t rows_per_segment)
+	{
+		bytes_start = next_anchor;
+		rows_left_in_segment = rows_per_segment;
+		if (anchors_left > 0) { next_anchor = wave64::read_first_lane((uint64_t) *following); following++; anchors_left--; }
+	}
+	/// call before every row: moves on to the next segment's anchor when the current segment is used up
+	__device__ __forceinline__ void before_row(uint32_t rows_per_segment)
+	{
+		if (rows_left_in_segment == 0) { begin_segment(rows_per_segment); }
+		rows_left_in_segment--;
+	}
+};
+
+/// segments a wavefront takes per trip around its outer loop: short segments are batched up to `rows_per_chunk` rows
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, unsigned row)
+{
+	if (segment_length % row != 0) { return 1; }
+	uint64_t rows_per_segment = segment_length / row;
+	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / rows_per_segment;
+}
+
 /// Everything the fast path knows about a group of R full rows
 template <unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 struct row_group {
@@ -120,25 +160,28 @@ struct row_group {
 	uintptr_t      first_chunk[R];
 	chunk_t        chunks[R];     // this lane's chunk of each row, in flight from HBM
 
-	/// byte offsets (DPP prefix sums) and chunk ranges; returns the byte position after the group
-	__device__ __forceinline__ uint64_t locate(const uint8_t* __restrict__ compressed_data, uint64_t bytes_start, unsigned min_size, unsigned bits)
+	/// byte offsets (DPP prefix sums) and chunk ranges of the next R rows; a row that starts an anchored segment
+	/// takes its byte position from the anchor.  `cursor` (wave-uniform) is advanced.
+	template <bool SpansSegments, unsigned IndexSize>
+	__device__ __forceinline__ void locate(const uint8_t* __restrict__ compressed_data, uint32_t rows_per_segment,
+		segment_cursor<IndexSize>& cursor, unsigned min_size, unsigned bits)
 	{
 		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) {
+			if (SpansSegments) { cursor.before_row(rows_per_segment); }
 			unsigned lane_bytes = 0;
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) { lane_bytes += size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask); }
 			const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
 			const unsigned row_bytes = wave64::read_last_lane(inclusive);
-			const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
+			const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + cursor.bytes_start;
 			first_chunk[k] = address & ~(uintptr_t) 15;
 			const unsigned head = (unsigned) (address - first_chunk[k]);
 			num_chunks[k] = row_bytes == 0 ? 0 : (head + row_bytes + 15) / 16;
 			offset[k] = inclusive - lane_bytes + head;
-			bytes_start += row_bytes;
+			cursor.bytes_start += row_bytes;
 		}
-		return bytes_start;
 	}
 	/// request the rows' bytes: exactly the 16-byte chunks that overlap them.  Every lane loads — lanes past
 	/// the last chunk re-read it (same cache line) — so there is no divergent branch around the loads.
@@ -289,8 +332,64 @@ __device__ __forceinline__ uint64_t decompress_rows(
 
 } // namespace detail
 
+namespace detail {
+
+/// The fast path: `num_groups` groups of R full rows starting at element `rows_start` (advanced), software-pipelined
+/// two deep so that a wavefront never waits for two HBM round trips in a row (CDNA4 retires vector-memory operations
+/// in order — loads queue behind earlier stores): while group g is cut out of LDS and stored, group g+1's bytes and
+/// group g+2's size words are already in flight.  With SpansSegments the rows may belong to several short segments.
+template <bool SpansSegments, unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+__device__ __forceinline__ void decompress_full_groups(
+	uint_t<UncompressedSize>* __restrict__ decompressed, const uint8_t* __restrict__ compressed_data,
+	const uint_t<ElementSizesContainerSize>* __restrict__ packed_element_sizes,
+	uint32_t* stage, unsigned lane, uint64_t& rows_start, uint64_t num_groups, segment_cursor<IndexSize>& cursor, uint32_t rows_per_segment,
+	unsigned min_size, unsigned bits, unsigned per, unsigned per_reciprocal, const size_masks& masks)
+{
+	using container_type = uint_t<ElementSizesContainerSize>;
+	using group_t = row_group<UncompressedSize, ElementSizesContainerSize>;
+	constexpr unsigned R = rows_in_flight;
+	constexpr unsigned group_elements = R * 64 * (16 / UncompressedSize);
+	if (num_groups == 0) { return; }
+
+	group_t current, next;
+	container_type after_next[R];
+	// wave-uniform position of the next group's first size field
+	uint64_t container_base = rows_start / per;
+	unsigned field_base = (unsigned) (rows_start - container_base * per);
+	auto fetch_fields = [&](container_type (&fields)[R]) {
+		load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per, per_reciprocal);
+		field_base += group_elements;
+		container_base += field_base / per;
+		field_base %= per;
+	};
+	fetch_fields(current.fields);
+	if (num_groups > 1) { fetch_fields(next.fields); }
+	current.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits);
+	current.request(lane, packed_element_sizes);
+	current.stage_into(stage, lane);
+	for (uint64_t g = 0; g < num_groups; g++) {
+		const bool has_next = g + 1 < num_groups;
+		if (has_next) {
+			next.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits);
+			next.request(lane, packed_element_sizes);
+		}
+		if (g + 2 < num_groups) { fetch_fields(after_next); }
+		current.extract_and_store(decompressed, stage, lane, rows_start, min_size, bits, masks);
+		rows_start += group_elements;
+		if (has_next) {
+			next.stage_into(stage, lane);
+			current = next;
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next.fields[k] = after_next[k]; }
+		}
+	}
+}
+
+} // namespace detail
+
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-__global__ void __launch_bounds__(256) decompress(
+// (scalar registers are capped so that eight wavefronts fit a SIMD: measured 3-5 % over what the allocator takes unasked)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) decompress(
 	uint_t<UncompressedSize>*  __restrict__  decompressed,
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>*
@@ -321,67 +420,60 @@ __global__ void __launch_bounds__(256) decompress(
 	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = segment_length, n = length;
 	if (L == 0 || bits_per_element_size == 0) { return; }
-	const uint64_t num_segments = (n + L - 1) / L;
 	const unsigned bits = bits_per_element_size;
 	const unsigned per = (8 * ElementSizesContainerSize) / bits;
 	const unsigned per_reciprocal = per == 1 ? 0u : (unsigned) ((((uint64_t) 1 << 32) + per - 1) / per);
 	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
 	const bool aligned_output = memory_access::is_aligned(decompressed, 16) && (L % E == 0);
 
-	for (uint64_t s = wave; s < num_segments; s += num_waves) {
-		const uint64_t segment_start = s * L;
-		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
-		uint64_t bytes_start = wave64::read_first_lane((uint64_t) position_anchors[s]);   // byte offset of the next row's first element (wave-uniform)
+	const bool rows_fit_segments = L % row == 0;
+	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, row);
+	const uint64_t chunk_length = segments_per_chunk * L;
+	const uint64_t num_segments = (n + L - 1) / L;
+	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
+	const uint64_t group_elements = (uint64_t) R * row;
 
-		uint64_t rows_start = segment_start;
-		if (packed && aligned_output) {
-			// Full groups of R rows, software-pipelined two deep so that a wavefront never waits for two HBM
-			// round trips in a row (CDNA4 retires vector-memory operations in order — loads queue behind
-			// earlier stores): while group g is cut out of LDS and stored, group g+1's bytes and group g+2's
-			// size words are already in flight.
-			using group_t = detail::row_group<UncompressedSize, ElementSizesContainerSize>;
-			const uint64_t group_elements = (uint64_t) R * row;
-			const uint64_t num_groups = (segment_end - segment_start) / group_elements;
-			if (num_groups > 0) {
-				group_t current, next;
-				container_type after_next[R];
-				// wave-uniform position of the next group's first size field
-				uint64_t container_base = segment_start / per;
-				unsigned field_base = (unsigned) (segment_start - container_base * per);
-				auto fetch_fields = [&](container_type (&fields)[R]) {
-					detail::load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per, per_reciprocal);
-					field_base += (unsigned) group_elements;
-					container_base += field_base / per;
-					field_base %= per;
-				};
-				fetch_fields(current.fields);
-				if (num_groups > 1) { fetch_fields(next.fields); }
-				bytes_start = current.locate(compressed_data, bytes_start, min_represented_element_size, bits);
-				current.request(lane, packed_element_sizes);
-				current.stage_into(stage, lane);
-				for (uint64_t g = 0; g < num_groups; g++) {
-					const bool has_next = g + 1 < num_groups;
-					if (has_next) {
-						bytes_start = next.locate(compressed_data, bytes_start, min_represented_element_size, bits);
-						next.request(lane, packed_element_sizes);
-					}
-					if (g + 2 < num_groups) { fetch_fields(after_next); }
-					current.extract_and_store(decompressed, stage, lane, rows_start, min_represented_element_size, bits, masks);
-					rows_start += group_elements;
-					if (has_next) {
-						next.stage_into(stage, lane);
-						current = next;
-						#pragma unroll
-						for (unsigned k = 0; k < R; k++) { next.fields[k] = after_next[k]; }
-					}
-				}
+	const bool fast_path = packed && aligned_output && rows_fit_segments;
+
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t chunk_start = c * chunk_length;
+		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
+		const uint64_t num_groups = fast_path ? (chunk_end - chunk_start) / group_elements : 0;
+		uint64_t rows_start = chunk_start;
+		detail::segment_cursor<IndexSize> cursor;
+
+		if (segments_per_chunk == 1) {
+			// one anchored segment: full groups of rows on the fast path, then whatever is left — ragged tails,
+			// unaligned outputs, segment lengths that are not whole rows, size fields straddling containers
+			cursor.bytes_start = wave64::read_first_lane((uint64_t) position_anchors[c]);
+			detail::decompress_full_groups<false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, 0,
+				min_represented_element_size, bits, per, per_reciprocal, masks);
+			for (; rows_start < chunk_end; rows_start += group_elements) {
+				cursor.bytes_start = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+					decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, chunk_end, cursor.bytes_start,
+					min_represented_element_size, bits, per, masks);
 			}
 		}
-		// whatever is left: ragged tails, unaligned outputs, size fields straddling containers
-		for (; rows_start < segment_end; rows_start += (uint64_t) R * row) {
-			bytes_start = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
-				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, segment_end, bytes_start,
-				min_represented_element_size, bits, per, masks);
+		else {
+			// a batch of short segments, each a whole number of rows: the groups of rows span segments
+			const uint32_t rows_per_segment = (uint32_t) (L / row);
+			cursor.start_at(position_anchors, c * segments_per_chunk, num_segments);
+			detail::decompress_full_groups<true, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, rows_per_segment,
+				min_represented_element_size, bits, per, per_reciprocal, masks);
+			while (rows_start < chunk_end) {
+				if (cursor.rows_left_in_segment == 0) { cursor.begin_segment(rows_per_segment); }
+				const uint64_t segment_end_ = rows_start + (uint64_t) cursor.rows_left_in_segment * row;
+				const uint64_t segment_end = segment_end_ < chunk_end ? segment_end_ : chunk_end;
+				cursor.rows_left_in_segment = 0;
+				for (; rows_start < segment_end; rows_start += group_elements) {
+					cursor.bytes_start = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+						decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, segment_end, cursor.bytes_start,
+						min_represented_element_size, bits, per, masks);
+				}
+				rows_start = segment_end;
+			}
 		}
 	}
 }
@@ -398,8 +490,9 @@ public:
 	{
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		grid_construction_resolution  = warp;              // one wavefront per anchored segment
-		length                        = util::div_rounding_up(length_in_elements, segment_length);
-		serialization_option          = auto_maximized;    // segments at grid stride
+		length                        = util::div_rounding_up(util::div_rounding_up(length_in_elements, segment_length),
+		                                    (size_t) detail::segments_per_wave_chunk(segment_length, 64 * (16 / UncompressedSize)));
+		serialization_option          = auto_maximized;    // (batches of short) segments at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best

@@ -77,6 +77,10 @@ def test_resolver_shapes():
     assert c.block_dimensions[0] == 256 and c.grid_dimensions[0] == (1 << 30) // 4096 // 4          # one wavefront per segment
     c = d.resolve_launch_configuration(N, {"length": r.size_t(1 << 30), "segment_length": r.size_t(1 << 20)})
     assert c.block_dimensions[0] == 1024 and c.grid_dimensions[0] == 1024                            # one workgroup per long segment
+    c = d.resolve_launch_configuration(N, {"length": r.size_t(1 << 30), "segment_length": r.size_t(128)})
+    assert c.block_dimensions[0] == 256 and c.grid_dimensions[0] == (1 << 30) // (32 * 128) // 4     # 32 one-row segments per wavefront
+    c = d.resolve_launch_configuration(N, {"length": r.size_t(1 << 30), "segment_length": r.size_t(8192)})
+    assert c.block_dimensions[0] == 512 and c.grid_dimensions[0] == (1 << 30) // 8192                # 64 rows: 8 wavefronts sweep a segment
 
 
 def test_one_time_limits():
