@@ -56,6 +56,9 @@ def make_workload(name, n, device):
         "dictionary_zipf": lambda: w.Dictionary(n, device, zipf=True),
         "frame_of_reference": lambda: w.FrameOfReference(n, device),
         "delta_patched": lambda: w.DeltaPatched(n, device),
+        "delta_fused_patches": lambda: w.DeltaFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
+        "frame_of_reference_fused_patches": lambda: w.FrameOfReferenceFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
+        "dictionary_fused_patches": lambda: w.DictionaryFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "run_length_encoding": lambda: w.RunLength(n, device),
         "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
         "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),

@@ -1,0 +1,81 @@
+// Kernel wrapper for Delta decompression fused with patching (an extension; the
+// reference runs delta.cu and then data_layout/scatter.cu).  Argument-map keys: those of the Delta wrapper
+// (src/kernel_wrappers/decompression/delta.cu:49-83) plus the patch arrays under the names "patch_values",
+// "patch_positions" (ascending) and "num_patches".
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/delta.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace delta {
+namespace patched {
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using compressed_type   = uint_t<CompressedSize>;
+	using uncompressed_type = uint_t<UncompressedSize>;
+	using index_type        = uint_t<IndexSize>;
+	using size_type         = size_type_by_index_size<IndexSize>;
+
+	/// the fused kernel is launched in the shape of the plain one: the patches ride along
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t           device_properties,
+		device_function::attributes_t  kernel_function_attributes,
+		size_t                         length,
+		size_t                         segment_length,
+		launch_configuration_limits_t  limits) const
+	{
+		delta::launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize> params(
+			device_properties, kernel_function_attributes, length, segment_length, limits.dynamic_shared_memory);
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+launch_configuration_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::resolve_launch_configuration(
+	device::properties_t           device_properties,
+	device_function::attributes_t  kernel_function_attributes,
+	arguments_type                 extra_arguments,
+	launch_configuration_limits_t  limits) const
+{
+	auto length         = argument<size_t>(extra_arguments, "length");
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
+	stream::id_t                   stream,
+	const launch_configuration_t&  launch_config,
+	arguments_type                 arguments) const
+{
+	auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
+	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
+	auto patch_values      = argument<const uncompressed_type*>(arguments, "patch_values");
+	auto patch_positions   = argument<const index_type*>(arguments, "patch_positions");
+	auto length            = argument<index_type>(arguments, "length");
+	auto segment_length    = argument<index_type>(arguments, "segment_length");
+	auto num_patches       = argument<index_type>(arguments, "num_patches");
+
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, compressed_input, anchor_values, patch_values, patch_positions,
+		(size_type) length, (size_type) segment_length, (size_type) num_patches);
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+const device_function_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::get_device_function() const
+{
+	return reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize>);
+}
+
+} // namespace patched
+} // namespace delta
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

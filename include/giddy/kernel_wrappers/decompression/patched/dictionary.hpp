@@ -1,0 +1,93 @@
+// Kernel wrapper for Dictionary decompression fused with patching (an extension).
+// Argument-map keys: those of the Dictionary wrapper (src/kernel_wrappers/decompression/dictionary.cu:52-96,
+// both spellings of the caching flag included) plus "patch_values", "patch_positions" (ascending) and
+// "num_patches".
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/dictionary.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace dictionary {
+namespace patched {
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using dictionary_index_type = uint_t<DictionaryIndexSize>;
+	using dictionary_size_type  = size_type_by_index_size<DictionaryIndexSize>;
+	using uncompressed_type     = uint_t<UncompressedSize>;
+	using index_type            = uint_t<IndexSize>;
+	using size_type             = size_type_by_index_size<IndexSize>;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t              device_properties,
+		device_function::attributes_t     kernel_function_attributes,
+		size_t                            num_dictionary_entries,
+		size_t                            data_length,
+		optional<bool>                    cache_input_data_in_shared_mem,
+		launch_configuration_limits_t     limits) const
+	{
+		dictionary::launch_config_resolution_params_t<IndexSize, UncompressedSize, DictionaryIndexSize> params(
+			device_properties, kernel_function_attributes, num_dictionary_entries, data_length,
+			cache_input_data_in_shared_mem, limits.dynamic_shared_memory);
+		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
+		params.length = util::div_rounding_up(data_length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+launch_configuration_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::resolve_launch_configuration(
+	device::properties_t           device_properties,
+	device_function::attributes_t  kernel_function_attributes,
+	arguments_type                 extra_arguments,
+	launch_configuration_limits_t  limits) const
+{
+	auto num_dictionary_entries = argument<size_t>(extra_arguments, "num_dictionary_entries");
+	auto data_length            = argument<size_t>(extra_arguments, "data_length");
+	auto cache_input_data_in_shared_mem = optional_argument<bool>(extra_arguments, "cache_input_data_in_shared_mem");
+	return resolve_launch_configuration(device_properties, kernel_function_attributes,
+		num_dictionary_entries, data_length, cache_input_data_in_shared_mem, limits);
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch(
+	stream::id_t                   stream,
+	const launch_configuration_t&  launch_config,
+	arguments_type                 arguments) const
+{
+	auto maybe_cache = optional_argument<bool>(arguments, "cache_dictionary_in_shared_mem");
+
+	auto decompressed            = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input        = argument<const dictionary_index_type*>(arguments, "compressed_input");
+	auto dictionary_entries      = argument<const uncompressed_type*>(arguments, "dictionary_entries");
+	auto patch_values            = argument<const uncompressed_type*>(arguments, "patch_values");
+	auto patch_positions         = argument<const index_type*>(arguments, "patch_positions");
+	auto length                  = argument<size_type>(arguments, "length");
+	auto num_dictionary_entries  = argument<dictionary_size_type>(arguments, "num_dictionary_entries");
+	auto num_patches             = argument<index_type>(arguments, "num_patches");
+
+	// The dictionary is staged in LDS iff the resolved configuration reserved room for it.
+	bool fits = (size_t) num_dictionary_entries * UncompressedSize <= launch_config.dynamic_shared_memory_size;
+	bool caching = maybe_cache.value_or(launch_config.dynamic_shared_memory_size > 0) && fits;
+
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, compressed_input, dictionary_entries, patch_values, patch_positions,
+		length, num_dictionary_entries, (size_type) num_patches, caching);
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+const device_function_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::get_device_function() const
+{
+	return reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, DictionaryIndexSize>);
+}
+
+} // namespace patched
+} // namespace dictionary
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

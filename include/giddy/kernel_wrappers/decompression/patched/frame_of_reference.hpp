@@ -1,0 +1,80 @@
+// Kernel wrapper for Frame-of-Reference decompression fused with patching (an extension, SURVEY.md
+// §8f.1).  Argument-map keys: those of the FOR wrapper (src/kernel_wrappers/decompression/
+// frame_of_reference.cu:58-102) plus "patch_values", "patch_positions" (ascending) and "num_patches".
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/decompression/frame_of_reference.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace frame_of_reference {
+namespace patched {
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using index_type              = uint_t<IndexSize>;
+	using size_type               = size_type_by_index_size<IndexSize>;
+	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t           device_properties,
+		device_function::attributes_t  kernel_function_attributes,
+		size_t                         length,
+		size_t                         segment_length,
+		launch_configuration_limits_t  limits = { nullopt, nullopt, nullopt }) const
+	{
+		frame_of_reference::launch_config_resolution_params_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction> params(
+			device_properties, kernel_function_attributes, length, segment_length);
+		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
+		params.length = util::div_rounding_up(length, (size_t) stream_tiles::elements_per_thread_per_chunk<Uncompressed>());
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+launch_configuration_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::resolve_launch_configuration(
+	device::properties_t           device_properties,
+	device_function::attributes_t  kernel_function_attributes,
+	arguments_type                 extra_arguments,
+	launch_configuration_limits_t  limits) const
+{
+	auto length         = argument<size_t>(extra_arguments, "length");
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_launch(
+	stream::id_t                   stream,
+	const launch_configuration_t&  launch_config,
+	arguments_type                 arguments) const
+{
+	auto decompressed               = argument<Uncompressed*>(arguments, "decompressed");
+	auto compressed_input           = argument<const Compressed*>(arguments, "compressed_input");
+	auto segment_model_coefficients = argument<const model_coefficients_type*>(arguments, "segment_model_coefficients");
+	auto patch_values               = argument<const Uncompressed*>(arguments, "patch_values");
+	auto patch_positions            = argument<const index_type*>(arguments, "patch_positions");
+	auto length                     = argument<index_type>(arguments, "length");
+	auto segment_length             = argument<index_type>(arguments, "segment_length");
+	auto num_patches                = argument<index_type>(arguments, "num_patches");
+
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, compressed_input, segment_model_coefficients, patch_values, patch_positions,
+		(size_type) length, (size_type) segment_length, (size_type) num_patches);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+const device_function_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::get_device_function() const
+{
+	return reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
+}
+
+} // namespace patched
+} // namespace frame_of_reference
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -40,6 +40,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -109,14 +110,16 @@ struct row_t {
 		for (unsigned j = 0; j < E; j++) { prefix[j] += exclusive; }
 		total = wave64::read_last_lane(inclusive);
 	}
+	template <typename Patches>
 	__device__ __forceinline__ void store(typename traits::uncompressed_type* __restrict__ out, uint64_t row_start, uint64_t end, unsigned lane,
-		typename traits::uncompressed_type base) const
+		typename traits::uncompressed_type base, Patches& patches) const
 	{
 		using U = typename traits::uncompressed_type;
 		uint64_t p = row_start + (uint64_t) lane * E;
 		memory_access::group<U, E> values;
 		#pragma unroll
 		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
+		patches.template apply_to_row<E>(row_start, lane, values);
 		if (p + E <= end) { memory_access::store_group(out + p, values); }
 		else {
 			#pragma unroll
@@ -133,10 +136,10 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_se
 }
 
 /// wave path: this wavefront decompresses whole segments on its own (several short ones per chunk)
-template <unsigned UncompressedSize, unsigned CompressedSize>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void wave_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -156,8 +159,10 @@ __device__ __forceinline__ void wave_per_segment(
 		// vector-memory operations in order, so a load issued after a store cannot be waited for without
 		// waiting for the store too; this way a wavefront waits for one HBM round trip per group, not two.
 		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		patches.begin_seek(start, lane);   // (its probes go out ahead of the first rows' loads, the rest behind them)
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) { rows[k].load(in, start + (uint64_t) k * traits::row, end, lane); }
+		patches.finish_seek(lane);
 		for (uint64_t row_start = start; row_start < end; row_start += (uint64_t) R * traits::row) {
 			const uint64_t next_start = row_start + (uint64_t) R * traits::row;
 			if (next_start < end) {
@@ -170,7 +175,7 @@ __device__ __forceinline__ void wave_per_segment(
 			for (unsigned k = 0; k < R; k++) {
 				const uint64_t this_row = row_start + (uint64_t) k * traits::row;
 				if (this_row == next_segment_start && this_row < end) { base = anchors[segment++]; next_segment_start += L; }   // wave-uniform
-				rows[k].store(out, this_row, end, lane, base);
+				rows[k].store(out, this_row, end, lane, base, patches);
 				base += (U) rows[k].total;
 			}
 			#pragma unroll
@@ -181,10 +186,10 @@ __device__ __forceinline__ void wave_per_segment(
 
 /// block path: the workgroup's wavefronts sweep one segment together — wavefront w takes R consecutive
 /// rows of every sweep, so a segment of up to waves*R rows needs ONE barrier
-template <unsigned UncompressedSize, unsigned CompressedSize>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void block_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -200,6 +205,7 @@ __device__ __forceinline__ void block_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
+		patches.seek(start, lane);   // (every wavefront walks the segment's patches and keeps those in its own rows)
 		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * R * traits::row) {
 			const uint64_t mine = sweep_start + (uint64_t) w * R * traits::row;
 			row_t<UncompressedSize, CompressedSize> rows[R];
@@ -219,7 +225,7 @@ __device__ __forceinline__ void block_per_segment(
 			U running = (U) (base + before);
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
-				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running);
+				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running, patches);
 				running += (U) rows[k].total;
 			}
 			base += all;
@@ -229,10 +235,10 @@ __device__ __forceinline__ void block_per_segment(
 }
 
 /// general path: any segment length, any alignment — segmented scan with reset at segment heads
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void segmented(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
 {
 	using U = uint_t<UncompressedSize>;
 	enum : unsigned { E = 4, row = 64 * E };
@@ -248,6 +254,7 @@ __device__ __forceinline__ void segmented(
 		const uint64_t start = c * chunk_length;
 		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
 		U carry = 0;   // sum since the last segment head before the current row (the chunk starts on a head)
+		patches.seek(start, lane);
 		for (uint64_t row_start = start; row_start < end; row_start += row) {
 			const uint64_t p0 = row_start + (uint64_t) lane * E;
 			uint64_t seg, within;
@@ -278,13 +285,42 @@ __device__ __forceinline__ void segmented(
 			for (unsigned j = 0; j < E; j++) {
 				if (p0 + j < end) {
 					U v = before_head[j] ? (U) (value[j] + lane_carry) : value[j];
-					out[p0 + j] = (U) (anchors[seg_of[j]] + v);
+					value[j] = (U) (anchors[seg_of[j]] + v);
 				}
 			}
+			patches.template apply_to_row<E>(row_start, lane, value);
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { if (p0 + j < end) { out[p0 + j] = value[j]; } }
 			U last_acc = wave64::read_last_lane(acc);
 			bool any_head = wave64::ballot(flag) >> 63;   // lane 63's inclusive flag
 			carry = any_head ? last_acc : (U) (carry + last_acc);
 		}
+	}
+}
+
+} // namespace detail
+
+namespace detail {
+
+/// picks the path (wave-uniform decision): see the notes at the top of this file
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void decompress(
+	uint_t<UncompressedSize>* __restrict__ decompressed, const uint_t<CompressedSize>* __restrict__ compressed_input,
+	const uint_t<UncompressedSize>* __restrict__ anchor_values, uint64_t n, uint64_t L, Patches patches)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	if (n == 0 || L == 0) { return; }
+	const bool rows_fit_segments = (L % traits::row == 0)
+		&& memory_access::is_aligned(decompressed, 16)
+		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
+	if (rows_fit_segments && L / traits::row <= rows_per_chunk) {
+		wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
+	}
+	else if (rows_fit_segments && wave64::per_block() <= max_waves_per_block) {
+		block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
+	}
+	else {
+		segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
 	}
 }
 
@@ -298,22 +334,32 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>             length,
 	size_type_by_index_size<IndexSize>             segment_length)
 {
-	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
-	const uint64_t n = length, L = segment_length;
-	if (n == 0 || L == 0) { return; }
-	const bool rows_fit_segments = (L % traits::row == 0)
-		&& memory_access::is_aligned(decompressed, 16)
-		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
-	if (rows_fit_segments && L / traits::row <= detail::rows_per_chunk) {
-		detail::wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
-	}
-	else if (rows_fit_segments && wave64::per_block() <= detail::max_waves_per_block) {
-		detail::block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
-	}
-	else {
-		detail::segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L);
-	}
+	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
+		decompressed, compressed_input, anchor_values, length, segment_length, sorted_patches::none());
 }
+
+namespace patched {
+
+/// Delta decompression and patching in one pass: the result of `delta::decompress` followed by
+/// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` — for ASCENDING
+/// patch positions (equal positions: the last one wins) — without the second launch or its read-modify-write.
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*        __restrict__  decompressed,
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*  __restrict__  anchor_values,
+	const uint_t<UncompressedSize>*  __restrict__  patch_values,
+	const uint_t<IndexSize>*         __restrict__  patch_positions,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length,
+	size_type_by_index_size<IndexSize>             num_patches)
+{
+	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
+		decompressed, compressed_input, anchor_values, length, segment_length,
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length));
+}
+
+} // namespace patched
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {

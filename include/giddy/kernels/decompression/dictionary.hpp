@@ -43,22 +43,55 @@ constexpr serialization_factor_t get_default_serialization_factor(bool cache_all
 namespace detail {
 
 /// out[p] = lookup(keys[p]) over the shared streaming tile loop
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
 	uint64_t                                          n,
-	Lookup                                            lookup)
+	Lookup                                            lookup,
+	Patches                                           patches)
 {
 	using key_type = uint_t<DictionaryIndexSize>;
 	using value_type = uint_t<UncompressedSize>;
 	constexpr unsigned G = stream_tiles::group_size<value_type>::value;
-	stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n,
-		[&](uint64_t, const memory_access::group<key_type, G>& keys, memory_access::group<value_type, G>& out) {
-			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
-		},
-		[&](uint64_t, key_type key) { return lookup(key); });
+	auto produce_group = [&](uint64_t, const memory_access::group<key_type, G>& keys, memory_access::group<value_type, G>& out) {
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
+	};
+	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
+	if constexpr (Patches::enabled) {
+		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches);
+	}
+	else {
+		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one);
+	}
+}
+
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches>
+__device__ __forceinline__ void decompress(
+	uint_t<UncompressedSize>*           __restrict__  decompressed,
+	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*     __restrict__  dictionary_entries,
+	uint64_t                                          length,
+	uint64_t                                          num_dictionary_entries,
+	bool                                              cache_dictionary_in_shared_memory,
+	Patches                                           patches)
+{
+	using value_type = uint_t<UncompressedSize>;
+	using key_type = uint_t<DictionaryIndexSize>;
+	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
+
+	if (cache_dictionary_in_shared_memory) {
+		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
+		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
+		__syncthreads();
+		translate<UncompressedSize, DictionaryIndexSize>(
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches);
+	}
+	else {
+		translate<UncompressedSize, DictionaryIndexSize>(
+			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches);
+	}
 }
 
 } // namespace detail
@@ -73,23 +106,34 @@ __global__ void decompress(
 	bool                                              cache_dictionary_in_shared_memory,
 	serialization_factor_t                            serialization_factor) // accepted and ignored, as in gather.cuh:24
 {
-	using value_type = uint_t<UncompressedSize>;
-	using key_type = uint_t<DictionaryIndexSize>;
 	(void) serialization_factor;
-	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
-
-	if (cache_dictionary_in_shared_memory) {
-		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
-		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
-		__syncthreads();
-		detail::translate<UncompressedSize, DictionaryIndexSize>(
-			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; });
-	}
-	else {
-		detail::translate<UncompressedSize, DictionaryIndexSize>(
-			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; });
-	}
+	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
+		length, num_dictionary_entries, cache_dictionary_in_shared_memory, sorted_patches::none());
 }
+
+namespace patched {
+
+/// Dictionary decompression and patching in one pass: what `dictionary::decompress` followed by
+/// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in `decompressed`,
+/// for ASCENDING patch positions (equal positions: the last one wins).
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*           __restrict__  decompressed,
+	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*     __restrict__  dictionary_entries,
+	const uint_t<UncompressedSize>*     __restrict__  patch_values,
+	const uint_t<IndexSize>*            __restrict__  patch_positions,
+	size_type_by_index_size<IndexSize>                length,
+	size_type_by_index_size<DictionaryIndexSize>      num_dictionary_entries,
+	size_type_by_index_size<IndexSize>                num_patches,
+	bool                                              cache_dictionary_in_shared_memory)
+{
+	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
+		length, num_dictionary_entries, cache_dictionary_in_shared_memory,
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length));
+}
+
+} // namespace patched
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {

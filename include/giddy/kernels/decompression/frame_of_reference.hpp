@@ -51,6 +51,57 @@ __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotien
 
 } // namespace detail
 
+namespace detail {
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, typename Patches>
+__device__ __forceinline__ void decompress(
+	Uncompressed*       __restrict__    decompressed,
+	const Compressed*   __restrict__    compressed_input,
+	const typename UnaryModelFunction::coefficients_type*
+	                    __restrict__    segment_model_coefficients,
+	uint64_t                            length,
+	uint64_t                            L,
+	Patches                             patches)
+{
+	using model_index_type = typename UnaryModelFunction::index_type;
+	using coefficients_type = typename UnaryModelFunction::coefficients_type;
+	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
+
+	auto predict = [](const coefficients_type& record, uint64_t within, Compressed offset) -> Uncompressed {
+		UnaryModelFunction segment_model(record);
+		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
+		return (Uncompressed) (predicted_value + offset);
+	};
+	auto produce_group = [&](uint64_t first_position, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out) {
+		uint64_t segment, within;
+		divide<IndexSize>(first_position, L, segment, within);
+		// the segment's record is fetched once per group (neighbouring lanes hit the same address) and
+		// again only if the group crosses into the next segment
+		coefficients_type record = segment_model_coefficients[segment];
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) {
+			out[j] = predict(record, within, in[j]);
+			if (++within == L) {
+				within = 0; segment++;
+				if (j + 1 < G) { record = segment_model_coefficients[segment]; }
+			}
+		}
+	};
+	auto produce_one = [&](uint64_t position, Compressed offset) {
+		uint64_t segment, within;
+		divide<IndexSize>(position, L, segment, within);
+		return predict(segment_model_coefficients[segment], within, offset);
+	};
+	if constexpr (Patches::enabled) {
+		stream_tiles::transform_and_patch<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, patches);
+	}
+	else {
+		stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one);
+	}
+}
+
+} // namespace detail
+
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
 __global__ void decompress(
 	Uncompressed*       __restrict__    decompressed,
@@ -61,39 +112,35 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>  segment_length,
 	uint_t<IndexSize>                   num_segments_to_decompress_per_block) // kept for signature parity; the tiling here does not depend on it
 {
-	using model_index_type = typename UnaryModelFunction::index_type;
-	using coefficients_type = typename UnaryModelFunction::coefficients_type;
-	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	(void) num_segments_to_decompress_per_block;
-	const uint64_t L = segment_length;
-
-	auto predict = [](const coefficients_type& record, uint64_t within, Compressed offset) -> Uncompressed {
-		UnaryModelFunction segment_model(record);
-		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
-		return (Uncompressed) (predicted_value + offset);
-	};
-	stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length,
-		[&](uint64_t first_position, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out) {
-			uint64_t segment, within;
-			detail::divide<IndexSize>(first_position, L, segment, within);
-			// the segment's record is fetched once per group (neighbouring lanes hit the same address) and
-			// again only if the group crosses into the next segment
-			coefficients_type record = segment_model_coefficients[segment];
-			#pragma unroll
-			for (unsigned j = 0; j < G; j++) {
-				out[j] = predict(record, within, in[j]);
-				if (++within == L) {
-					within = 0; segment++;
-					if (j + 1 < G) { record = segment_model_coefficients[segment]; }
-				}
-			}
-		},
-		[&](uint64_t position, Compressed offset) {
-			uint64_t segment, within;
-			detail::divide<IndexSize>(position, L, segment, within);
-			return predict(segment_model_coefficients[segment], within, offset);
-		});
+	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
+		decompressed, compressed_input, segment_model_coefficients, length, segment_length, sorted_patches::none());
 }
+
+namespace patched {
+
+/// Frame-of-reference decompression and patching in one pass: what `frame_of_reference::decompress`
+/// followed by `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in
+/// `decompressed`, for ASCENDING patch positions (equal positions: the last one wins).
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+__global__ void decompress(
+	Uncompressed*       __restrict__    decompressed,
+	const Compressed*   __restrict__    compressed_input,
+	const typename UnaryModelFunction::coefficients_type*
+	                    __restrict__    segment_model_coefficients,
+	const Uncompressed* __restrict__    patch_values,
+	const uint_t<IndexSize>*
+	                    __restrict__    patch_positions,
+	size_type_by_index_size<IndexSize>  length,
+	size_type_by_index_size<IndexSize>  segment_length,
+	size_type_by_index_size<IndexSize>  num_patches)
+{
+	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
+		decompressed, compressed_input, segment_model_coefficients, length, segment_length,
+		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length));
+}
+
+} // namespace patched
 
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {

@@ -56,6 +56,12 @@ def key_delta(index_size, uncompressed_size, compressed_size):
     return "decompression::delta::kernel_t<%du, %du, %du>" % (index_size, uncompressed_size, compressed_size)
 
 
+def key_patched(key):
+    """the fused decompress-and-patch variant of a Delta / Dictionary / Frame-of-Reference key (an extension)"""
+    assert "::kernel_t<" in key and "::patched::" not in key
+    return key.replace("::kernel_t<", "::patched::kernel_t<", 1)
+
+
 def key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size):
     return ("decompression::discard_zero_bytes::fixed_width::kernel_t<%du, %du, %du, (util::endianness_t)1, (unsigned short)32>"
             % (index_size, uncompressed_size, compressed_size))
@@ -143,6 +149,62 @@ def delta(decompressed, compressed_input, anchor_values, length, segment_length,
          "anchor_values": r.const_pointer(anchor_values, "u%d" % (8 * uncompressed_size)),
          "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)},
         stream, device, limits, launch_config)
+
+
+# ---- fused decompress-and-patch launches (extension; patch positions ascending) ---------------------
+
+def _patch_arguments(patch_values, patch_positions, num_patches, value_code, index_size):
+    return {"patch_values": r.const_pointer(patch_values, value_code),
+            "patch_positions": r.const_pointer(patch_positions, "u%d" % (8 * index_size)),
+            "num_patches": r.uint_t(index_size)(num_patches)}
+
+
+def patched_delta(decompressed, compressed_input, anchor_values, patch_values, patch_positions, length, segment_length, num_patches, *,
+                  uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """delta() followed by scatter(decompressed, patch_values, patch_positions, num_patches), in one kernel"""
+    launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
+              "anchor_values": r.const_pointer(anchor_values, "u%d" % (8 * uncompressed_size)),
+              "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)}
+    launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "u%d" % (8 * uncompressed_size), index_size))
+    return _run(key_patched(key_delta(index_size, uncompressed_size, compressed_size)),
+                {"length": r.size_t(length), "segment_length": r.size_t(segment_length)}, launch,
+                stream, device, limits, launch_config)
+
+
+def patched_frame_of_reference(decompressed, compressed_input, segment_model_coefficients, patch_values, patch_positions,
+                               length, segment_length, num_patches, *,
+                               uncompressed_size=4, compressed_size=2, model="constant", index_size=4, model_index_size=4,
+                               stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """frame_of_reference() followed by scatter(), in one kernel"""
+    dim = 1 if model == "constant" else 2
+    launch = {"decompressed": r.pointer(decompressed, "i%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "i%d" % (8 * compressed_size)),
+              "segment_model_coefficients": r.const_coefficients_pointer(segment_model_coefficients, "i32", dim),
+              "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)}
+    launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "i%d" % (8 * uncompressed_size), index_size))
+    return _run(key_patched(key_frame_of_reference(index_size, uncompressed_size, compressed_size, model, model_index_size, 4)),
+                {"length": r.size_t(length), "segment_length": r.size_t(segment_length)}, launch,
+                stream, device, limits, launch_config)
+
+
+def patched_dictionary(decompressed, compressed_input, dictionary_entries, patch_values, patch_positions,
+                       length, num_dictionary_entries, num_patches, *,
+                       uncompressed_size=4, dictionary_index_size=1, index_size=4, cache_dictionary_in_shared_mem=None,
+                       stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """dictionary() followed by scatter(), in one kernel"""
+    resolve = {"num_dictionary_entries": r.size_t(num_dictionary_entries), "data_length": r.size_t(length)}
+    launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * dictionary_index_size)),
+              "dictionary_entries": r.const_pointer(dictionary_entries, "u%d" % (8 * uncompressed_size)),
+              "length": r.size_type_by_index_size(index_size)(length),
+              "num_dictionary_entries": r.size_type_by_index_size(dictionary_index_size)(num_dictionary_entries)}
+    launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "u%d" % (8 * uncompressed_size), index_size))
+    if cache_dictionary_in_shared_mem is not None:
+        resolve["cache_input_data_in_shared_mem"] = r.boolean(cache_dictionary_in_shared_mem)
+        launch["cache_dictionary_in_shared_mem"] = r.boolean(cache_dictionary_in_shared_mem)
+    return _run(key_patched(key_dictionary(index_size, uncompressed_size, dictionary_index_size)), resolve, launch,
+                stream, device, limits, launch_config)
 
 
 def discard_zero_bytes_fixed(decompressed, compressed_input, length, *, uncompressed_size=8, compressed_size=4,

@@ -122,7 +122,12 @@ int main()
 	// ---- factory + type-erased path -----------------------------------------------------------------------------
 	{
 		auto& factory = registered::kernel_t::getSubclassFactory();
-		CHECK(factory.getInsantiators().size() == 163);
+		size_t reference_registrations = 0, fused_patch_extensions = 0;
+		for (const auto& entry : factory.getInsantiators()) {
+			(entry.first.find("::patched::") == std::string::npos ? reference_registrations : fused_patch_extensions)++;
+		}
+		CHECK(reference_registrations == 163);
+		CHECK(fused_patch_extensions == 12 + 20 + 8);
 		const char* key = "decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
 		CHECK(factory.canProduce(key));
 		auto k = registered::kernel_t::produceSubclass(key);

@@ -25,8 +25,16 @@ def test_every_declared_symbol_is_exported():
 
 
 def test_factory_has_the_163_reference_registrations():
-    keys = r.kernel_t.registered_keys()
-    assert len(keys) == 163 and len(set(keys)) == 163
+    all_keys = r.kernel_t.registered_keys()
+    assert len(set(all_keys)) == len(all_keys)
+    # the fused decompress-and-patch wrappers are this library's extension, under keys of their own
+    extensions = [k for k in all_keys if "::patched::" in k]
+    assert sorted(extensions) == sorted(schemes.key_patched(k) for k in all_keys
+                                        if k.startswith(("decompression::delta::kernel_t", "decompression::dictionary::kernel_t",
+                                                         "decompression::frame_of_reference::kernel_t")))
+    assert len(extensions) == 12 + 20 + 8
+    keys = [k for k in all_keys if "::patched::" not in k]
+    assert len(keys) == 163
     counts = {}
     for k in keys:
         counts[k.split("::kernel_t")[0]] = counts.get(k.split("::kernel_t")[0], 0) + 1

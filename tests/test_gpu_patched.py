@@ -1,0 +1,182 @@
+"""GPU parity of the fused decompress-and-patch kernels (the extension of SURVEY.md §8f.1): the result must be
+bit-for-bit what the oracle's decoder followed by the oracle's naive scatter leaves — for every registered
+instantiation, patch densities from none to every element, patches on row / tile / segment boundaries, duplicate
+positions (the last one wins), ragged tails, unaligned bases and one-time launch limits."""
+import numpy as np
+import pytest
+
+import cases
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def _imports():
+    from libgiddy_amd import schemes, registered
+    import gpu_util
+    return schemes, registered, gpu_util
+
+
+def _patches(n, how, value_dtype, index_size, seed):
+    """ascending positions (with the odd duplicate) and values"""
+    r = cases.rng(seed)
+    if how == "none" or n == 0:
+        positions = np.zeros(0, np.int64)
+    elif how == "sparse":     # ~0.1 %, the C3 density
+        positions = np.sort(r.choice(n, size=max(1, n // 1000), replace=False))
+    elif how == "dense":      # every third element on average: more than 64 patches per row-group
+        positions = np.flatnonzero(r.random(n) < 0.35)
+    elif how == "all":
+        positions = np.arange(n)
+    elif how == "edges":      # first / last elements and everything around multiples of 64, 256, 1024, 4096
+        marks = np.concatenate([np.arange(0, n, 64), np.arange(0, n, 4096) - 1, np.arange(0, n, 1024) + 1, [0, n - 1]])
+        positions = np.unique(marks[(marks >= 0) & (marks < n)])
+    elif how == "duplicates":
+        positions = np.sort(r.integers(0, n, size=max(2, n // 50)))     # many repeats
+    elif how == "clustered":  # a few hundred consecutive patches, then nothing for a long while
+        starts = r.integers(0, max(1, n - 300), size=max(1, n // 100000 + 1))
+        positions = np.unique(np.concatenate([np.arange(s, min(n, s + 300)) for s in starts]))
+    else:
+        raise ValueError(how)
+    values = r.integers(0, np.iinfo(value_dtype).max, size=len(positions), dtype=value_dtype, endpoint=True)
+    return positions.astype("u%d" % index_size), values
+
+
+def _expected(decoded, positions, values):
+    out = decoded.copy()
+    if len(positions):
+        # sequential semantics of the scatter for equal positions: the last one wins
+        out = oracle.scatter(out, values, positions, threads=1)
+    return out
+
+
+PATCH_SHAPES = ["none", "sparse", "dense", "all", "edges", "duplicates", "clustered"]
+DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]
+
+
+@pytest.mark.parametrize("usize,csize", DELTA_TUPLES)
+@pytest.mark.parametrize("index_size", [4, 8])
+@pytest.mark.parametrize("n,seglen", [(1, 1), (4096, 4096), (1000003, 4096), (300000, 256), (100000, 100), (1 << 20, 1 << 18), (70000, 65536 + 512)])
+def test_patched_delta(usize, csize, index_size, n, seglen):
+    schemes, r, g = _imports()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + seglen + usize)
+    d_in, d_anchor = g.dev(f["compressed_input"]), g.dev(f["anchor_values"])
+    for how in PATCH_SHAPES:
+        positions, values = _patches(n, how, ud, index_size, seed=len(how) + n)
+        expect = _expected(truth, positions, values)
+        out = g.dev_empty(n, ud)
+        schemes.patched_delta(out, d_in, d_anchor, g.dev(values), g.dev(positions), n, seglen, len(positions),
+                              uncompressed_size=usize, compressed_size=csize, index_size=index_size, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != expect)
+        assert len(bad) == 0, (how, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
+FOR_TUPLES = [(4, 2, 1, "linear", 4), (4, 4, 1, "linear", 4), (4, 4, 2, "linear", 4), (8, 4, 2, "linear", 4),
+              (8, 4, 2, "linear", 8), (4, 2, 1, "constant", 4), (4, 4, 1, "constant", 4), (4, 4, 2, "constant", 4)]
+
+
+@pytest.mark.parametrize("index_size,usize,csize,model,model_index_size", FOR_TUPLES)
+@pytest.mark.parametrize("n,seglen", [(1, 4), (4099, 64), (1000003, 4096), (70000, 12)])
+def test_patched_frame_of_reference(index_size, usize, csize, model, model_index_size, n, seglen):
+    schemes, r, g = _imports()
+    ud, cd = np.dtype("i%d" % usize), np.dtype("i%d" % csize)
+    f = cases.for_case(n, seglen, ud, cd, model, seed=n + usize)
+    decoded = oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, seglen, ud, model,
+                                        model_index_size=model_index_size)
+    d_in, d_coef = g.dev(f["compressed_input"]), g.dev(f["segment_model_coefficients"])
+    for how in PATCH_SHAPES:
+        positions, values = _patches(n, how, ud, index_size, seed=len(how) + n)
+        expect = _expected(decoded, positions, values)
+        out = g.dev_empty(n, ud)
+        schemes.patched_frame_of_reference(out, d_in, d_coef, g.dev(values), g.dev(positions), n, seglen, len(positions),
+                                           uncompressed_size=usize, compressed_size=csize, model=model, index_size=index_size,
+                                           model_index_size=model_index_size, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != expect)
+        assert len(bad) == 0, (how, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
+DICT_TUPLES = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
+
+
+@pytest.mark.parametrize("usize,dsize", DICT_TUPLES)
+@pytest.mark.parametrize("index_size", [4, 8])
+def test_patched_dictionary(usize, dsize, index_size):
+    schemes, r, g = _imports()
+    ud, kd = np.dtype("u%d" % usize), np.dtype("u%d" % dsize)
+    for n, entries in [(1, 1), (1027, 256 if dsize == 1 else 3000), (1 << 20, 256 if dsize == 1 else 40000)]:
+        entries = min(entries, 1 << (8 * dsize))
+        f = cases.dictionary_case(n, entries, ud, kd, seed=n + usize)
+        decoded = oracle.dictionary(f["compressed_input"], f["dictionary_entries"])
+        d_in, d_dict = g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"])
+        for how in PATCH_SHAPES:
+            positions, values = _patches(n, how, ud, index_size, seed=len(how) + n)
+            expect = _expected(decoded, positions, values)
+            for cache in (None, False):
+                out = g.dev_empty(n, ud)
+                schemes.patched_dictionary(out, d_in, d_dict, g.dev(values), g.dev(positions), n, entries, len(positions),
+                                           uncompressed_size=usize, dictionary_index_size=dsize, index_size=index_size,
+                                           cache_dictionary_in_shared_mem=cache, stream=g.stream())
+                got = g.host(out, ud, n)
+                bad = np.flatnonzero(got != expect)
+                assert len(bad) == 0, (n, how, cache, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
+def test_patched_kernels_equal_the_two_launch_pipeline_on_the_golden_fixture():
+    """C3 in miniature, fused: same golden fixture as the two-launch pipeline test"""
+    import os
+    schemes, r, g = _imports()
+    fx = np.load(os.path.join(os.path.dirname(__file__), "golden", "delta_u64_u16_patched.npz"))
+    n, seglen = int(fx["length"]), int(fx["segment_length"])
+    order = np.argsort(fx["patch_indices"], kind="stable")
+    out = g.dev_empty(n, np.uint64)
+    schemes.patched_delta(out, g.dev(fx["compressed_input"]), g.dev(fx["anchor_values"]), g.dev(fx["patch_data"][order]),
+                          g.dev(fx["patch_indices"][order]), n, seglen, len(order), stream=g.stream())
+    assert (g.host(out, np.uint64, n) == fx["expected_patched"]).all()
+
+
+def test_patched_unaligned_bases_and_limits():
+    """scalar fall-backs (misaligned pointers) and tiny one-time launch limits patch correctly too"""
+    schemes, r, g = _imports()
+    n, seglen = 200001, 1024
+    f, truth = cases.delta_case(n + 8, seglen, np.uint32, np.uint16, seed=9)
+    positions, values = _patches(n, "dense", np.uint32, 4, seed=10)
+    d_pos, d_val = g.dev(positions), g.dev(values)
+    # Delta: input 2 bytes off its natural vector alignment -> the general path
+    comp = f["compressed_input"]
+    expect = _expected(oracle.delta(comp[1:n + 1], f["anchor_values"], seglen), positions, values)
+    out = g.dev_empty(n, np.uint32)
+    schemes.patched_delta(out, g.dev(comp).data_ptr() + 2, g.dev(f["anchor_values"]), d_val, d_pos, n, seglen, len(positions),
+                          uncompressed_size=4, compressed_size=2, stream=g.stream())
+    assert (g.host(out, np.uint32, n) == expect).all()
+    for limits in (r.launch_configuration_limits_t(block_size=64), r.launch_configuration_limits_t(grid_size=3),
+                   r.launch_configuration_limits_t(block_size=128, grid_size=1)):
+        expect = _expected(truth[:n], positions, values)
+        out = g.dev_empty(n, np.uint32)
+        schemes.patched_delta(out, g.dev(comp[:n]), g.dev(f["anchor_values"]), d_val, d_pos, n, seglen, len(positions),
+                              uncompressed_size=4, compressed_size=2, stream=g.stream(), limits=limits)
+        assert (g.host(out, np.uint32, n) == expect).all()
+    # Dictionary: keys one byte off -> everything through the scalar tail with per-element searches
+    d = cases.dictionary_case(n + 4, 256, np.uint32, np.uint8, seed=11)
+    keys = d["compressed_input"]
+    expect = _expected(oracle.dictionary(keys[1:n + 1], d["dictionary_entries"]), positions, values)
+    out = g.dev_empty(n, np.uint32)
+    schemes.patched_dictionary(out, g.dev(keys).data_ptr() + 1, g.dev(d["dictionary_entries"]), d_val, d_pos, n, 256, len(positions),
+                               stream=g.stream())
+    assert (g.host(out, np.uint32, n) == expect).all()
+    for limits in (r.launch_configuration_limits_t(block_size=64, grid_size=2),):
+        expect = _expected(oracle.dictionary(keys[:n], d["dictionary_entries"]), positions, values)
+        out = g.dev_empty(n, np.uint32)
+        schemes.patched_dictionary(out, g.dev(keys[:n]), g.dev(d["dictionary_entries"]), d_val, d_pos, n, 256, len(positions),
+                                   stream=g.stream(), limits=limits)
+        assert (g.host(out, np.uint32, n) == expect).all()

@@ -119,6 +119,45 @@ class FrameOfReference:
         return (lambda: oracle.frame_of_reference(comp, coefs, sample, self.L, np.int32, threads=threads, out=out)), 4 * sample
 
 
+class FrameOfReferenceFused(FrameOfReference):
+    """FOR int32 <- int16 plus 0.1 % ascending patches merged inside the kernel"""
+    name = "frame_of_reference::patched<4,int,short,constant>"
+    kernel = "frame_of_reference::patched::decompress"
+
+    def __init__(self, n, device, seed=1, segment_length=4096, patch_fraction=0.001):
+        super().__init__(n, device, seed=seed, segment_length=segment_length)
+        self.p = max(1, int(round(n * patch_fraction)))
+        self.patch_idx = torch.sort(torch.randperm(n, generator=_gen(seed + 1, device), device=device)[: self.p])[0].to(torch.int32)
+        self.patch_val = torch.randint(-(1 << 31), 1 << 31, (self.p,), dtype=torch.int32, generator=_gen(seed + 2, device), device=device)
+        self.algorithmic_bytes += 8 * self.p
+        self.config = schemes.patched_frame_of_reference(self.output, self.comp, self.coefs, self.patch_val, self.patch_idx,
+                                                         n, segment_length, self.p, stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_frame_of_reference(self.output, self.comp, self.coefs, self.patch_val, self.patch_idx, self.n, self.L, self.p,
+                                           stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, L, idx = self.n, self.L, self.patch_idx.to(torch.int64)
+        sample = (sample // L) * L
+        pidx, pval = _np(self.patch_idx, np.uint32).astype(np.int64), _np(self.patch_val)
+        for lo, hi in ((0, min(sample, n)), (max(0, (n - sample) // L * L), n)):
+            expect = oracle.frame_of_reference(_np(self.comp[lo:hi]), _np(self.coefs[lo // L:(hi + L - 1) // L]), hi - lo, L, np.int32)
+            inside = (pidx >= lo) & (pidx < hi)
+            expect[pidx[inside] - lo] = pval[inside]
+            assert (expect == _np(self.output[lo:hi])).all(), "FOR+patches: sample mismatch vs oracle"
+        step = 1 << 28
+        for lo in range(0, n, step):   # full size: out - in == per-segment constant except at patched positions, which hold the patch
+            hi = min(n, lo + step)
+            ref = self.coefs[lo // L:(hi + L - 1) // L].view(-1).repeat_interleave(L)[: hi - lo]
+            ok = (self.output[lo:hi] - self.comp[lo:hi].to(torch.int32)) == ref
+            inside = idx[(idx >= lo) & (idx < hi)]
+            ok[inside - lo] = True
+            assert bool(ok.all())
+        assert bool((self.output[idx] == self.patch_val).all())
+
+
 class DeltaPatched:
     """C3: Delta, uint64 <- uint16 deltas, segment 4096, anchors = exact prefix at segment starts (base 2^40),
     then 0.1 % naive patches (scatter<4,8,4>) on the same stream."""
@@ -193,6 +232,62 @@ class DeltaPatched:
         a = _np(self.anchors[: sample // self.L], np.uint64).copy()
         out = np.empty(sample, dtype=np.uint64)
         return (lambda: oracle.delta(d, a, self.L, threads=threads, out=out)), 8 * sample
+
+
+class DeltaFused(DeltaPatched):
+    """C3 with the patches merged inside the Delta kernel (the SURVEY.md §8f.1 extension): one launch, no scattered
+    read-modify-write.  Same inputs and same expected output as DeltaPatched."""
+    name = "delta::patched<4,8,2>"
+    kernel = "delta::patched::decompress"
+
+    def __init__(self, n, device, **kw):
+        super().__init__(n, device, **kw)
+        self.algorithmic_bytes = 10 * n + 8 * ((n + self.L - 1) // self.L) + self.p * 12   # + patch position and value, read once
+        self.step_algorithmic_bytes = self.algorithmic_bytes
+        self.config = schemes.patched_delta(self.output, self.deltas, self.anchors, self.patch_val, self.patch_idx, n, self.L, self.p,
+                                            stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_delta(self.output, self.deltas, self.anchors, self.patch_val, self.patch_idx, self.n, self.L, self.p,
+                              stream=stream, launch_config=self.config)
+
+
+class DictionaryFused(Dictionary):
+    """C2 plus 0.1 % ascending patches merged inside the Dictionary kernel"""
+    name = "dictionary::patched<4,4,1>"
+    kernel = "dictionary::patched::decompress"
+
+    def __init__(self, n, device, seed=2, patch_fraction=0.001):
+        super().__init__(n, device, seed=seed)
+        self.p = max(1, int(round(n * patch_fraction)))
+        self.patch_idx = torch.sort(torch.randperm(n, generator=_gen(seed + 1, device), device=device)[: self.p])[0].to(torch.int32)
+        self.patch_val = torch.randint(0, 1 << 31, (self.p,), dtype=torch.int32, generator=_gen(seed + 2, device), device=device)
+        self.algorithmic_bytes += 8 * self.p
+        self.config = schemes.patched_dictionary(self.output, self.keys, self.entries, self.patch_val, self.patch_idx, n, 256, self.p,
+                                                 stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_dictionary(self.output, self.keys, self.entries, self.patch_val, self.patch_idx, self.n, 256, self.p,
+                                   stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        n, idx = self.n, self.patch_idx.to(torch.int64)
+        pidx, pval = _np(self.patch_idx, np.uint32).astype(np.int64), _np(self.patch_val, np.uint32)
+        entries = _np(self.entries, np.uint32)
+        for lo, hi in ((0, min(sample, n)), (max(0, n - sample), n)):
+            expect = oracle.dictionary(_np(self.keys[lo:hi]), entries)
+            inside = (pidx >= lo) & (pidx < hi)
+            expect[pidx[inside] - lo] = pval[inside]
+            assert (expect == _np(self.output[lo:hi], np.uint32)).all(), "dictionary+patches: sample mismatch vs oracle"
+        step = 1 << 28
+        for lo in range(0, n, step):   # full size, against an independent torch gather + index_put
+            hi = min(n, lo + step)
+            expect = self.entries[self.keys[lo:hi].to(torch.int64)]
+            inside = idx[(idx >= lo) & (idx < hi)]
+            expect[inside - lo] = self.output[inside]          # patched positions: checked separately below
+            assert bool((expect == self.output[lo:hi]).all())
+        assert bool((self.output[idx] == self.patch_val).all())
 
 
 def _geometric_runs(n, mean_run, device, seed, max_run=65535):
