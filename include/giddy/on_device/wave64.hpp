@@ -68,10 +68,57 @@ __device__ __forceinline__ uint32_t inclusive_max(uint32_t v)
 	return v;
 }
 
+/// DPP move of a 1..8-byte value; lanes with no valid source (or masked out by RowMask) get `otherwise`
+template <int Control, int RowMask = 0xf, typename T>
+__device__ __forceinline__ T dpp_or(T v, T otherwise)
+{
+	static_assert(sizeof(T) <= 8, "DPP moves handle values of up to 8 bytes");
+	if constexpr (sizeof(T) <= 4) {
+		uint32_t bits = 0, other_bits = 0;
+		__builtin_memcpy(&bits, &v, sizeof(T)); __builtin_memcpy(&other_bits, &otherwise, sizeof(T));
+		uint32_t moved = (uint32_t) __builtin_amdgcn_update_dpp((int) other_bits, (int) bits, Control, RowMask, 0xf, false);
+		T result; __builtin_memcpy(&result, &moved, sizeof(T));
+		return result;
+	}
+	else {
+		uint64_t bits, other_bits;
+		__builtin_memcpy(&bits, &v, 8); __builtin_memcpy(&other_bits, &otherwise, 8);
+		uint32_t lo = (uint32_t) __builtin_amdgcn_update_dpp((int) (uint32_t) other_bits, (int) (uint32_t) bits, Control, RowMask, 0xf, false);
+		uint32_t hi = (uint32_t) __builtin_amdgcn_update_dpp((int) (uint32_t) (other_bits >> 32), (int) (uint32_t) (bits >> 32), Control, RowMask, 0xf, false);
+		uint64_t moved = ((uint64_t) hi << 32) | lo;
+		T result; __builtin_memcpy(&result, &moved, 8);
+		return result;
+	}
+}
+
+/// Inclusive prefix reduction across the 64 lanes with any associative, commutative operator that has a
+/// neutral value (cuda::functors::plus, minimum, maximum, bit_or ...): the same six DPP steps as inclusive_sum
+template <typename Op>
+__device__ __forceinline__ typename Op::result_type inclusive_scan(typename Op::result_type v)
+{
+	using T = typename Op::result_type;
+	const T neutral = Op::neutral_value();
+	Op op;
+	v = op(dpp_or<row_shr_1>(v, neutral), v);
+	v = op(dpp_or<row_shr_2>(v, neutral), v);
+	v = op(dpp_or<row_shr_4>(v, neutral), v);
+	v = op(dpp_or<row_shr_8>(v, neutral), v);
+	v = op(dpp_or<row_bcast_15, 0xA>(v, neutral), v);
+	v = op(dpp_or<row_bcast_31, 0xC>(v, neutral), v);
+	return v;
+}
+
 template <typename T>
 __device__ __forceinline__ T read_lane(T v, unsigned lane)
 {
-	if constexpr (sizeof(T) <= 4) { return (T) __builtin_amdgcn_readlane((int) v, (int) lane); }
+	if constexpr (std::is_floating_point<T>::value) {
+		typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type bits;
+		__builtin_memcpy(&bits, &v, sizeof(T));
+		bits = read_lane(bits, lane);
+		T result; __builtin_memcpy(&result, &bits, sizeof(T));
+		return result;
+	}
+	else if constexpr (sizeof(T) <= 4) { return (T) __builtin_amdgcn_readlane((int) v, (int) lane); }
 	else {
 		uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) lane);
 		uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) ((uint64_t) v >> 32), (int) lane);

@@ -217,3 +217,35 @@ def test_config_c1_frame_of_reference_single_segment_1m():
     assert (a == (1000000 + comp.astype(np.int64)).astype(np.int32)).all()
     assert (a == oracle.frame_of_reference(comp, coefs, n, n, np.int32, "constant", threads=8)).all()
     assert (a[:5000] == naive.frame_of_reference(comp[:5000], coefs, 5000, n, np.int32, "constant")).all()
+
+
+def test_scan_oracle_against_plain_loops():
+    """oracle/scan.py (numpy) == element-by-element Python loops with explicit wrap-around, for every operator used"""
+    from oracle import scan as s
+    r = np.random.default_rng(0)
+    cases = [("plus", np.uint16, np.uint16, "identity"), ("plus", np.uint16, np.uint64, "identity"), ("maximum", np.int32, np.int32, "identity"),
+             ("minimum", np.int64, np.int64, "identity"), ("bit_or", np.uint32, np.uint32, "identity"), ("plus", np.int32, np.int64, "absolute")]
+    for op, in_dtype, out_dtype, pre in cases:
+        info = np.iinfo(in_dtype)
+        data = r.integers(info.min, info.max, size=300, dtype=in_dtype, endpoint=True)
+        bits = 8 * np.dtype(out_dtype).itemsize
+        apply = {"plus": lambda a, b: a + b, "maximum": max, "minimum": min, "bit_or": lambda a, b: a | b}[op]
+
+        def wrap(v):
+            v &= (1 << bits) - 1
+            return v - (1 << bits) if np.dtype(out_dtype).kind == "i" and v >> (bits - 1) else v
+        acc, inclusive, exclusive = int(s.neutral_value(op, out_dtype)), [], []
+        for x in data.tolist():
+            x = abs(x) if pre == "absolute" else x
+            exclusive.append(acc)
+            acc = wrap(apply(acc, x))
+            inclusive.append(acc)
+        assert s.scan(data, op, out_dtype, True, pre).tolist() == inclusive
+        assert s.scan(data, op, out_dtype, False, pre).tolist() == exclusive
+        segs = s.reduce_segments(data, 64, op, out_dtype, pre).tolist()
+        for i, lo in enumerate(range(0, 300, 64)):
+            acc = int(s.neutral_value(op, out_dtype))
+            for x in data[lo:lo + 64].tolist():
+                acc = wrap(apply(acc, abs(x) if pre == "absolute" else x))
+            assert segs[i] == acc
+    assert s.scan(np.zeros(0, np.uint32), "plus", np.uint32).shape == (0,)
