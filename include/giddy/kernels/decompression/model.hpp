@@ -4,8 +4,8 @@
 // src/kernels/decompression/model.cuh:38-53.  Nothing is read from memory: the kernel is a pure
 // 16-byte-per-lane store stream (G = 16/sizeof(Uncompressed) consecutive elements per lane per
 // step, K steps per tile, tiles at grid stride).  HBM bytes per element: sizeof(Uncompressed).
-// (The reference's decompress_with_intervals, model.cuh:55-98, has no wrapper and no launch
-// parameters and is unreachable; it is not part of the hot path.)
+// decompress_with_intervals (model.cuh:55-98: wrapper-less in the reference) is below;
+// it is launched with the same parameters class.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -37,6 +37,57 @@ __global__ void decompress(
 			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
 		},
 		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); });
+}
+
+/// Piecewise models:  out[p] = model_{p / modeling_period}(p % modeling_period)  — one coefficient record per
+/// interval of `modeling_period` elements, the model evaluated at the position WITHIN the interval.  Kernel
+/// template name and parameter list as the reference's wrapper-less decompress_with_intervals
+/// (src/kernels/decompression/model.cuh:55-98): this is Frame of Reference without the offsets —
+/// the missing piece for segment-wise Model + patches columns.  `intervals_per_block` is accepted for signature
+/// parity; the tiling here does not depend on it.  (The reference's one-interval-per-block branch writes a whole
+/// period even past `length`, model.cuh:84-92; here nothing is written at or after `length`.)
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+__global__ void decompress_with_intervals(
+	Uncompressed* __restrict__          decompressed,
+	const typename UnaryModelFunction::coefficients_type* __restrict__
+	                                    interval_model_coefficients,
+	size_type_by_index_size<IndexSize>  modeling_period,
+	size_type_by_index_size<IndexSize>  intervals_per_block,
+	size_type_by_index_size<IndexSize>  length)
+{
+	using model_index_type = typename UnaryModelFunction::index_type;
+	using coefficients_type = typename UnaryModelFunction::coefficients_type;
+	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
+	(void) intervals_per_block;
+	const uint64_t period = modeling_period;
+	if (period == 0) { return; }
+
+	auto split = [period](uint64_t p, uint64_t& interval, uint64_t& within) {
+		if (IndexSize <= 4 || ((p | period) >> 32) == 0) {
+			uint32_t q = (uint32_t) p / (uint32_t) period;
+			interval = q; within = (uint32_t) p - q * (uint32_t) period;
+		}
+		else { interval = p / period; within = p - interval * period; }
+	};
+	stream_tiles::generate<Uncompressed>(decompressed, length,
+		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
+			uint64_t interval, within;
+			split(first_position, interval, within);
+			coefficients_type record = interval_model_coefficients[interval];   // once per group, again only across a boundary
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) {
+				out[j] = static_cast<Uncompressed>(UnaryModelFunction(record)((model_index_type) within));
+				if (++within == period) {
+					within = 0; interval++;
+					if (j + 1 < G) { record = interval_model_coefficients[interval]; }
+				}
+			}
+		},
+		[&](uint64_t position) {
+			uint64_t interval, within;
+			split(position, interval, within);
+			return static_cast<Uncompressed>(UnaryModelFunction(interval_model_coefficients[interval])((model_index_type) within));
+		});
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>

@@ -1,22 +1,141 @@
 """Transfer/decode overlap: decompress a column whose COMPRESSED form lives in (pinned) host memory.
 
 The point of lightweight compression on a discrete GPU is to move the compressed bytes across the
-host link and expand them on the device (reference README.md:15-24).  This module does that for any
-elementwise-shardable scheme by cutting the column into chunks of whole segments and pipelining, on
-`depth` HIP streams:   H2D copy of chunk i+1   ||   decode of chunk i.
-The kernels are the same ones the device-resident path uses (libgiddy_amd.schemes); torch supplies
-pinned buffers, streams and async copies only.
+host link and expand them on the device (reference README.md:15-24).  This module
+does that for every scheme that shards (libgiddy_amd.sharding): the column is cut into `num_chunks`
+ranges of whole anchored segments — a chunk is exactly a shard, with anchors rebased on the host —
+and pipelined on `depth` HIP streams:   H2D copy of chunk i+1   ||   decode of chunk i.
+The kernels are the ones the device-resident path uses (libgiddy_amd.schemes); torch supplies pinned
+buffers, streams, events and async copies only.
+
+Host fields: the dictionary a libgiddy_amd.formats writer returns, with the LARGE arrays replaced by
+pinned torch tensors (`pin(fields)` does that) so that their slices copy asynchronously; small arrays
+(anchors, dictionaries, model records) stay numpy and are rebased per chunk.
 """
+import numpy as np
 import torch
 
-from . import schemes
+from . import schemes, sharding
+
+_LARGE = 1 << 16   # bytes from which a host array is worth pinning
+
+
+def pin(fields):
+    """numpy arrays of at least 64 KiB -> pinned torch tensors (same bits); everything else unchanged"""
+    out = {}
+    for name, value in fields.items():
+        if isinstance(value, np.ndarray) and value.nbytes >= _LARGE:
+            out[name] = torch.from_numpy(np.ascontiguousarray(value)).pin_memory()
+        else:
+            out[name] = value
+    return out
+
+
+def _itemsize(x):
+    return x.element_size() if isinstance(x, torch.Tensor) else np.asarray(x).dtype.itemsize
+
+
+def _launch_dictionary(out, f, stream, kw):
+    schemes.dictionary(out, f["compressed_input"], f["dictionary_entries"], f["length"], kw["num_dictionary_entries"],
+                       uncompressed_size=kw["out_size"], dictionary_index_size=kw["sizes"]["compressed_input"], stream=stream)
+
+
+def _launch_frame_of_reference(out, f, stream, kw):
+    schemes.frame_of_reference(out, f["compressed_input"], f["segment_model_coefficients"], f["length"], f["segment_length"],
+                               uncompressed_size=kw["out_size"], compressed_size=kw["sizes"]["compressed_input"],
+                               model=kw.get("model", "constant"), stream=stream)
+
+
+def _launch_delta(out, f, stream, kw):
+    schemes.delta(out, f["compressed_input"], f["anchor_values"], f["length"], f["segment_length"],
+                  uncompressed_size=kw["out_size"], compressed_size=kw["sizes"]["compressed_input"], stream=stream)
+
+
+def _launch_dzb_fixed(out, f, stream, kw):
+    schemes.discard_zero_bytes_fixed(out, f["compressed_input"], f["length"], uncompressed_size=kw["out_size"],
+                                     compressed_size=kw["sizes"]["compressed_input"], stream=stream)
+
+
+def _launch_dzb_variable(out, f, stream, kw):
+    schemes.discard_zero_bytes_variable(out, f["compressed_data"], f["packed_element_sizes"], f["position_anchors"],
+                                        f["segment_length"], f["length"], f["min_represented_element_size"], f["bits_per_element_size"],
+                                        uncompressed_size=kw["out_size"], index_size=kw["sizes"]["position_anchors"],
+                                        container_size=kw["sizes"]["packed_element_sizes"], stream=stream)
+
+
+def _launch_rle(out, f, stream, kw):
+    schemes.run_length_encoding(out, f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"],
+                                f["segment_length"], f["num_segments"], f["num_element_runs"], f["length"],
+                                uncompressed_size=kw["out_size"], run_length_size=kw["sizes"]["run_lengths"],
+                                index_size=kw["sizes"]["position_anchors"], stream=stream)
+
+
+def _launch_rpe(out, f, stream, kw):
+    schemes.run_position_encoding(out, f["run_data"], f["run_start_positions"], f["position_anchors"], f["segment_length"],
+                                  f["num_anchors"], f["num_element_runs"], f["length"], uncompressed_size=kw["out_size"],
+                                  position_size=kw["sizes"]["run_start_positions"], relative=kw.get("relative", True),
+                                  index_size=kw["sizes"]["position_anchors"], stream=stream)
+
+
+_SCHEMES = {   # name -> (how a chunk is cut out of the column, how it is launched)
+    "dictionary": (sharding.elementwise, _launch_dictionary),
+    "frame_of_reference": (sharding.frame_of_reference, _launch_frame_of_reference),
+    "delta": (sharding.delta, _launch_delta),
+    "discard_zero_bytes_fixed": (sharding.elementwise, _launch_dzb_fixed),
+    "discard_zero_bytes_variable": (sharding.discard_zero_bytes_variable, _launch_dzb_variable),
+    "run_length_encoding": (sharding.run_length_encoding, _launch_rle),
+    "run_position_encoding": (lambda f, k, n: sharding.run_position_encoding(f, k, n, relative=True), _launch_rpe),
+}
+
+
+def _as_bytes(value):
+    """host array (pinned torch tensor or numpy) -> flat uint8 torch tensor over the same bits"""
+    if isinstance(value, torch.Tensor):
+        return value.contiguous().view(torch.uint8).reshape(-1)
+    return torch.from_numpy(np.ascontiguousarray(value).reshape(-1).view(np.uint8))
+
+
+def decode_from_host(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **instantiation):
+    """Decompress `host_fields` (see the module docstring) into the device tensor `out_dev`, `num_chunks` chunks of
+    whole segments pipelined over `depth` streams.  Returns the streams used; the caller synchronises them.
+    `instantiation`: what the field dtypes do not say (model=..., num_dictionary_entries=..., relative=...)."""
+    shard, launch = _SCHEMES[scheme]
+    arrays = [k for k, v in host_fields.items() if isinstance(v, (torch.Tensor, np.ndarray))]
+    kw = dict(instantiation, out_size=out_dev.element_size(), sizes={k: _itemsize(host_fields[k]) for k in arrays})
+    if scheme == "dictionary":
+        kw.setdefault("num_dictionary_entries", len(host_fields["dictionary_entries"]))
+    flat_out = out_dev.view(-1)
+    streams = [torch.cuda.Stream(device=out_dev.device) for _ in range(depth)]
+    staging = [dict() for _ in range(depth)]   # per slot: field name -> device byte buffer, grown on demand
+    decoded = [None] * depth
+    for chunk in range(num_chunks):
+        piece = shard(host_fields, chunk, num_chunks)
+        if piece.stop <= piece.start:
+            continue
+        slot = chunk % depth
+        stream = streams[slot]
+        with torch.cuda.stream(stream):
+            if decoded[slot] is not None:
+                stream.wait_event(decoded[slot])   # the previous decode out of this slot's staging buffers
+            fields = dict(piece.fields)
+            for name in arrays:
+                source = _as_bytes(piece.fields[name])
+                room = staging[slot].get(name)
+                if room is None or room.numel() < source.numel():
+                    room = torch.empty(max(source.numel(), 16) * 5 // 4, dtype=torch.uint8, device=out_dev.device)
+                    staging[slot][name] = room
+                room[: source.numel()].copy_(source, non_blocking=True)
+                fields[name] = room
+            launch(flat_out[piece.start:piece.stop], fields, stream.cuda_stream, kw)
+            decoded[slot] = torch.cuda.Event()
+            decoded[slot].record(stream)
+    return streams
 
 
 def dictionary_from_host(keys_host, entries_dev, out_dev, *, uncompressed_size=4, dictionary_index_size=1,
                          chunk_elements=1 << 26, depth=3):
-    """keys_host: pinned CPU tensor of keys; entries_dev / out_dev: device tensors.  Returns the streams used
-    (the caller synchronises).  Each chunk is copied into one of `depth` staging buffers and decoded
-    straight into its slice of out_dev."""
+    """The Dictionary special case with the dictionary already on the device: keys_host is a pinned CPU tensor of
+    keys.  Returns the streams used (the caller synchronises)."""
     n = keys_host.numel()
     num_entries = entries_dev.numel()
     streams = [torch.cuda.Stream() for _ in range(depth)]

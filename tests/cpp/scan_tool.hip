@@ -1,6 +1,7 @@
 // Driver for the un-anchored scan kernels (include/giddy/kernels/reduction/scan.hpp), used by
 // tests/test_gpu_scan.py:   scan_tool <instantiation> <mode> <n> <segment_length> <grid> <offset> <in.bin> <out.bin>
-//   mode: gather     -> data_layout gather; n = number of indices, segment_length = table length
+//   mode: intervals  -> model::decompress_with_intervals; n outputs, segment_length = modeling period, in.bin = coefficient records
+//         gather     -> data_layout gather; n = number of indices, segment_length = table length
 //         two_phase  -> reduce_segments, then scan_using_segment_reductions; out.bin = results, out.bin.segments = phase-1 output
 //         single     -> scan_single_segment
 //   grid: 0 = as resolved by the launch parameters, otherwise imposed (any grid must be correct)
@@ -15,6 +16,7 @@
 #include "cuda/api_wrappers.h"
 #include "cuda/functors.hpp"
 #include "kernels/data_layout/gather.cuh"
+#include "kernels/decompression/model.cuh"
 #include "kernels/reduction/scan.cuh"
 #include "kernels/resolve_launch_configuration.h"
 
@@ -150,6 +152,43 @@ static int run_gather(size_t num_indices, size_t data_length, unsigned grid, siz
 	return 0;
 }
 
+/// mode "intervals": n outputs, segment_length = modeling period; in.bin holds one coefficient record (int32 x Dimension) per interval
+template <unsigned IndexSize, typename Uncompressed, typename Model>
+static int run_intervals(size_t n, size_t period, unsigned grid, size_t offset, const std::string& in_path, const std::string& out_path)
+{
+	namespace model = cuda::kernels::decompression::model;
+	using coefficients_type = typename Model::coefficients_type;
+	using size_type = cuda::size_type_by_index_size<IndexSize>;
+	size_t num_intervals = (n + period - 1) / period;
+	auto host_records = read_file<coefficients_type>(in_path, num_intervals);
+	coefficients_type* d_records; Uncompressed* d_out_base;
+	HIP_OK(hipMalloc(&d_records, (num_intervals + 1) * sizeof(coefficients_type)));
+	HIP_OK(hipMalloc(&d_out_base, (n + offset + 64) * sizeof(Uncompressed)));
+	Uncompressed* d_out = d_out_base + offset;
+	if (num_intervals) { HIP_OK(hipMemcpy(d_records, host_records.data(), num_intervals * sizeof(coefficients_type), hipMemcpyHostToDevice)); }
+	HIP_OK(hipMemset(d_out_base, 0xCD, (n + offset + 64) * sizeof(Uncompressed)));
+	auto properties = cuda::device::current::get().properties();
+	auto kernel = model::decompress_with_intervals<IndexSize, Uncompressed, Model>;
+	model::launch_config_resolution_params_t<IndexSize, Uncompressed, Model> params(properties, cuda::device_function_t(kernel).attributes(), n);
+	auto config = cuda::kernels::resolve_launch_configuration(params);
+	if (grid) { config.grid_dimensions.x = grid; }
+	hipEvent_t begin, end; HIP_OK(hipEventCreate(&begin)); HIP_OK(hipEventCreate(&end));
+	float ms = 0;
+	for (int repetition = 0; repetition < 5 && config.grid_dimensions.x > 0; repetition++) {
+		HIP_OK(hipEventRecord(begin, 0));
+		cuda::launch(kernel, config, d_out, (const coefficients_type*) d_records, (size_type) period, (size_type) 1, (size_type) n);
+		HIP_OK(hipEventRecord(end, 0));
+		HIP_OK(hipEventSynchronize(end));
+		HIP_OK(hipEventElapsedTime(&ms, begin, end));
+	}
+	HIP_OK(hipDeviceSynchronize());
+	std::vector<Uncompressed> host_out(n + 64);
+	HIP_OK(hipMemcpy(host_out.data(), d_out, (n + 64) * sizeof(Uncompressed), hipMemcpyDeviceToHost));
+	write_file(out_path, host_out);
+	std::printf("OK %.4f\n", ms);
+	return 0;
+}
+
 int main(int argc, char** argv)
 {
 	if (argc != 9) { std::fprintf(stderr, "usage: %s instantiation mode n segment_length grid offset in.bin out.bin\n", argv[0]); return 2; }
@@ -158,6 +197,14 @@ int main(int argc, char** argv)
 	unsigned grid = (unsigned) std::strtoul(argv[5], nullptr, 10);
 	size_t offset = std::strtoull(argv[6], nullptr, 10);
 	std::string in = argv[7], out = argv[8];
+	if (mode == "intervals") {
+		namespace models = cuda::functors::unary::parametric_model;
+		if (which == "intervals_4_int_linear")    { return run_intervals<4, int32_t, models::linear<4, int32_t>>(n, L, grid, offset, in, out); }
+		if (which == "intervals_4_short_linear")  { return run_intervals<4, int16_t, models::linear<4, int32_t>>(n, L, grid, offset, in, out); }
+		if (which == "intervals_8_int_constant")  { return run_intervals<8, int32_t, models::constant<4, int32_t>>(n, L, grid, offset, in, out); }
+		std::fprintf(stderr, "unknown instantiation %s\n", which.c_str());
+		return 2;
+	}
 	if (mode == "gather") {
 		if (which == "gather_4_4_2") { return run_gather<4, 4, 2>(n, L, grid, offset, in, out); }
 		if (which == "gather_4_1_1") { return run_gather<4, 1, 1>(n, L, grid, offset, in, out); }

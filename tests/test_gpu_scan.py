@@ -123,6 +123,30 @@ def test_stand_alone_gather(tmp_path, name, element, index):
         assert (out[:num_indices] == table[indices.astype(np.int64)]).all(), (name, num_indices, table_length)
 
 
+@pytest.mark.parametrize("name,out_dtype,model", [("intervals_4_int_linear", np.int32, "linear"), ("intervals_4_short_linear", np.int16, "linear"),
+                                                  ("intervals_8_int_constant", np.int32, "constant")])
+def test_model_decompress_with_intervals(tmp_path, name, out_dtype, model):
+    """model::decompress_with_intervals (model.cuh:55-98) is Frame of Reference with all offsets zero: checked against the C oracle's FOR"""
+    from oracle import oracle
+    for n, period in [(1, 4), (4099, 64), (1000003, 4096), (70000, 12), (333, 1000), (1 << 20, 1 << 20)]:
+        for grid, offset in ((0, 0), (3, 1)):
+            r = np.random.default_rng(n + period)
+            num_intervals = -(-n // period)
+            records = r.integers(-1000000, 1000000, size=(num_intervals, 2 if model == "linear" else 1)).astype(np.int32)
+            if model == "linear":
+                records[:, 1] = r.integers(-300, 300, size=num_intervals)
+            in_path, out_path = str(tmp_path / "in.bin"), str(tmp_path / "out.bin")
+            records.tofile(in_path)
+            done = subprocess.run([TOOL, name, "intervals", str(n), str(period), str(grid), str(offset), in_path, out_path],
+                                  capture_output=True, text=True, timeout=300)
+            assert done.returncode == 0 and done.stdout.startswith("OK"), done.stdout + done.stderr
+            out = np.fromfile(out_path, dtype=out_dtype)
+            assert (out[n:].view(np.uint8) == 0xCD).all(), "wrote past the last element"
+            zero_offsets = np.zeros(n, dtype=np.int8)
+            expect = oracle.frame_of_reference(zero_offsets, records, n, period, out_dtype, model)
+            assert (out[:n] == expect).all(), (name, n, period, grid, offset)
+
+
 def test_scan_throughput_is_reported(tmp_path, capsys):
     """not a pass/fail bar: prints the two-phase rate at 2^28 elements so that the log of the GPU run holds it"""
     n, L = 1 << 28, 1 << 17

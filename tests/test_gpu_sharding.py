@@ -73,3 +73,34 @@ def test_pipelined_decode_from_pinned_host_memory():
     for s in pipeline.dictionary_from_host(keys_host, entries, out, chunk_elements=1 << 20, depth=3):
         s.synchronize()
     assert bool((out == entries[keys_host.cuda().long()]).all())
+
+
+@pytest.mark.parametrize("num_chunks,depth", [(1, 1), (5, 2), (16, 3)])
+def test_pipelined_decode_of_every_sharding_scheme_from_host(num_chunks, depth):
+    """libgiddy_amd.pipeline.decode_from_host: chunk = shard (anchors rebased on the host), copies and decodes overlapped
+    on several streams; the result must be the column, for every scheme that shards"""
+    from libgiddy_amd import pipeline
+    n = 300000 + 77
+
+    def check(scheme, fields, truth, **extra):
+        out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
+        out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
+        for s in pipeline.decode_from_host(scheme, pipeline.pin(fields), out, num_chunks=num_chunks, depth=depth, **extra):
+            s.synchronize()
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
+
+    f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=3)
+    check("delta", f, truth)
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 3, seed=4)
+    check("discard_zero_bytes_variable", formats.discard_zero_bytes_variable(col, 1024, 1, 3, np.uint32, 8, element_sizes=sizes), col)
+    col = cases.runs_column(n, 32, np.uint32, seed=5)
+    check("run_length_encoding", formats.run_length_encoding(col, 4096, np.uint16), col)
+    check("run_position_encoding", formats.run_position_encoding(col, 4096, np.uint16, True), col, relative=True)
+    f = cases.dictionary_case(n, 256, np.uint32, np.uint8, seed=2)
+    check("dictionary", dict(f, length=n), f["dictionary_entries"][f["compressed_input"].astype(np.int64)])
+    f = cases.for_case(n, 4096, np.int32, np.int16, "linear", seed=6)
+    from oracle import oracle
+    check("frame_of_reference", f, oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, 4096, np.int32, "linear"), model="linear")
+    small = (cases.rng(7).integers(0, 1 << 20, size=n)).astype(np.uint64)
+    check("discard_zero_bytes_fixed", formats.discard_zero_bytes_fixed(small, np.uint32), small)
