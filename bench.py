@@ -228,7 +228,8 @@ def main():
         names = ["dictionary_zipf", "frame_of_reference", "delta_patched", "run_length_encoding", "run_position_encoding_relative",
                  "run_position_encoding_absolute", "discard_zero_bytes_variable"]
         if args.schemes == "coverage":
-            names += ["discard_zero_bytes_variable_3bit", "discard_zero_bytes_fixed", "model", "incidence_bitmaps"]
+            names += ["discard_zero_bytes_variable_3bit", "discard_zero_bytes_fixed", "model", "incidence_bitmaps",
+                      "delta_fused_patches", "dictionary_fused_patches", "frame_of_reference_fused_patches"]
         elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
         del work

@@ -354,9 +354,10 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>             segment_length,
 	size_type_by_index_size<IndexSize>             num_patches)
 {
+	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length));
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows));
 }
 
 } // namespace patched

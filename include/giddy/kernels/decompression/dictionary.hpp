@@ -59,7 +59,7 @@ __device__ __forceinline__ void translate(
 		for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
-	if constexpr (Patches::enabled) {
+	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
 		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches);
 	}
 	else {
@@ -128,9 +128,10 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>                num_patches,
 	bool                                              cache_dictionary_in_shared_memory)
 {
+	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
 	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory,
-		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length));
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows));
 }
 
 } // namespace patched
@@ -155,7 +156,8 @@ public:
 		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
 	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
 	{
-		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
+		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
+			: stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		bool cache = cache_dictionary_in_shared_memory_override.value_or(
 			should_cache_dictionary_in_shared_memory(num_dictionary_entries));
 		grid_construction_resolution  = thread;

@@ -92,7 +92,7 @@ __device__ __forceinline__ void decompress(
 		divide<IndexSize>(position, L, segment, within);
 		return predict(segment_model_coefficients[segment], within, offset);
 	};
-	if constexpr (Patches::enabled) {
+	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
 		stream_tiles::transform_and_patch<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, patches);
 	}
 	else {
@@ -135,9 +135,10 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>  segment_length,
 	size_type_by_index_size<IndexSize>  num_patches)
 {
+	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length));
+		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length, patch_windows));
 }
 
 } // namespace patched
@@ -159,7 +160,8 @@ public:
 		if (segment_length % sizeof(native_word_t) != 0) {
 			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
 		}
-		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed>();
+		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<Uncompressed>()
+			: stream_tiles::elements_per_thread_per_tile<Uncompressed>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride

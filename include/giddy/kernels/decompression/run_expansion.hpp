@@ -99,18 +99,26 @@ __device__ __forceinline__ void expand(
 		const uint32_t p = row_start + lane * E;
 		if (p >= tile_len) { continue; }
 		const tile_entry entry = table[p >> 5];   // E divides 32: all E positions share the word
-		uint32_t ranks[E];
-		#pragma unroll
-		for (unsigned j = 0; j < E; j++) {
-			unsigned bit = (p + j) & 31;
-			ranks[j] = entry.rank_before + __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - bit)));
-		}
+		auto rank_of = [&](unsigned j) {
+			const unsigned bit = (p + j) & 31;
+			return entry.rank_before + (uint32_t) __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - bit)));
+		};
 		group<element_type, E> values;
 		if (use_staged) {
+			// one output dword (4 / ElementSize elements) at a time, so that at most that many ranks and looked-up
+			// values are alive at once (all 16 of a 1-byte column at once cost two wavefronts per SIMD of occupancy)
+			constexpr unsigned per_dword = 4 / (ElementSize > 4 ? 4 : ElementSize);
 			#pragma unroll
-			for (unsigned j = 0; j < E; j++) { values[j] = staged[ranks[j]]; }
+			for (unsigned first = 0; first < E; first += per_dword) {
+				#pragma unroll
+				for (unsigned j = first; j < first + per_dword && j < E; j++) { values[j] = staged[rank_of(j)]; }
+				__builtin_amdgcn_sched_barrier(0);
+			}
 		}
 		else {
+			uint32_t ranks[E];
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { ranks[j] = rank_of(j); }
 			element_type first = first_run_data[ranks[0]];
 			if (ranks[E - 1] == ranks[0]) {
 				#pragma unroll

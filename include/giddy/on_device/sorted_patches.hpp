@@ -6,11 +6,11 @@
 // outputs in ascending order can merge them in registers just before its 16-byte stores:
 //
 //   * begin_seek() / finish_seek(): first patch at or after a position, found by the whole wavefront — a guess
-//     from the patch density, checked 64 positions at a time (evenly spread patches: one load), else a
+//     from the patch density, checked 16 positions at a time (evenly spread patches: one load), else a
 //     64-ary search narrowing the candidates 64-fold per load;
-//   * cursor_t: a window of 64 patches (one per lane) with a wave-uniform read position; advancing
-//     is two v_readlane, refilling is one coalesced load per 64 patches;
-//   * apply(): overwrites the patched elements of a row of 64*E outputs held E per lane.
+//   * cursor_t: a window of 64 patches in wave-private LDS with a wave-uniform read position; advancing
+//     is two LDS reads, refilling is one coalesced load per 64 patches;
+//   * apply_to_row(): overwrites the patched elements of a row of 64*E outputs held E per lane.
 //
 // `none` is the same interface doing nothing: the plain decoders are the patched ones instantiated
 // with it, at no cost.
@@ -57,11 +57,17 @@ struct none {
 	__device__ __forceinline__ void begin_seek(uint64_t, unsigned) { }
 	__device__ __forceinline__ void finish_seek(unsigned) { }
 	__device__ __forceinline__ void seek(uint64_t, unsigned) { }
-	struct handoff_t { };
-	__device__ __forceinline__ void publish(handoff_t&, unsigned) const { }
-	__device__ __forceinline__ void adopt(const handoff_t&, unsigned) { }
 	template <unsigned E, typename Values> __device__ __forceinline__ void apply_to_row(uint64_t, unsigned, Values&) { }
 	template <typename T> __device__ __forceinline__ T patched(uint64_t, T value) const { return value; }
+};
+
+/// Wave-private LDS for the cursors of a workgroup's wavefronts: a window of 64 patches each.  Declared __shared__
+/// by the kernel (at most 16 wavefronts = 1024 threads per workgroup).
+template <unsigned PositionSize, typename Value>
+struct window_storage {
+	enum : unsigned { max_waves_per_block = 16 };
+	uint_t<PositionSize> positions[max_waves_per_block][64];
+	Value values[max_waves_per_block][64];
 };
 
 template <unsigned PositionSize, typename Value>
@@ -69,44 +75,60 @@ struct cursor_t {
 	enum : bool { enabled = true };
 	enum : unsigned { guess_probes = 16 };
 	using position_type = uint_t<PositionSize>;
+	using storage_type = window_storage<PositionSize, Value>;
+	static constexpr position_type no_patch = (position_type) ~(position_type) 0;   // (no column has an element at the all-ones index)
 
+	// Everything here is wave-uniform (scalar registers) but `probed_position`; the window itself lives in
+	// wave-private LDS, so that walking it costs LDS reads only.  (A window held in vector registers and refilled
+	// by loads inside the row loops makes the compiler wait for ALL outstanding memory operations before every
+	// access to it — CDNA4 counts them in order: the next rows' loads, the previous rows' stores — and costs the
+	// streaming decoders a wavefront or two of occupancy per SIMD.)
 	const position_type* __restrict__ positions;
 	const Value* __restrict__ values;
 	uint64_t num;
 	float patches_per_output;                   // where to look first: patch index ~ output position * this
-	unsigned guess_shift;                       // ... give or take 32 << guess_shift patches
-
-	uint64_t lane_position; Value lane_value;   // the window: lane l holds patch window_start + l
-	uint64_t window_start;                      // wave-uniform from here on
+	unsigned guess_shift;                       // ... give or take (guess_probes / 2) << guess_shift patches
+	position_type* window_positions;            // LDS: entry l is patch window_start + l (no_patch past the last one)
+	Value* window_values;
+	uint64_t window_start;
 	unsigned index_in_window;
 	uint64_t position;                          // the current patch; ~0 once the patches are exhausted
 	Value value;
+	uint64_t seek_target, seek_base, probed_position;
 
 	/// `length`: the column's length in elements (only used to guess where a position's patches are)
-	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length)
+	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage)
 	: positions(positions_), values(values_), num(num_), position(~(uint64_t) 0)
 	{
 		patches_per_output = length ? (float) num_ / (float) length : 0.0f;
 		// evenly spread patches deviate from the guess by a few sqrt(num): reach (guess_probes / 2) << shift >= 2 * sqrt(num)
 		const unsigned log_num = 64 - (unsigned) __builtin_clzll(num_ | 1);
 		guess_shift = log_num / 2 > 10 ? log_num / 2 - 2 : 8;
+		const unsigned wave = wave64::index_in_block() % storage_type::max_waves_per_block;
+		window_positions = storage.positions[wave];
+		window_values = storage.values[wave];
 	}
 
 	__device__ __forceinline__ void read_current()
 	{
-		position = wave64::read_lane(lane_position, index_in_window);
-		value = wave64::read_lane(lane_value, index_in_window);
+		const position_type p = wave64::read_first_lane(window_positions[index_in_window]);
+		position = p == no_patch ? ~(uint64_t) 0 : (uint64_t) p;
+		value = wave64::read_first_lane(window_values[index_in_window]);
 	}
 	__device__ __forceinline__ void fill_window(unsigned lane)
 	{
 		const uint64_t mine = window_start + lane;
 		const bool have = mine < num;
-		lane_position = have ? (uint64_t) positions[mine] : ~(uint64_t) 0;
-		lane_value = have ? values[mine] : Value();
+		const position_type p = have ? positions[mine] : no_patch;
+		const Value v = have ? values[mine] : Value();
+		wave64::lds_fence();   // (earlier reads of the window are done)
+		window_positions[lane] = p;
+		window_values[lane] = v;
+		wave64::lds_fence();
 	}
 	__device__ __forceinline__ void advance(unsigned lane)
 	{
-		if (++index_in_window == 64) { window_start += 64; fill_window(lane); index_in_window = 0; }
+		if (++index_in_window == 64) { window_start += 64; index_in_window = 0; fill_window(lane); }
 		read_current();
 	}
 
@@ -116,8 +138,6 @@ struct cursor_t {
 	/// patches sit within a few sqrt(num) of first_output * num / length — and probes 16 positions `1 << guess_shift`
 	/// apart around the guess; finish_seek() turns the answers into a bracket (falling back to the 64-ary search from
 	/// whatever bracket the guess did establish) and loads its <= 64 candidates, which are at once the first window.
-	uint64_t seek_target, seek_base, probed_position;
-
 	__device__ __forceinline__ void begin_seek(uint64_t first_output, unsigned lane)
 	{
 		seek_target = first_output;
@@ -148,28 +168,13 @@ struct cursor_t {
 		window_start = lo;
 		fill_window(lane);
 		// (positions from index hi on are >= the target, so counting over the whole window counts [lo, hi) only)
-		index_in_window = (unsigned) __builtin_popcountll(wave64::ballot(lane_position < seek_target));
-		if (index_in_window == 64) { window_start += 64; fill_window(lane); index_in_window = 0; }
-		read_current();
+		const position_type mine = window_positions[lane];
+		const bool before = mine != no_patch && (uint64_t) mine < seek_target;
+		index_in_window = (unsigned) __builtin_popcountll(wave64::ballot(before));
+		if (index_in_window == 64) { index_in_window = 63; advance(lane); }
+		else { read_current(); }
 	}
 	__device__ __forceinline__ void seek(uint64_t first_output, unsigned lane) { begin_seek(first_output, lane); finish_seek(lane); }
-
-	/// A sought cursor handed from one wavefront of a workgroup to the others through LDS (one seek per tile
-	/// instead of one per wavefront): publish(), barrier, adopt().
-	struct handoff_t { uint64_t window_start; unsigned index_in_window; uint64_t lane_position[64]; Value lane_value[64]; };
-
-	__device__ __forceinline__ void publish(handoff_t& handoff, unsigned lane) const
-	{
-		handoff.lane_position[lane] = lane_position; handoff.lane_value[lane] = lane_value;
-		if (lane == 0) { handoff.window_start = window_start; handoff.index_in_window = index_in_window; }
-	}
-	__device__ __forceinline__ void adopt(const handoff_t& handoff, unsigned lane)
-	{
-		lane_position = handoff.lane_position[lane]; lane_value = handoff.lane_value[lane];
-		window_start = wave64::read_first_lane(handoff.window_start);
-		index_in_window = wave64::read_first_lane(handoff.index_in_window);
-		read_current();
-	}
 
 	/// Overwrite the patched elements among the 64*E outputs starting at `row_start`, lane l holding
 	/// elements [l*E, l*E+E) in `row` (anything indexable).  Rows must come in ascending order after a

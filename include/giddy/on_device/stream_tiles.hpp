@@ -54,6 +54,9 @@ __device__ __forceinline__ void transform(
 				group<Out, G> outputs;
 				produce_group(g * G, inputs[k], outputs);
 				store_group(out + g * G, outputs);
+				// narrow elements: G look-ups per step — keep the steps' work from being hoisted above one another
+				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
+				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
 			}
 			continue;
 		}
@@ -139,6 +142,9 @@ __device__ __forceinline__ void transform_and_patch(
 				produce_group(p, current[k], outputs);
 				patches.template apply_to_row<G>((r + k) * row, lane, outputs);
 				store_group(out + p, outputs);
+				// narrow elements: G look-ups per row — keep the rows' look-ups from being hoisted above one another
+				// (all 4 x 16 of a 1-byte column in flight at once spill)
+				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
 			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { current[k] = next[k]; }

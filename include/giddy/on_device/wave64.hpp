@@ -168,12 +168,34 @@ template <> struct chunk<4>  { using type = uint32_t; };
 template <> struct chunk<8>  { using type = uint32_t __attribute__((ext_vector_type(2))); };
 template <> struct chunk<16> { using type = uint32_t __attribute__((ext_vector_type(4))); };
 
-/// N elements of T moved as one memory instruction when N*sizeof(T) <= 16 (more: 16-byte pieces)
-template <typename T, unsigned N>
+/// N elements of T moved as one memory instruction when N*sizeof(T) <= 16 (more: 16-byte pieces).
+template <typename T, unsigned N, bool Packed = (sizeof(T) < 4 && (N * sizeof(T)) % 4 == 0)>
 struct alignas(N * sizeof(T) >= 16 ? 16 : N * sizeof(T)) group {
 	T e[N];
 	__device__ __forceinline__ T& operator[](unsigned i) { return e[i]; }
 	__device__ __forceinline__ const T& operator[](unsigned i) const { return e[i]; }
+};
+
+/// 1- and 2-byte elements filling whole dwords are kept AS dwords and cut out / put in with shifts: left as an
+/// array of bytes the compiler gives every element a vector register of its own (a lane's sixteen 1-byte
+/// elements: 16 registers instead of 4, and the narrow decoders lose half their occupancy or spill).
+template <typename T, unsigned N>
+struct alignas(N * sizeof(T) >= 16 ? 16 : N * sizeof(T)) group<T, N, true> {
+	enum : unsigned { per_word = 4 / sizeof(T), bits = 8 * sizeof(T), mask = (1u << bits) - 1 };
+	uint32_t words[N / per_word];
+
+	struct reference {
+		uint32_t& word; unsigned shift;
+		__device__ __forceinline__ operator T() const { return (T) ((word >> shift) & mask); }
+		__device__ __forceinline__ reference& operator=(T v)
+		{
+			word = (word & ~((uint32_t) mask << shift)) | (((uint32_t) v & mask) << shift);
+			return *this;
+		}
+		__device__ __forceinline__ reference& operator=(const reference& other) { return *this = (T) other; }
+	};
+	__device__ __forceinline__ reference operator[](unsigned i) { return reference { words[i / per_word], (i % per_word) * bits }; }
+	__device__ __forceinline__ T operator[](unsigned i) const { return (T) ((words[i / per_word] >> ((i % per_word) * bits)) & mask); }
 };
 
 template <typename T, unsigned N>

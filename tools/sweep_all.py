@@ -61,20 +61,43 @@ def chunks(n, step=1 << 26):
         yield lo, min(n, lo + step)
 
 
-def run_dictionary(I, U, D, n):
+def make_patches(n, U, I, seed):
+    """0.1 % ascending patch positions (I-byte indices) and U-byte values"""
+    g = gen(seed)
+    count = max(1, int(n * float(os.environ.get("PATCH_FRACTION", "0.001"))))
+    idx = torch.sort(torch.randperm(n, generator=g, device=DEV)[:count])[0]
+    return idx, idx.to(INT[I]), rand_bits(count, U, g)
+
+
+def patched_ok(expect, out, idx, vals, lo, hi):
+    """expect (the plain decode of [lo, hi)) with the patches inside the range applied == out[lo:hi]"""
+    inside = (idx >= lo) & (idx < hi)
+    expect = expect.clone()
+    expect[idx[inside] - lo] = vals[inside]
+    return bool((expect == out[lo:hi]).all())
+
+
+def run_dictionary(I, U, D, n, patched=False):
     g = gen(U * 10 + D)
     entries_n = min(1 << (8 * D), 4096 if D > 1 else 256)
     entries = rand_bits(entries_n, U, g)
     keys = rand_bits(n, D, g, high=entries_n)
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
+    if patched:
+        idx, pidx, pval = make_patches(n, U, I, U + D)
+        kw = dict(uncompressed_size=U, dictionary_index_size=D, index_size=I, stream=st)
+        cfg = schemes.patched_dictionary(out, keys, entries, pval, pidx, n, entries_n, len(idx), **kw)
+        ms = timeit(lambda: schemes.patched_dictionary(out, keys, entries, pval, pidx, n, entries_n, len(idx), launch_config=cfg, **kw))
+        ok = all(patched_ok(entries[unsigned(keys[lo:hi], D)], out, idx, pval, lo, hi) for lo, hi in chunks(n))
+        return ms, (U + D) * n + (U + I) * len(idx), ok
     cfg = schemes.dictionary(out, keys, entries, n, entries_n, uncompressed_size=U, dictionary_index_size=D, index_size=I, stream=st)
     ms = timeit(lambda: schemes.dictionary(out, keys, entries, n, entries_n, uncompressed_size=U, dictionary_index_size=D, index_size=I, stream=st, launch_config=cfg))
     ok = all(bool((entries[unsigned(keys[lo:hi], D)] == out[lo:hi]).all()) for lo, hi in chunks(n))
     return ms, (U + D) * n, ok
 
 
-def run_delta(I, U, C, n, L=4096):
+def run_delta(I, U, C, n, L=4096, patched=False):
     g = gen(U * 10 + C)
     d = rand_bits(n, C, g)
     du = unsigned(d, C)
@@ -83,13 +106,19 @@ def run_delta(I, U, C, n, L=4096):
     anchors = anchors64.to(INT[U])
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    cfg = schemes.delta(out, d, anchors, n, L, uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
-    ms = timeit(lambda: schemes.delta(out, d, anchors, n, L, uncompressed_size=U, compressed_size=C, index_size=I, stream=st, launch_config=cfg))
+    kw = dict(uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
+    if patched:
+        idx, pidx, pval = make_patches(n, U, I, U + C)
+        cfg = schemes.patched_delta(out, d, anchors, pval, pidx, n, L, len(idx), **kw)
+        ms = timeit(lambda: schemes.patched_delta(out, d, anchors, pval, pidx, n, L, len(idx), launch_config=cfg, **kw))
+    else:
+        cfg = schemes.delta(out, d, anchors, n, L, **kw)
+        ms = timeit(lambda: schemes.delta(out, d, anchors, n, L, launch_config=cfg, **kw))
     ok = True
     for lo, hi in chunks(n, 1 << 26):
         expect = (torch.cumsum(du[lo:hi].view(-1, L), dim=1) + anchors64[lo // L: hi // L, None]).view(-1).to(INT[U])
-        ok = ok and bool((expect == out[lo:hi]).all())
-    return ms, (U + C) * n + U * (n // L), ok
+        ok = ok and (patched_ok(expect, out, idx, pval, lo, hi) if patched else bool((expect == out[lo:hi]).all()))
+    return ms, (U + C) * n + U * (n // L) + ((U + I) * len(idx) if patched else 0), ok
 
 
 def run_dzb_fixed(I, U, C, n):
@@ -132,7 +161,7 @@ def run_dzb_variable(I, U, CS, n, L=1024, bits=2, min_size=1):
     return ms, total + CS * ncont + U * n + I * len(anchors), ok
 
 
-def run_for(I, U, C, model, MI, n, L=4096):
+def run_for(I, U, C, model, MI, n, L=4096, patched=False):
     g = gen(U + C)
     comp = rand_bits(n, C, g)
     dim = 1 if model == "constant" else 2
@@ -142,8 +171,13 @@ def run_for(I, U, C, model, MI, n, L=4096):
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, compressed_size=C, model=model, index_size=I, model_index_size=MI, stream=st)
-    cfg = schemes.frame_of_reference(out, comp, coefs, n, L, **kw)
-    ms = timeit(lambda: schemes.frame_of_reference(out, comp, coefs, n, L, launch_config=cfg, **kw))
+    if patched:
+        idx, pidx, pval = make_patches(n, U, I, U + C)
+        cfg = schemes.patched_frame_of_reference(out, comp, coefs, pval, pidx, n, L, len(idx), **kw)
+        ms = timeit(lambda: schemes.patched_frame_of_reference(out, comp, coefs, pval, pidx, n, L, len(idx), launch_config=cfg, **kw))
+    else:
+        cfg = schemes.frame_of_reference(out, comp, coefs, n, L, **kw)
+        ms = timeit(lambda: schemes.frame_of_reference(out, comp, coefs, n, L, launch_config=cfg, **kw))
     pos = torch.arange(L, device=DEV, dtype=torch.int64)
     ok = True
     for lo, hi in chunks(n):
@@ -151,8 +185,8 @@ def run_for(I, U, C, model, MI, n, L=4096):
         pred = c[:, :1] + (c[:, 1:2] * pos[None, :] if dim == 2 else 0)
         pred = pred.to(torch.int32).to(INT[U]).to(torch.int64)       # trunc to T = int32, then to Uncompressed
         expect = (pred.expand(-1, L).reshape(-1) + comp[lo:hi].to(torch.int64)).to(INT[U])
-        ok = ok and bool((expect == out[lo:hi]).all())
-    return ms, (U + C) * n + 4 * dim * (n // L), ok
+        ok = ok and (patched_ok(expect, out, idx, pval, lo, hi) if patched else bool((expect == out[lo:hi]).all()))
+    return ms, (U + C) * n + 4 * dim * (n // L) + ((U + I) * len(idx) if patched else 0), ok
 
 
 def run_model(I, U, model, n):
@@ -255,17 +289,18 @@ def main():
     for key in r.kernel_t.registered_keys():
         torch.cuda.empty_cache()
         try:
+            patched = "::patched::" in key   # the fused decompress-and-patch extensions: 0.1 % patches
             if key.startswith("decompression::dictionary"):
-                I, U, D = num(key); res = run_dictionary(I, U, D, n)
+                I, U, D = num(key); res = run_dictionary(I, U, D, n, patched=patched)
             elif key.startswith("decompression::delta"):
-                I, U, C = num(key); res = run_delta(I, U, C, n)
+                I, U, C = num(key); res = run_delta(I, U, C, n, patched=patched)
             elif "fixed_width" in key:
                 I, U, C = num(key)[:3]; res = run_dzb_fixed(I, U, C, n)
             elif "variable_width" in key:
                 I, U, CS = num(key); res = run_dzb_variable(I, U, CS, min(n, 1 << 26))
             elif key.startswith("decompression::frame_of_reference"):
                 m = re.match(r".*kernel_t<(\d)u, ([a-z ]+), ([a-z ]+), .*::(constant|linear)<(\d)u", key)
-                res = run_for(int(m.group(1)), ctype[m.group(2)], ctype[m.group(3)], m.group(4), int(m.group(5)), n)
+                res = run_for(int(m.group(1)), ctype[m.group(2)], ctype[m.group(3)], m.group(4), int(m.group(5)), n, patched=patched)
             elif key.startswith("decompression::model"):
                 m = re.match(r".*kernel_t<(\d)u, ([a-z ]+), .*::(constant|linear)<", key)
                 res = run_model(int(m.group(1)), ctype[m.group(2)], m.group(3), n)
