@@ -68,18 +68,25 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 	return wave64::read_last_lane(inclusive);
 }
 
-/// Narrow elements (1-2 bytes) are looked up E = 8..16 times per lane: through the vector memory pipeline
-/// that is 64 byte-sized gathers per instruction and it, not HBM, becomes the limit.  Their run values are
-/// therefore staged into wave-private LDS first (one coalesced sweep) and looked up there.
-template <unsigned ElementSize>
+/// A tile's run values are staged into wave-private LDS first (one coalesced sweep) and looked up there:
+///  * narrow elements (1-2 bytes) are looked up E = 8..16 times per lane — through the vector memory pipeline that
+///    is 64 byte-sized gathers per instruction and it, not HBM, becomes the limit;
+///  * wide elements (8 bytes) have only 128 outputs per row, so a tile is 32 rows whose gathers, one dependent
+///    L2 round trip each, serialise (measured at 2^30 outputs, run values beyond the last-level cache: 49 %
+///    of peak with gathers).
+///  * 4-byte elements read through L1/L2 are 4 % faster than staged ones when the run descriptors (lengths or
+///    positions) are 1-2 bytes wide — 79.5 vs 75.9 % of peak for RLE <4,4,2> — and 12-15 points slower when they
+///    are 4-8 bytes wide, so those are staged too.
+/// Tiles with more runs than fit fall back to gathers through L1/L2.
+template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { enabled = ElementSize <= 2, bytes = 2048, capacity = bytes / ElementSize };
+	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 2048, capacity = bytes / ElementSize };
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
 /// `staged` (may be null) is a wave-private LDS area of value_staging<ElementSize>::capacity elements;
 /// `num_runs_in_tile` = marks + 1.
-template <unsigned ElementSize>
+template <unsigned ElementSize, bool Staged>
 __device__ __forceinline__ void expand(
 	uint_t<ElementSize>* __restrict__ out, uint32_t tile_len, const tile_entry* table,
 	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane,
@@ -89,7 +96,7 @@ __device__ __forceinline__ void expand(
 	using element_type = uint_t<ElementSize>;
 	constexpr unsigned E = 16 / ElementSize;
 	const bool aligned = is_aligned(out, 16);
-	const bool use_staged = value_staging<ElementSize>::enabled && staged != nullptr && num_runs_in_tile <= value_staging<ElementSize>::capacity;
+	const bool use_staged = Staged && staged != nullptr && num_runs_in_tile <= value_staging<ElementSize>::capacity;
 	if (use_staged) {
 		for (uint32_t i = lane; i < num_runs_in_tile; i += 64) { staged[i] = first_run_data[i]; }
 		wave64::lds_fence();

@@ -41,7 +41,7 @@ __global__ void decompress(
 {
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
-	using staging = value_staging<UncompressedSize>;
+	using staging = value_staging<UncompressedSize, RunLengthSize>;
 	__shared__ uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::capacity : 1];
 	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
 
@@ -105,7 +105,7 @@ __global__ void decompress(
 			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			expand<UncompressedSize, staging::enabled>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 
 			if (need_carry) {
 				uint64_t who = wave64::ballot(found);

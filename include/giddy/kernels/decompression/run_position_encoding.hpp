@@ -44,7 +44,7 @@ __global__ void decompress(
 		"If run positions are in absolute values, their type must be able to cover the entire potential range of data");
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
-	using staging = value_staging<UncompressedSize>;
+	using staging = value_staging<UncompressedSize, PositionOffsetSize>;
 	__shared__ uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::capacity : 1];
 	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
 
@@ -94,7 +94,7 @@ __global__ void decompress(
 			} while (!reached_past_tile);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			expand<UncompressedSize, staging::enabled>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));

@@ -297,7 +297,7 @@ def main():
             elif "fixed_width" in key:
                 I, U, C = num(key)[:3]; res = run_dzb_fixed(I, U, C, n)
             elif "variable_width" in key:
-                I, U, CS = num(key); res = run_dzb_variable(I, U, CS, min(n, 1 << 26))
+                I, U, CS = num(key); res = run_dzb_variable(I, U, CS, min(n, 1 << 28))
             elif key.startswith("decompression::frame_of_reference"):
                 m = re.match(r".*kernel_t<(\d)u, ([a-z ]+), ([a-z ]+), .*::(constant|linear)<(\d)u", key)
                 res = run_for(int(m.group(1)), ctype[m.group(2)], ctype[m.group(3)], m.group(4), int(m.group(5)), n, patched=patched)
@@ -305,7 +305,7 @@ def main():
                 m = re.match(r".*kernel_t<(\d)u, ([a-z ]+), .*::(constant|linear)<", key)
                 res = run_model(int(m.group(1)), ctype[m.group(2)], m.group(3), n)
             elif key.startswith("decompression::incidence_bitmaps"):
-                I, U, A = num(key); res = run_ib(I, U, A, key.endswith("true>"), min(n, 1 << 26))
+                I, U, A = num(key); res = run_ib(I, U, A, key.endswith("true>"), min(n, 1 << 28))
             elif key.startswith("decompression::run_length_encoding"):
                 I, U, LS, RI = num(key); res = run_rle(I, U, LS, RI, n)
             elif key.startswith("decompression::run_position_encoding"):
