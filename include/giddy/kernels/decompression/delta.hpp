@@ -26,7 +26,9 @@
 //    owns a segment; wavefront w takes 8 consecutive rows of each sweep, all its loads are issued
 //    before the single barrier of the sweep, carries cross wavefronts through a double-buffered
 //    16-entry LDS table: one barrier per waves*8 rows.
-//  * general path (any other segment_length >= 1, or unaligned pointers): a segmented scan
+//  * ragged wave path (segment_length a multiple of E but not of a row, e.g. 1000): the same wave path with rows laid
+//    out from each segment's start and the last row of a segment cut short; the block path takes any such length as is.
+//  * general path (segment_length not a multiple of E, or unaligned pointers): a segmented scan
 //    (reset flags at segment heads) over rows, anchors gathered per element.  Slower, correct for
 //    every L — including L < blockDim, which the reference gets wrong.
 //
@@ -119,7 +121,7 @@ struct row_t {
 		memory_access::group<U, E> values;
 		#pragma unroll
 		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
-		patches.template apply_to_row<E>(row_start, lane, values);
+		patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values);
 		if (p + E <= end) { memory_access::store_group(out + p, values); }
 		else {
 			#pragma unroll
@@ -180,6 +182,67 @@ __device__ __forceinline__ void wave_per_segment(
 			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; }
+		}
+	}
+}
+
+/// wave path for segments that are not whole rows (segment_length % E == 0 is all it takes for 16-byte access:
+/// 1000, 3000, 10000 ...): rows are laid out from each segment's start, the last row of a segment is cut short,
+/// and the next segment's first row begins right where it ends — same pipeline, rows of two lengths.
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void wave_per_ragged_segment(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	constexpr unsigned R = rows_in_flight;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
+	const uint64_t chunk_length = segments_per_chunk * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+
+	struct row_bounds { uint64_t start, end; bool first_of_segment; };   // wave-uniform
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t chunk_start = c * chunk_length;
+		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
+		uint64_t segment = c * segments_per_chunk;
+		// the walk over the chunk's rows: [start, end) with end = start + row, or the segment's end if that comes first
+		uint64_t walk_start = chunk_start;
+		uint64_t walk_segment_end = (chunk_start + L < chunk_end) ? chunk_start + L : chunk_end;
+		bool walk_first = true;
+		auto take_row = [&]() {
+			row_bounds r;
+			r.start = walk_start; r.first_of_segment = walk_first;
+			r.end = (walk_start + traits::row < walk_segment_end) ? walk_start + traits::row : walk_segment_end;
+			walk_start = r.end;
+			walk_first = walk_start == walk_segment_end;
+			if (walk_first) { walk_segment_end = (walk_segment_end + L < chunk_end) ? walk_segment_end + L : chunk_end; }
+			return r;   // past the chunk's end: start == end == chunk_end, an empty row
+		};
+		U base = 0;
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		row_bounds bounds[R], next_bounds[R];
+		patches.begin_seek(chunk_start, lane);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].load(in, bounds[k].start, bounds[k].end, lane); }
+		patches.finish_seek(lane);
+		while (bounds[0].start < chunk_end) {
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].load(in, next_bounds[k].start, next_bounds[k].end, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
+				if (bounds[k].first_of_segment) { base = anchors[segment++]; }
+				rows[k].store(out, bounds[k].start, bounds[k].end, lane, base, patches);
+				base += (U) rows[k].total;
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; }
 		}
 	}
 }
@@ -310,13 +373,16 @@ __device__ __forceinline__ void decompress(
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	if (n == 0 || L == 0) { return; }
-	const bool rows_fit_segments = (L % traits::row == 0)
+	// 16-byte access works whenever segments start on a lane's group boundary
+	const bool vector_access = (L % traits::E == 0)
 		&& memory_access::is_aligned(decompressed, 16)
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
-	if (rows_fit_segments && L / traits::row <= rows_per_chunk) {
-		wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
+	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
+	if (vector_access && rows_per_segment <= rows_per_chunk) {
+		if (L % traits::row == 0) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
+		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
 	}
-	else if (rows_fit_segments && wave64::per_block() <= max_waves_per_block) {
+	else if (vector_access && wave64::per_block() <= max_waves_per_block) {
 		block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
 	}
 	else {
@@ -378,11 +444,12 @@ public:
 		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		auto num_segments = util::div_rounding_up(data_length, segment_length);
-		bool wave_path = segment_length % traits::row == 0 && segment_length / traits::row <= detail::rows_per_chunk;
-		bool block_path = segment_length % traits::row == 0 && !wave_path;
+		bool vector_access = segment_length % traits::E == 0;
+		size_t rows_per_segment = util::div_rounding_up(segment_length, (size_t) traits::row);
+		bool wave_path = vector_access && rows_per_segment <= detail::rows_per_chunk;
+		bool block_path = vector_access && !wave_path;
 		if (block_path) {
 			// one workgroup per segment (segments at grid stride), as many wavefronts as one sweep needs
-			size_t rows_per_segment = segment_length / traits::row;
 			size_t waves = std::min<size_t>(detail::max_waves_per_block,
 				util::div_rounding_up(rows_per_segment, (size_t) detail::rows_per_wave_per_sweep));
 			grid_construction_resolution = block;
@@ -391,10 +458,10 @@ public:
 			upper_limits.threads_in_block = (grid_block_dimension_t) (waves * warp_size);
 		}
 		else {
-			// one wavefront per segment (or per row-sized run of short segments), at grid stride
+			// one wavefront per segment (or per batch of short segments), at grid stride
 			grid_construction_resolution = warp;
 			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
-			length = wave_path ? util::div_rounding_up(num_segments, (size_t) detail::segments_per_wave_chunk(segment_length / traits::row))
+			length = wave_path ? util::div_rounding_up(num_segments, (size_t) detail::segments_per_wave_chunk(rows_per_segment))
 			                   : util::div_rounding_up(num_segments, per_chunk);
 			upper_limits.threads_in_block = detail::wave_path_threads;
 		}

@@ -58,6 +58,7 @@ struct none {
 	__device__ __forceinline__ void finish_seek(unsigned) { }
 	__device__ __forceinline__ void seek(uint64_t, unsigned) { }
 	template <unsigned E, typename Values> __device__ __forceinline__ void apply_to_row(uint64_t, unsigned, Values&) { }
+	template <unsigned E, typename Values> __device__ __forceinline__ void apply_to_row(uint64_t, uint64_t, unsigned, Values&) { }
 	template <typename T> __device__ __forceinline__ T patched(uint64_t, T value) const { return value; }
 };
 
@@ -182,8 +183,14 @@ struct cursor_t {
 	template <unsigned E, typename Values>
 	__device__ __forceinline__ void apply_to_row(uint64_t row_start, unsigned lane, Values& row)
 	{
+		apply_to_row<E>(row_start, row_start + 64 * E, lane, row);
+	}
+	/// ... a row cut short at `row_end` (the end of an anchored segment): later patches stay for the rows to come
+	template <unsigned E, typename Values>
+	__device__ __forceinline__ void apply_to_row(uint64_t row_start, uint64_t row_end, unsigned lane, Values& row)
+	{
 		while (position < row_start) { advance(lane); }
-		while (position < row_start + 64 * E) {
+		while (position < row_end) {
 			const unsigned offset = (unsigned) (position - row_start);
 			if (lane == offset / E) {
 				#pragma unroll

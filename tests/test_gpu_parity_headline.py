@@ -116,7 +116,8 @@ DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]  # delta.cu:94-1
 @pytest.mark.parametrize("index_size", [4, 8])
 @pytest.mark.parametrize("n,seglen", [
     (1, 1), (63, 7), (4096, 4096), (1000003, 4096), (300000, 512), (100000, 1), (50000, 100), (100, 1000),
-    (1 << 20, 1 << 18), (3000000, 1 << 20), (70000, 65536 + 512), (12345, 1024)])
+    (1 << 20, 1 << 18), (3000000, 1 << 20), (70000, 65536 + 512), (12345, 1024),
+    (1000003, 1000), (300000, 3000), (500000, 5000), (200000, 136), (99999, 6)])   # not whole rows: ragged wave path / block path
 def test_delta(usize, csize, index_size, n, seglen):
     schemes, r, g = _imports()
     ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)

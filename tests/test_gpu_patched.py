@@ -64,7 +64,8 @@ DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]
 
 @pytest.mark.parametrize("usize,csize", DELTA_TUPLES)
 @pytest.mark.parametrize("index_size", [4, 8])
-@pytest.mark.parametrize("n,seglen", [(1, 1), (4096, 4096), (1000003, 4096), (300000, 256), (100000, 100), (1 << 20, 1 << 18), (70000, 65536 + 512)])
+@pytest.mark.parametrize("n,seglen", [(1, 1), (4096, 4096), (1000003, 4096), (300000, 256), (100000, 100), (1 << 20, 1 << 18), (70000, 65536 + 512),
+                                      (1000003, 1000), (500000, 5000)])
 def test_patched_delta(usize, csize, index_size, n, seglen):
     schemes, r, g = _imports()
     ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)

@@ -115,7 +115,7 @@ def run_delta(I, U, C, n, L=4096, patched=False):
         cfg = schemes.delta(out, d, anchors, n, L, **kw)
         ms = timeit(lambda: schemes.delta(out, d, anchors, n, L, launch_config=cfg, **kw))
     ok = True
-    for lo, hi in chunks(n, 1 << 26):
+    for lo, hi in chunks(n, max(L, (1 << 26) // L * L)):
         expect = (torch.cumsum(du[lo:hi].view(-1, L), dim=1) + anchors64[lo // L: hi // L, None]).view(-1).to(INT[U])
         ok = ok and (patched_ok(expect, out, idx, pval, lo, hi) if patched else bool((expect == out[lo:hi]).all()))
     return ms, (U + C) * n + U * (n // L) + ((U + I) * len(idx) if patched else 0), ok
@@ -180,7 +180,7 @@ def run_for(I, U, C, model, MI, n, L=4096, patched=False):
         ms = timeit(lambda: schemes.frame_of_reference(out, comp, coefs, n, L, launch_config=cfg, **kw))
     pos = torch.arange(L, device=DEV, dtype=torch.int64)
     ok = True
-    for lo, hi in chunks(n):
+    for lo, hi in chunks(n, max(L, (1 << 26) // L * L)):
         c = coefs[lo // L: hi // L].to(torch.int64)
         pred = c[:, :1] + (c[:, 1:2] * pos[None, :] if dim == 2 else 0)
         pred = pred.to(torch.int32).to(INT[U]).to(torch.int64)       # trunc to T = int32, then to Uncompressed
