@@ -4,7 +4,8 @@
 //
 // Same kernel template name, parameter list and element semantics as the reference's
 // src/kernels/decompression/run_length_encoding.cuh:342-374 (per-segment parameters :271-326).
-// Execution (see run_expansion.hpp): one WAVEFRONT per anchored segment, segments at grid stride;
+// Execution (see run_expansion.hpp): one WAVEFRONT per anchored segment (or per tile-sized batch of short
+// segments), at grid stride;
 // the segment is cut into tiles of <= 4096 outputs; per tile the run lengths are read 4 per lane,
 // prefix-summed across the wave with DPP (lengths clamped just past the tile length, so 32 bits always
 // suffice) to get run START positions, which are marked in an LDS bitmap, ranked, and expanded
@@ -26,6 +27,16 @@ namespace cuda {
 namespace kernels {
 namespace decompression {
 namespace run_length_encoding {
+
+namespace detail {
+
+/// segments a wavefront takes per trip around its outer loop: as many short ones as fill one tile
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length)
+{
+	return segment_length >= run_expansion::tile_length ? 1 : run_expansion::tile_length / segment_length;
+}
+
+} // namespace detail
 
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
 __global__ void decompress(
@@ -55,15 +66,22 @@ __global__ void decompress(
 	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = segment_length, n = total_uncompressed_length, num_runs = num_element_runs;
 
-	for (uint64_t s = wave; s < num_segments; s += num_waves) {
+	// Short segments are taken several at a time: the runs of consecutive segments are consecutive too — anchors are
+	// only entry points — so k segments starting at segment s decode exactly like one segment of k * L outputs
+	// entered at anchor s.  (A wavefront pays four dependent memory round trips per entry point.)
+	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L);
+	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t s = c * segments_per_chunk;
 		const uint64_t segment_start = s * L;
 		if (segment_start >= n) { break; }
-		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
+		const uint64_t chunk_outputs = segments_per_chunk * L;
+		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
 		uint64_t first_run = segment_position_anchors[s];
 		uint64_t left_in_first_run = (uint64_t) run_lengths[first_run] - segment_position_anchor_intra_run_offsets[s];
 		uint64_t run_limit = num_runs;   // exclusive
-		if (s + 1 < num_segments) {
-			uint64_t through = (uint64_t) segment_position_anchors[s + 1] + 1;
+		if (s + segments_per_chunk < num_segments) {
+			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk] + 1;
 			if (through < run_limit) { run_limit = through; }
 		}
 
@@ -134,8 +152,9 @@ public:
 	{
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		grid_construction_resolution  = warp;                // one wavefront per anchored segment
-		length                        = util::div_rounding_up(uncompressed_length, segment_length);
-		serialization_option          = auto_maximized;      // segments at grid stride
+		length                        = util::div_rounding_up(util::div_rounding_up(uncompressed_length, segment_length),
+		                                    (size_t) detail::segments_per_wave_chunk(segment_length));
+		serialization_option          = auto_maximized;      // (batches of short) segments at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
