@@ -181,3 +181,25 @@ def test_patched_unaligned_bases_and_limits():
         schemes.patched_dictionary(out, g.dev(keys[:n]), g.dev(d["dictionary_entries"]), d_val, d_pos, n, 256, len(positions),
                                    stream=g.stream(), limits=limits)
         assert (g.host(out, np.uint32, n) == expect).all()
+
+
+@pytest.mark.parametrize("usize,csize", DELTA_TUPLES)
+def test_patched_delta_fuzz(usize, csize):
+    """seeded random lengths, segment lengths of every kind (tiny, not whole rows, longer than the column) and patch densities"""
+    schemes, r, g = _imports()
+    rnd = cases.rng(usize * 10 + csize)
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    for _ in range(40):
+        n = int(rnd.integers(1, 60000))
+        seglen = int(rnd.choice([int(rnd.integers(1, 40)), int(rnd.choice([64, 128, 1000, 1024, 3000, 4096, 8192, 16384])),
+                                 int(rnd.integers(40, 20000)), n + int(rnd.integers(0, 5))]))
+        how = str(rnd.choice(PATCH_SHAPES))
+        f, truth = cases.delta_case(n, seglen, ud, cd, seed=n)
+        positions, values = _patches(n, how, ud, 4, seed=n + 1)
+        expect = _expected(truth, positions, values)
+        out = g.dev_empty(n, ud)
+        schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values), g.dev(positions), n, seglen,
+                              len(positions), uncompressed_size=usize, compressed_size=csize, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != expect)
+        assert len(bad) == 0, (n, seglen, how, bad[:5], got[bad[:5]], expect[bad[:5]])
