@@ -138,6 +138,20 @@ int main()
 		CHECK_THROWS(k->resolve_launch_configuration(props, attrs, { { "length", length } }), std::out_of_range);
 		CHECK_THROWS(k->resolve_launch_configuration(props, attrs, { { "length", (int) 5 }, { "segment_length", segment_length } }), cuda::bad_any_cast);
 		CHECK(k->get_device_function().ptr() != nullptr);
+
+		// the fused decompress-and-patch extensions: same factory, same resolver inputs as the plain wrapper, its launch shape for Delta
+		auto patched = registered::kernel_t::produceSubclass("decompression::delta::patched::kernel_t<4u, 8u, 2u>");
+		auto plain = registered::kernel_t::produceSubclass("decompression::delta::kernel_t<4u, 8u, 2u>");
+		auto cp = patched->resolve_launch_configuration(props, attrs, MAKE_KERNEL_ARGUMENTS(length, segment_length));
+		auto cq = plain->resolve_launch_configuration(props, attrs, MAKE_KERNEL_ARGUMENTS(length, segment_length));
+		CHECK(cp.grid_dimensions.x == cq.grid_dimensions.x && cp.block_dimensions.x == cq.block_dimensions.x);
+		CHECK(patched->get_device_function().ptr() != plain->get_device_function().ptr());
+		size_t num_dictionary_entries = 256, data_length = 1 << 24;
+		auto pd = registered::kernel_t::produceSubclass("decompression::dictionary::patched::kernel_t<4u, 4u, 1u>");
+		auto cd = pd->resolve_launch_configuration(props, attrs, MAKE_KERNEL_ARGUMENTS(num_dictionary_entries, data_length));
+		CHECK(cd.dynamic_shared_memory_size == 1024 && cd.block_dimensions.x == 256);
+		CHECK(cd.grid_dimensions.x == (1u << 24) / (8 * 64 * 4) / 4);   // a wavefront per 8 rows of 64 x 4 elements, 4 wavefronts per workgroup
+		CHECK_THROWS(pd->enqueue_launch(0, cd, { { "length", length } }), std::out_of_range);
 	}
 
 	std::printf(failures == 0 ? "api_surface OK\n" : "api_surface: %d failure(s)\n", failures);
