@@ -45,6 +45,40 @@ def test_dictionary_more_than_2_to_32_elements():
     assert int((counts * entries.to(torch.int64)).sum()) == total
 
 
+def test_patched_dictionary_more_than_2_to_32_elements():
+    """the fused decompress-and-patch kernel with 64-bit patch positions on both sides of 2^32"""
+    from libgiddy_amd import schemes
+    n = (1 << 32) + 4099
+    try:
+        gen = torch.Generator(device="cuda"); gen.manual_seed(8)
+        keys = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=gen, device="cuda")
+        entries = (torch.randperm(1 << 24, generator=gen, device="cuda")[:256] * 131 + 17).to(torch.int32)
+        out = torch.empty(n, dtype=torch.int32, device="cuda")
+        num_patches = 1 << 20
+        positions = torch.sort(torch.randint(0, n, (num_patches,), dtype=torch.int64, generator=gen, device="cuda"))[0]
+        positions[-3:] = torch.tensor([n - 3, n - 2, n - 1], device="cuda")            # the very end of the column
+        positions[:2] = torch.tensor([0, 1], device="cuda")
+        positions = torch.sort(positions)[0]
+        values = torch.randint(-(1 << 31), 1 << 31, (num_patches,), dtype=torch.int32, generator=gen, device="cuda")
+    except torch.OutOfMemoryError:
+        pytest.skip("not enough device memory")
+    schemes.patched_dictionary(out, keys, entries, values, positions, n, 256, num_patches, uncompressed_size=4, dictionary_index_size=1,
+                               index_size=8, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    # patched positions hold the LAST patch for that position; everything else is the plain decode
+    last = torch.ones(num_patches, dtype=torch.bool, device="cuda")
+    last[:-1] = positions[1:] != positions[:-1]
+    assert bool((out[positions[last]] == values[last]).all())
+    assert int((positions >= (1 << 32)).sum()) > 0
+    step = 1 << 30
+    for lo in range(0, n, step):
+        hi = min(n, lo + step)
+        expect = entries[keys[lo:hi].to(torch.int64)]
+        inside = positions[(positions >= lo) & (positions < hi)]
+        expect[inside - lo] = out[inside]
+        assert bool((expect == out[lo:hi]).all())
+
+
 def test_dzb_variable_byte_offsets_beyond_32_bits():
     """discard_zero_bytes::variable_width<8,8,4>: position anchors above 2^33.  The compressed bytes live in
     an ordinary buffer; the kernel is handed (buffer - 2^33) as compressed_data and anchors + 2^33, so every
