@@ -112,25 +112,27 @@ __device__ __forceinline__ unsigned size_of(Container fields, unsigned j, unsign
 /// where a wavefront is in the compressed byte stream (all wave-uniform)
 template <unsigned IndexSize>
 struct segment_cursor {
-	uint64_t bytes_start;                  // byte offset of the next row's first element
-	uint64_t next_anchor;                  // the next segment's anchor, fetched a segment ahead so that nobody waits for it
-	const uint_t<IndexSize>* following;    // where the anchor after that one lives ...
-	uint32_t anchors_left;                 // ... if the column has one
+	uint64_t bytes_start;                  // byte offset of the next row's first element (wave-uniform)
+	uint64_t first_anchor;                 // the anchor of the chunk's first segment (wave-uniform) ...
+	uint32_t later_anchors;                // ... and, PER LANE, how far beyond it the chunk's l-th segment begins: all of a chunk's
+	                                       // anchors arrive with one load, ahead of the rows, instead of one scalar load per segment
+	uint32_t next_segment_in_chunk;
 	uint32_t rows_left_in_segment;
 
-	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t num_segments)
+	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t num_segments,
+		unsigned segments_per_chunk, unsigned lane)
 	{
-		const uint64_t left = num_segments - segment - 1;
-		next_anchor = wave64::read_first_lane((uint64_t) position_anchors[segment]);
-		following = position_anchors + segment + 1;
-		anchors_left = left > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) left;
-		rows_left_in_segment = 0; bytes_start = 0;
+		const bool have = lane < segments_per_chunk && segment + lane < num_segments;
+		const uint64_t mine = have ? (uint64_t) position_anchors[segment + lane] : 0;
+		first_anchor = wave64::read_first_lane(mine);
+		later_anchors = (uint32_t) (mine - first_anchor);   // (a chunk is at most rows_per_chunk rows: kilobytes)
+		next_segment_in_chunk = 0; rows_left_in_segment = 0; bytes_start = 0;
 	}
 	__device__ __forceinline__ void begin_segment(uint32_t rows_per_segment)
 	{
-		bytes_start = next_anchor;
+		bytes_start = first_anchor + wave64::read_lane(later_anchors, next_segment_in_chunk);
+		next_segment_in_chunk++;
 		rows_left_in_segment = rows_per_segment;
-		if (anchors_left > 0) { next_anchor = wave64::read_first_lane((uint64_t) *following); following++; anchors_left--; }
 	}
 	/// call before every row: moves on to the next segment's anchor when the current segment is used up
 	__device__ __forceinline__ void before_row(uint32_t rows_per_segment)
@@ -458,7 +460,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 		else {
 			// a batch of short segments, each a whole number of rows: the groups of rows span segments
 			const uint32_t rows_per_segment = (uint32_t) (L / row);
-			cursor.start_at(position_anchors, c * segments_per_chunk, num_segments);
+			cursor.start_at(position_anchors, c * segments_per_chunk, num_segments, (unsigned) segments_per_chunk, lane);
 			detail::decompress_full_groups<true, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, rows_per_segment,
 				min_represented_element_size, bits, per, per_reciprocal, masks);
