@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--schemes", default="all", help="extra per-scheme measurements at N=1: all (the BASELINE configs) | "
                    "coverage (all + DZB-fixed, Model, incidence bitmaps) | none | comma list")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--gather", action="store_true", help="N > 1: after the timed region also time the one optional collective — the RCCL "
+                   "point-to-point gather of every rank's decoded shard into one contiguous buffer on rank 0 (reported separately, never part of `value`)")
+    p.add_argument("--gather-log2n", type=int, default=28, help="elements of each rank's decoded shard that are gathered")
     p.add_argument("--cpu-sample-log2", type=int, default=27)
     return p.parse_args()
 
@@ -163,6 +166,34 @@ def cpu_baseline(work, sample, unit_bytes_label="decompressed GB/s"):
             "single_thread_value": round(results[1], 3), "cpu": cpu_model()}
 
 
+def time_gather(work, count, rank, world, device, barrier, repetitions=3):
+    """The single optional collective: every rank's first `count` decoded elements gathered into one
+    contiguous buffer on rank 0 by point-to-point RCCL transfers — each shard crosses one xGMI link once."""
+    import torch
+    import torch.distributed as dist
+    from libgiddy_amd.distributed import gather_decoded
+    local = work.output.view(-1)[:count]
+    out = torch.empty(world * count, dtype=local.dtype, device=device) if rank == 0 else None
+    best = float("inf")
+    synchronize = torch.cuda.synchronize if local.is_cuda else (lambda: None)   # (CPU tensors: the gloo test of this function)
+    for repetition in range(repetitions + 1):   # the first one sets the connections up
+        barrier(); synchronize()
+        t0 = time.perf_counter()
+        gather_decoded(local, [count] * world, dst=0, out=out)
+        synchronize(); barrier()
+        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        if repetition > 0:
+            best = min(best, float(elapsed[0]))
+    ok = True
+    if rank == 0:
+        ok = bool((out[:count] == local).all())   # own shard in place; the others' contents are theirs (different seeds)
+    inbound = (world - 1) * count * local.element_size()
+    return {"bytes_per_rank": count * local.element_size(), "ms": round(best * 1e3, 3), "inbound_GBps_at_root": round(inbound / best / 1e9, 1),
+            "links": world - 1, "own_shard_in_place": ok,
+            "note": "point-to-point receives from every peer (one xGMI link each, about 153 GB/s per link); not part of `value`"}
+
+
 def main():
     args = parse()
     import torch
@@ -215,6 +246,9 @@ def main():
         "pct_hbm_peak_decompressed": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
         "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel)),
     }
+
+    if args.gather and world > 1:
+        line["gather"] = time_gather(work, min(n, 1 << args.gather_log2n), rank, world, device, barrier)
 
     if rank == 0 and world == 1:
         ceiling = measured_copy_ceiling()

@@ -136,6 +136,14 @@ def _worker(rank, world, port, results):
         gathered = distributed.gather_decoded(torch.from_numpy(local.view(np.int64).copy()), counts, dst=0)
         if rank == 0:
             results.put(("dzbv", bool((gathered.numpy().view(np.uint64) == colv).all())))
+        # bench.py's --gather leg (the timing harness around the same collective), on CPU tensors
+        import bench
+
+        class Work:
+            output = torch.arange(5000, dtype=torch.int32) + 100000 * rank
+        report = bench.time_gather(Work, 4096, rank, world, torch.device("cpu"), dist.barrier, repetitions=1)
+        if rank == 0:
+            results.put(("bench_gather", report["own_shard_in_place"] and report["bytes_per_rank"] == 4096 * 4 and report["links"] == world - 1))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -153,5 +161,5 @@ def test_gather_with_gloo(world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = dict(results.get(timeout=10) for _ in range(2))
-    assert got == {"rle": True, "dzbv": True}
+    got = dict(results.get(timeout=10) for _ in range(3))
+    assert got == {"rle": True, "dzbv": True, "bench_gather": True}
