@@ -55,7 +55,7 @@ namespace detail {
 
 // build-time tuning knobs (defaults measured on MI355X)
 #ifndef GIDDY_DELTA_ROWS_IN_FLIGHT
-#define GIDDY_DELTA_ROWS_IN_FLIGHT 2
+#define GIDDY_DELTA_ROWS_IN_FLIGHT 0   // 0: the measured best per instantiation (rows_in_flight_for below); n > 0: n for all
 #endif
 #ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
 #define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
@@ -65,7 +65,6 @@ namespace detail {
 #endif
 
 enum : unsigned {
-	rows_in_flight = GIDDY_DELTA_ROWS_IN_FLIGHT,                                  // wave path
 	rows_per_wave_per_sweep = GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP,                // block path
 	wave_path_threads = GIDDY_DELTA_WAVE_PATH_THREADS,
 	rows_per_chunk = 32,                                                          // wave path: rows a wavefront takes per outer-loop trip;
@@ -73,9 +72,21 @@ enum : unsigned {
 	max_waves_per_block = 16,
 };
 
+/// Rows a wavefront of the wave path keeps in flight.  Measured on MI355X at 2^30 elements, segments of 4096, with 1, 2, 4
+/// and 8 rows (% of the 8 TB/s peak): <8,1>: 63 57 55 51; <8,2>: 70 75 73 74; <8,4>: 74 76 73 68; <4,1>: 70 75 73 72;
+/// <4,2>: 77 72 72 72; <2,1>: 65 67 74 77 — there is no single best value, so each instantiation gets its own.
+template <unsigned UncompressedSize, unsigned CompressedSize>
+constexpr unsigned rows_in_flight_for()
+{
+	if (GIDDY_DELTA_ROWS_IN_FLIGHT > 0) { return GIDDY_DELTA_ROWS_IN_FLIGHT; }
+	if (UncompressedSize == 2) { return 8; }
+	if ((UncompressedSize == 8 && CompressedSize == 1) || (UncompressedSize == 4 && CompressedSize == 2)) { return 1; }
+	return 2;
+}
+
 template <unsigned UncompressedSize, unsigned CompressedSize>
 struct row_traits {
-	enum : unsigned { E = 16 / UncompressedSize, row = 64 * E };
+	enum : unsigned { E = 16 / UncompressedSize, row = 64 * E, rows_in_flight = rows_in_flight_for<UncompressedSize, CompressedSize>() };
 	using uncompressed_type = uint_t<UncompressedSize>;
 	using compressed_type = uint_t<CompressedSize>;
 	// type the in-row prefix is formed in: 64*E elements of at most 2^(8*CompressedSize)-1 each
@@ -145,7 +156,7 @@ __device__ __forceinline__ void wave_per_segment(
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
-	constexpr unsigned R = rows_in_flight;
+	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
@@ -186,6 +197,58 @@ __device__ __forceinline__ void wave_per_segment(
 	}
 }
 
+/// wave path for 1-byte deltas of 8-byte elements, where a row's input is only 128 bytes: the chunk's whole input
+/// (at most 4 KiB) arrives first, as 16-byte-per-lane loads, and is handed out row by row through wave-private LDS.
+/// (Measured with the bare access pattern, tools/stream_probe4.hip: 68 % of peak with 2-byte loads per row, 73 % with
+/// wide loads through LDS; the decoder itself: 63 -> see DESIGN.md.)
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void wave_per_segment_with_staged_input(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using C = typename traits::compressed_type;
+	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t chunk_length = segments_per_wave_chunk(L / traits::row) * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+	const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(in);
+
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t start = c * chunk_length;
+		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
+		const unsigned chunk_bytes = (unsigned) (end - start) * CompressedSize;
+		patches.begin_seek(start, lane);
+		wave64::lds_fence();   // (the previous chunk's rows have been read)
+		for (unsigned at = lane * 16; at < chunk_bytes; at += 64 * 16) {
+			if (at + 16 <= chunk_bytes) {
+				*reinterpret_cast<piece_t*>(staging + at) = *reinterpret_cast<const piece_t*>(in_bytes + start * CompressedSize + at);
+			}
+			else {
+				for (unsigned b = at; b < chunk_bytes; b++) { staging[b] = in_bytes[start * CompressedSize + b]; }
+			}
+		}
+		patches.finish_seek(lane);
+		wave64::lds_fence();
+		uint64_t segment = start / L, next_segment_start = start;   // the chunk starts on a segment boundary
+		U base = 0;
+		for (uint64_t row_start = start; row_start < end; row_start += traits::row) {
+			row_t<UncompressedSize, CompressedSize> row;
+			const uint64_t p = row_start + (uint64_t) lane * traits::E;
+			const C* staged = reinterpret_cast<const C*>(staging + (p - start) * CompressedSize);
+			#pragma unroll
+			for (unsigned j = 0; j < traits::E; j++) { row.deltas[j] = (p + j < end) ? staged[j] : (C) 0; }
+			row.scan();
+			if (row_start == next_segment_start) { base = anchors[segment++]; next_segment_start += L; }   // wave-uniform
+			row.store(out, row_start, end, lane, base, patches);
+			base += (U) row.total;
+		}
+	}
+}
+
 /// wave path for segments that are not whole rows (segment_length % E == 0 is all it takes for 16-byte access:
 /// 1000, 3000, 10000 ...): rows are laid out from each segment's start, the last row of a segment is cut short,
 /// and the next segment's first row begins right where it ends — same pipeline, rows of two lengths.
@@ -196,7 +259,7 @@ __device__ __forceinline__ void wave_per_ragged_segment(
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
-	constexpr unsigned R = rows_in_flight;
+	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
@@ -379,6 +442,15 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	if (vector_access && rows_per_segment <= rows_per_chunk) {
+		if constexpr (traits::E * CompressedSize <= 2) {
+			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
+			__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][rows_per_chunk * traits::row * CompressedSize];
+			if (L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
+				wave_per_segment_with_staged_input<UncompressedSize, CompressedSize>(
+					decompressed, compressed_input, anchor_values, n, L, patches, input_staging[wave64::index_in_block()]);
+				return;
+			}
+		}
 		if (L % traits::row == 0) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
 		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
 	}

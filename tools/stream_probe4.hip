@@ -70,6 +70,56 @@ __global__ void dword_loads_two_stores(u32x4* __restrict__ out, const uint32_t* 
 	}
 }
 
+// (d) the Delta wave path's loop without the scan: a wavefront owns 32 consecutive rows, R rows in flight, the next
+//     group's 2-byte loads issued before this group's stores
+template <int R>
+__global__ void wave_chunks_narrow(u32x4* __restrict__ out, const uint16_t* __restrict__ in, uint64_t groups)
+{
+	const unsigned lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t rows = groups / 64, waves_per_block = blockDim.x >> 6;
+	for (uint64_t first_row = ((uint64_t) blockIdx.x * waves_per_block + w) * 32; first_row < rows; first_row += (uint64_t) gridDim.x * waves_per_block * 32) {
+		uint32_t v[R], next[R];
+		#pragma unroll
+		for (int k = 0; k < R; k++) v[k] = in[(first_row + k) * 64 + lane];
+		for (int r = 0; r < 32; r += R) {
+			if (r + R < 32) {
+				#pragma unroll
+				for (int k = 0; k < R; k++) next[k] = in[(first_row + r + R + k) * 64 + lane];
+			}
+			#pragma unroll
+			for (int k = 0; k < R; k++) __builtin_nontemporal_store(widen(v[k]), out + (first_row + r + k) * 64 + lane);
+			#pragma unroll
+			for (int k = 0; k < R; k++) v[k] = next[k];
+		}
+	}
+}
+
+// (e) the same chunk of 32 rows, but the input of K rows at a time arrives as one 16-byte-per-lane load by the first K*8 lanes
+//     and is redistributed through wave-private LDS; the next group's load is issued before this group's stores
+template <int K>
+__global__ void wave_chunks_wide(u32x4* __restrict__ out, const uint8_t* __restrict__ in, uint64_t groups)
+{
+	__shared__ __attribute__((aligned(16))) uint8_t staging[4][2][K * 128];
+	const unsigned lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const uint64_t rows = groups / 64, waves_per_block = blockDim.x >> 6;
+	for (uint64_t first_row = ((uint64_t) blockIdx.x * waves_per_block + w) * 32; first_row < rows; first_row += (uint64_t) gridDim.x * waves_per_block * 32) {
+		u32x4 piece = u32x4{0, 0, 0, 0}, next_piece = u32x4{0, 0, 0, 0};
+		if (lane < K * 8) piece = *reinterpret_cast<const u32x4*>(in + first_row * 128 + lane * 16);
+		int buffer = 0;
+		for (int r = 0; r < 32; r += K) {
+			if (r + K < 32 && lane < K * 8) next_piece = *reinterpret_cast<const u32x4*>(in + (first_row + r + K) * 128 + lane * 16);
+			if (lane < K * 8) *reinterpret_cast<u32x4*>(&staging[w][buffer][lane * 16]) = piece;
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			#pragma unroll
+			for (int k = 0; k < K; k++) {
+				uint32_t v = *reinterpret_cast<const uint16_t*>(&staging[w][buffer][k * 128 + lane * 2]);
+				__builtin_nontemporal_store(widen(v), out + (first_row + r + k) * 64 + lane);
+			}
+			piece = next_piece; buffer ^= 1;
+		}
+	}
+}
+
 template <typename F>
 double time_ms(F f, int reps = 10)
 {
@@ -95,6 +145,12 @@ int main()
 	report("wide loads through LDS, 8 rows per wavefront", time_ms([&] { wide_loads_through_lds<8><<<groups / 64 / (4 * 8), 256>>>(out, in, groups); }));
 	report("4-byte loads, two stores per lane", time_ms([&] { dword_loads_two_stores<4><<<groups / 2 / (256 * 4), 256>>>(out, (const uint32_t*) in, groups); }));
 	report("4-byte loads, two stores per lane, 2 steps", time_ms([&] { dword_loads_two_stores<2><<<groups / 2 / (256 * 2), 256>>>(out, (const uint32_t*) in, groups); }));
+	const unsigned chunk_grid = (unsigned) (groups / 64 / 32 / 4);
+	report("wave chunks of 32 rows, 2-byte loads, 2 rows in flight", time_ms([&] { wave_chunks_narrow<2><<<chunk_grid, 256>>>(out, (const uint16_t*) in, groups); }));
+	report("wave chunks of 32 rows, 2-byte loads, 4 rows in flight", time_ms([&] { wave_chunks_narrow<4><<<chunk_grid, 256>>>(out, (const uint16_t*) in, groups); }));
+	report("wave chunks of 32 rows, 2-byte loads, 8 rows in flight", time_ms([&] { wave_chunks_narrow<8><<<chunk_grid, 256>>>(out, (const uint16_t*) in, groups); }));
+	report("wave chunks of 32 rows, wide loads via LDS, 4 rows a group", time_ms([&] { wave_chunks_wide<4><<<chunk_grid, 256>>>(out, in, groups); }));
+	report("wave chunks of 32 rows, wide loads via LDS, 8 rows a group", time_ms([&] { wave_chunks_wide<8><<<chunk_grid, 256>>>(out, in, groups); }));
 	CHECK(hipDeviceSynchronize());
 	return 0;
 }
