@@ -36,6 +36,7 @@ public:
 			cache_input_data_in_shared_mem, limits.dynamic_shared_memory);
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(data_length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
+		params.resident_blocks_per_multiprocessor_cap = nullopt;   // (the plain kernel's occupancy throttle was not measured for this one)
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };

@@ -31,6 +31,7 @@ public:
 			device_properties, kernel_function_attributes, length, segment_length);
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(length, (size_t) stream_tiles::elements_per_thread_per_chunk<Uncompressed>());
+		params.resident_blocks_per_multiprocessor_cap = nullopt;   // (the plain kernel's occupancy throttle was not measured for this one)
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };

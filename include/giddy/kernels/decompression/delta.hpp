@@ -57,6 +57,9 @@ namespace detail {
 #ifndef GIDDY_DELTA_ROWS_IN_FLIGHT
 #define GIDDY_DELTA_ROWS_IN_FLIGHT 0   // 0: the measured best per instantiation (rows_in_flight_for below); n > 0: n for all
 #endif
+#ifndef GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO
+#define GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO 4   // bytes of input per lane per row up to which a chunk's input goes through LDS (wave path)
+#endif
 #ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
 #define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
 #endif
@@ -442,7 +445,7 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	if (vector_access && rows_per_segment <= rows_per_chunk) {
-		if constexpr (traits::E * CompressedSize <= 2) {
+		if constexpr (traits::E * CompressedSize <= GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
 			__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][rows_per_chunk * traits::row * CompressedSize];
 			if (L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
@@ -536,6 +539,8 @@ public:
 			length = wave_path ? util::div_rounding_up(num_segments, (size_t) detail::segments_per_wave_chunk(rows_per_segment))
 			                   : util::div_rounding_up(num_segments, per_chunk);
 			upper_limits.threads_in_block = detail::wave_path_threads;
+			// 1-byte deltas of 8-byte elements: 4 resident workgroups per CU are 7 points faster than what fits (measured per instantiation, tools/occupancy_sweep.py)
+			if (wave_path && UncompressedSize == 8 && CompressedSize == 1) { resident_blocks_per_multiprocessor_cap = 4u; }
 		}
 		serialization_option = auto_maximized;
 		keep_gpu_busy_factor = 1024;

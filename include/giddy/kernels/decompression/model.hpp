@@ -107,6 +107,8 @@ public:
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		default_serialization_factor  = warp_size / sizeof(Uncompressed);
+		// a pure store stream: 71 -> 76-79 % of HBM peak with 2-3 resident workgroups per CU instead of 8 (measured per instantiation, tools/occupancy_sweep.py)
+		if (sizeof(Uncompressed) <= 4) { resident_blocks_per_multiprocessor_cap = sizeof(Uncompressed) == 4 ? 2u : 3u; }
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_)

@@ -58,6 +58,12 @@ public:
 	/// workgroups-per-SIMD multiplier for auto_maximized grids
 	unsigned              keep_gpu_busy_factor { 50 };
 
+	/// Occupancy throttle: at most this many workgroups resident on a compute unit, enforced the only way a launch
+	/// can — by reserving dynamic LDS (160 KiB per CU on MI355X).  Write-heavy streams go FASTER with fewer
+	/// resident workgroups (fewer write streams interleaved at the memory controllers); the per-kernel values
+	/// were measured (tools/occupancy_sweep.py).  Unset: whatever fits.
+	optional<unsigned>    resident_blocks_per_multiprocessor_cap { nullopt };
+
 	bool use_dynamic_shared_memory() const
 	{
 		return dynamic_shared_memory_requirement.per_block || dynamic_shared_memory_requirement.per_length_unit;

@@ -176,6 +176,18 @@ launch_configuration_t resolve_launch_configuration(
 		params.dynamic_shared_memory_requirement.per_block.value_or(0) +
 		block_length * params.dynamic_shared_memory_requirement.per_length_unit.value_or(0);
 
+	if (params.resident_blocks_per_multiprocessor_cap && params.resident_blocks_per_multiprocessor_cap.value() > 0) {
+		// reserve so much LDS that exactly `cap` workgroups fit a compute unit.  (Not all of a CU's 160 KiB can be had:
+		// measured, five 32 KiB or three 53 KiB workgroups do not fit, three of 52 KiB do — a 4 KiB margin.)
+		size_t lds_per_cu = params.device_properties.maxSharedMemoryPerMultiProcessor ? params.device_properties.maxSharedMemoryPerMultiProcessor : 65536;
+		size_t per_block = ((lds_per_cu - 4096) / params.resident_blocks_per_multiprocessor_cap.value()) / 1024 * 1024;
+		size_t statically_used = params.kernel_function_attributes.sharedSizeBytes;
+		size_t reserve = per_block > statically_used ? per_block - statically_used : 0;
+		reserve = std::min<size_t>(reserve, params.available_dynamic_shared_memory_per_block);
+		if (limits.dynamic_shared_memory) { reserve = std::min<size_t>(reserve, limits.dynamic_shared_memory.value()); }
+		dynamic_lds = std::max(dynamic_lds, reserve);
+	}
+
 	linear_grid::launch_configuration_t config;
 	config.grid_length = (grid_dimension_t) grid_length;
 	config.block_length = (grid_block_dimension_t) block_length;
