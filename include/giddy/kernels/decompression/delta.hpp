@@ -445,7 +445,8 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	if (vector_access && rows_per_segment <= rows_per_chunk) {
-		if constexpr (traits::E * CompressedSize <= GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO) {
+		// (with patches the cursor's windows already take 12 KiB of LDS per workgroup: only the narrowest rows are staged then)
+		if constexpr (traits::E * CompressedSize <= (Patches::enabled ? 2 : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO)) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
 			__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][rows_per_chunk * traits::row * CompressedSize];
 			if (L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {

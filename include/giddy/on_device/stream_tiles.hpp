@@ -92,15 +92,22 @@ __device__ __forceinline__ void transform(
 // — the Delta shape — is 8 % slower, 4 rows 17-40 % slower.
 
 #ifndef GIDDY_PATCHED_ROWS_PER_CHUNK
-#define GIDDY_PATCHED_ROWS_PER_CHUNK 8
+#define GIDDY_PATCHED_ROWS_PER_CHUNK 0   // 0: by output width (below); n > 0: n rows for every instantiation
 #endif
 #ifndef GIDDY_PATCHED_ROWS_IN_FLIGHT
 #define GIDDY_PATCHED_ROWS_IN_FLIGHT 4
 #endif
-enum : unsigned { rows_per_chunk = GIDDY_PATCHED_ROWS_PER_CHUNK, rows_in_flight = GIDDY_PATCHED_ROWS_IN_FLIGHT };
+enum : unsigned { rows_in_flight = GIDDY_PATCHED_ROWS_IN_FLIGHT };
+
+/// rows a wavefront takes per chunk: 8 — except for 8-byte outputs, whose rows hold only 128 elements (measured at 8, 16 and 32
+/// rows: Dictionary <4,8,1> 40 / 47 / 51 % of peak, <4,8,2> 58 / 66 / 69 %; 4-byte outputs lose 5-9 points going from 8 to 16+)
+template <typename Out> constexpr unsigned rows_per_chunk_for()
+{
+	return GIDDY_PATCHED_ROWS_PER_CHUNK > 0 ? GIDDY_PATCHED_ROWS_PER_CHUNK : (sizeof(Out) >= 8 ? 32 : 8);
+}
 
 /// elements one thread produces per chunk — what the patched launch parameters divide the column length by
-template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { return group_size<Out>::value * rows_per_chunk; }
+template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { return group_size<Out>::value * rows_per_chunk_for<Out>(); }
 
 template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename Patches>
 __device__ __forceinline__ void transform_and_patch(
@@ -109,6 +116,7 @@ __device__ __forceinline__ void transform_and_patch(
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
 	constexpr unsigned R = rows_in_flight;
+	constexpr unsigned rows_per_chunk = rows_per_chunk_for<Out>();
 	constexpr unsigned row = wave64::size * G;
 	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
 
