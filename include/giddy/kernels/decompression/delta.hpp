@@ -19,9 +19,12 @@
 //    in-row scan runs in 32 bits even for 64-bit outputs (a row's prefix cannot overflow).
 //  * wave path (segment_length % row == 0, at most 32 rows = 32 KiB of output per segment): one
 //    wavefront per anchored segment — or per batch of short segments adding up to 32 rows — carry in
-//    a register, NO barriers and no LDS at all; the next group's loads are issued before this group's
-//    stores.  (Measured on MI355X: 2 rows in flight is the best setting; at 4096-element segments of
-//    64-bit values the block path is no faster, from 8192 elements on it is.)
+//    a register, no barriers; the next group's loads are issued before this group's stores.  (Rows in
+//    flight were measured per instantiation — 1, 2 or 8, rows_in_flight_for below; at 4096-element
+//    segments of 64-bit values the block path is no faster, from 8192 elements on it is.)
+//  * staged wave path (a lane's deltas of a row are at most 4 bytes: <8,1>, <8,2>, <4,1>): the chunk's whole
+//    input — at most 8 KiB — arrives first as 16-byte-per-lane loads and is handed out row by row through
+//    wave-private LDS, so the row loop issues stores only.  C3 (uint64 <- uint16): 74 -> 79 % of HBM peak.
 //  * block path (longer segments): a workgroup of ceil(rows per segment / 8) wavefronts (at most 16)
 //    owns a segment; wavefront w takes 8 consecutive rows of each sweep, all its loads are issued
 //    before the single barrier of the sweep, carries cross wavefronts through a double-buffered
