@@ -43,13 +43,14 @@ constexpr serialization_factor_t get_default_serialization_factor(bool cache_all
 namespace detail {
 
 /// out[p] = lookup(keys[p]) over the shared streaming tile loop
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
 	uint64_t                                          n,
 	Lookup                                            lookup,
-	Patches                                           patches)
+	Patches                                           patches,
+	AfterLoads                                        after_loads = AfterLoads())
 {
 	using key_type = uint_t<DictionaryIndexSize>;
 	using value_type = uint_t<UncompressedSize>;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void translate(
 		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches);
 	}
 	else {
-		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one);
+		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
 	}
 }
 
@@ -81,7 +82,23 @@ __device__ __forceinline__ void decompress(
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
 
-	if (cache_dictionary_in_shared_memory) {
+	if (!Patches::enabled && !GIDDY_STREAM_BY_WAVE_CHUNKS && cache_dictionary_in_shared_memory && num_dictionary_entries <= blockDim.x) {
+		// A dictionary of at most one entry per thread: the entry is REQUESTED now, but put into LDS (and the barrier
+		// taken) only after the first tile's key loads have been issued — the two memory round trips overlap
+		// instead of following each other.
+		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
+		const value_type my_entry = threadIdx.x < num_dictionary_entries ? dictionary_entries[threadIdx.x] : value_type();
+		bool staged_yet = false;   // (uniform over the workgroup)
+		auto stage = [&]() {
+			if (staged_yet) { return; }
+			if (threadIdx.x < num_dictionary_entries) { staged[threadIdx.x] = my_entry; }
+			__syncthreads();
+			staged_yet = true;
+		};
+		translate<UncompressedSize, DictionaryIndexSize>(
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, stage);
+	}
+	else if (cache_dictionary_in_shared_memory) {
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();

@@ -25,11 +25,17 @@ template <typename Out> struct group_size { enum : unsigned { value = 16 / sizeo
 /// elements one thread produces per tile — what the launch parameters divide the column length by
 template <typename Out> constexpr unsigned elements_per_thread_per_tile() { return group_size<Out>::value * steps_per_tile; }
 
+struct nothing_to_do { __device__ __forceinline__ void operator()() const { } };
+
 /// out[p] = produce(p, in[p]) for p < n.  `produce_group(first_position, inputs, outputs)` handles G
 /// consecutive elements at once (it may hoist per-group work such as a segment lookup).
-template <typename In, typename Out, typename ProduceGroup, typename ProduceOne>
+/// `after_loads()` is called by every thread of the workgroup — the same number of times — once a tile's loads
+/// have been issued and before the first produce (and once before the scalar tail): the place for a side table's
+/// trip through LDS, so that its latency overlaps the tile's own loads.  It must be idempotent.
+template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do>
 __device__ __forceinline__ void transform(
-	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one)
+	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
+	AfterLoads after_loads = AfterLoads())
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -48,6 +54,7 @@ __device__ __forceinline__ void transform(
 			// K stores form straight-line code the compiler can schedule with counted waits
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) { inputs[k] = load_group<In, G>(in + (first_group + (uint64_t) k * blockDim.x) * G); }
+			after_loads();
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) {
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
@@ -65,6 +72,7 @@ __device__ __forceinline__ void transform(
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
 			if (g < num_groups) { inputs[k] = load_group<In, G>(in + g * G); }
 		}
+		after_loads();
 		#pragma unroll
 		for (unsigned k = 0; k < K; k++) {
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
@@ -75,6 +83,7 @@ __device__ __forceinline__ void transform(
 		}
 	}
 
+	after_loads();
 	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
 	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) { out[p] = produce_one(p, in[p]); }
