@@ -61,7 +61,7 @@ __device__ __forceinline__ void translate(
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
 	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
-		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches);
+		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads);
 	}
 	else {
 		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
@@ -82,13 +82,13 @@ __device__ __forceinline__ void decompress(
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
 
-	if (!Patches::enabled && !GIDDY_STREAM_BY_WAVE_CHUNKS && cache_dictionary_in_shared_memory && num_dictionary_entries <= blockDim.x) {
+	if (cache_dictionary_in_shared_memory && num_dictionary_entries <= blockDim.x) {
 		// A dictionary of at most one entry per thread: the entry is REQUESTED now, but put into LDS (and the barrier
 		// taken) only after the first tile's key loads have been issued — the two memory round trips overlap
 		// instead of following each other.
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		const value_type my_entry = threadIdx.x < num_dictionary_entries ? dictionary_entries[threadIdx.x] : value_type();
-		bool staged_yet = false;   // (uniform over the workgroup)
+		bool staged_yet = false;   // (every thread gets here exactly once: the barrier inside is taken once by each)
 		auto stage = [&]() {
 			if (staged_yet) { return; }
 			if (threadIdx.x < num_dictionary_entries) { staged[threadIdx.x] = my_entry; }

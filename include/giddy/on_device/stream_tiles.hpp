@@ -118,9 +118,10 @@ template <typename Out> constexpr unsigned rows_per_chunk_for()
 /// elements one thread produces per chunk — what the patched launch parameters divide the column length by
 template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { return group_size<Out>::value * rows_per_chunk_for<Out>(); }
 
-template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename Patches>
+template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
 __device__ __forceinline__ void transform_and_patch(
-	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches)
+	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
+	AfterLoads after_loads = AfterLoads())   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -145,6 +146,7 @@ __device__ __forceinline__ void transform_and_patch(
 		for (unsigned k = 0; k < R; k++) {
 			if (first_row + k < end_row) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }
 		}
+		after_loads();
 		patches.finish_seek(lane);
 		for (uint64_t r = first_row; r < end_row; r += R) {
 			#pragma unroll
@@ -168,6 +170,7 @@ __device__ __forceinline__ void transform_and_patch(
 		}
 	}
 
+	after_loads();
 	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
 	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
 	for (uint64_t p = num_rows * row + global_thread; p < n; p += num_threads) { out[p] = patches.patched(p, produce_one(p, in[p])); }

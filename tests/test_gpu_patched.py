@@ -157,7 +157,8 @@ def test_patched_unaligned_bases_and_limits():
     comp = f["compressed_input"]
     expect = _expected(oracle.delta(comp[1:n + 1], f["anchor_values"], seglen), positions, values)
     out = g.dev_empty(n, np.uint32)
-    schemes.patched_delta(out, g.dev(comp).data_ptr() + 2, g.dev(f["anchor_values"]), d_val, d_pos, n, seglen, len(positions),
+    d_comp = g.dev(comp)   # (kept alive: a raw address does not hold the buffer)
+    schemes.patched_delta(out, d_comp.data_ptr() + 2, g.dev(f["anchor_values"]), d_val, d_pos, n, seglen, len(positions),
                           uncompressed_size=4, compressed_size=2, stream=g.stream())
     assert (g.host(out, np.uint32, n) == expect).all()
     for limits in (r.launch_configuration_limits_t(block_size=64), r.launch_configuration_limits_t(grid_size=3),
@@ -172,7 +173,8 @@ def test_patched_unaligned_bases_and_limits():
     keys = d["compressed_input"]
     expect = _expected(oracle.dictionary(keys[1:n + 1], d["dictionary_entries"]), positions, values)
     out = g.dev_empty(n, np.uint32)
-    schemes.patched_dictionary(out, g.dev(keys).data_ptr() + 1, g.dev(d["dictionary_entries"]), d_val, d_pos, n, 256, len(positions),
+    d_keys = g.dev(keys)
+    schemes.patched_dictionary(out, d_keys.data_ptr() + 1, g.dev(d["dictionary_entries"]), d_val, d_pos, n, 256, len(positions),
                                stream=g.stream())
     assert (g.host(out, np.uint32, n) == expect).all()
     for limits in (r.launch_configuration_limits_t(block_size=64, grid_size=2),):
