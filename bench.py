@@ -209,11 +209,18 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device is visible")
+    # (GIDDY_BENCH_SHARE_DEVICE=1 GIDDY_BENCH_BACKEND=gloo: rehearse the N > 1 flow with every rank on GPU 0 of a 1-GPU box)
+    if os.environ.get("GIDDY_BENCH_SHARE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("GIDDY_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
 
     def barrier():
         if world > 1:
@@ -228,7 +235,7 @@ def main():
     work.verify(oracle)                                   # bit-exact before anything is reported
     elapsed, mean_launch_ms = timed_steps(work, args.steps, args.warmup, barrier)
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t[0])
     value = world * work.decompressed_bytes * args.steps / elapsed / 1e9
