@@ -71,7 +71,9 @@ def make_workload(name, n, device):
         "model": lambda: w.Model(n, device),
         "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, 1 << 28), device),
     }
-    return table[name]()
+    work = table[name]()
+    work.workload_name = name
+    return work
 
 
 def timed_steps(work, steps, warmup, barrier):
@@ -138,15 +140,16 @@ def cpu_model():
     return "unknown"
 
 
-def committed_traffic(kernel, algorithmic_bytes=None):
+def committed_traffic(kernel, algorithmic_bytes=None, workload=None):
     """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json) — or None if there is
     no measurement for this kernel AT THIS SIZE (the passes ran the default workloads: 2^30 elements, DZB-V 2^28)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         with open(path) as f:
-            entry = json.load(f).get(kernel, {})
+            committed = json.load(f)
     except (OSError, ValueError):
         return None
+    entry = committed.get("by_workload", {}).get(workload) or committed.get(kernel, {})
     measured_for = entry.get("algorithmic_bytes_per_launch")
     if algorithmic_bytes is not None and measured_for and abs(measured_for - algorithmic_bytes) > 0.001 * algorithmic_bytes:
         return None
@@ -256,7 +259,7 @@ def main():
                    "launch": repr(work.config)},
         "per_gpu_value": round(value / world, 1),
         "pct_hbm_peak_decompressed": round(100.0 * value / world / HBM_PEAK_GBPS, 2),
-        "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel, work.algorithmic_bytes)),
+        "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel, work.algorithmic_bytes, getattr(work, "workload_name", None))),
     }
 
     if args.gather and world > 1:
@@ -290,7 +293,7 @@ def main():
             entry = {"instantiation": w.name, "elements": w.n,
                      "decompressed_GBps": round(w.decompressed_bytes * steps / el / 1e9, 1),
                      "ms_per_step": round(el / steps * 1e3, 4),
-                     "roofline": roofline(w, launch_ms, committed_traffic(w.kernel, w.algorithmic_bytes)), "bit_exact": True}
+                     "roofline": roofline(w, launch_ms, committed_traffic(w.kernel, w.algorithmic_bytes, getattr(w, "workload_name", None))), "bit_exact": True}
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
             schemes_out[name] = entry
