@@ -9,12 +9,15 @@ export TMPDIR=/tmp
 OUT=gpurun_out/prof
 rm -rf $OUT; mkdir -p $OUT
 hipcc --offload-arch=gfx950 -O3 tools/pmc_calibrate.hip -o /tmp/pmc_calibrate
-# 1. kernel trace + stats of the bench command itself
+# 1. kernel trace + stats of the bench command itself (ONLY_PMC=1 skips it)
+if [ -z "${ONLY_PMC:-}" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-# 2. PMC passes (separate runs)
+fi
+# 2. PMC passes (separate runs); WORKLOADS="a b" overrides the list
+WORKLOADS=${WORKLOADS:-dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable discard_zero_bytes_variable_3bit discard_zero_bytes_fixed model incidence_bitmaps delta_fused_patches dictionary_fused_patches frame_of_reference_fused_patches}
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter -d $OUT/pmc_$counter/calibrate -o cal --output-format csv -- /tmp/pmc_calibrate > $OUT/cal_$counter.log 2>&1
-  for w in dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable; do
+  for w in $WORKLOADS; do
     VERIFY=0 rocprofv3 --pmc $counter -d $OUT/pmc_$counter/$w -o pmc --output-format csv -- python3 tools/bench_one.py $w 30 3 > $OUT/pmc_${counter}_$w.log 2>&1
   done
 done

@@ -21,6 +21,13 @@ KERNELS = {  # workload -> (substring of the kernel name, algorithmic bytes per 
     "run_position_encoding_relative": "run_position_encoding::decompress",
     "run_position_encoding_absolute": "run_position_encoding::decompress",
     "discard_zero_bytes_variable": "variable_width::decompress",
+    "discard_zero_bytes_variable_3bit": "variable_width::decompress",
+    "discard_zero_bytes_fixed": "fixed_width::decompress",
+    "model": "model::decompress",
+    "incidence_bitmaps": "incidence_bitmaps::decompress",
+    "delta_fused_patches": "delta::patched::decompress",
+    "dictionary_fused_patches": "dictionary::patched::decompress",
+    "frame_of_reference_fused_patches": "frame_of_reference::patched::decompress",
 }
 
 
@@ -71,10 +78,19 @@ def main():
     for name, entry in bench.get("schemes", {}).items():
         algorithmic[name] = entry["roofline"]["algorithmic_bytes_per_launch"]
         durations[name] = entry["roofline"]["mean_launch_ms"]
+    try:   # workloads outside the default bench line: algorithmic bytes from the committed coverage bench
+        coverage = json.load(open(os.path.join(OUT, ROUND + "_bench.json")))
+        for name, entry in coverage.get("schemes", {}).items():
+            algorithmic.setdefault(name, entry["roofline"]["algorithmic_bytes_per_launch"])
+    except (OSError, ValueError, KeyError):
+        pass
     traffic, lines = {}, []
     for workload, kernel in KERNELS.items():
-        fetch, nf = mean_counter(os.path.join(RAW, "pmc_FETCH_SIZE", workload, "pmc_counter_collection.csv"), kernel)
-        write, nw = mean_counter(os.path.join(RAW, "pmc_WRITE_SIZE", workload, "pmc_counter_collection.csv"), kernel)
+        try:
+            fetch, nf = mean_counter(os.path.join(RAW, "pmc_FETCH_SIZE", workload, "pmc_counter_collection.csv"), kernel)
+            write, nw = mean_counter(os.path.join(RAW, "pmc_WRITE_SIZE", workload, "pmc_counter_collection.csv"), kernel)
+        except OSError:
+            continue
         if fetch is None or write is None:
             continue
         read_bytes = fetch * 1024 * read_factor
