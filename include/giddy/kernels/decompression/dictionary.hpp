@@ -29,6 +29,13 @@
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
+#ifndef GIDDY_DICT_RESTAGE_ENTRIES_PER_THREAD
+#define GIDDY_DICT_RESTAGE_ENTRIES_PER_THREAD 16  // entries a thread carries from its request to the LDS write (overlapped staging)
+#endif
+#ifndef GIDDY_DICT_RESTAGE_UP_TO_BYTES
+#define GIDDY_DICT_RESTAGE_UP_TO_BYTES 32768     // larger staged dictionaries run on a persistent grid that stages once per workgroup
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -82,16 +89,27 @@ __device__ __forceinline__ void decompress(
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
 
-	if (cache_dictionary_in_shared_memory && num_dictionary_entries <= blockDim.x) {
-		// A dictionary of at most one entry per thread: the entry is REQUESTED now, but put into LDS (and the barrier
+	// (1-byte keys: at most 256 entries, one per thread of the usual workgroup — no need to hold registers for more)
+	constexpr unsigned entries_per_thread = DictionaryIndexSize == 1 ? 1 : GIDDY_DICT_RESTAGE_ENTRIES_PER_THREAD;
+	if (cache_dictionary_in_shared_memory && num_dictionary_entries <= (uint64_t) blockDim.x * entries_per_thread) {
+		// A dictionary of a few entries per thread: the entries are REQUESTED now, but put into LDS (and the barrier
 		// taken) only after the first tile's key loads have been issued — the two memory round trips overlap
 		// instead of following each other.
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
-		const value_type my_entry = threadIdx.x < num_dictionary_entries ? dictionary_entries[threadIdx.x] : value_type();
+		value_type my_entries[entries_per_thread];
+		#pragma unroll
+		for (unsigned i = 0; i < entries_per_thread; i++) {
+			const uint64_t at = (uint64_t) i * blockDim.x + threadIdx.x;
+			if (at < num_dictionary_entries) { my_entries[i] = dictionary_entries[at]; }
+		}
 		bool staged_yet = false;   // (every thread gets here exactly once: the barrier inside is taken once by each)
 		auto stage = [&]() {
 			if (staged_yet) { return; }
-			if (threadIdx.x < num_dictionary_entries) { staged[threadIdx.x] = my_entry; }
+			#pragma unroll
+			for (unsigned i = 0; i < entries_per_thread; i++) {
+				const uint64_t at = (uint64_t) i * blockDim.x + threadIdx.x;
+				if (at < num_dictionary_entries) { staged[at] = my_entries[i]; }
+			}
 			__syncthreads();
 			staged_yet = true;
 		};
@@ -188,7 +206,7 @@ public:
 		// LDS each (at most 8 per CU), every one staging once and walking tiles at grid stride.
 		keep_gpu_busy_factor          = 1024;
 		size_t dictionary_bytes = num_dictionary_entries * UncompressedSize;
-		if (cache && dictionary_bytes > 2048) {
+		if (cache && dictionary_bytes > GIDDY_DICT_RESTAGE_UP_TO_BYTES) {
 			size_t lds_per_cu = device_properties.maxSharedMemoryPerMultiProcessor ? device_properties.maxSharedMemoryPerMultiProcessor : 65536;
 			// (measured: five 32 KiB workgroups do NOT fit a 160 KiB CU — leave a 1 KiB margin)
 			size_t workgroups_per_cu = std::min<size_t>(8, std::max<size_t>(1, (lds_per_cu - 1024) / dictionary_bytes));
