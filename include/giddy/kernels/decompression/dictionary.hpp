@@ -200,10 +200,11 @@ public:
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
-		// Small dictionaries: one tile per workgroup (tiles handed out in address order, which HBM likes best —
-		// DESIGN.md §4); re-staging <= 2 KiB per 20 KiB of traffic is noise.  A large staged dictionary must be
-		// amortised instead: a persistent grid of exactly as many workgroups as fit on the chip with that much
-		// LDS each (at most 8 per CU), every one staging once and walking tiles at grid stride.
+		// Dictionaries of up to 32 KiB: one tile per workgroup (tiles handed out in address order, which HBM likes
+		// best — DESIGN.md §4), the dictionary re-staged for every tile from L2 with its request overlapped by the
+		// tile's key loads (measured better than staging once on a persistent grid: 4096 x 4 bytes 66 -> 73 %).
+		// A larger staged dictionary is amortised instead: a persistent grid of exactly as many workgroups as fit
+		// on the chip with that much LDS each (at most 8 per CU), every one staging once and walking tiles at grid stride.
 		keep_gpu_busy_factor          = 1024;
 		size_t dictionary_bytes = num_dictionary_entries * UncompressedSize;
 		if (cache && dictionary_bytes > GIDDY_DICT_RESTAGE_UP_TO_BYTES) {
