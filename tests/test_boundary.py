@@ -129,3 +129,18 @@ def test_untyped_arguments_are_rejected_before_reaching_c():
     k = schemes.kernel(schemes.key_delta(4, 8, 2))
     with pytest.raises(TypeError, match="typed constructors"):
         k.resolve_launch_configuration(N, {"length": 100, "segment_length": 4096})
+
+
+def test_occupancy_throttle_is_an_lds_reservation_a_caller_can_refuse():
+    """resident_blocks_per_multiprocessor_cap: Model reserves dynamic LDS it never touches, so that only a few
+    workgroups share a CU; launch_configuration_limits_t::dynamic_shared_memory takes it back; the headline Dictionary has none"""
+    k = schemes.kernel(schemes.key_model(4, 4, "linear"))
+    arguments = {"length": r.size_t(1 << 24)}
+    throttled = k.resolve_launch_configuration(r.NOMINAL_MI355X, arguments, None)
+    assert throttled.dynamic_shared_memory_size >= 32 * 1024
+    refused = k.resolve_launch_configuration(r.NOMINAL_MI355X, arguments, r.launch_configuration_limits_t(dynamic_shared_memory=0))
+    assert refused.dynamic_shared_memory_size == 0
+    assert refused.grid_dimensions == throttled.grid_dimensions and refused.block_dimensions == throttled.block_dimensions
+    d = schemes.kernel(schemes.key_dictionary(4, 4, 1))
+    config = d.resolve_launch_configuration(r.NOMINAL_MI355X, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 24)}, None)
+    assert config.dynamic_shared_memory_size == 1024
