@@ -17,7 +17,9 @@ original_run = schemes._run
 def padded_run(key, resolve_arguments, launch_arguments, stream, device, limits, launch_config):
     k = schemes.kernel(key)
     if launch_config is None:
-        launch_config = k.resolve_launch_configuration(device, resolve_arguments, limits)
+        # the kernels' own occupancy throttles are refused (2 KiB is all a small dictionary needs); the pad is the throttle here
+        from libgiddy_amd import registered as r
+        launch_config = k.resolve_launch_configuration(device, resolve_arguments, r.launch_configuration_limits_t(dynamic_shared_memory=2048))
         launch_config.dynamic_shared_memory_size = max(launch_config.dynamic_shared_memory_size, current_pad[0] * 1024)
     k.enqueue_launch(stream, launch_config, launch_arguments)
     return launch_config
