@@ -220,6 +220,7 @@ public:
 		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) dictionary_bytes; }
 		// 1-byte values: 3 resident workgroups per CU are 3-5 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
 		if (UncompressedSize == 1 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 3u; }
+		if (UncompressedSize == 2 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 6u; }   // (+2..4 points)
 		default_serialization_factor  = get_default_serialization_factor(cache);
 	}
 
