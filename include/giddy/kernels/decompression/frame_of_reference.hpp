@@ -72,12 +72,25 @@ __device__ __forceinline__ void decompress(
 		Uncompressed predicted_value = static_cast<Uncompressed>(segment_model((model_index_type) within));
 		return (Uncompressed) (predicted_value + offset);
 	};
-	auto produce_group = [&](uint64_t first_position, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out) {
-		uint64_t segment, within;
-		divide<IndexSize>(first_position, L, segment, within);
-		// the segment's record is fetched once per group (neighbouring lanes hit the same address) and
-		// again only if the group crosses into the next segment
-		coefficients_type record = segment_model_coefficients[segment];
+	// A group's context: its first element's segment record and position within the segment.  When segments are whole
+	// groups (segment_length % G == 0 — always so for 4-byte outputs, whose segment lengths are multiples of 4) a group
+	// never crosses into the next segment and that one record is all it needs.
+	struct group_context { coefficients_type record; uint64_t segment, within; };
+	const bool groups_stay_in_segment = L % G == 0;
+	auto prepare = [&](uint64_t first_position) {
+		group_context context;
+		divide<IndexSize>(first_position, L, context.segment, context.within);
+		context.record = segment_model_coefficients[context.segment];
+		return context;
+	};
+	auto produce_group = [&](uint64_t, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out, const group_context& context) {
+		if (groups_stay_in_segment) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = predict(context.record, context.within + j, in[j]); }
+			return;
+		}
+		uint64_t segment = context.segment, within = context.within;
+		coefficients_type record = context.record;
 		#pragma unroll
 		for (unsigned j = 0; j < G; j++) {
 			out[j] = predict(record, within, in[j]);
@@ -87,16 +100,20 @@ __device__ __forceinline__ void decompress(
 			}
 		}
 	};
+	// (the patched decoder's row loop has no context phase: it prepares inside)
+	auto produce_group_unprepared = [&](uint64_t first_position, const memory_access::group<Compressed, G>& in, memory_access::group<Uncompressed, G>& out) {
+		produce_group(first_position, in, out, prepare(first_position));
+	};
 	auto produce_one = [&](uint64_t position, Compressed offset) {
 		uint64_t segment, within;
 		divide<IndexSize>(position, L, segment, within);
 		return predict(segment_model_coefficients[segment], within, offset);
 	};
 	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
-		stream_tiles::transform_and_patch<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, patches);
+		stream_tiles::transform_and_patch<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches);
 	}
 	else {
-		stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one);
+		stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
 	}
 }
 
@@ -168,8 +185,8 @@ public:
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
-		// 32-bit values from 16-bit offsets: 6 resident workgroups per CU are 2-3 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
-		if (sizeof(Uncompressed) == 4 && sizeof(Compressed) == 2) { resident_blocks_per_multiprocessor_cap = 6u; }
+		// 6 resident workgroups per CU are 1-9 points faster than 8, for every registered width (tools/occupancy_sweep.py)
+		resident_blocks_per_multiprocessor_cap = 6u;
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t data_length, size_t segment_length)

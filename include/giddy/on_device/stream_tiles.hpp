@@ -32,10 +32,24 @@ struct nothing_to_do { __device__ __forceinline__ void operator()() const { } };
 /// `after_loads()` is called by every thread of the workgroup — the same number of times — once a tile's loads
 /// have been issued and before the first produce (and once before the scalar tail): the place for a side table's
 /// trip through LDS, so that its latency overlaps the tile's own loads.  It must be idempotent.
-template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do>
+struct no_context { };
+struct nothing_to_prepare { __device__ __forceinline__ no_context operator()(uint64_t) const { return no_context(); } };
+
+/// calls produce_group with or without the group's context, whichever it takes
+template <typename ProduceGroup, typename Inputs, typename Outputs, typename Context>
+__device__ __forceinline__ auto produce_with(ProduceGroup& produce_group, uint64_t position, const Inputs& inputs, Outputs& outputs, const Context& context)
+	-> decltype(produce_group(position, inputs, outputs, context), void()) { produce_group(position, inputs, outputs, context); }
+template <typename ProduceGroup, typename Inputs, typename Outputs>
+__device__ __forceinline__ auto produce_with(ProduceGroup& produce_group, uint64_t position, const Inputs& inputs, Outputs& outputs, const no_context&)
+	-> decltype(produce_group(position, inputs, outputs), void()) { produce_group(position, inputs, outputs); }
+
+/// `prepare(first_position)` -> a group's context (say, its segment's record): for a whole tile ALL the contexts are
+/// requested right behind the tile's input loads and before its first store — a load issued between two stores would
+/// have to wait for the earlier store (CDNA4 counts vector memory operations in order).
+template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
-	AfterLoads after_loads = AfterLoads())
+	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare())
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -54,12 +68,15 @@ __device__ __forceinline__ void transform(
 			// K stores form straight-line code the compiler can schedule with counted waits
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) { inputs[k] = load_group<In, G>(in + (first_group + (uint64_t) k * blockDim.x) * G); }
+			decltype(prepare((uint64_t) 0)) contexts[K];
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { contexts[k] = prepare((first_group + (uint64_t) k * blockDim.x) * G); }
 			after_loads();
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) {
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
 				group<Out, G> outputs;
-				produce_group(g * G, inputs[k], outputs);
+				produce_with(produce_group, g * G, inputs[k], outputs, contexts[k]);
 				store_group(out + g * G, outputs);
 				// narrow elements: G look-ups per step — keep the steps' work from being hoisted above one another
 				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
@@ -78,7 +95,7 @@ __device__ __forceinline__ void transform(
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
 			if (g >= num_groups) { continue; }
 			group<Out, G> outputs;
-			produce_group(g * G, inputs[k], outputs);
+			produce_with(produce_group, g * G, inputs[k], outputs, prepare(g * G));
 			store_group(out + g * G, outputs);
 		}
 	}
