@@ -40,6 +40,10 @@ for U, C in ((8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1)):
 for U in (2, 4, 8):
     CASES.append(("rle<%d,2>" % U, lambda U=U: sw.run_rle(4, U, 2, 4, n)))
 CASES.append(("rpe<4,2,rel>", lambda: sw.run_rpe(4, 4, 2, True, 4, n)))
+CASES.append(("rpe<4,4,abs>", lambda: sw.run_rpe(4, 4, 4, False, 4, n)))
+CASES.append(("rle<4,1>", lambda: sw.run_rle(4, 4, 1, 4, n)))
+CASES.append(("rle<4,4>", lambda: sw.run_rle(4, 4, 4, 4, n)))
+CASES.append(("rle<1,1>", lambda: sw.run_rle(4, 1, 1, 4, n)))
 for U in (4, 8):
     CASES.append(("dzbv<8,%d,4>" % U, lambda U=U: sw.run_dzb_variable(8, U, 4, min(n, 1 << 28))))
 for U, D in ((4, 1), (8, 1), (2, 1)):
