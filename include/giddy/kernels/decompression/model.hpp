@@ -69,7 +69,7 @@ __global__ void decompress_with_intervals(
 		}
 		else { interval = p / period; within = p - interval * period; }
 	};
-	stream_tiles::generate<Uncompressed>(decompressed, length,
+	stream_tiles::generate<Uncompressed, true>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			uint64_t interval, within;
 			split(first_position, interval, within);

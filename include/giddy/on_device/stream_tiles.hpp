@@ -194,7 +194,9 @@ __device__ __forceinline__ void transform_and_patch(
 }
 
 /// out[p] = produce(p): the same loop for a decoder with no input array (Model)
-template <typename Out, typename ProduceGroup, typename ProduceOne>
+/// ProduceAllFirst: a produce_group that loads from memory (a per-interval record) runs for all K steps of a whole tile
+/// before the tile's first store — a load issued between two stores would wait for the earlier store.
+template <typename Out, bool ProduceAllFirst = false, typename ProduceGroup, typename ProduceOne>
 __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one)
 {
 	using namespace memory_access;
@@ -204,6 +206,14 @@ __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, Prod
 	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
 	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
 		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		if (ProduceAllFirst && (tile + 1) * groups_per_tile <= num_groups) {
+			group<Out, G> outputs[K];
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { produce_group((first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { store_group(out + (first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
+			continue;
+		}
 		#pragma unroll
 		for (unsigned k = 0; k < K; k++) {
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
