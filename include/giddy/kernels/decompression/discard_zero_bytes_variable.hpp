@@ -428,14 +428,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
 	const bool aligned_output = memory_access::is_aligned(decompressed, 16) && (L % E == 0);
 
-	const bool rows_fit_segments = L % row == 0;
 	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_segments = (n + L - 1) / L;
 	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
 	const uint64_t group_elements = (uint64_t) R * row;
 
-	const bool fast_path = packed && aligned_output && rows_fit_segments;
+	// (segments that are not whole rows are taken one per trip: their full groups of rows go the fast way, the tail the slow way)
+	const bool fast_path = packed && aligned_output;
 
 	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
 		const uint64_t chunk_start = c * chunk_length;
