@@ -58,13 +58,20 @@ __global__ void decompress(
 	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
 
-	for (uint64_t s = wave; s < num_anchors; s += num_waves) {
+	// Absolute positions: short segments are taken a tile's worth at a time — the runs of consecutive segments are
+	// consecutive, so k segments entered at the first one's anchor decode like one segment of k * L outputs.  (Relative
+	// positions restart in every segment: one segment per trip.)
+	const uint64_t segments_per_chunk = (PositionsAreRelative || L >= tile_length) ? 1 : tile_length / L;
+	const uint64_t num_chunks = ((uint64_t) num_anchors + segments_per_chunk - 1) / segments_per_chunk;
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t s = c * segments_per_chunk;
 		const uint64_t segment_start = s * L;
 		if (segment_start >= n) { break; }
-		const uint64_t segment_end = (segment_start + L < n) ? segment_start + L : n;
+		const uint64_t nominal_end = segment_start + segments_per_chunk * L;   // where the first segment after this chunk starts
+		const uint64_t segment_end = nominal_end < n ? nominal_end : n;
 		uint64_t first_run = position_anchors[s];
-		// candidates for runs starting inside this segment: first_run+1 .. last_candidate (inclusive)
-		const uint64_t last_candidate = (s + 1 < num_anchors) ? (uint64_t) position_anchors[s + 1] : num_runs - 1;
+		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
+		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk] : num_runs - 1;
 
 		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
 			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
@@ -84,7 +91,7 @@ __global__ void decompress(
 					uint64_t position = run_start_positions[r];
 					uint64_t start = PositionsAreRelative ? segment_start + position : position;
 					// a run at relative position 0 (absolute: at/after the segment's end) opens the NEXT segment
-					bool starts_in_segment = PositionsAreRelative ? (position != 0) : (start < segment_start + L);
+					bool starts_in_segment = PositionsAreRelative ? (position != 0) : (start < nominal_end);
 					if (!starts_in_segment || start > tile_end) { past = true; continue; }
 					if (start > tile_start && start < tile_end) { mark(table, (uint32_t) (start - tile_start)); }
 					last_at_or_before_end = (uint32_t) (r - first_run) + 1;   // r increases with j
@@ -120,6 +127,9 @@ public:
 		if (position_anchoring_period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
 		grid_construction_resolution  = warp;                // one wavefront per anchored segment
 		length                        = util::div_rounding_up(uncompressed_length, position_anchoring_period);
+		if (!PositionsAreRelative && position_anchoring_period < run_expansion::tile_length) {   // batches of short segments
+			length = util::div_rounding_up(length, (size_t) (run_expansion::tile_length / position_anchoring_period));
+		}
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
