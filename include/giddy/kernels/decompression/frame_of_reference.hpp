@@ -110,7 +110,8 @@ __device__ __forceinline__ void decompress(
 		return predict(segment_model_coefficients[segment], within, offset);
 	};
 	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
-		stream_tiles::transform_and_patch<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches);
+		// (8 rows in flight — a 4-byte column's whole chunk at once — measured 3-9 points faster than 4 for this decoder; Dictionary is best at 4)
+		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches);
 	}
 	else {
 		stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);

@@ -135,14 +135,14 @@ template <typename Out> constexpr unsigned rows_per_chunk_for()
 /// elements one thread produces per chunk — what the patched launch parameters divide the column length by
 template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { return group_size<Out>::value * rows_per_chunk_for<Out>(); }
 
-template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
+template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
 __device__ __forceinline__ void transform_and_patch(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
 	AfterLoads after_loads = AfterLoads())   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
-	constexpr unsigned R = rows_in_flight;
+	constexpr unsigned R = RowsInFlight;
 	constexpr unsigned rows_per_chunk = rows_per_chunk_for<Out>();
 	constexpr unsigned row = wave64::size * G;
 	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
