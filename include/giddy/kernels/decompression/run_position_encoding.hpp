@@ -29,6 +29,19 @@ namespace kernels {
 namespace decompression {
 namespace run_position_encoding {
 
+namespace detail {
+
+/// segments a wavefront takes per trip around its outer loop: as many short ones as fill one tile — with relative
+/// positions at most 32, the reach of the search over the chunk's anchors
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, bool positions_are_relative)
+{
+	if (segment_length >= run_expansion::tile_length) { return 1; }
+	uint64_t fit = run_expansion::tile_length / segment_length;
+	return (positions_are_relative && fit > 32) ? 32 : fit;
+}
+
+} // namespace detail
+
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
 __global__ void decompress(
 	uint_t<UncompressedSize>*          __restrict__  decompressed,
@@ -58,10 +71,10 @@ __global__ void decompress(
 	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
 
-	// Absolute positions: short segments are taken a tile's worth at a time — the runs of consecutive segments are
-	// consecutive, so k segments entered at the first one's anchor decode like one segment of k * L outputs.  (Relative
-	// positions restart in every segment: one segment per trip.)
-	const uint64_t segments_per_chunk = (PositionsAreRelative || L >= tile_length) ? 1 : tile_length / L;
+	// Short segments are taken a tile's worth at a time — the runs of consecutive segments are consecutive, so k segments
+	// entered at the first one's anchor decode like one segment of k * L outputs.  Relative positions restart in every
+	// segment: a run's segment within the chunk is found by searching the chunk's anchors (one per lane).
+	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, PositionsAreRelative);
 	const uint64_t num_chunks = ((uint64_t) num_anchors + segments_per_chunk - 1) / segments_per_chunk;
 	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
 		const uint64_t s = c * segments_per_chunk;
@@ -72,6 +85,9 @@ __global__ void decompress(
 		uint64_t first_run = position_anchors[s];
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
 		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk] : num_runs - 1;
+		// lane j: the anchor of the chunk's j-th segment (past the chunk / the column: no run index reaches it)
+		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
+			? (uint64_t) position_anchors[s + lane] : ~(uint64_t) 0;
 
 		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
 			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
@@ -87,11 +103,27 @@ __global__ void decompress(
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					uint64_t r = batch_base + (uint64_t) lane * runs_per_lane + j;
+					// Relative positions: run r lies in the chunk's segment i = #{j >= 1 : anchor_j < r} — a binary search over
+					// the anchors held one per lane.  (Done by every lane before any lane leaves the iteration: a shuffle
+					// cannot read from an inactive lane.)
+					unsigned segment_in_chunk = 0;
+					if (PositionsAreRelative && segments_per_chunk > 1) {   // wave-uniform
+						#pragma unroll
+						for (unsigned step = 16; step >= 1; step >>= 1) {
+							const unsigned probe = segment_in_chunk + step;
+							const uint64_t anchor = __shfl(chunk_anchor, (int) (probe < 64 ? probe : 63), 64);
+							if (probe < segments_per_chunk && anchor < r) { segment_in_chunk = probe; }
+						}
+					}
 					if (r > last_candidate) { past = true; continue; }
 					uint64_t position = run_start_positions[r];
-					uint64_t start = PositionsAreRelative ? segment_start + position : position;
-					// a run at relative position 0 (absolute: at/after the segment's end) opens the NEXT segment
-					bool starts_in_segment = PositionsAreRelative ? (position != 0) : (start < nominal_end);
+					uint64_t start = position;
+					if (PositionsAreRelative) {
+						// ... and at relative position 0 it starts the NEXT segment
+						start = segment_start + (uint64_t) segment_in_chunk * L + (position != 0 ? position : L);
+					}
+					// a run starting at/after the chunk's nominal end opens the NEXT chunk
+					bool starts_in_segment = start < nominal_end;
 					if (!starts_in_segment || start > tile_end) { past = true; continue; }
 					if (start > tile_start && start < tile_end) { mark(table, (uint32_t) (start - tile_start)); }
 					last_at_or_before_end = (uint32_t) (r - first_run) + 1;   // r increases with j
@@ -127,9 +159,7 @@ public:
 		if (position_anchoring_period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
 		grid_construction_resolution  = warp;                // one wavefront per anchored segment
 		length                        = util::div_rounding_up(uncompressed_length, position_anchoring_period);
-		if (!PositionsAreRelative && position_anchoring_period < run_expansion::tile_length) {   // batches of short segments
-			length = util::div_rounding_up(length, (size_t) (run_expansion::tile_length / position_anchoring_period));
-		}
+		length = util::div_rounding_up(length, (size_t) detail::segments_per_wave_chunk(position_anchoring_period, PositionsAreRelative));   // batches of short segments
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
