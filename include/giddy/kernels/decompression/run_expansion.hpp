@@ -28,8 +28,14 @@ namespace kernels {
 namespace decompression {
 namespace run_expansion {
 
+#ifndef GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST
+#define GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST 2   // segments shorter than a tile are taken at least this many at a time
+#endif
+#ifndef GIDDY_RUN_TILE_WORDS_PER_LANE
+#define GIDDY_RUN_TILE_WORDS_PER_LANE 2
+#endif
 enum : unsigned {
-	words_per_lane      = 2,
+	words_per_lane      = GIDDY_RUN_TILE_WORDS_PER_LANE,
 	tile_words          = 64 * words_per_lane,     // 128
 	tile_length         = 32 * tile_words,         // 4096 outputs per tile
 	runs_per_lane       = 4,                       // run descriptors examined per lane per batch
@@ -44,8 +50,8 @@ struct tile_entry {
 
 __device__ __forceinline__ void clear(tile_entry* table, unsigned lane)
 {
-	table[words_per_lane * lane].bits = 0;
-	table[words_per_lane * lane + 1].bits = 0;
+	#pragma unroll
+	for (unsigned i = 0; i < words_per_lane; i++) { table[words_per_lane * lane + i].bits = 0; }
 	wave64::lds_fence();
 }
 
@@ -58,12 +64,13 @@ __device__ __forceinline__ void mark(tile_entry* table, uint32_t position_in_til
 __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 {
 	wave64::lds_fence();
-	uint32_t a = __builtin_popcount(table[words_per_lane * lane].bits);
-	uint32_t b = __builtin_popcount(table[words_per_lane * lane + 1].bits);
-	uint32_t inclusive = wave64::inclusive_sum(a + b);
-	uint32_t exclusive = inclusive - (a + b);
-	table[words_per_lane * lane].rank_before = exclusive;
-	table[words_per_lane * lane + 1].rank_before = exclusive + a;
+	uint32_t counts[words_per_lane], total = 0;
+	#pragma unroll
+	for (unsigned i = 0; i < words_per_lane; i++) { counts[i] = __builtin_popcount(table[words_per_lane * lane + i].bits); total += counts[i]; }
+	uint32_t inclusive = wave64::inclusive_sum(total);
+	uint32_t before = inclusive - total;
+	#pragma unroll
+	for (unsigned i = 0; i < words_per_lane; i++) { table[words_per_lane * lane + i].rank_before = before; before += counts[i]; }
 	wave64::lds_fence();
 	return wave64::read_last_lane(inclusive);
 }
@@ -80,7 +87,7 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 2048, capacity = bytes / ElementSize };
+	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize };
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].

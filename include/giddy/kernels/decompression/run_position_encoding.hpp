@@ -37,6 +37,7 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 {
 	if (segment_length >= run_expansion::tile_length) { return 1; }
 	uint64_t fit = run_expansion::tile_length / segment_length;
+	if (fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST) { fit = GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST; }   // (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile)
 	return (positions_are_relative && fit > 32) ? 32 : fit;
 }
 

@@ -16,6 +16,13 @@ for mean_run in (2, 4, 8, 32, 128, 1000, 20000):
         show("rle<4,4,2> mean_run=%d L=%d" % (mean_run, L), sw.run_rle(4, 4, 2, 4, n, L, mean_run))
 for mean_run in (2, 32, 1000):
     show("rpe<4,4,2,rel> mean_run=%d L=4096" % mean_run, sw.run_rpe(4, 4, 2, True, 4, n, 4096, mean_run))
+for L in (128, 256, 1000, 3000):   # short segments and segments that are not whole tiles / rows
+    m = n // L * L
+    show("rle<4,4,2> L=%d" % L, sw.run_rle(4, 4, 2, 4, m, L))
+    show("rpe<4,4,2,rel> L=%d" % L, sw.run_rpe(4, 4, 2, True, 4, m, L))
+    show("rpe<4,4,4,abs> L=%d" % L, sw.run_rpe(4, 4, 4, False, 4, m, L))
+    show("delta<4,8,2> L=%d" % L, sw.run_delta(4, 8, 2, m, L))
+    show("dzbv<8,8,4> L=%d" % L, sw.run_dzb_variable(8, 8, 4, (1 << 27) // (L * 16) * (L * 16), L))
 for L in (128, 256, 1024, 4096, 65536):
     show("dzbv<8,8,4> 2-bit L=%d" % L, sw.run_dzb_variable(8, 8, 4, 1 << 27, L))
 for L in (64, 1024, 4096, 1 << 20):
