@@ -114,7 +114,7 @@ __device__ __forceinline__ void decompress(
 		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches);
 	}
 	else {
-		stream_tiles::transform<Compressed, Uncompressed>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
+		stream_tiles::transform<Compressed, Uncompressed, GIDDY_FOR_STEPS_PER_TILE>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
 	}
 }
 
@@ -179,7 +179,7 @@ public:
 			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
 		}
 		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<Uncompressed>()
-			: stream_tiles::elements_per_thread_per_tile<Uncompressed>();
+			: stream_tiles::elements_per_thread_per_tile<Uncompressed, GIDDY_FOR_STEPS_PER_TILE>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride

@@ -31,7 +31,7 @@ __global__ void decompress(
 	using model_index_type = typename UnaryModelFunction::index_type;
 	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	UnaryModelFunction model(model_coefficients);
-	stream_tiles::generate<Uncompressed>(decompressed, length,
+	stream_tiles::generate<Uncompressed, false, GIDDY_MODEL_STEPS_PER_TILE>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			#pragma unroll
 			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
@@ -69,7 +69,7 @@ __global__ void decompress_with_intervals(
 		}
 		else { interval = p / period; within = p - interval * period; }
 	};
-	stream_tiles::generate<Uncompressed, true>(decompressed, length,
+	stream_tiles::generate<Uncompressed, true, GIDDY_MODEL_STEPS_PER_TILE>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			uint64_t interval, within;
 			split(first_position, interval, within);
@@ -99,7 +99,7 @@ public:
 		device::properties_t device_properties_, device_function::attributes_t kernel_function_attributes_, size_t length_)
 	: parent(device_properties_, kernel_function_attributes_)
 	{
-		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed>();
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed, GIDDY_MODEL_STEPS_PER_TILE>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(length_, (size_t) elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;
@@ -107,8 +107,9 @@ public:
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		default_serialization_factor  = warp_size / sizeof(Uncompressed);
-		// a pure store stream: 71 -> 76-79 % of HBM peak with 2-3 resident workgroups per CU instead of 8 (measured per instantiation, tools/occupancy_sweep.py)
-		if (sizeof(Uncompressed) <= 4) { resident_blocks_per_multiprocessor_cap = sizeof(Uncompressed) == 4 ? 2u : 3u; }
+		// a pure store stream likes shallow tiles (one 16-byte store per lane) and few wavefronts: 4 resident workgroups per CU
+		// reach 83-89 % of HBM peak where 8 reach 77 and four-store tiles 71-78 (tools/occupancy_sweep.py)
+		if (sizeof(Uncompressed) <= 4) { resident_blocks_per_multiprocessor_cap = 4u; }
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_)

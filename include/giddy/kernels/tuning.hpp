@@ -11,3 +11,9 @@
 #ifndef GIDDY_STREAM_BY_WAVE_CHUNKS
 #define GIDDY_STREAM_BY_WAVE_CHUNKS 0      // 1: FOR and Dictionary without patches also run by wavefront chunks (stream_tiles.hpp)
 #endif
+#ifndef GIDDY_FOR_STEPS_PER_TILE
+#define GIDDY_FOR_STEPS_PER_TILE GIDDY_STREAM_STEPS_PER_TILE     // Frame of Reference's own tile depth
+#endif
+#ifndef GIDDY_MODEL_STEPS_PER_TILE
+#define GIDDY_MODEL_STEPS_PER_TILE 1       // Model's own tile depth: nothing to load, nothing to overlap
+#endif

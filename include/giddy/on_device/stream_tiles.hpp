@@ -23,7 +23,7 @@ enum : unsigned { steps_per_tile = GIDDY_STREAM_STEPS_PER_TILE };
 template <typename Out> struct group_size { enum : unsigned { value = 16 / sizeof(Out) }; };
 
 /// elements one thread produces per tile — what the launch parameters divide the column length by
-template <typename Out> constexpr unsigned elements_per_thread_per_tile() { return group_size<Out>::value * steps_per_tile; }
+template <typename Out, unsigned Steps = steps_per_tile> constexpr unsigned elements_per_thread_per_tile() { return group_size<Out>::value * Steps; }
 
 struct nothing_to_do { __device__ __forceinline__ void operator()() const { } };
 
@@ -46,14 +46,14 @@ __device__ __forceinline__ auto produce_with(ProduceGroup& produce_group, uint64
 /// `prepare(first_position)` -> a group's context (say, its segment's record): for a whole tile ALL the contexts are
 /// requested right behind the tile's input loads and before its first store — a load issued between two stores would
 /// have to wait for the earlier store (CDNA4 counts vector memory operations in order).
-template <typename In, typename Out, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
+template <typename In, typename Out, unsigned Steps = steps_per_tile, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
 	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare())
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
-	constexpr unsigned K = steps_per_tile;
+	constexpr unsigned K = Steps;
 	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
 
 	const bool vectorizable = is_aligned(out, 16) && is_aligned(in, in_bytes);
@@ -196,12 +196,12 @@ __device__ __forceinline__ void transform_and_patch(
 /// out[p] = produce(p): the same loop for a decoder with no input array (Model)
 /// ProduceAllFirst: a produce_group that loads from memory (a per-interval record) runs for all K steps of a whole tile
 /// before the tile's first store — a load issued between two stores would wait for the earlier store.
-template <typename Out, bool ProduceAllFirst = false, typename ProduceGroup, typename ProduceOne>
+template <typename Out, bool ProduceAllFirst = false, unsigned Steps = steps_per_tile, typename ProduceGroup, typename ProduceOne>
 __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
-	constexpr unsigned K = steps_per_tile;
+	constexpr unsigned K = Steps;
 	const uint64_t num_groups = is_aligned(out, 16) ? n / G : 0;
 	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
 	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {

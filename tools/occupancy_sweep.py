@@ -9,7 +9,7 @@ from libgiddy_amd import schemes
 
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
 n = 1 << log2n
-PADS = (0, 22, 26, 31, 39, 52, 79)
+PADS = tuple(int(p) for p in os.environ.get("PADS", "0,22,26,31,39,52,79").split(","))
 current_pad = [0]
 original_run = schemes._run
 
@@ -31,8 +31,8 @@ for U, C, model in ((4, 2, "constant"), (4, 2, "linear"), (4, 1, "linear"), (2, 
     CASES.append(("for<%d,%d,%s>" % (U, C, model), lambda U=U, C=C, model=model: sw.run_for(4, U, C, model, 4, n)))
 for U, C in ((8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1)):
     CASES.append(("dzb_fixed<%d,%d>" % (U, C), lambda U=U, C=C: sw.run_dzb_fixed(4, U, C, n)))
-for U in (2, 4, 8):
-    CASES.append(("model<%d,linear>" % U, lambda U=U: sw.run_model(4 if U < 8 else 8, U, "linear", n)))
+for I, U in ((4, 2), (4, 4), (8, 4)):
+    CASES.append(("model<%d,%d,linear>" % (I, U), lambda I=I, U=U: sw.run_model(I, U, "linear", n)))
 for U, D in ((1, 1), (2, 1), (4, 1), (8, 1)):
     CASES.append(("dictionary<%d,%d>" % (U, D), lambda U=U, D=D: sw.run_dictionary(4, U, D, n)))
 for U, C in ((8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1)):
