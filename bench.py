@@ -60,6 +60,8 @@ def make_workload(name, n, device):
         "frame_of_reference": lambda: w.FrameOfReference(n, device),
         "delta_patched": lambda: w.DeltaPatched(n, device),
         "delta_fused_patches": lambda: w.DeltaFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
+        "delta_compressed_patches": lambda: w.DeltaCompressedPatches(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
+        "delta_fused_compressed_patches": lambda: w.DeltaFusedCompressedPatches(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "frame_of_reference_fused_patches": lambda: w.FrameOfReferenceFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "dictionary_fused_patches": lambda: w.DictionaryFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "run_length_encoding": lambda: w.RunLength(n, device),

@@ -1,9 +1,11 @@
 // Kernel wrapper for Delta decompression fused with patching (an extension; the
 // reference runs delta.cu and then data_layout/scatter.cu).  Argument-map keys: those of the Delta wrapper
 // (src/kernel_wrappers/decompression/delta.cu:49-83) plus the patch arrays under the names "patch_values",
-// "patch_positions" (ascending) and "num_patches".
+// "patch_positions" (ascending) and "num_patches" — or, in place of "patch_positions", the compressed-indices arrays
+// and a "patch_positions_scratch" (patched/patch_positions.hpp).
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 
 namespace cuda {
@@ -58,10 +60,10 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
 	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
 	auto patch_values      = argument<const uncompressed_type*>(arguments, "patch_values");
-	auto patch_positions   = argument<const index_type*>(arguments, "patch_positions");
 	auto length            = argument<index_type>(arguments, "length");
 	auto segment_length    = argument<index_type>(arguments, "segment_length");
 	auto num_patches       = argument<index_type>(arguments, "num_patches");
+	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, anchor_values, patch_values, patch_positions,

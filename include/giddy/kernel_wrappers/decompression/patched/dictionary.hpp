@@ -1,9 +1,11 @@
 // Kernel wrapper for Dictionary decompression fused with patching (an extension).
 // Argument-map keys: those of the Dictionary wrapper (src/kernel_wrappers/decompression/dictionary.cu:52-96,
 // both spellings of the caching flag included) plus "patch_values", "patch_positions" (ascending) and
-// "num_patches".
+// "num_patches" — or, in place of "patch_positions", the compressed-indices arrays and a "patch_positions_scratch"
+// (patched/patch_positions.hpp).
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/dictionary.hpp"
 
 namespace cuda {
@@ -67,10 +69,10 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch(
 	auto compressed_input        = argument<const dictionary_index_type*>(arguments, "compressed_input");
 	auto dictionary_entries      = argument<const uncompressed_type*>(arguments, "dictionary_entries");
 	auto patch_values            = argument<const uncompressed_type*>(arguments, "patch_values");
-	auto patch_positions         = argument<const index_type*>(arguments, "patch_positions");
 	auto length                  = argument<size_type>(arguments, "length");
 	auto num_dictionary_entries  = argument<dictionary_size_type>(arguments, "num_dictionary_entries");
 	auto num_patches             = argument<index_type>(arguments, "num_patches");
+	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
 	// The dictionary is staged in LDS iff the resolved configuration reserved room for it.
 	bool fits = (size_t) num_dictionary_entries * UncompressedSize <= launch_config.dynamic_shared_memory_size;

@@ -1,8 +1,10 @@
 // Kernel wrapper for Frame-of-Reference decompression fused with patching (an extension, SURVEY.md
 // §8f.1).  Argument-map keys: those of the FOR wrapper (src/kernel_wrappers/decompression/
-// frame_of_reference.cu:58-102) plus "patch_values", "patch_positions" (ascending) and "num_patches".
+// frame_of_reference.cu:58-102) plus "patch_values", "patch_positions" (ascending) and "num_patches" — or, in place
+// of "patch_positions", the compressed-indices arrays and a "patch_positions_scratch" (patched/patch_positions.hpp).
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/frame_of_reference.hpp"
 
 namespace cuda {
@@ -58,10 +60,10 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto compressed_input           = argument<const Compressed*>(arguments, "compressed_input");
 	auto segment_model_coefficients = argument<const model_coefficients_type*>(arguments, "segment_model_coefficients");
 	auto patch_values               = argument<const Uncompressed*>(arguments, "patch_values");
-	auto patch_positions            = argument<const index_type*>(arguments, "patch_positions");
 	auto length                     = argument<index_type>(arguments, "length");
 	auto segment_length             = argument<index_type>(arguments, "segment_length");
 	auto num_patches                = argument<index_type>(arguments, "num_patches");
+	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, segment_model_coefficients, patch_values, patch_positions,

@@ -43,30 +43,21 @@ struct run_descriptor {
 	uint32_t width;      // bytes per offset, 0 = skip
 };
 
-} // namespace detail
-
-template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>
-__global__ void scatter(
-	uint_t<ElementSize>*            __restrict__  target,
-	const uint_t<ElementSize>*      __restrict__  data,
+/// The walk over the compressed positions, shared by the scatter and by the stand-alone expansion of the positions:
+/// calls sink(patch index, position, representable) once per patch, consecutive lanes taking consecutive patches.
+template <unsigned OutputIndexSize, unsigned InputIndexSize, unsigned RunLengthSize, typename Sink>
+__device__ __forceinline__ void for_each_patch(
 	const uint_t<RunLengthSize>*    __restrict__  scatter_position_run_lengths,
 	const unsigned char*            __restrict__  scatter_position_run_individual_offset_sizes,
 	const uint_t<OutputIndexSize>*  __restrict__  scatter_position_run_baseline_values,
 	const uint_t<InputIndexSize>*   __restrict__  scatter_position_run_offsets_start_positions,
 	const unsigned char*            __restrict__  scatter_position_offset_bytes,
 	const uint_t<InputIndexSize>*   __restrict__  scatter_position_anchors,
-	uint_t<InputIndexSize>                        anchoring_period,
-	uint_t<InputIndexSize>                        num_output_position_runs,
-	size_type_by_index_size<InputIndexSize>       data_length)
+	uint64_t period, uint64_t num_runs, uint64_t n, run_descriptor* mine, Sink sink)
 {
-	using detail::run_descriptor;
-	__shared__ run_descriptor descriptors[detail::max_waves_per_block][64];
-	run_descriptor* mine = descriptors[wave64::index_in_block() % detail::max_waves_per_block];
-
 	const unsigned lane = wave64::lane_id();
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
-	const uint64_t period = anchoring_period, n = data_length, num_runs = num_output_position_runs;
 	if (period == 0) { return; }
 	const uint64_t num_blocks = (n + period - 1) / period;
 
@@ -106,22 +97,76 @@ __global__ void scatter(
 				while (lo > 0 && mine[lo].length == 0) { lo--; }
 				const run_descriptor r = mine[lo];
 				const uint64_t t = k - r.cursor;
-				if (t < r.length && r.width != 0) {
-					const unsigned char* where = scatter_position_offset_bytes + r.offsets + t * r.width;
-					uint64_t offset;
-					switch (r.width) {
-					case 1: offset = *where; break;
-					case 2: offset = *reinterpret_cast<const uint16_t*>(where); break;
-					case 4: offset = *reinterpret_cast<const uint32_t*>(where); break;
-					default: offset = *reinterpret_cast<const uint64_t*>(where); break;
+				if (t < r.length) {
+					uint64_t offset = 0;
+					if (r.width != 0) {
+						const unsigned char* where = scatter_position_offset_bytes + r.offsets + t * r.width;
+						switch (r.width) {
+						case 1: offset = *where; break;
+						case 2: offset = *reinterpret_cast<const uint16_t*>(where); break;
+						case 4: offset = *reinterpret_cast<const uint32_t*>(where); break;
+						default: offset = *reinterpret_cast<const uint64_t*>(where); break;
+						}
 					}
-					target[(uint_t<OutputIndexSize>) (r.baseline + offset)] = data[block_first_patch + k];
+					sink(block_first_patch + k, (uint_t<OutputIndexSize>) (r.baseline + offset), r.width != 0);
 				}
 			}
 			consumed += batch_total;
 			wave64::lds_fence();
 		}
 	}
+}
+
+} // namespace detail
+
+template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>
+__global__ void scatter(
+	uint_t<ElementSize>*            __restrict__  target,
+	const uint_t<ElementSize>*      __restrict__  data,
+	const uint_t<RunLengthSize>*    __restrict__  scatter_position_run_lengths,
+	const unsigned char*            __restrict__  scatter_position_run_individual_offset_sizes,
+	const uint_t<OutputIndexSize>*  __restrict__  scatter_position_run_baseline_values,
+	const uint_t<InputIndexSize>*   __restrict__  scatter_position_run_offsets_start_positions,
+	const unsigned char*            __restrict__  scatter_position_offset_bytes,
+	const uint_t<InputIndexSize>*   __restrict__  scatter_position_anchors,
+	uint_t<InputIndexSize>                        anchoring_period,
+	uint_t<InputIndexSize>                        num_output_position_runs,
+	size_type_by_index_size<InputIndexSize>       data_length)
+{
+	__shared__ detail::run_descriptor descriptors[detail::max_waves_per_block][64];
+	detail::for_each_patch<OutputIndexSize, InputIndexSize, RunLengthSize>(
+		scatter_position_run_lengths, scatter_position_run_individual_offset_sizes, scatter_position_run_baseline_values,
+		scatter_position_run_offsets_start_positions, scatter_position_offset_bytes, scatter_position_anchors,
+		anchoring_period, num_output_position_runs, data_length, descriptors[wave64::index_in_block() % detail::max_waves_per_block],
+		[&](uint64_t patch, uint_t<OutputIndexSize> position, bool representable) {
+			if (representable) { target[position] = data[patch]; }
+		});
+}
+
+/// The positions alone, as a plain array (positions[k] = where patch k goes; all-ones for the patches of a run whose
+/// offset width is none of 8/16/32/64 bits, which scatter() skips): what the fused decoders merge from
+/// (kernel_wrappers/decompression/patched/*.hpp) — bytes proportional to the patches, not to the column.
+template <unsigned OutputIndexSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>
+__global__ void expand_positions(
+	uint_t<OutputIndexSize>*        __restrict__  positions,
+	const uint_t<RunLengthSize>*    __restrict__  scatter_position_run_lengths,
+	const unsigned char*            __restrict__  scatter_position_run_individual_offset_sizes,
+	const uint_t<OutputIndexSize>*  __restrict__  scatter_position_run_baseline_values,
+	const uint_t<InputIndexSize>*   __restrict__  scatter_position_run_offsets_start_positions,
+	const unsigned char*            __restrict__  scatter_position_offset_bytes,
+	const uint_t<InputIndexSize>*   __restrict__  scatter_position_anchors,
+	uint_t<InputIndexSize>                        anchoring_period,
+	uint_t<InputIndexSize>                        num_output_position_runs,
+	size_type_by_index_size<InputIndexSize>       data_length)
+{
+	__shared__ detail::run_descriptor descriptors[detail::max_waves_per_block][64];
+	detail::for_each_patch<OutputIndexSize, InputIndexSize, RunLengthSize>(
+		scatter_position_run_lengths, scatter_position_run_individual_offset_sizes, scatter_position_run_baseline_values,
+		scatter_position_run_offsets_start_positions, scatter_position_offset_bytes, scatter_position_anchors,
+		anchoring_period, num_output_position_runs, data_length, descriptors[wave64::index_in_block() % detail::max_waves_per_block],
+		[&](uint64_t patch, uint_t<OutputIndexSize> position, bool representable) {
+			positions[patch] = representable ? position : (uint_t<OutputIndexSize>) ~(uint_t<OutputIndexSize>) 0;
+		});
 }
 
 template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>

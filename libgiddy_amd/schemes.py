@@ -153,10 +153,32 @@ def delta(decompressed, compressed_input, anchor_values, length, segment_length,
 
 # ---- fused decompress-and-patch launches (extension; patch positions ascending) ---------------------
 
+_COMPRESSED_POSITION_ARRAYS = (   # name, element width (None: the column's index size)
+    ("scatter_position_run_lengths", None), ("scatter_position_run_individual_offset_sizes", 1),
+    ("scatter_position_run_baseline_values", None), ("scatter_position_run_offsets_start_pos", None),
+    ("scatter_position_offset_bytes", 1), ("scatter_position_anchors", None))
+
+
+def _compressed_position_arguments(compressed, output_index_size, input_index_size, run_length_size):
+    widths = {"scatter_position_run_lengths": run_length_size, "scatter_position_run_baseline_values": output_index_size}
+    arguments = {name: r.const_pointer(compressed[name], "u%d" % (8 * (width or widths.get(name, input_index_size))))
+                 for name, width in _COMPRESSED_POSITION_ARRAYS}
+    arguments["anchoring_period"] = r.uint_t(input_index_size)(compressed["anchoring_period"])
+    arguments["num_scatter_position_runs"] = r.uint_t(input_index_size)(compressed["num_scatter_position_runs"])
+    return arguments
+
+
 def _patch_arguments(patch_values, patch_positions, num_patches, value_code, index_size):
-    return {"patch_values": r.const_pointer(patch_values, value_code),
-            "patch_positions": r.const_pointer(patch_positions, "u%d" % (8 * index_size)),
-            "num_patches": r.uint_t(index_size)(num_patches)}
+    """`patch_positions`: a plain ascending array, or a dict of the compressed-indices arrays (formats.compressed_indices,
+    built with output_index_size = input_index_size = the column's index size) plus "patch_positions_scratch", a
+    buffer of num_patches indices the positions are expanded into on the way (patched/patch_positions.hpp)"""
+    arguments = {"patch_values": r.const_pointer(patch_values, value_code), "num_patches": r.uint_t(index_size)(num_patches)}
+    if isinstance(patch_positions, dict):
+        arguments.update(_compressed_position_arguments(patch_positions, index_size, index_size, index_size))
+        arguments["patch_positions_scratch"] = r.pointer(patch_positions["patch_positions_scratch"], "u%d" % (8 * index_size))
+    else:
+        arguments["patch_positions"] = r.const_pointer(patch_positions, "u%d" % (8 * index_size))
+    return arguments
 
 
 def patched_delta(decompressed, compressed_input, anchor_values, patch_values, patch_positions, length, segment_length, num_patches, *,
@@ -322,3 +344,22 @@ def compressed_indices_scatter(target, data_to_scatter, scatter_position_run_len
          "num_scatter_position_runs": r.uint_t(input_index_size)(num_scatter_position_runs),
          "input_data_length": r.size_type_by_index_size(input_index_size)(input_data_length)},
         stream, device, limits, launch_config)
+
+
+def key_compressed_indices_positions(output_index_size, input_index_size, run_length_size=None):
+    return "scatter::compressed_indices::positions::kernel_t<%du, %du, %du>" % (
+        output_index_size, input_index_size, run_length_size or input_index_size)
+
+
+def compressed_indices_positions(positions, compressed, input_data_length, *, output_index_size=4, input_index_size=4,
+                                 run_length_size=None, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """positions[k] = where patch k goes: the position half of compressed_indices_scatter(), as a plain ascending array
+    (`compressed`: the arrays of formats.compressed_indices, on the device)"""
+    run_length_size = run_length_size or input_index_size
+    launch = {"positions": r.pointer(positions, "u%d" % (8 * output_index_size)),
+              "input_data_length": r.size_type_by_index_size(input_index_size)(input_data_length)}
+    launch.update(_compressed_position_arguments(compressed, output_index_size, input_index_size, run_length_size))
+    return _run(key_compressed_indices_positions(output_index_size, input_index_size, run_length_size),
+                {"input_data_length": r.size_t(input_data_length), "anchoring_period": r.size_t(compressed["anchoring_period"])},
+                launch, stream, device, limits, launch_config)
+

@@ -33,7 +33,10 @@ def test_factory_has_the_163_reference_registrations():
                                         if k.startswith(("decompression::delta::kernel_t", "decompression::dictionary::kernel_t",
                                                          "decompression::frame_of_reference::kernel_t")))
     assert len(extensions) == 12 + 20 + 8
-    keys = [k for k in all_keys if "::patched::" not in k]
+    # ... and so is the stand-alone expansion of compressed patch positions the fused wrappers use
+    expansions = [k for k in all_keys if "::positions::" in k]
+    assert sorted(expansions) == sorted(schemes.key_compressed_indices_positions(o, i) for o in (4, 8) for i in (1, 2, 4, 8))
+    keys = [k for k in all_keys if "::patched::" not in k and "::positions::" not in k]
     assert len(keys) == 163
     counts = {}
     for k in keys:
@@ -55,6 +58,16 @@ def test_factory_has_the_163_reference_registrations():
                 schemes.key_scatter(8, 1, 2), schemes.key_compressed_indices_scatter(4, 8, 1),
                 schemes.key_frame_of_reference(8, 4, 2, "linear", 8)]:
         assert r.kernel_t.canProduce(key), key
+
+
+def test_expansion_of_compressed_positions_resolves_without_a_device_query():
+    k = schemes.kernel(schemes.key_compressed_indices_positions(4, 4))
+    c = k.resolve_launch_configuration(N, {"input_data_length": r.size_t(1 << 20), "anchoring_period": r.size_t(1024)})
+    assert c.block_dimensions == (256, 1, 1) and c.grid_dimensions[0] == 256    # a wavefront per block of patches
+    with pytest.raises(r.InvalidArgument):
+        k.resolve_launch_configuration(N, {"input_data_length": r.size_t(0), "anchoring_period": r.size_t(1024)})
+    with pytest.raises(r.InvalidArgument):
+        k.resolve_launch_configuration(N, {"input_data_length": r.size_t(10), "anchoring_period": r.size_t(0)})
 
 
 def test_unknown_key_is_invalid_argument():

@@ -205,3 +205,99 @@ def test_patched_delta_fuzz(usize, csize):
         got = g.host(out, ud, n)
         bad = np.flatnonzero(got != expect)
         assert len(bad) == 0, (n, seglen, how, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
+# ---- patch positions in the compressed-indices form ------------------------------------------------
+
+def _compressed(positions, values, period, index_size, g, max_run_length=None):
+    """formats.compressed_indices on the device, plus the scratch the fused decoders expand the positions into"""
+    from libgiddy_amd import formats
+    c = formats.compressed_indices(positions, values, period, output_index_size=index_size, input_index_size=index_size,
+                                   max_run_length=max_run_length)
+    on_device = {k: (g.dev(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    on_device["patch_positions_scratch"] = g.dev_empty(len(positions), np.dtype("u%d" % index_size))
+    return on_device
+
+
+def _distinct(positions, values):
+    keep = np.concatenate([positions[1:] != positions[:-1], [True]]) if len(positions) else np.zeros(0, bool)
+    return positions[keep], values[keep]
+
+
+@pytest.mark.parametrize("output_index_size,input_index_size", [(4, 4), (8, 8), (4, 2), (8, 4), (4, 1), (4, 8)])
+@pytest.mark.parametrize("n_patches,period,max_run", [(1, 1, None), (200, 64, None), (100000, 1024, None), (100000, 100, 3), (65000, 65000, 1), (5000, 7, None)])
+def test_compressed_positions_expand_to_the_plain_ones(output_index_size, input_index_size, n_patches, period, max_run):
+    schemes, r, g = _imports()
+    from libgiddy_amd import formats
+    if n_patches > np.iinfo("u%d" % input_index_size).max:
+        n_patches, period = 200, min(period, 100)
+    rng = cases.rng(n_patches + period)
+    span = min(1 << 40 if output_index_size == 8 else 1 << 31, n_patches * 3000)
+    positions = np.unique(rng.integers(0, span, size=n_patches, dtype=np.uint64))
+    c = formats.compressed_indices(positions, np.zeros(len(positions), np.uint8), period, output_index_size=output_index_size,
+                                   input_index_size=input_index_size, max_run_length=max_run)
+    if c["num_scatter_position_runs"] > np.iinfo("u%d" % input_index_size).max:
+        pytest.skip("more runs than the index type counts")
+    on_device = {k: (g.dev(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    out = g.dev_empty(len(positions), np.dtype("u%d" % output_index_size))
+    schemes.compressed_indices_positions(out, on_device, len(positions), output_index_size=output_index_size,
+                                         input_index_size=input_index_size, stream=g.stream())
+    got = g.host(out, np.dtype("u%d" % output_index_size), len(positions))
+    assert np.array_equal(got, positions.astype(got.dtype))
+
+
+@pytest.mark.parametrize("index_size", [4, 8])
+@pytest.mark.parametrize("how", ["sparse", "dense", "edges", "clustered", "all"])
+@pytest.mark.parametrize("period,max_run", [(1024, None), (100, 5)])
+def test_fused_decoders_take_compressed_patch_positions(index_size, how, period, max_run):
+    schemes, r, g = _imports()
+    n, seglen = 300007, 1024
+    # Delta
+    ud, cd = np.dtype("u4"), np.dtype("u1")
+    f, truth = cases.delta_case(n, seglen, ud, cd, seed=11)
+    positions, values = _distinct(*_patches(n, how, ud, index_size, seed=5))
+    expect = _expected(truth, positions, values)
+    compressed = _compressed(positions, values, period, index_size, g, max_run)
+    out = g.dev_empty(n, ud)
+    schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values), compressed, n, seglen, len(positions),
+                          uncompressed_size=4, compressed_size=1, index_size=index_size, stream=g.stream())
+    assert np.array_equal(g.host(out, ud, n), expect)
+    assert np.array_equal(g.host(compressed["patch_positions_scratch"], np.dtype("u%d" % index_size), len(positions)), positions)
+    # Frame of Reference
+    sd, scd = np.dtype("i4"), np.dtype("i2")
+    f = cases.for_case(n, seglen, sd, scd, "linear", seed=12)
+    decoded = oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, seglen, sd, "linear", model_index_size=4)
+    positions, values = _distinct(*_patches(n, how, sd, index_size, seed=6))
+    expect = _expected(decoded, positions, values)
+    compressed = _compressed(positions, values, period, index_size, g, max_run)
+    out = g.dev_empty(n, sd)
+    schemes.patched_frame_of_reference(out, g.dev(f["compressed_input"]), g.dev(f["segment_model_coefficients"]), g.dev(values), compressed,
+                                       n, seglen, len(positions), uncompressed_size=4, compressed_size=2, model="linear",
+                                       index_size=index_size, model_index_size=4, stream=g.stream())
+    assert np.array_equal(g.host(out, sd, n), expect)
+    # Dictionary
+    kd = np.dtype("u1")
+    f = cases.dictionary_case(n, 256, ud, kd, seed=13)
+    decoded = oracle.dictionary(f["compressed_input"], f["dictionary_entries"])
+    positions, values = _distinct(*_patches(n, how, ud, index_size, seed=7))
+    expect = _expected(decoded, positions, values)
+    compressed = _compressed(positions, values, period, index_size, g, max_run)
+    out = g.dev_empty(n, ud)
+    schemes.patched_dictionary(out, g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"]), g.dev(values), compressed,
+                               n, 256, len(positions), uncompressed_size=4, dictionary_index_size=1, index_size=index_size, stream=g.stream())
+    assert np.array_equal(g.host(out, ud, n), expect)
+
+
+def test_fused_decoder_with_no_compressed_patches_launches_no_expansion():
+    schemes, r, g = _imports()
+    n, seglen = 5000, 1000
+    ud, cd = np.dtype("u4"), np.dtype("u2")
+    f, truth = cases.delta_case(n, seglen, ud, cd, seed=3)
+    empty = np.zeros(1, np.uint32)
+    compressed = {name: g.dev(empty.astype(np.uint8 if "bytes" in name or "sizes" in name else np.uint32))
+                  for name, _ in schemes._COMPRESSED_POSITION_ARRAYS}
+    compressed.update(anchoring_period=64, num_scatter_position_runs=0, patch_positions_scratch=g.dev(empty))
+    out = g.dev_empty(n, ud)
+    schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(empty), compressed, n, seglen, 0,
+                          uncompressed_size=4, compressed_size=2, index_size=4, stream=g.stream())
+    assert np.array_equal(g.host(out, ud, n), truth)

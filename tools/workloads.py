@@ -252,6 +252,63 @@ class DeltaFused(DeltaPatched):
                               stream=stream, launch_config=self.config)
 
 
+def _compressed_positions_on_device(patch_idx, period, device):
+    """formats.compressed_indices of the (ascending, distinct) patch positions, as device tensors"""
+    from libgiddy_amd import formats
+    c = formats.compressed_indices(_np(patch_idx, np.uint32), np.zeros(0, np.uint8), period)
+    return {k: (torch.from_numpy(v.view({1: np.uint8, 4: np.int32}[v.dtype.itemsize])).to(device) if isinstance(v, np.ndarray) and v.size else v)
+            for k, v in c.items() if k != "data_to_scatter"}
+
+
+class DeltaCompressedPatches(DeltaPatched):
+    """C3 with the patch positions in the compressed-indices form (runs of baseline + 8/16/32-bit offsets, anchored
+    every 1024 patches): Delta, then the compressed-indices scatter on the same stream — the reference's pipeline."""
+    name = "delta<4,8,2>+scatter::compressed_indices<4,8,4>"
+
+    def __init__(self, n, device, anchoring_period=1024, **kw):
+        super().__init__(n, device, **kw)
+        self.positions = _compressed_positions_on_device(self.patch_idx, anchoring_period, device)
+        c = self.positions
+        self.position_bytes = sum(v.numel() * v.element_size() for v in c.values() if torch.is_tensor(v))
+        self.step_algorithmic_bytes = self.algorithmic_bytes + self.p * 16 + self.position_bytes
+        self.patch_config = self._scatter(torch.cuda.current_stream().cuda_stream, None)
+
+    def _scatter(self, stream, config):
+        c = self.positions
+        return schemes.compressed_indices_scatter(
+            self.output, self.patch_val, c["scatter_position_run_lengths"], c["scatter_position_run_individual_offset_sizes"],
+            c["scatter_position_run_baseline_values"], c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"],
+            c["scatter_position_anchors"], c["anchoring_period"], c["num_scatter_position_runs"], self.p,
+            output_index_size=4, element_size=8, input_index_size=4, stream=stream, launch_config=config)
+
+    def run(self, stream, around_dominant_kernel=None):
+        if around_dominant_kernel:
+            around_dominant_kernel[0]()
+        schemes.delta(self.output, self.deltas, self.anchors, self.n, self.L, stream=stream, launch_config=self.config)
+        if around_dominant_kernel:
+            around_dominant_kernel[1]()
+        self._scatter(stream, self.patch_config)
+
+
+class DeltaFusedCompressedPatches(DeltaCompressedPatches):
+    """... and with those compressed positions handed to the fused Delta wrapper: a small kernel expands them into a
+    scratch array (bytes proportional to the patches), then the one pass over the column merges them"""
+    name = "delta::patched<4,8,2> (compressed positions)"
+    kernel = "delta::patched::decompress"
+
+    def __init__(self, n, device, **kw):
+        super().__init__(n, device, **kw)
+        self.positions["patch_positions_scratch"] = torch.empty(self.p, dtype=torch.int32, device=device)
+        self.algorithmic_bytes = 10 * n + 8 * ((n + self.L - 1) // self.L) + self.p * 12
+        self.step_algorithmic_bytes = self.algorithmic_bytes + self.position_bytes + 4 * self.p
+        self.config = schemes.patched_delta(self.output, self.deltas, self.anchors, self.patch_val, self.positions, n, self.L, self.p,
+                                            stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_delta(self.output, self.deltas, self.anchors, self.patch_val, self.positions, self.n, self.L, self.p,
+                              stream=stream, launch_config=self.config)
+
+
 class DictionaryFused(Dictionary):
     """C2 plus 0.1 % ascending patches merged inside the Dictionary kernel"""
     name = "dictionary::patched<4,4,1>"
