@@ -87,7 +87,8 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize };
+	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
+		allocated = capacity + 16 / ElementSize };   // (the byte-permuting expansion reads up to 11 bytes past a lane's first run)
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
@@ -118,7 +119,34 @@ __device__ __forceinline__ void expand(
 			return entry.rank_before + (uint32_t) __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - bit)));
 		};
 		group<element_type, E> values;
-		if (use_staged) {
+		bool done = false;
+		if constexpr (Staged && ElementSize == 1) {
+			// A lane's 16 one-byte outputs: when at most 8 runs cover them (any mean run length above ~2) they are a byte
+			// permutation of the 8 staged values from the lane's first run on — three LDS dword reads and one
+			// v_perm_b32 per output dword, instead of sixteen masked popcounts and sixteen byte-sized LDS reads.
+			const unsigned first_bit = p & 31;   // 0 or 16
+			const uint32_t starts = (entry.bits >> first_bit >> 1) & 0x7FFFu;   // bit i: a run starts at output p + 1 + i
+			if (use_staged && wave64::ballot(__builtin_popcount(starts) > 7) == 0) {
+				const uint32_t first_rank = entry.rank_before + (uint32_t) __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - first_bit)));
+				const uint32_t* words = reinterpret_cast<const uint32_t*>(staged) + (first_rank >> 2);
+				const uint32_t w0 = words[0], w1 = words[1], w2 = words[2];
+				const uint32_t low = __builtin_amdgcn_alignbyte(w1, w0, first_rank & 3), high = __builtin_amdgcn_alignbyte(w2, w1, first_rank & 3);
+				uint32_t runs_before = 0;   // runs starting at the lane's outputs 1 .. 4k - 1, replicated in all four bytes
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) {
+					// bit t: a run starts at output 4k + t (the lane's first run, at or before output 0, is not counted)
+					const uint32_t nibble = k == 0 ? (starts << 1) & 0xEu : (starts >> (4 * k - 1)) & 0xFu;
+					uint32_t selector = (nibble * 0x00204081u) & 0x01010101u;   // bit t -> byte t
+					selector += selector << 8;
+					selector += selector << 16;                                 // byte t: starts at outputs 4k .. 4k + t
+					values.words[k] = __builtin_amdgcn_perm(high, low, selector + runs_before);
+					runs_before += (uint32_t) __builtin_popcount(nibble) * 0x01010101u;
+				}
+				done = true;
+			}
+		}
+		if (done) { }
+		else if (use_staged) {
 			// one output dword (4 / ElementSize elements) at a time, so that at most that many ranks and looked-up
 			// values are alive at once (all 16 of a 1-byte column at once cost two wavefronts per SIMD of occupancy)
 			constexpr unsigned per_dword = 4 / (ElementSize > 4 ? 4 : ElementSize);

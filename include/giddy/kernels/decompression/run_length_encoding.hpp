@@ -56,7 +56,7 @@ __global__ void decompress(
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
 	using staging = value_staging<UncompressedSize, RunLengthSize>;
-	__shared__ uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::capacity : 1];
+	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::allocated : 1];
 	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
 
 	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256

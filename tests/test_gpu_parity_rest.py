@@ -98,6 +98,11 @@ def _run_columns():
     yield "one", np.array([5], dtype=np.uint32)
     yield "alldistinct", np.arange(30000, dtype=np.uint32)
     yield "boundary", np.repeat(np.arange(10, dtype=np.uint32) * 3 + 1, [1024, 512, 512, 2048, 1, 1023, 1024, 100, 924, 1000])
+    # one-byte columns expand 16 outputs per lane by byte permutation when at most 8 runs cover them: around that limit
+    yield "pairs", np.repeat(np.arange(20000, dtype=np.uint32), 2)
+    yield "eight_per_16", np.repeat(np.arange(24000, dtype=np.uint32), np.tile([1, 1, 1, 1, 1, 1, 1, 9], 3000))
+    yield "nine_per_16", np.repeat(np.arange(27000, dtype=np.uint32), np.tile([1, 1, 1, 1, 1, 1, 1, 1, 8], 3000))
+    yield "short_mix", np.repeat(np.arange(30000, dtype=np.uint32), cases.rng(21).integers(1, 5, size=30000))
     yield "tileboundary", np.repeat(np.arange(6, dtype=np.uint32) + 9, [4096, 4096, 8192, 1, 4095, 12288])
 
 
