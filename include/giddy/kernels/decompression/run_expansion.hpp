@@ -88,13 +88,18 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
 	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
-		allocated = capacity + 16 / ElementSize };   // (the byte-permuting expansion reads up to 11 bytes past a lane's first run)
+		allocated = capacity + 16 / ElementSize,
+		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);
+		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)
+		with_descriptors = enabled && ElementSize >= 4 };   // (the byte-permuting expansion reads up to 11 bytes past a lane's first run)
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
 /// `staged` (may be null) is a wave-private LDS area of value_staging<ElementSize>::capacity elements;
 /// `num_runs_in_tile` = marks + 1.
-template <unsigned ElementSize, bool Staged>
+/// AlreadyStaged: the caller has put the tile's run values into `staged` itself (next to its own loads of the run
+/// descriptors, instead of one more dependent round trip here)
+template <unsigned ElementSize, bool Staged, bool AlreadyStaged = false>
 __device__ __forceinline__ void expand(
 	uint_t<ElementSize>* __restrict__ out, uint32_t tile_len, const tile_entry* table,
 	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane,
@@ -105,10 +110,10 @@ __device__ __forceinline__ void expand(
 	constexpr unsigned E = 16 / ElementSize;
 	const bool aligned = is_aligned(out, 16);
 	const bool use_staged = Staged && staged != nullptr && num_runs_in_tile <= value_staging<ElementSize>::capacity;
-	if (use_staged) {
+	if (use_staged && !AlreadyStaged) {
 		for (uint32_t i = lane; i < num_runs_in_tile; i += 64) { staged[i] = first_run_data[i]; }
-		wave64::lds_fence();
 	}
+	if (use_staged) { wave64::lds_fence(); }
 
 	for (uint32_t row_start = 0; row_start < tile_len; row_start += 64 * E) {
 		const uint32_t p = row_start + lane * E;

@@ -106,6 +106,8 @@ __global__ void decompress(
 					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) run_lengths[first_run + k]);
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
+					// the runs' values travel with their lengths (staged for the expansion; runs past the tile's last are harmless)
+					if (staging::with_descriptors && have[j] && k < staging::capacity) { staged[k] = run_data[first_run + k]; }
 				}
 				uint32_t inclusive = wave64::inclusive_sum(lane_total);
 				uint32_t start = running + inclusive - lane_total;
@@ -126,7 +128,7 @@ __global__ void decompress(
 			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize, staging::enabled>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			expand<UncompressedSize, staging::enabled, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 
 			if (need_carry) {
 				uint64_t who = wave64::ballot(found);

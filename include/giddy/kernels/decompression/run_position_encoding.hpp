@@ -95,6 +95,7 @@ __global__ void decompress(
 			const uint64_t tile_end = tile_start + tile_len;
 			const bool need_carry = tile_end < segment_end;
 			clear(table, lane);
+			if (staging::with_descriptors && lane == 0) { staged[0] = run_data[first_run]; }
 
 			uint64_t batch_base = first_run + 1;
 			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= tile_end
@@ -118,6 +119,8 @@ __global__ void decompress(
 					}
 					if (r > last_candidate) { past = true; continue; }
 					uint64_t position = run_start_positions[r];
+					// the runs' values travel with their positions (staged for the expansion; runs past the tile's last are harmless)
+					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = run_data[r]; }
 					uint64_t start = position;
 					if (PositionsAreRelative) {
 						// ... and at relative position 0 it starts the NEXT segment
@@ -134,7 +137,7 @@ __global__ void decompress(
 			} while (!reached_past_tile);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize, staging::enabled>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			expand<UncompressedSize, staging::enabled, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
