@@ -77,7 +77,7 @@ int main()
 		ks::decompression::incidence_bitmaps::kernel_t<4, 4, 2, true> k;
 		CHECK(k.resolve_launch_configuration(props, attrs, (size_t) 1 << 20, no_limits).grid_dimensions.x == (1u << 20) / 2048 / 4);
 		ks::decompression::model::kernel_t<4, int32_t, models::linear<4, int32_t>> m;
-		CHECK(m.resolve_launch_configuration(props, attrs, (size_t) 1 << 20, no_limits).grid_dimensions.x == (1u << 20) / (256 * 16));
+		CHECK(m.resolve_launch_configuration(props, attrs, (size_t) 1 << 20, no_limits).grid_dimensions.x == (1u << 20) / (256 * 4));   // one 16-byte store per thread per tile
 	}
 	{
 		ks::decompression::run_length_encoding::kernel_t<4, 4, 2> k;
@@ -122,12 +122,14 @@ int main()
 	// ---- factory + type-erased path -----------------------------------------------------------------------------
 	{
 		auto& factory = registered::kernel_t::getSubclassFactory();
-		size_t reference_registrations = 0, fused_patch_extensions = 0;
+		size_t reference_registrations = 0, fused_patch_extensions = 0, position_expansions = 0;
 		for (const auto& entry : factory.getInsantiators()) {
-			(entry.first.find("::patched::") == std::string::npos ? reference_registrations : fused_patch_extensions)++;
+			(entry.first.find("::patched::") != std::string::npos ? fused_patch_extensions :
+			 entry.first.find("::positions::") != std::string::npos ? position_expansions : reference_registrations)++;
 		}
 		CHECK(reference_registrations == 163);
 		CHECK(fused_patch_extensions == 12 + 20 + 8);
+		CHECK(position_expansions == 8);
 		const char* key = "decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
 		CHECK(factory.canProduce(key));
 		auto k = registered::kernel_t::produceSubclass(key);
