@@ -88,10 +88,10 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
 	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
-		allocated = capacity + 16 / ElementSize,
+		allocated = capacity + 16 / ElementSize,   // (the permuting expansions read up to 11 bytes past a lane's first run)
 		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);
 		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)
-		with_descriptors = enabled && ElementSize >= 4 };   // (the byte-permuting expansion reads up to 11 bytes past a lane's first run)
+		with_descriptors = enabled && ElementSize >= 4 };
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].
@@ -146,6 +146,26 @@ __device__ __forceinline__ void expand(
 					selector += selector << 16;                                 // byte t: starts at outputs 4k .. 4k + t
 					values.words[k] = __builtin_amdgcn_perm(high, low, selector + runs_before);
 					runs_before += (uint32_t) __builtin_popcount(nibble) * 0x01010101u;
+				}
+				done = true;
+			}
+		}
+		if constexpr (Staged && ElementSize == 2) {
+			// ... and a lane's 8 two-byte outputs, when at most 4 runs cover them, of the 4 staged values from its first run on
+			const unsigned first_bit = p & 31;   // 0, 8, 16 or 24
+			const uint32_t starts = (entry.bits >> first_bit >> 1) & 0x7Fu;   // bit i: a run starts at output p + 1 + i
+			if (use_staged && wave64::ballot(__builtin_popcount(starts) > 3) == 0) {
+				const uint32_t first_rank = entry.rank_before + (uint32_t) __builtin_popcount(entry.bits & (0xFFFFFFFFu >> (31 - first_bit)));
+				const uint32_t* words = reinterpret_cast<const uint32_t*>(staged) + (first_rank >> 1);
+				const uint32_t w0 = words[0], w1 = words[1], w2 = words[2];
+				const uint32_t low = __builtin_amdgcn_alignbyte(w1, w0, 2 * (first_rank & 1)), high = __builtin_amdgcn_alignbyte(w2, w1, 2 * (first_rank & 1));
+				uint32_t selector = 0x01000100u;   // bytes {2r, 2r + 1} of value r, for both outputs of a dword; r = 0 so far
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) {
+					const uint32_t at_even = k == 0 ? 0 : (starts >> (2 * k - 1)) & 1u, at_odd = (starts >> (2 * k)) & 1u;   // a run starts at output 2k / 2k + 1
+					selector += at_even * 0x02020202u;
+					values.words[k] = __builtin_amdgcn_perm(high, low, selector + at_odd * 0x02020000u);
+					selector += at_odd * 0x02020202u;
 				}
 				done = true;
 			}
