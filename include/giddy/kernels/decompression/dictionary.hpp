@@ -50,6 +50,11 @@ constexpr serialization_factor_t get_default_serialization_factor(bool cache_all
 namespace detail {
 
 /// out[p] = lookup(keys[p]) over the shared streaming tile loop
+/// whether an instantiation runs by wavefront chunks (stream_tiles::transform_and_patch) rather than by workgroup tiles: the
+/// fused ones do.  (Their 1-byte keys of 8-byte values come in with 16-byte loads through LDS instead of 2 bytes per lane and
+/// row: 57 -> 81 % of HBM peak with 2 resident workgroups per CU.  The plain kernel in the same shape stays at its tiles' 70-73 %.)
+template <bool Patched> constexpr bool by_wave_chunks() { return Patched || GIDDY_STREAM_BY_WAVE_CHUNKS; }
+
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
@@ -57,6 +62,7 @@ __device__ __forceinline__ void translate(
 	uint64_t                                          n,
 	Lookup                                            lookup,
 	Patches                                           patches,
+	stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>>* chunk_staging,
 	AfterLoads                                        after_loads = AfterLoads())
 {
 	using key_type = uint_t<DictionaryIndexSize>;
@@ -67,8 +73,8 @@ __device__ __forceinline__ void translate(
 		for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
-	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
-		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads);
+	if constexpr (by_wave_chunks<Patches::enabled>()) {
+		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
 	}
 	else {
 		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
@@ -88,6 +94,12 @@ __device__ __forceinline__ void decompress(
 	using value_type = uint_t<UncompressedSize>;
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
+	// (1-byte keys of 8-byte values in the wave-chunk shape: a chunk's keys come in wide and go through LDS — stream_tiles.hpp)
+	stream_tiles::chunk_input_storage<key_type, value_type>* chunk_staging = nullptr;
+	if constexpr (by_wave_chunks<Patches::enabled>()) {
+		__shared__ stream_tiles::chunk_input_storage<key_type, value_type> chunk_staging_storage;
+		chunk_staging = &chunk_staging_storage;
+	}
 
 	// (1-byte keys: at most 256 entries, one per thread of the usual workgroup — no need to hold registers for more)
 	constexpr unsigned entries_per_thread = DictionaryIndexSize == 1 ? 1 : GIDDY_DICT_RESTAGE_ENTRIES_PER_THREAD;
@@ -114,18 +126,18 @@ __device__ __forceinline__ void decompress(
 			staged_yet = true;
 		};
 		translate<UncompressedSize, DictionaryIndexSize>(
-			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, stage);
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage);
 	}
 	else if (cache_dictionary_in_shared_memory) {
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();
 		translate<UncompressedSize, DictionaryIndexSize>(
-			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches);
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging);
 	}
 	else {
 		translate<UncompressedSize, DictionaryIndexSize>(
-			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches);
+			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches, chunk_staging);
 	}
 }
 
@@ -191,7 +203,8 @@ public:
 		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
 	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
 	{
-		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
+		constexpr bool by_chunks = detail::by_wave_chunks<false>();
+		constexpr unsigned elements_per_thread_per_tile = by_chunks ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
 			: stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		bool cache = cache_dictionary_in_shared_memory_override.value_or(
 			should_cache_dictionary_in_shared_memory(num_dictionary_entries));

@@ -135,10 +135,22 @@ template <typename Out> constexpr unsigned rows_per_chunk_for()
 /// elements one thread produces per chunk — what the patched launch parameters divide the column length by
 template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { return group_size<Out>::value * rows_per_chunk_for<Out>(); }
 
+/// Rows of at most 2 input bytes per lane (1-byte inputs of 8-byte outputs): a wavefront-wide load instruction would fetch
+/// 128 bytes.  Given a chunk_input_storage (wave-private LDS, declared __shared__ by the kernel), a chunk's input comes in
+/// with 16-byte loads instead and is dealt out to the rows through LDS (as in Delta's staged-input path).
+template <typename In, typename Out> constexpr bool stages_chunk_input() { return group_size<Out>::value * sizeof(In) <= 2; }
+enum : unsigned { chunk_staging_waves = 4 };   // wavefronts per workgroup the storage is provisioned for; others load row by row
+template <typename In, typename Out, bool Enabled = stages_chunk_input<In, Out>()>
+struct alignas(16) chunk_input_storage {
+	enum : unsigned { elements = rows_per_chunk_for<Out>() * wave64::size * group_size<Out>::value };
+	In inputs[Enabled ? chunk_staging_waves : 1][Enabled ? elements : 1];
+};
+
 template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
 __device__ __forceinline__ void transform_and_patch(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
-	AfterLoads after_loads = AfterLoads())   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
+	AfterLoads after_loads = AfterLoads(),   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
+	chunk_input_storage<In, Out>* staging = nullptr)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -154,9 +166,41 @@ __device__ __forceinline__ void transform_and_patch(
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
 
+	constexpr bool stage_chunk_input = stages_chunk_input<In, Out>();
+	constexpr unsigned chunk_input_bytes = rows_per_chunk * row * sizeof(In);
+	const bool may_stage = stage_chunk_input && staging != nullptr && wave64::index_in_block() < chunk_staging_waves && is_aligned(in, 16);
+
 	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
 		const uint64_t first_row = c * rows_per_chunk;
 		const uint64_t end_row = first_row + rows_per_chunk < num_rows ? first_row + rows_per_chunk : num_rows;
+		if constexpr (stage_chunk_input) {
+			if (may_stage && end_row - first_row == rows_per_chunk) {   // wave-uniform
+				using piece_t = typename chunk<16>::type;
+				constexpr unsigned pieces_per_lane = chunk_input_bytes / 16 / wave64::size;
+				static_assert(pieces_per_lane >= 1 && chunk_input_bytes % (16 * wave64::size) == 0, "a chunk's input is a whole number of 16-byte pieces per lane");
+				In* mine = staging->inputs[wave64::index_in_block()];
+				const piece_t* source = reinterpret_cast<const piece_t*>(in + first_row * row);
+				piece_t pieces[pieces_per_lane];
+				patches.begin_seek(first_row * row, lane);
+				#pragma unroll
+				for (unsigned i = 0; i < pieces_per_lane; i++) { pieces[i] = source[i * wave64::size + lane]; }
+				after_loads();
+				patches.finish_seek(lane);
+				wave64::lds_fence();   // (the previous chunk's rows have been read)
+				#pragma unroll
+				for (unsigned i = 0; i < pieces_per_lane; i++) { reinterpret_cast<piece_t*>(mine)[i * wave64::size + lane] = pieces[i]; }
+				wave64::lds_fence();
+				for (uint64_t r = first_row; r < end_row; r++) {
+					const uint64_t p = r * row + lane * G;
+					const group<In, G> inputs = load_group<In, G>(mine + (r - first_row) * row + lane * G);
+					group<Out, G> outputs;
+					produce_group(p, inputs, outputs);
+					patches.template apply_to_row<G>(r * row, lane, outputs);
+					store_group(out + p, outputs);
+				}
+				continue;
+			}
+		}
 		group<In, G> current[R], next[R];
 		patches.begin_seek(first_row * row, lane);   // (its probes go out ahead of the first rows' loads, the rest behind them)
 		#pragma unroll
