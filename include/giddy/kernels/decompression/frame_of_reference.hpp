@@ -111,7 +111,11 @@ __device__ __forceinline__ void decompress(
 	};
 	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
 		// (8 rows in flight — a 4-byte column's whole chunk at once — measured 3-9 points faster than 4 for this decoder; Dictionary is best at 4)
-		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches);
+		constexpr unsigned stage_up_to = GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO;
+		constexpr bool stages = stream_tiles::stages_chunk_input<Compressed, Uncompressed, stage_up_to>();
+		__shared__ stream_tiles::chunk_input_storage<Compressed, Uncompressed, stages> chunk_staging;
+		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8, stage_up_to>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches,
+			stream_tiles::nothing_to_do(), &chunk_staging);
 	}
 	else {
 		stream_tiles::transform<Compressed, Uncompressed, GIDDY_FOR_STEPS_PER_TILE>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);

@@ -17,3 +17,6 @@
 #ifndef GIDDY_MODEL_STEPS_PER_TILE
 #define GIDDY_MODEL_STEPS_PER_TILE 1       // Model's own tile depth: nothing to load, nothing to overlap
 #endif
+#ifndef GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO
+#define GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO 2   // fused FOR: chunks whose rows take at most this many input bytes per lane come in through LDS
+#endif

@@ -138,7 +138,7 @@ template <typename Out> constexpr unsigned elements_per_thread_per_chunk() { ret
 /// Rows of at most 2 input bytes per lane (1-byte inputs of 8-byte outputs): a wavefront-wide load instruction would fetch
 /// 128 bytes.  Given a chunk_input_storage (wave-private LDS, declared __shared__ by the kernel), a chunk's input comes in
 /// with 16-byte loads instead and is dealt out to the rows through LDS (as in Delta's staged-input path).
-template <typename In, typename Out> constexpr bool stages_chunk_input() { return group_size<Out>::value * sizeof(In) <= 2; }
+template <typename In, typename Out, unsigned UpToBytesPerLane = 2> constexpr bool stages_chunk_input() { return group_size<Out>::value * sizeof(In) <= UpToBytesPerLane; }
 enum : unsigned { chunk_staging_waves = 4 };   // wavefronts per workgroup the storage is provisioned for; others load row by row
 template <typename In, typename Out, bool Enabled = stages_chunk_input<In, Out>()>
 struct alignas(16) chunk_input_storage {
@@ -146,11 +146,12 @@ struct alignas(16) chunk_input_storage {
 	In inputs[Enabled ? chunk_staging_waves : 1][Enabled ? elements : 1];
 };
 
-template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
+template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, unsigned StageUpToBytesPerLane = 2,
+	typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
 __device__ __forceinline__ void transform_and_patch(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
 	AfterLoads after_loads = AfterLoads(),   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
-	chunk_input_storage<In, Out>* staging = nullptr)
+	chunk_input_storage<In, Out, stages_chunk_input<In, Out, StageUpToBytesPerLane>()>* staging = nullptr)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void transform_and_patch(
 	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
 
-	constexpr bool stage_chunk_input = stages_chunk_input<In, Out>();
+	constexpr bool stage_chunk_input = stages_chunk_input<In, Out, StageUpToBytesPerLane>();
 	constexpr unsigned chunk_input_bytes = rows_per_chunk * row * sizeof(In);
 	const bool may_stage = stage_chunk_input && staging != nullptr && wave64::index_in_block() < chunk_staging_waves && is_aligned(in, 16);
 
