@@ -39,9 +39,9 @@ public:
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(data_length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
 		params.resident_blocks_per_multiprocessor_cap = nullopt;   // (the plain kernel's occupancy throttle was not measured for this one)
-		// 1-byte keys of 8-byte values (a chunk's keys staged through LDS): 2 resident workgroups per CU reach 80-83 % of HBM peak,
-		// 3 to 5 reach 70-73 (tools/occupancy_sweep.py)
-		if (stream_tiles::stages_chunk_input<dictionary_index_type, uncompressed_type>()) { params.resident_blocks_per_multiprocessor_cap = 2u; }
+		// chunks' keys staged through LDS (1- and 2-byte keys of 8-byte values): 2 resident workgroups per CU reach 80-83 % of HBM
+		// peak, 3 to 5 reach 70-73 (tools/occupancy_sweep.py)
+		if (dictionary::detail::stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()) { params.resident_blocks_per_multiprocessor_cap = 2u; }
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };

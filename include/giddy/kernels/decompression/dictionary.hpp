@@ -54,6 +54,16 @@ namespace detail {
 /// fused ones do.  (Their 1-byte keys of 8-byte values come in with 16-byte loads through LDS instead of 2 bytes per lane and
 /// row: 57 -> 81 % of HBM peak with 2 resident workgroups per CU.  The plain kernel in the same shape stays at its tiles' 70-73 %.)
 template <bool Patched> constexpr bool by_wave_chunks() { return Patched || GIDDY_STREAM_BY_WAVE_CHUNKS; }
+/// ... whose chunks' keys come in through LDS when a row takes at most this many key bytes per lane: 4 for 8-byte values (1- and
+/// 2-byte keys: 55-58 -> 81-83 % and 69 -> 80 % of HBM peak, at 2 resident workgroups per CU), 2 otherwise (4-byte values with
+/// 1-byte keys lose 6 points staged)
+template <unsigned UncompressedSize> constexpr unsigned stage_keys_up_to() { return UncompressedSize == 8 ? 4 : 2; }
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr bool stages_chunk_keys()
+{
+	return stream_tiles::stages_chunk_input<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stage_keys_up_to<UncompressedSize>()>();
+}
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
+using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
 __device__ __forceinline__ void translate(
@@ -62,7 +72,7 @@ __device__ __forceinline__ void translate(
 	uint64_t                                          n,
 	Lookup                                            lookup,
 	Patches                                           patches,
-	stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>>* chunk_staging,
+	chunk_key_storage<UncompressedSize, DictionaryIndexSize>* chunk_staging,
 	AfterLoads                                        after_loads = AfterLoads())
 {
 	using key_type = uint_t<DictionaryIndexSize>;
@@ -74,7 +84,7 @@ __device__ __forceinline__ void translate(
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
 	if constexpr (by_wave_chunks<Patches::enabled>()) {
-		stream_tiles::transform_and_patch<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
+		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
 	}
 	else {
 		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
@@ -95,9 +105,9 @@ __device__ __forceinline__ void decompress(
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
 	// (1-byte keys of 8-byte values in the wave-chunk shape: a chunk's keys come in wide and go through LDS — stream_tiles.hpp)
-	stream_tiles::chunk_input_storage<key_type, value_type>* chunk_staging = nullptr;
+	chunk_key_storage<UncompressedSize, DictionaryIndexSize>* chunk_staging = nullptr;
 	if constexpr (by_wave_chunks<Patches::enabled>()) {
-		__shared__ stream_tiles::chunk_input_storage<key_type, value_type> chunk_staging_storage;
+		__shared__ chunk_key_storage<UncompressedSize, DictionaryIndexSize> chunk_staging_storage;
 		chunk_staging = &chunk_staging_storage;
 	}
 
