@@ -280,7 +280,8 @@ def main():
                  "run_position_encoding_absolute", "discard_zero_bytes_variable"]
         if args.schemes == "coverage":
             names += ["discard_zero_bytes_variable_3bit", "discard_zero_bytes_fixed", "model", "incidence_bitmaps",
-                      "delta_fused_patches", "dictionary_fused_patches", "frame_of_reference_fused_patches"]
+                      "delta_fused_patches", "dictionary_fused_patches", "frame_of_reference_fused_patches",
+                      "delta_compressed_patches", "delta_fused_compressed_patches"]
         elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
         del work

@@ -28,6 +28,7 @@ KERNELS = {  # workload -> (substring of the kernel name, algorithmic bytes per 
     "delta_fused_patches": "delta::patched::decompress",
     "dictionary_fused_patches": "dictionary::patched::decompress",
     "frame_of_reference_fused_patches": "frame_of_reference::patched::decompress",
+    "delta_fused_compressed_patches": "delta::patched::decompress",
 }
 
 
