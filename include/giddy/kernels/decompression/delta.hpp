@@ -63,6 +63,9 @@ namespace detail {
 #ifndef GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO
 #define GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO 4   // bytes of input per lane per row up to which a chunk's input goes through LDS (wave path)
 #endif
+#ifndef GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO
+#define GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO 2   // ... of the fused kernels, whose patch windows share the LDS
+#endif
 #ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
 #define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
 #endif
@@ -449,7 +452,7 @@ __device__ __forceinline__ void decompress(
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	if (vector_access && rows_per_segment <= rows_per_chunk) {
 		// (with patches the cursor's windows already take 12 KiB of LDS per workgroup: only the narrowest rows are staged then)
-		if constexpr (traits::E * CompressedSize <= (Patches::enabled ? 2 : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO)) {
+		if constexpr (traits::E * CompressedSize <= (Patches::enabled ? GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO)) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
 			__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][rows_per_chunk * traits::row * CompressedSize];
 			if (L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
