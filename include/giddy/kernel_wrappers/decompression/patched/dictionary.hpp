@@ -39,9 +39,7 @@ public:
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(data_length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
 		params.resident_blocks_per_multiprocessor_cap = nullopt;   // (the plain kernel's occupancy throttle was not measured for this one)
-		// chunks' keys staged through LDS (1- and 2-byte keys of 8-byte values): 2 resident workgroups per CU reach 80-83 % of HBM
-		// peak, 3 to 5 reach 70-73 (tools/occupancy_sweep.py)
-		if (dictionary::detail::stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()) { params.resident_blocks_per_multiprocessor_cap = 2u; }
+		params.reserve_chunk_key_staging();   // (narrow keys of 8-byte values: staged through LDS, 2 resident workgroups per CU)
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };
@@ -81,9 +79,14 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch(
 	bool fits = (size_t) num_dictionary_entries * UncompressedSize <= launch_config.dynamic_shared_memory_size;
 	bool caching = maybe_cache.value_or(launch_config.dynamic_shared_memory_size > 0) && fits;
 
+	// (2-byte keys of 8-byte values: a chunk's keys go through dynamic LDS behind the dictionary iff the configuration has the room)
+	size_t behind = caching ? ((size_t) num_dictionary_entries * UncompressedSize + 15) / 16 * 16 : 0;
+	bool chunk_key_staging = DictionaryIndexSize > 1 && dictionary::detail::stages_chunk_keys<UncompressedSize, DictionaryIndexSize>() &&
+		launch_config.dynamic_shared_memory_size >= behind + sizeof(dictionary::detail::chunk_key_storage<UncompressedSize, DictionaryIndexSize>);
+
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, dictionary_entries, patch_values, patch_positions,
-		length, num_dictionary_entries, (size_type) num_patches, caching);
+		length, num_dictionary_entries, (size_type) num_patches, caching, chunk_key_staging);
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>

@@ -53,7 +53,12 @@ namespace detail {
 /// whether an instantiation runs by wavefront chunks (stream_tiles::transform_and_patch) rather than by workgroup tiles: the
 /// fused ones do.  (Their 1-byte keys of 8-byte values come in with 16-byte loads through LDS instead of 2 bytes per lane and
 /// row: 57 -> 81 % of HBM peak with 2 resident workgroups per CU.  The plain kernel in the same shape stays at its tiles' 70-73 %.)
-template <bool Patched> constexpr bool by_wave_chunks() { return Patched || GIDDY_STREAM_BY_WAVE_CHUNKS; }
+template <bool Patched, unsigned UncompressedSize = 0, unsigned DictionaryIndexSize = 0, bool RestagedDictionary = false> constexpr bool by_wave_chunks()
+{
+	// (plain 2-byte keys of 8-byte values as well where every workgroup re-stages the dictionary: 32 KiB are then staged per
+	// 128 KiB of output instead of per 32 KiB tile — 60-64 -> 75 % of HBM peak; staged once or looked up through L2, tiles are 3 points better)
+	return Patched || GIDDY_STREAM_BY_WAVE_CHUNKS || (RestagedDictionary && UncompressedSize == 8 && DictionaryIndexSize == 2);
+}
 /// ... whose chunks' keys come in through LDS when a row takes at most this many key bytes per lane: 4 for 8-byte values (1- and
 /// 2-byte keys: 55-58 -> 81-83 % and 69 -> 80 % of HBM peak, at 2 resident workgroups per CU), 2 otherwise (4-byte values with
 /// 1-byte keys lose 6 points staged)
@@ -65,7 +70,7 @@ template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr boo
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -83,7 +88,7 @@ __device__ __forceinline__ void translate(
 		for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
-	if constexpr (by_wave_chunks<Patches::enabled>()) {
+	if constexpr (by_wave_chunks<Patches::enabled, UncompressedSize, DictionaryIndexSize, RestagedDictionary>()) {
 		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
 	}
 	else {
@@ -99,16 +104,28 @@ __device__ __forceinline__ void decompress(
 	uint64_t                                          length,
 	uint64_t                                          num_dictionary_entries,
 	bool                                              cache_dictionary_in_shared_memory,
-	Patches                                           patches)
+	Patches                                           patches,
+	bool                                              chunk_key_staging_in_dynamic_lds = false)   // (behind the dictionary)
 {
 	using value_type = uint_t<UncompressedSize>;
 	using key_type = uint_t<DictionaryIndexSize>;
 	extern __shared__ __attribute__((aligned(16))) unsigned char dynamic_lds[];
-	// (1-byte keys of 8-byte values in the wave-chunk shape: a chunk's keys come in wide and go through LDS — stream_tiles.hpp)
+	// (narrow keys of 8-byte values in the wave-chunk shape: a chunk's keys come in wide and go through LDS — stream_tiles.hpp)
 	chunk_key_storage<UncompressedSize, DictionaryIndexSize>* chunk_staging = nullptr;
-	if constexpr (by_wave_chunks<Patches::enabled>()) {
-		__shared__ chunk_key_storage<UncompressedSize, DictionaryIndexSize> chunk_staging_storage;
-		chunk_staging = &chunk_staging_storage;
+	if constexpr (Patches::enabled && stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()) {
+		if constexpr (DictionaryIndexSize == 1) {
+			// (a dictionary of at most 256 entries never competes for the LDS: static storage — measured 4 points faster than dynamic)
+			__shared__ chunk_key_storage<UncompressedSize, DictionaryIndexSize> chunk_staging_storage;
+			chunk_staging = &chunk_staging_storage;
+		}
+		else {
+			// (wider keys: only where the launch reserved dynamic LDS for it behind the dictionary — launches of dictionaries staged
+			// once on a persistent grid, or looked up through L2, do not; the wrapper says which)
+			if (chunk_key_staging_in_dynamic_lds) {
+				const uint64_t dictionary_bytes_in_lds = cache_dictionary_in_shared_memory ? (num_dictionary_entries * UncompressedSize + 15) / 16 * 16 : 0;
+				chunk_staging = reinterpret_cast<chunk_key_storage<UncompressedSize, DictionaryIndexSize>*>(dynamic_lds + dictionary_bytes_in_lds);
+			}
+		}
 	}
 
 	// (1-byte keys: at most 256 entries, one per thread of the usual workgroup — no need to hold registers for more)
@@ -135,7 +152,7 @@ __device__ __forceinline__ void decompress(
 			__syncthreads();
 			staged_yet = true;
 		};
-		translate<UncompressedSize, DictionaryIndexSize>(
+		translate<UncompressedSize, DictionaryIndexSize, true>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage);
 	}
 	else if (cache_dictionary_in_shared_memory) {
@@ -183,12 +200,14 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>                length,
 	size_type_by_index_size<DictionaryIndexSize>      num_dictionary_entries,
 	size_type_by_index_size<IndexSize>                num_patches,
-	bool                                              cache_dictionary_in_shared_memory)
+	bool                                              cache_dictionary_in_shared_memory,
+	bool                                              chunk_key_staging_in_dynamic_lds)   // room for detail::chunk_key_storage behind the dictionary
 {
 	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
 	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory,
-		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows),
+		chunk_key_staging_in_dynamic_lds);
 }
 
 } // namespace patched
@@ -197,6 +216,26 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryInde
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
 public:
 	using parent = kernels::launch_config_resolution_params_t;
+
+	bool caches_dictionary = false;
+	size_t staged_dictionary_bytes = 0;
+
+	/// Room behind the dictionary for the wave-chunk shape's staging of narrow keys (stream_tiles::chunk_input_storage) and the
+	/// residency that goes with it — 2 workgroups per CU: 80-83 % of HBM peak, 3 to 5: 70-73 (tools/occupancy_sweep.py).  Not
+	/// for dictionaries staged once on a persistent grid (they keep the LDS) nor for look-ups through L2 (they want the occupancy).  (Asked for by the fused wrapper; the plain kernels, with the
+	/// reference's parameter list, have no way to be told and stage nothing.)
+	void reserve_chunk_key_staging()
+	{
+		if (!detail::stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()) { return; }
+		if (!caches_dictionary || staged_dictionary_bytes > GIDDY_DICT_RESTAGE_UP_TO_BYTES) { return; }
+		if (DictionaryIndexSize > 1) {   // (1-byte keys: the kernel has static storage for it)
+			size_t behind = (staged_dictionary_bytes + 15) / 16 * 16;
+			size_t wanted = behind + sizeof(detail::chunk_key_storage<UncompressedSize, DictionaryIndexSize>);
+			if (wanted > available_dynamic_shared_memory_per_block) { return; }
+			dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) wanted;
+		}
+		resident_blocks_per_multiprocessor_cap = 2u;
+	}
 
 	/// whether a dictionary of this many entries is staged in LDS (unless overridden)
 	bool should_cache_dictionary_in_shared_memory(size_t num_dictionary_entries) const
@@ -213,11 +252,15 @@ public:
 		optional<shared_memory_size_t>  dynamic_shared_mem_limit = nullopt)
 	: parent(device_properties_, kernel_function_attributes_, dynamic_shared_mem_limit)
 	{
-		constexpr bool by_chunks = detail::by_wave_chunks<false>();
-		constexpr unsigned elements_per_thread_per_tile = by_chunks ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
-			: stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		bool cache = cache_dictionary_in_shared_memory_override.value_or(
 			should_cache_dictionary_in_shared_memory(num_dictionary_entries));
+		// (the kernel takes wave chunks where it re-stages the dictionary per workgroup with a few entries per thread: its first branch)
+		constexpr unsigned restaged_entries_per_thread = DictionaryIndexSize == 1 ? 1 : GIDDY_DICT_RESTAGE_ENTRIES_PER_THREAD;
+		const bool restaged = cache && num_dictionary_entries <= (size_t) GIDDY_STREAM_THREADS_PER_BLOCK * restaged_entries_per_thread;
+		const bool by_chunks = detail::by_wave_chunks<false, UncompressedSize, DictionaryIndexSize, false>() ||
+			(restaged && detail::by_wave_chunks<false, UncompressedSize, DictionaryIndexSize, true>());
+		const unsigned elements_per_thread_per_tile = by_chunks ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
+			: stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;
@@ -241,6 +284,8 @@ public:
 			keep_gpu_busy_factor = (unsigned) std::max<size_t>(1, workgroups_per_cu * (threads / warp_size) / 4);
 		}
 		if (cache) { dynamic_shared_memory_requirement.per_block = (shared_memory_size_t) dictionary_bytes; }
+		caches_dictionary = cache;
+		staged_dictionary_bytes = dictionary_bytes;
 		// 1-byte values: 3 resident workgroups per CU are 3-5 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
 		if (UncompressedSize == 1 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 3u; }
 		if (UncompressedSize == 2 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 6u; }   // (+2..4 points)

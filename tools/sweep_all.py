@@ -77,9 +77,9 @@ def patched_ok(expect, out, idx, vals, lo, hi):
     return bool((expect == out[lo:hi]).all())
 
 
-def run_dictionary(I, U, D, n, patched=False):
+def run_dictionary(I, U, D, n, patched=False, entries_n=None):
     g = gen(U * 10 + D)
-    entries_n = min(1 << (8 * D), 4096 if D > 1 else 256)
+    entries_n = entries_n or min(1 << (8 * D), 4096 if D > 1 else 256)
     entries = rand_bits(entries_n, U, g)
     keys = rand_bits(n, D, g, high=entries_n)
     out = torch.empty(n, dtype=INT[U], device=DEV)
