@@ -31,6 +31,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST
 #define GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST 2   // segments shorter than a tile are taken at least this many at a time
 #endif
+#ifndef GIDDY_RUN_STAGE_ALL_VALUES
+#define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
+#endif
 #ifndef GIDDY_RUN_TILE_WORDS_PER_LANE
 #define GIDDY_RUN_TILE_WORDS_PER_LANE 2
 #endif
@@ -87,7 +90,7 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { enabled = ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
+	enum : unsigned { enabled = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
 		allocated = capacity + 16 / ElementSize,   // (the permuting expansions read up to 11 bytes past a lane's first run)
 		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);
 		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)

@@ -231,6 +231,7 @@ def _runs(n, mean_run, g, max_run):
 
 
 def run_rle(I, U, LS, RI, n, L=4096, mean_run=32):
+    mean_run = int(os.environ.get("MEAN_RUN", mean_run))   # (development: tools/occupancy_sweep.py at other run lengths)
     g = gen(U * 10 + LS)
     lengths, starts = _runs(n, mean_run, g, min((1 << (8 * LS)) - 1 if LS < 8 else 1 << 40, 65535))
     count = len(lengths)
