@@ -150,3 +150,24 @@ def compressed_indices_scatter(target, data, run_lengths, offset_sizes, baseline
                 target[(int(baselines[r]) + offs.astype(np.int64))] = data[k:k + ln]
             k += ln
     return target
+
+
+def compressed_indices_positions(num_patches, run_lengths, offset_sizes, baselines, start_pos, offset_bytes,
+                                 anchors, anchoring_period, output_index_size):
+    """positions[k] = where compressed_indices_scatter() puts data[k] (all-ones where it skips a run): the position half of
+    compressed_indices_scatter.cuh:83-124,236-269 — what the fused decoders are handed as plain ascending positions"""
+    positions = np.full(num_patches, np.iinfo("u%d" % output_index_size).max, dtype="u%d" % output_index_size)
+    nblocks = -(-num_patches // anchoring_period)
+    for a in range(nblocks):
+        first = int(anchors[a])
+        last = len(run_lengths) if (a + 1) * anchoring_period >= num_patches else int(anchors[a + 1])
+        k = a * anchoring_period
+        for r in range(first, last):
+            w = int(offset_sizes[r])
+            ln = int(run_lengths[r])
+            if w in (8, 16, 32, 64):
+                begin = int(start_pos[r]) * output_index_size
+                offs = np.frombuffer(bytes(offset_bytes[begin:begin + ln * w // 8]), dtype="<u%d" % (w // 8))
+                positions[k:k + ln] = int(baselines[r]) + offs.astype(np.uint64)
+            k += ln
+    return positions

@@ -244,6 +244,11 @@ def test_compressed_positions_expand_to_the_plain_ones(output_index_size, input_
                                          input_index_size=input_index_size, stream=g.stream())
     got = g.host(out, np.dtype("u%d" % output_index_size), len(positions))
     assert np.array_equal(got, positions.astype(got.dtype))
+    from oracle import naive
+    assert np.array_equal(got, naive.compressed_indices_positions(
+        len(positions), c["scatter_position_run_lengths"], c["scatter_position_run_individual_offset_sizes"],
+        c["scatter_position_run_baseline_values"], c["scatter_position_run_offsets_start_pos"],
+        c["scatter_position_offset_bytes"], c["scatter_position_anchors"], period, output_index_size))
 
 
 @pytest.mark.parametrize("index_size", [4, 8])
@@ -301,3 +306,26 @@ def test_fused_decoder_with_no_compressed_patches_launches_no_expansion():
     schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(empty), compressed, n, seglen, 0,
                           uncompressed_size=4, compressed_size=2, index_size=4, stream=g.stream())
     assert np.array_equal(g.host(out, ud, n), truth)
+
+
+def test_expanded_positions_of_runs_the_scatter_skips_are_all_ones():
+    """a run whose offset width is none of 8/16/32/64 bits is skipped by the scatter (compressed_indices_scatter.cuh:93-118);
+    its patches' positions come out as all-ones, exactly as the oracle's restatement has them"""
+    schemes, r, g = _imports()
+    from libgiddy_amd import formats
+    from oracle import naive
+    rng = cases.rng(77)
+    positions = np.unique(rng.integers(0, 1 << 24, size=5000, dtype=np.uint64))
+    c = formats.compressed_indices(positions, np.zeros(len(positions), np.uint8), 256, max_run_length=7)
+    widths = c["scatter_position_run_individual_offset_sizes"].copy()
+    widths[::5] = 24
+    c["scatter_position_run_individual_offset_sizes"] = widths
+    on_device = {k: (g.dev(v) if isinstance(v, np.ndarray) else v) for k, v in c.items()}
+    out = g.dev_empty(len(positions), np.dtype("u4"))
+    schemes.compressed_indices_positions(out, on_device, len(positions), stream=g.stream())
+    got = g.host(out, np.dtype("u4"), len(positions))
+    expect = naive.compressed_indices_positions(
+        len(positions), c["scatter_position_run_lengths"], widths, c["scatter_position_run_baseline_values"],
+        c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"], c["scatter_position_anchors"], 256, 4)
+    assert np.array_equal(got, expect)
+    assert (got == 0xFFFFFFFF).sum() > 0 and (got != 0xFFFFFFFF).sum() > 0

@@ -204,6 +204,12 @@ def test_scatter_and_compressed_indices(esize, osize, isize):
             c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"],
             c["scatter_position_anchors"], period, osize)
         assert (got2 == expect).all()
+        # ... and the positions alone (what the fused decoders merge from) are the original ascending indices
+        positions = naive.compressed_indices_positions(
+            len(p["indices"]), c["scatter_position_run_lengths"], c["scatter_position_run_individual_offset_sizes"],
+            c["scatter_position_run_baseline_values"], c["scatter_position_run_offsets_start_pos"],
+            c["scatter_position_offset_bytes"], c["scatter_position_anchors"], period, osize)
+        assert (positions == p["indices"]).all()
 
 
 def test_config_c1_frame_of_reference_single_segment_1m():
