@@ -1,0 +1,73 @@
+// Kernel wrapper for Model decompression fused with patching (an extension; the reference runs
+// model.cu and then data_layout/scatter.cu).  Argument-map keys: those of the Model wrapper
+// (src/kernel_wrappers/decompression/model.cu:44-75) plus "patch_values", "patch_positions" (ascending) and
+// "num_patches" — or, in place of "patch_positions", the compressed-indices arrays and a "patch_positions_scratch"
+// (patched/patch_positions.hpp).
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
+#include "giddy/kernels/decompression/model.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace model {
+namespace patched {
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using index_type = uint_t<IndexSize>;
+	using size_type  = size_type_by_index_size<IndexSize>;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+		size_t length, launch_configuration_limits_t limits) const
+	{
+		model::launch_config_resolution_params_t<IndexSize, Uncompressed, UnaryModelFunction> params(
+			device_properties, kernel_function_attributes, length);
+		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
+		params.length = util::div_rounding_up(length, (size_t) stream_tiles::group_size<Uncompressed>::value * GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK);
+		params.resident_blocks_per_multiprocessor_cap = GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP > 0
+			? optional<unsigned>(GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP) : optional<unsigned>(nullopt);
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+launch_configuration_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::resolve_launch_configuration(
+	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+	arguments_type extra_arguments, launch_configuration_limits_t limits) const
+{
+	auto length = argument<size_t>(extra_arguments, "length");
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch(
+	stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
+	auto length             = argument<index_type>(arguments, "length");
+	auto decompressed       = argument<Uncompressed*>(arguments, "decompressed");
+	auto model_coefficients = argument<model_coefficients_type>(arguments, "model_coefficients");
+	auto patch_values       = argument<const Uncompressed*>(arguments, "patch_values");
+	auto num_patches        = argument<index_type>(arguments, "num_patches");
+	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, model_coefficients, patch_values, patch_positions, (size_type) length, (size_type) num_patches);
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+const device_function_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::get_device_function() const
+{
+	return reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction>);
+}
+
+} // namespace patched
+} // namespace model
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

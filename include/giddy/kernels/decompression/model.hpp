@@ -13,6 +13,7 @@
 #include "giddy/functors/model_functors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
@@ -38,6 +39,36 @@ __global__ void decompress(
 		},
 		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); });
 }
+
+namespace patched {
+
+/// Model decompression and patching in one pass: what `model::decompress` followed by
+/// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in `decompressed`,
+/// for ASCENDING patch positions (equal positions: the last one wins) — the usual way a modelled column is stored:
+/// the model plus the elements it misses.
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+__global__ void decompress(
+	Uncompressed* __restrict__                      decompressed,
+	typename UnaryModelFunction::coefficients_type  model_coefficients,
+	const Uncompressed* __restrict__                patch_values,
+	const uint_t<IndexSize>* __restrict__           patch_positions,
+	size_type_by_index_size<IndexSize>              length,
+	size_type_by_index_size<IndexSize>              num_patches)
+{
+	using model_index_type = typename UnaryModelFunction::index_type;
+	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
+	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
+	UnaryModelFunction model(model_coefficients);
+	stream_tiles::generate_and_patch<Uncompressed, GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK>(decompressed, length,
+		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
+		},
+		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); },
+		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length, patch_windows));
+}
+
+} // namespace patched
 
 /// Piecewise models:  out[p] = model_{p / modeling_period}(p % modeling_period)  — one coefficient record per
 /// interval of `modeling_period` elements, the model evaluated at the position WITHIN the interval.  Kernel

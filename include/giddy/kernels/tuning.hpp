@@ -20,3 +20,9 @@
 #ifndef GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO
 #define GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO 2   // fused FOR: chunks whose rows take at most this many input bytes per lane come in through LDS
 #endif
+#ifndef GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP
+#define GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP 3   // fused Model: resident workgroups per CU (0: no throttle)
+#endif
+#ifndef GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK
+#define GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK 32  // fused Model: rows of 1 KiB a wavefront produces per seek (8 / 32 / 128 measured: 71-73 / 74-76 / 68-70 % at the best residency)
+#endif

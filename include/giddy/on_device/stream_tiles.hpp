@@ -238,6 +238,38 @@ __device__ __forceinline__ void transform_and_patch(
 	for (uint64_t p = num_rows * row + global_thread; p < n; p += num_threads) { out[p] = patches.patched(p, produce_one(p, in[p])); }
 }
 
+/// out[p] = produce(p) with patches merged in: the wave-chunk loop of transform_and_patch() for a decoder with no input
+/// array (Model) — a wavefront seeks once per chunk of RowsPerChunk rows and then only produces, patches and stores.
+template <typename Out, unsigned RowsPerChunk, typename ProduceGroup, typename ProduceOne, typename Patches>
+__device__ __forceinline__ void generate_and_patch(Out* __restrict__ out, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches)
+{
+	using namespace memory_access;
+	constexpr unsigned G = group_size<Out>::value;
+	constexpr unsigned rows_per_chunk = RowsPerChunk;
+	constexpr unsigned row = wave64::size * G;
+	const uint64_t num_rows = is_aligned(out, 16) ? n / row : 0;   // whole rows; the rest goes one element at a time
+	const uint64_t num_chunks = (num_rows + rows_per_chunk - 1) / rows_per_chunk;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t first_row = c * rows_per_chunk;
+		const uint64_t end_row = first_row + rows_per_chunk < num_rows ? first_row + rows_per_chunk : num_rows;
+		patches.seek(first_row * row, lane);
+		for (uint64_t r = first_row; r < end_row; r++) {
+			const uint64_t p = r * row + lane * G;
+			group<Out, G> outputs;
+			produce_group(p, outputs);
+			patches.template apply_to_row<G>(r * row, lane, outputs);
+			store_group(out + p, outputs);
+		}
+	}
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	for (uint64_t p = num_rows * row + global_thread; p < n; p += num_threads) { out[p] = patches.patched(p, produce_one(p)); }
+}
+
 /// out[p] = produce(p): the same loop for a decoder with no input array (Model)
 /// ProduceAllFirst: a produce_group that loads from memory (a per-interval record) runs for all K steps of a whole tile
 /// before the tile's first store — a load issued between two stores would wait for the earlier store.

@@ -107,6 +107,35 @@ def test_patched_frame_of_reference(index_size, usize, csize, model, model_index
         assert len(bad) == 0, (how, bad[:5], got[bad[:5]], expect[bad[:5]])
 
 
+MODEL_TUPLES = [(4, 2, "linear"), (4, 4, "linear"), (8, 4, "linear"), (4, 2, "constant"), (4, 4, "constant")]
+
+
+@pytest.mark.parametrize("index_size,usize,model", MODEL_TUPLES)
+@pytest.mark.parametrize("n", [1, 255, 4099, 1000003])
+def test_patched_model(index_size, usize, model, n):
+    schemes, r, g = _imports()
+    ud = np.dtype("i%d" % usize)
+    coefficients = np.array([-12345, 37] if model == "linear" else [-4321], dtype=ud)
+    decoded = oracle.model(coefficients, n, ud, model, model_index_size=index_size)
+    for how in PATCH_SHAPES:
+        positions, values = _patches(n, how, ud, index_size, seed=len(how) + n)
+        expect = _expected(decoded, positions, values)
+        out = g.dev_empty(n, ud)
+        schemes.patched_model(out, coefficients, g.dev(values), g.dev(positions), n, len(positions),
+                              uncompressed_size=usize, model=model, index_size=index_size, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != expect)
+        assert len(bad) == 0, (how, bad[:5], got[bad[:5]], expect[bad[:5]])
+    # ... and with the positions compressed
+    positions, values = _distinct(*_patches(n, "dense", ud, index_size, seed=n))
+    if len(positions):
+        compressed = _compressed(positions, values, 100, index_size, g, 5)
+        out = g.dev_empty(n, ud)
+        schemes.patched_model(out, coefficients, g.dev(values), compressed, n, len(positions),
+                              uncompressed_size=usize, model=model, index_size=index_size, stream=g.stream())
+        assert np.array_equal(g.host(out, ud, n), _expected(decoded, positions, values))
+
+
 DICT_TUPLES = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
 
 

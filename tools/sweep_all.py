@@ -189,15 +189,24 @@ def run_for(I, U, C, model, MI, n, L=4096, patched=False):
     return ms, (U + C) * n + 4 * dim * (n // L) + ((U + I) * len(idx) if patched else 0), ok
 
 
-def run_model(I, U, model, n):
+def run_model(I, U, model, n, patched=False):
     coefs = np.array([-12345, 37] if model == "linear" else [-4321], dtype="i%d" % U)
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    cfg = schemes.model(out, coefs, n, uncompressed_size=U, model=model, index_size=I, stream=st)
-    ms = timeit(lambda: schemes.model(out, coefs, n, uncompressed_size=U, model=model, index_size=I, stream=st, launch_config=cfg))
-    p = torch.arange(n, device=DEV, dtype=torch.int64)
-    expect = (p * 37 - 12345 if model == "linear" else torch.full_like(p, -4321)).to(INT[U])
-    return ms, U * n, bool((expect == out).all())
+    kw = dict(uncompressed_size=U, model=model, index_size=I, stream=st)
+    if patched:
+        idx, pidx, pval = make_patches(n, U, I, U + 40)
+        cfg = schemes.patched_model(out, coefs, pval, pidx, n, len(idx), **kw)
+        ms = timeit(lambda: schemes.patched_model(out, coefs, pval, pidx, n, len(idx), launch_config=cfg, **kw))
+    else:
+        cfg = schemes.model(out, coefs, n, **kw)
+        ms = timeit(lambda: schemes.model(out, coefs, n, launch_config=cfg, **kw))
+    ok = True
+    for lo, hi in chunks(n):
+        p = torch.arange(lo, hi, device=DEV, dtype=torch.int64)
+        expect = (p * 37 - 12345 if model == "linear" else torch.full_like(p, -4321)).to(INT[U])
+        ok = ok and (patched_ok(expect, out, idx, pval, lo, hi) if patched else bool((expect == out[lo:hi]).all()))
+    return ms, U * n + ((U + I) * len(idx) if patched else 0), ok
 
 
 def run_ib(I, U, A, use_dict, n, nb=16):
@@ -304,7 +313,7 @@ def main():
                 res = run_for(int(m.group(1)), ctype[m.group(2)], ctype[m.group(3)], m.group(4), int(m.group(5)), n, patched=patched)
             elif key.startswith("decompression::model"):
                 m = re.match(r".*kernel_t<(\d)u, ([a-z ]+), .*::(constant|linear)<", key)
-                res = run_model(int(m.group(1)), ctype[m.group(2)], m.group(3), n)
+                res = run_model(int(m.group(1)), ctype[m.group(2)], m.group(3), n, patched=patched)
             elif key.startswith("decompression::incidence_bitmaps"):
                 I, U, A = num(key); res = run_ib(I, U, A, key.endswith("true>"), min(n, 1 << 28))
             elif key.startswith("decompression::run_length_encoding"):
