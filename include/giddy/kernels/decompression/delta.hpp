@@ -437,11 +437,22 @@ __device__ __forceinline__ void segmented(
 
 namespace detail {
 
+/// whether an instantiation's wave path brings a chunk's input in through LDS, and the bytes of LDS a wavefront needs for it
+template <unsigned UncompressedSize, unsigned CompressedSize, bool Patched> constexpr bool stages_row_inputs()
+{
+	return row_traits<UncompressedSize, CompressedSize>::E * CompressedSize <= (Patched ? GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO);
+}
+template <unsigned UncompressedSize, unsigned CompressedSize> constexpr unsigned staged_chunk_bytes()
+{
+	return rows_per_chunk * row_traits<UncompressedSize, CompressedSize>::row * CompressedSize;
+}
+
 /// picks the path (wave-uniform decision): see the notes at the top of this file
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>* __restrict__ decompressed, const uint_t<CompressedSize>* __restrict__ compressed_input,
-	const uint_t<UncompressedSize>* __restrict__ anchor_values, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchor_values, uint64_t n, uint64_t L, Patches patches,
+	uint8_t* provided_input_staging = nullptr)   // (the fused kernel's: 4 x staged_chunk_bytes, shared with its patch windows)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	if (n == 0 || L == 0) { return; }
@@ -451,13 +462,17 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	if (vector_access && rows_per_segment <= rows_per_chunk) {
-		// (with patches the cursor's windows already take 12 KiB of LDS per workgroup: only the narrowest rows are staged then)
-		if constexpr (traits::E * CompressedSize <= (Patches::enabled ? GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO)) {
+		if constexpr (stages_row_inputs<UncompressedSize, CompressedSize, Patches::enabled>()) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
-			__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][rows_per_chunk * traits::row * CompressedSize];
-			if (L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
+			uint8_t* staging = provided_input_staging;
+			if constexpr (!Patches::enabled) {
+				__shared__ __attribute__((aligned(16))) uint8_t input_staging[4][staged_chunk_bytes<UncompressedSize, CompressedSize>()];
+				staging = &input_staging[0][0];
+			}
+			if (staging != nullptr && L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
 				wave_per_segment_with_staged_input<UncompressedSize, CompressedSize>(
-					decompressed, compressed_input, anchor_values, n, L, patches, input_staging[wave64::index_in_block()]);
+					decompressed, compressed_input, anchor_values, n, L, patches,
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
 				return;
 			}
 		}
@@ -502,10 +517,21 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>             segment_length,
 	size_type_by_index_size<IndexSize>             num_patches)
 {
-	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
+	// LDS: patch windows for up to 16 wavefronts, and input staging for the 4 of the wave path's workgroups.  The two never meet in
+	// full — staging is for workgroups of at most 4 wavefronts — so the windows of wavefronts 4..15 overlay the staging area.
+	using value_type = uint_t<UncompressedSize>;
+	using more_windows = sorted_patches::window_storage<IndexSize, value_type, 12>;
+	constexpr bool stages = detail::stages_row_inputs<UncompressedSize, CompressedSize, true>();
+	constexpr unsigned staging_bytes = stages ? 4 * detail::staged_chunk_bytes<UncompressedSize, CompressedSize>() : 0;
+	__shared__ sorted_patches::window_storage<IndexSize, value_type, 4> first_windows;
+	__shared__ __attribute__((aligned(16))) uint8_t overlay[staging_bytes > sizeof(more_windows) ? staging_bytes : sizeof(more_windows)];
+	const unsigned w = wave64::index_in_block() % 16;
+	more_windows& later_windows = *reinterpret_cast<more_windows*>(overlay);
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, value_type>(patch_values, patch_positions, num_patches, length,
+			w < 4 ? first_windows.positions[w] : later_windows.positions[w - 4], w < 4 ? first_windows.values[w] : later_windows.values[w - 4]),
+		stages ? overlay : nullptr);
 }
 
 } // namespace patched

@@ -64,9 +64,9 @@ struct none {
 
 /// Wave-private LDS for the cursors of a workgroup's wavefronts: a window of 64 patches each.  Declared __shared__
 /// by the kernel (at most 16 wavefronts = 1024 threads per workgroup).
-template <unsigned PositionSize, typename Value>
+template <unsigned PositionSize, typename Value, unsigned MaxWaves = 16>
 struct window_storage {
-	enum : unsigned { max_waves_per_block = 16 };
+	enum : unsigned { max_waves_per_block = MaxWaves };
 	uint_t<PositionSize> positions[max_waves_per_block][64];
 	Value values[max_waves_per_block][64];
 };
@@ -99,15 +99,19 @@ struct cursor_t {
 
 	/// `length`: the column's length in elements (only used to guess where a position's patches are)
 	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage)
-	: positions(positions_), values(values_), num(num_), position(~(uint64_t) 0)
+	: cursor_t(values_, positions_, num_, length,
+		storage.positions[wave64::index_in_block() % storage_type::max_waves_per_block],
+		storage.values[wave64::index_in_block() % storage_type::max_waves_per_block]) { }
+
+	/// ... with this wavefront's window (64 positions, 64 values of LDS) placed by the caller
+	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length,
+		position_type* window_positions_, Value* window_values_)
+	: positions(positions_), values(values_), num(num_), window_positions(window_positions_), window_values(window_values_), position(~(uint64_t) 0)
 	{
 		patches_per_output = length ? (float) num_ / (float) length : 0.0f;
 		// evenly spread patches deviate from the guess by a few sqrt(num): reach (guess_probes / 2) << shift >= 2 * sqrt(num)
 		const unsigned log_num = 64 - (unsigned) __builtin_clzll(num_ | 1);
 		guess_shift = log_num / 2 > 10 ? log_num / 2 - 2 : 8;
-		const unsigned wave = wave64::index_in_block() % storage_type::max_waves_per_block;
-		window_positions = storage.positions[wave];
-		window_values = storage.values[wave];
 	}
 
 	__device__ __forceinline__ void read_current()
