@@ -1,0 +1,89 @@
+// Kernel wrapper for fixed-width discard-zero-bytes decompression fused with patching (an extension, SURVEY.md §8f.1;
+// the reference runs discard_zero_bytes_fixed.cu and then data_layout/scatter.cu).  Argument-map keys: those of the
+// DZB-fixed wrapper (src/kernel_wrappers/decompression/discard_zero_bytes_fixed.cu:60-97) plus "patch_values",
+// "patch_positions" (ascending) and "num_patches" — or, in place of "patch_positions", the compressed-indices arrays and
+// a "patch_positions_scratch" (patched/patch_positions.hpp).
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
+#include "giddy/kernels/decompression/discard_zero_bytes_fixed.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace decompression {
+namespace discard_zero_bytes {
+namespace fixed_width {
+namespace patched {
+
+using util::endianness_t;
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	endianness_t UncompressedEndianness = util::compilation_target_endianness(),
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+
+	using uncompressed_type = uint_t<UncompressedSize>;
+	using compressed_type   = uint_t<CompressedSize>;
+	using index_type        = uint_t<IndexSize>;
+	using size_type         = size_type_by_index_size<IndexSize>;
+
+	launch_configuration_t resolve_launch_configuration(
+		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+		size_t length, launch_configuration_limits_t limits) const
+	{
+		fixed_width::launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>
+			params(device_properties, kernel_function_attributes, length);
+		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
+		params.length = util::div_rounding_up(length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
+		// resident workgroups per CU, measured per instantiation (tools/occupancy_sweep.py): 8-byte outputs 2 (72 -> 77-81 % of HBM
+		// peak; 1- and 2-byte inputs are staged through LDS), <4,2> and <2,1> 4 (71-74 -> 77), <4,1> unthrottled (80)
+		params.resident_blocks_per_multiprocessor_cap = nullopt;
+		if (UncompressedSize == 8) { params.resident_blocks_per_multiprocessor_cap = 2u; }
+		else if (!(UncompressedSize == 4 && CompressedSize == 1)) { params.resident_blocks_per_multiprocessor_cap = 4u; }
+		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+};
+
+#define GIDDY_DZBFP_TEMPLATE template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, endianness_t UncompressedEndianness, serialization_factor_t SerializationFactor>
+#define GIDDY_DZBFP_KERNEL kernel_t<IndexSize, UncompressedSize, CompressedSize, UncompressedEndianness, SerializationFactor>
+
+GIDDY_DZBFP_TEMPLATE
+launch_configuration_t GIDDY_DZBFP_KERNEL::resolve_launch_configuration(
+	device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
+	arguments_type extra_arguments, launch_configuration_limits_t limits) const
+{
+	auto length = argument<size_t>(extra_arguments, "length");
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
+}
+
+GIDDY_DZBFP_TEMPLATE
+void GIDDY_DZBFP_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
+	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
+	auto patch_values     = argument<const uncompressed_type*>(arguments, "patch_values");
+	auto length           = argument<index_type>(arguments, "length");
+	auto num_patches      = argument<index_type>(arguments, "num_patches");
+	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		decompressed, compressed_input, patch_values, patch_positions, (size_type) length, (size_type) num_patches);
+}
+
+GIDDY_DZBFP_TEMPLATE
+const device_function_t GIDDY_DZBFP_KERNEL::get_device_function() const
+{
+	return reinterpret_cast<const void*>(
+		patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
+}
+
+#undef GIDDY_DZBFP_TEMPLATE
+#undef GIDDY_DZBFP_KERNEL
+
+} // namespace patched
+} // namespace fixed_width
+} // namespace discard_zero_bytes
+} // namespace decompression
+} // namespace kernels
+} // namespace cuda

@@ -11,6 +11,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
@@ -51,6 +52,49 @@ __global__ void decompress(
 		},
 		[&](uint64_t, C x) { return widen(x); });
 }
+
+namespace patched {
+
+/// rows of an 8-byte column take 2 or 4 input bytes per lane: a chunk's input comes in with 16-byte loads through LDS then
+/// (stream_tiles::chunk_input_storage; as the fused Dictionary's narrow keys)
+template <unsigned UncompressedSize> constexpr unsigned stage_input_up_to() { return UncompressedSize == 8 ? 4 : 2; }
+template <unsigned UncompressedSize, unsigned CompressedSize> constexpr bool stages_chunk_input()
+{
+	return stream_tiles::stages_chunk_input<uint_t<CompressedSize>, uint_t<UncompressedSize>, stage_input_up_to<UncompressedSize>()>();
+}
+
+/// Fixed-width discard-zero-bytes decompression and patching in one pass: what
+/// `fixed_width::decompress` followed by `data_layout::scatter::scatter(decompressed, patch_values, patch_positions,
+/// num_patches)` leaves in `decompressed`, for ASCENDING patch positions (equal positions: the last one wins) — narrow
+/// storage for the elements that fit, patches for the few that do not.
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+__global__ void decompress(
+	uint_t<UncompressedSize>*        __restrict__  decompressed,
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*  __restrict__  patch_values,
+	const uint_t<IndexSize>*         __restrict__  patch_positions,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             num_patches)
+{
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	constexpr unsigned G = stream_tiles::group_size<U>::value;
+	__shared__ sorted_patches::window_storage<IndexSize, U> patch_windows;
+	__shared__ stream_tiles::chunk_input_storage<C, U, stages_chunk_input<UncompressedSize, CompressedSize>()> chunk_staging;
+	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
+	stream_tiles::transform_and_patch<C, U, stream_tiles::rows_in_flight, stage_input_up_to<UncompressedSize>()>(decompressed, compressed_input, length,
+		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
+		},
+		[&](uint64_t, C x) { return widen(x); },
+		sorted_patches::cursor_t<IndexSize, U>(patch_values, patch_positions, num_patches, length, patch_windows),
+		stream_tiles::nothing_to_do(), &chunk_staging);
+}
+
+} // namespace patched
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
 	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,

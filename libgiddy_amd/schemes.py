@@ -57,7 +57,7 @@ def key_delta(index_size, uncompressed_size, compressed_size):
 
 
 def key_patched(key):
-    """the fused decompress-and-patch variant of a Delta / Dictionary / Frame-of-Reference / Model key (an extension)"""
+    """the fused decompress-and-patch variant of a Delta / Dictionary / Frame-of-Reference / Model / DZB-fixed key (an extension)"""
     assert "::kernel_t<" in key and "::patched::" not in key
     return key.replace("::kernel_t<", "::patched::kernel_t<", 1)
 
@@ -202,6 +202,17 @@ def patched_model(decompressed, model_coefficients, patch_values, patch_position
               "length": r.uint_t(index_size)(length)}
     launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "i%d" % (8 * uncompressed_size), index_size))
     return _run(key_patched(key_model(index_size, uncompressed_size, model)), {"length": r.size_t(length)}, launch,
+                stream, device, limits, launch_config)
+
+
+def patched_discard_zero_bytes_fixed(decompressed, compressed_input, patch_values, patch_positions, length, num_patches, *,
+                                     uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """discard_zero_bytes_fixed() followed by scatter(decompressed, patch_values, patch_positions, num_patches), in one kernel"""
+    launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
+              "length": r.uint_t(index_size)(length)}
+    launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "u%d" % (8 * uncompressed_size), index_size))
+    return _run(key_patched(key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size)), {"length": r.size_t(length)}, launch,
                 stream, device, limits, launch_config)
 
 

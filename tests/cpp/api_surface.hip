@@ -128,7 +128,7 @@ int main()
 			 entry.first.find("::positions::") != std::string::npos ? position_expansions : reference_registrations)++;
 		}
 		CHECK(reference_registrations == 163);
-		CHECK(fused_patch_extensions == 12 + 20 + 8 + 5);
+		CHECK(fused_patch_extensions == 12 + 20 + 8 + 5 + 12);
 		CHECK(position_expansions == 8);
 		const char* key = "decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
 		CHECK(factory.canProduce(key));

@@ -31,8 +31,9 @@ def test_factory_has_the_163_reference_registrations():
     extensions = [k for k in all_keys if "::patched::" in k]
     assert sorted(extensions) == sorted(schemes.key_patched(k) for k in all_keys
                                         if k.startswith(("decompression::delta::kernel_t", "decompression::dictionary::kernel_t",
-                                                         "decompression::frame_of_reference::kernel_t", "decompression::model::kernel_t")))
-    assert len(extensions) == 12 + 20 + 8 + 5
+                                                         "decompression::frame_of_reference::kernel_t", "decompression::model::kernel_t",
+                                                         "decompression::discard_zero_bytes::fixed_width::kernel_t")))
+    assert len(extensions) == 12 + 20 + 8 + 5 + 12
     # ... and so is the stand-alone expansion of compressed patch positions the fused wrappers use
     expansions = [k for k in all_keys if "::positions::" in k]
     assert sorted(expansions) == sorted(schemes.key_compressed_indices_positions(o, i) for o in (4, 8) for i in (1, 2, 4, 8))

@@ -136,6 +136,42 @@ def test_patched_model(index_size, usize, model, n):
         assert np.array_equal(g.host(out, ud, n), _expected(decoded, positions, values))
 
 
+DZB_FIXED_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]
+
+
+@pytest.mark.parametrize("usize,csize", DZB_FIXED_TUPLES)
+@pytest.mark.parametrize("index_size", [4, 8])
+def test_patched_discard_zero_bytes_fixed(usize, csize, index_size):
+    schemes, r, g = _imports()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    for n in (1, 255, 4099, 70001, 1000003):
+        narrow = cases.rng(n + usize).integers(0, np.iinfo(cd).max, size=n, endpoint=True).astype(cd)
+        decoded = narrow.astype(ud)
+        d_in = g.dev(narrow)
+        for how in PATCH_SHAPES:
+            positions, values = _patches(n, how, ud, index_size, seed=len(how) + n)
+            expect = _expected(decoded, positions, values)
+            out = g.dev_empty(n, ud)
+            schemes.patched_discard_zero_bytes_fixed(out, d_in, g.dev(values), g.dev(positions), n, len(positions),
+                                                     uncompressed_size=usize, compressed_size=csize, index_size=index_size, stream=g.stream())
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != expect)
+            assert len(bad) == 0, (n, how, bad[:5], got[bad[:5]], expect[bad[:5]])
+        # ... with the positions compressed, and from a displaced (unaligned) input
+        positions, values = _distinct(*_patches(n, "sparse", ud, index_size, seed=n))
+        if len(positions):
+            compressed = _compressed(positions, values, 100, index_size, g, 5)
+            out = g.dev_empty(n, ud)
+            schemes.patched_discard_zero_bytes_fixed(out, d_in, g.dev(values), compressed, n, len(positions),
+                                                     uncompressed_size=usize, compressed_size=csize, index_size=index_size, stream=g.stream())
+            assert np.array_equal(g.host(out, ud, n), _expected(decoded, positions, values))
+            padded = g.dev(np.concatenate([np.zeros(1, cd), narrow]))
+            out = g.dev_empty(n, ud)
+            schemes.patched_discard_zero_bytes_fixed(out, padded.data_ptr() + csize, g.dev(values), g.dev(positions), n, len(positions),
+                                                     uncompressed_size=usize, compressed_size=csize, index_size=index_size, stream=g.stream())
+            assert np.array_equal(g.host(out, ud, n), _expected(decoded, positions, values))
+
+
 DICT_TUPLES = [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4), (8, 8)]
 
 

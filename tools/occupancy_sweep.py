@@ -50,6 +50,8 @@ for U, D in ((4, 1), (8, 1), (2, 1)):
     CASES.append(("patched_dictionary<%d,%d>" % (U, D), lambda U=U, D=D: sw.run_dictionary(4, U, D, n, patched=True)))
 for U, C, model in ((4, 2, "constant"), (4, 1, "linear")):
     CASES.append(("patched_for<%d,%d,%s>" % (U, C, model), lambda U=U, C=C, model=model: sw.run_for(4, U, C, model, 4, n, patched=True)))
+for U, C in ((8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1)):
+    CASES.append(("patched_dzb_fixed<%d,%d>" % (U, C), lambda U=U, C=C: sw.run_dzb_fixed(4, U, C, n, patched=True)))
 for U in (2, 4):
     CASES.append(("patched_model<%d,linear>" % U, lambda U=U: sw.run_model(4, U, "linear", n, patched=True)))
 for U, C in ((8, 1), (8, 2), (8, 4), (4, 1), (4, 2), (2, 1)):

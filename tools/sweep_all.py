@@ -121,12 +121,19 @@ def run_delta(I, U, C, n, L=4096, patched=False):
     return ms, (U + C) * n + U * (n // L) + ((U + I) * len(idx) if patched else 0), ok
 
 
-def run_dzb_fixed(I, U, C, n):
+def run_dzb_fixed(I, U, C, n, patched=False):
     c = rand_bits(n, C, gen(U + C))
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
-    cfg = schemes.discard_zero_bytes_fixed(out, c, n, uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
-    ms = timeit(lambda: schemes.discard_zero_bytes_fixed(out, c, n, uncompressed_size=U, compressed_size=C, index_size=I, stream=st, launch_config=cfg))
+    kw = dict(uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
+    if patched:
+        idx, pidx, pval = make_patches(n, U, I, U + C + 50)
+        cfg = schemes.patched_discard_zero_bytes_fixed(out, c, pval, pidx, n, len(idx), **kw)
+        ms = timeit(lambda: schemes.patched_discard_zero_bytes_fixed(out, c, pval, pidx, n, len(idx), launch_config=cfg, **kw))
+        ok = all(patched_ok(unsigned(c[lo:hi], C).to(INT[U]), out, idx, pval, lo, hi) for lo, hi in chunks(n))
+        return ms, (U + C) * n + (U + I) * len(idx), ok
+    cfg = schemes.discard_zero_bytes_fixed(out, c, n, **kw)
+    ms = timeit(lambda: schemes.discard_zero_bytes_fixed(out, c, n, launch_config=cfg, **kw))
     ok = bool((unsigned(c, C).to(INT[U]) == out).all())
     return ms, (U + C) * n, ok
 
@@ -305,7 +312,7 @@ def main():
             elif key.startswith("decompression::delta"):
                 I, U, C = num(key); res = run_delta(I, U, C, n, patched=patched)
             elif "fixed_width" in key:
-                I, U, C = num(key)[:3]; res = run_dzb_fixed(I, U, C, n)
+                I, U, C = num(key)[:3]; res = run_dzb_fixed(I, U, C, n, patched=patched)
             elif "variable_width" in key:
                 I, U, CS = num(key); res = run_dzb_variable(I, U, CS, min(n, 1 << 28))
             elif key.startswith("decompression::frame_of_reference"):
