@@ -71,6 +71,12 @@ def test_expansion_of_compressed_positions_resolves_without_a_device_query():
         k.resolve_launch_configuration(N, {"input_data_length": r.size_t(10), "anchoring_period": r.size_t(0)})
 
 
+def test_the_build_entry_point_accepts_the_library_as_built():
+    """what __graft_entry__.build() asserts after compiling (kept in step with the registrations)"""
+    import __graft_entry__
+    __graft_entry__.check_library()
+
+
 def test_unknown_key_is_invalid_argument():
     with pytest.raises(r.InvalidArgument, match="No subclass of the base type cuda::registered::kernel_t is registered with key"):
         r.kernel_t.produceSubclass("decompression::nope::kernel_t<4u>")
