@@ -71,6 +71,8 @@ def make_workload(name, n, device):
         "discard_zero_bytes_variable_3bit": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device, bits=3),
         "discard_zero_bytes_fixed": lambda: w.DiscardZeroBytesFixed(n, device),
         "model": lambda: w.Model(n, device),
+        "model_fused_patches": lambda: w.ModelFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
+        "discard_zero_bytes_fixed_fused_patches": lambda: w.DiscardZeroBytesFixedFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, 1 << 28), device),
     }
     work = table[name]()
@@ -281,7 +283,7 @@ def main():
         if args.schemes == "coverage":
             names += ["discard_zero_bytes_variable_3bit", "discard_zero_bytes_fixed", "model", "incidence_bitmaps",
                       "delta_fused_patches", "dictionary_fused_patches", "frame_of_reference_fused_patches",
-                      "delta_compressed_patches", "delta_fused_compressed_patches"]
+                      "delta_compressed_patches", "delta_fused_compressed_patches", "model_fused_patches", "discard_zero_bytes_fixed_fused_patches"]
         elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
         del work

@@ -14,7 +14,7 @@ if [ -z "${ONLY_PMC:-}" ]; then
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 fi
 # 2. PMC passes (separate runs); WORKLOADS="a b" overrides the list
-WORKLOADS=${WORKLOADS:-dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable discard_zero_bytes_variable_3bit discard_zero_bytes_fixed model incidence_bitmaps delta_fused_patches dictionary_fused_patches frame_of_reference_fused_patches delta_fused_compressed_patches}
+WORKLOADS=${WORKLOADS:-dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable discard_zero_bytes_variable_3bit discard_zero_bytes_fixed model incidence_bitmaps delta_fused_patches dictionary_fused_patches frame_of_reference_fused_patches delta_fused_compressed_patches model_fused_patches discard_zero_bytes_fixed_fused_patches}
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter -d $OUT/pmc_$counter/calibrate -o cal --output-format csv -- /tmp/pmc_calibrate > $OUT/cal_$counter.log 2>&1
   for w in $WORKLOADS; do

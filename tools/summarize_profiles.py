@@ -29,6 +29,8 @@ KERNELS = {  # workload -> (substring of the kernel name, algorithmic bytes per 
     "dictionary_fused_patches": "dictionary::patched::decompress",
     "frame_of_reference_fused_patches": "frame_of_reference::patched::decompress",
     "delta_fused_compressed_patches": "delta::patched::decompress",
+    "model_fused_patches": "model::patched::decompress",
+    "discard_zero_bytes_fixed_fused_patches": "fixed_width::patched::decompress",
 }
 
 

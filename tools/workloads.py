@@ -597,6 +597,70 @@ class Model:
         return (lambda: oracle.model(self.coefs, sample, np.int32, "linear", threads=threads)), 4 * sample
 
 
+def _ascending_patches(n, fraction, value_dtype, high, device, seed):
+    p = max(1, int(round(n * fraction)))
+    idx = torch.sort(torch.randperm(n, generator=_gen(seed, device), device=device)[:p])[0]
+    val = torch.randint(0, high, (p,), dtype=value_dtype, generator=_gen(seed + 1, device), device=device)
+    return p, idx, val
+
+
+class ModelFused(Model):
+    """Model int32 plus 0.1 % ascending patches merged inside the kernel — how a modelled column is stored"""
+    name = "model::patched<4,int,linear>"
+    kernel = "model::patched::decompress"
+
+    def __init__(self, n, device, seed=10, patch_fraction=0.001):
+        super().__init__(n, device, seed=seed)
+        self.p, self.patch_idx64, self.patch_val = _ascending_patches(n, patch_fraction, torch.int32, 1 << 31, device, seed + 5)
+        self.patch_idx = self.patch_idx64.to(torch.int32)
+        self.algorithmic_bytes += 8 * self.p
+        self.config = schemes.patched_model(self.output, self.coefs, self.patch_val, self.patch_idx, n, self.p,
+                                            stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_model(self.output, self.coefs, self.patch_val, self.patch_idx, self.n, self.p, stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        s = min(sample, self.n)
+        expect = oracle.model(self.coefs, s, np.int32, "linear")
+        inside = _np(self.patch_idx64[self.patch_idx64 < s], np.int64)
+        expect[inside] = _np(self.patch_val[: len(inside)])
+        assert (expect == _np(self.output[:s])).all(), "fused model: sample mismatch vs oracle + scatter"
+        full = (torch.arange(self.n, device=self.output.device, dtype=torch.int64) * 37 - 12345).to(torch.int32)
+        full[self.patch_idx64] = self.patch_val
+        assert bool((self.output == full).all())
+
+
+class DiscardZeroBytesFixedFused(DiscardZeroBytesFixed):
+    """DZB-fixed uint64 <- uint16 plus 0.1 % ascending patches (the elements that do not fit two bytes) merged inside the kernel"""
+    name = "discard_zero_bytes::fixed_width::patched<4,8,2>"
+    kernel = "fixed_width::patched::decompress"
+
+    def __init__(self, n, device, seed=9, patch_fraction=0.001):
+        super().__init__(n, device, seed=seed)
+        self.p, self.patch_idx64, self.patch_val = _ascending_patches(n, patch_fraction, torch.int64, 1 << 62, device, seed + 5)
+        self.patch_idx = self.patch_idx64.to(torch.int32)
+        self.algorithmic_bytes += 12 * self.p
+        self.config = schemes.patched_discard_zero_bytes_fixed(self.output, self.comp, self.patch_val, self.patch_idx, n, self.p,
+                                                               stream=torch.cuda.current_stream().cuda_stream)
+
+    def run(self, stream):
+        schemes.patched_discard_zero_bytes_fixed(self.output, self.comp, self.patch_val, self.patch_idx, self.n, self.p,
+                                                 stream=stream, launch_config=self.config)
+
+    def verify(self, oracle, sample=1 << 22):
+        torch.cuda.synchronize()
+        s = min(sample, self.n)
+        expect = oracle.dzb_fixed(_np(self.comp[:s], np.uint16), np.uint64)
+        inside = _np(self.patch_idx64[self.patch_idx64 < s], np.int64)
+        expect[inside] = _np(self.patch_val[: len(inside)], np.uint64)
+        assert (expect == _np(self.output[:s], np.uint64)).all(), "fused DZB-fixed: sample mismatch vs oracle + scatter"
+        full = self.comp.to(torch.int64) & 0xFFFF
+        full[self.patch_idx64] = self.patch_val
+        assert bool((self.output == full).all())
+
+
 class IncidenceBitmaps:
     """Incidence bitmaps, 16 distinct uint32 values (coverage sweep)."""
     name = "incidence_bitmaps<4,4,2,true>"
