@@ -394,3 +394,31 @@ def test_expanded_positions_of_runs_the_scatter_skips_are_all_ones():
         c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"], c["scatter_position_anchors"], 256, 4)
     assert np.array_equal(got, expect)
     assert (got == 0xFFFFFFFF).sum() > 0 and (got != 0xFFFFFFFF).sum() > 0
+
+
+def test_fused_decoder_with_compressed_positions_is_graph_capturable():
+    """the expansion of the positions and the decoder are two plain launches on the caller's stream: captured into a HIP
+    graph and replayed they give the same bits (no hidden synchronisation or allocation)"""
+    schemes, r, g = _imports()
+    n, L = 1 << 20, 4096
+    ud = np.dtype("u8")
+    f, truth = cases.delta_case(n, L, ud, np.uint16, seed=321)
+    positions, values = _distinct(*_patches(n, "sparse", ud, 4, seed=9))
+    expect = _expected(truth, positions, values)
+    compressed = _compressed(positions, values, 256, 4, g)
+    d_in, d_anchor, d_val = g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values)
+    out = g.dev_empty(n, ud)
+    side = torch.cuda.Stream()
+    kw = dict(uncompressed_size=8, compressed_size=2, index_size=4)
+    with torch.cuda.stream(side):
+        cfg = schemes.patched_delta(out, d_in, d_anchor, d_val, compressed, n, L, len(positions), stream=side.cuda_stream, **kw)   # resolve outside the capture
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        schemes.patched_delta(out, d_in, d_anchor, d_val, compressed, n, L, len(positions),
+                              stream=torch.cuda.current_stream().cuda_stream, launch_config=cfg, **kw)
+    out.fill_(0xCD)
+    compressed["patch_positions_scratch"].fill_(0)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(g.host(out, ud, n), expect)
