@@ -66,7 +66,14 @@ inline void enqueue_launch(
 	const launch_configuration_t& launch_config, KernelParameters... parameters)
 {
 	if (launch_config.grid_dimensions.volume() == 0) { return; } // empty input: nothing to do
-	void* argument_pointers[] = { const_cast<void*>(reinterpret_cast<const void*>(&parameters))..., nullptr };
+	// The runtime reads one pointer per KERNEL parameter.  A caller may pass fewer values than the kernel has
+	// parameters — the reference's own mode-B example gives frame_of_reference::decompress five of its six
+	// (examples/src/modes_of_use/instantiation_of_wrapper.cu:31-38) — so spare slots follow the given ones, each
+	// pointing at zeroes: the missing trailing parameters read as 0 / nullptr instead of whatever lies past the array.
+	alignas(16) static const unsigned char zeroes[64] = { };
+	void* const spare = const_cast<void*>(static_cast<const void*>(zeroes));
+	void* argument_pointers[] = { const_cast<void*>(reinterpret_cast<const void*>(&parameters))...,
+		spare, spare, spare, spare, spare, spare, spare, spare };
 	throw_if_error(
 		hipLaunchKernel(reinterpret_cast<const void*>(kernel_function),
 			launch_config.grid_dimensions, launch_config.block_dimensions,

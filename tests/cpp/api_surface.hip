@@ -156,6 +156,42 @@ int main()
 		CHECK_THROWS(pd->enqueue_launch(0, cd, { { "length", length } }), std::out_of_range);
 	}
 
+	// ---- cuda::any: what the reference's callers store, what the wrappers cast to ---------------------------------
+	{
+		int target[4] = { 1, 2, 3, 4 };
+		int*       __restrict__ restricted = target;
+		const int* __restrict__ restricted_to_const = target;
+		int* const constant_pointer = target;
+		const size_t constant_size = 7;
+		any a = restricted, b = restricted_to_const, c = constant_pointer, d = constant_size;
+		CHECK(any_cast<int*>(a) == target && a.type() == typeid(int*));          // top-level __restrict__ is dropped on the way in
+		CHECK(any_cast<const int*>(b) == target);
+		CHECK(any_cast<int*>(c) == target);                                      // as are const and volatile
+		CHECK(any_cast<size_t>(d) == 7 && any_cast<const size_t&>(d) == 7);
+		CHECK_THROWS(any_cast<const int*>(a), cuda::bad_any_cast);               // but pointee qualifiers are part of the type
+		CHECK_THROWS(any_cast<int*>(b), cuda::bad_any_cast);
+		CHECK_THROWS(any_cast<unsigned>(d), std::bad_any_cast);                  // (catchable as the standard exception too)
+		CHECK_THROWS(any_cast<int>(any()), cuda::bad_any_cast);
+		CHECK(any().empty() && !any().has_value() && any().type() == typeid(void) && d.has_value());
+		any e = std::string("a value too big for the in-place buffer, so it lives on the heap .............");
+		any f = e;                                                               // deep copy
+		any g = std::move(e);
+		CHECK(e.empty() && any_cast<std::string>(f) == any_cast<std::string>(g) && any_cast<std::string>(f).size() > 32);
+		f = 5u; CHECK(any_cast<unsigned>(f) == 5u);
+		f = d;  CHECK(any_cast<size_t>(f) == 7);
+		f.swap(g); CHECK(any_cast<size_t>(g) == 7 && any_cast<std::string>(f).size() > 32);
+		g.clear(); CHECK(g.empty());
+		CHECK(any_cast<int>(&d) == nullptr && *any_cast<size_t>(&d) == 7);
+		cuda::array<int, 1> record { { 42 } };
+		any h = record; CHECK((any_cast<cuda::array<int, 1>>(h)[0] == 42));
+		optional<any> none; CHECK(!any_cast<int>(none));
+		// an argument map written the way factory_provided_type_erased_wrapper.cu:33-39 writes it
+		size_t length = 16;
+		kernel_t::arguments_type arguments = { { "decompressed", restricted }, { "compressed_input", restricted_to_const }, { "length", length } };
+		CHECK(argument<int*>(arguments, "decompressed") == target && argument<const int*>(arguments, "compressed_input") == target);
+		CHECK(!optional_argument<size_t>(arguments, "segment_length") && *optional_argument<size_t>(arguments, "length") == 16);
+	}
+
 	std::printf(failures == 0 ? "api_surface OK\n" : "api_surface: %d failure(s)\n", failures);
 	return failures == 0 ? EXIT_SUCCESS : EXIT_FAILURE;
 }

@@ -22,3 +22,24 @@ def test_mode_of_use(program):
     result = subprocess.run([path], capture_output=True, text=True, timeout=120)
     assert result.returncode == 0, result.stdout + result.stderr
     assert "OK" in result.stdout
+
+
+REFERENCE_MODES = ["factory_provided_type_erased_wrapper", "instantiation_of_wrapper", "direct_use_of_kernel"]
+
+
+@pytest.mark.parametrize("mode", REFERENCE_MODES)
+def test_reference_caller_runs(mode):
+    """examples/bin/reference_<mode>: the reference's OWN caller for this mode (its source compiled unchanged from the
+    reference tree by examples/Makefile where that tree exists; the binary travels with the snapshot) decoding its
+    known-answer column through this library and checking it in its own main() (examples/src/modes_of_use/common.cuh:91-102)."""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    path = os.path.join(ROOT, "examples", "bin", "reference_" + mode)
+    if not os.path.exists(path):
+        if not os.path.exists("/root/reference/examples/src/modes_of_use"):
+            pytest.skip("neither the prebuilt program nor the reference tree is here")
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    result = subprocess.run([path], capture_output=True, text=True, timeout=120)
+    assert result.returncode == 0, result.stdout + result.stderr
+    assert "Unexpected value" not in result.stderr
