@@ -23,9 +23,17 @@
 //   4. each element is cut out of LDS with aligned 32-bit reads + v_alignbyte and masked to n_i bytes through
 //      a 9-entry mask table kept in LDS;
 //   5. one 16-byte store per lane, contiguous across the wavefront.
-// Rows are processed four at a time and software-pipelined two groups deep (see the kernel body), so
-// HBM round trips overlap instead of adding up.  No __syncthreads; wavefronts are independent.  HBM bytes per element: mean n_i + field bits/8 +
-// UncompressedSize + anchor/segment_length  (10.76 B for 1..4-byte sizes into 64 bits, config C5).
+// Rows are processed two at a time and software-pipelined two groups deep (see the kernel body), so
+// HBM round trips overlap instead of adding up.  No __syncthreads; wavefronts are independent.
+//
+// The WIDE path (detail::decompress_wide; 1-, 2- and 4-bit fields, 4- and 8-byte elements, segments of at least 8
+// rows): a lane takes a whole 32-bit word of size fields, so ONE prefix sum covers up to 1024 elements, the
+// segment's whole byte range is staged with two to five loads, and a row costs two ds_bpermute and a SWAR prefix
+// instead of a size-word load, a scan and a chunk-address computation.  C5 (2^28 x u64, 2-bit fields): 67-72 -> 74-77 %
+// of the HBM peak across boxes.
+//
+// HBM bytes per element: mean n_i + field bits/8 + UncompressedSize + anchor/segment_length
+// (10.76 B for 1..4-byte sizes into 64 bits, config C5).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -45,6 +53,28 @@ using element_size_t = native_word_t;
 // build-time tuning knob (default measured on MI355X)
 #ifndef GIDDY_DZBV_ROWS_IN_FLIGHT
 #define GIDDY_DZBV_ROWS_IN_FLIGHT 2
+#endif
+
+// the wide path (see detail::decompress_wide): 1 = on where it applies
+#ifndef GIDDY_DZBV_WIDE
+#define GIDDY_DZBV_WIDE 1
+#endif
+// 1 KiB pieces of a super-row's bytes requested before the first is written to LDS (measured: 2 >= 3 > 4, which costs a wavefront of occupancy)
+#ifndef GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT
+#define GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT 2
+#endif
+// wavefronts per SIMD the register allocator must leave room for; 0 = its own choice (65-67 vector registers, 7 wavefronts:
+// measured 1-3 points FASTER than forcing 64 registers, which turns scalar spills into extra vector work)
+#ifndef GIDDY_DZBV_WAVES_PER_SIMD
+#define GIDDY_DZBV_WAVES_PER_SIMD 0
+#endif
+#if GIDDY_DZBV_WAVES_PER_SIMD > 0
+#define GIDDY_DZBV_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GIDDY_DZBV_WAVES_PER_SIMD)))
+#else
+#define GIDDY_DZBV_OCCUPANCY
+#endif
+#ifndef GIDDY_DZBV_SGPRS
+#define GIDDY_DZBV_SGPRS 94
 #endif
 
 namespace detail {
@@ -119,10 +149,10 @@ struct segment_cursor {
 	uint32_t next_segment_in_chunk;
 	uint32_t rows_left_in_segment;
 
-	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t num_segments,
+	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t segment_length, uint64_t length,
 		unsigned segments_per_chunk, unsigned lane)
 	{
-		const bool have = lane < segments_per_chunk && segment + lane < num_segments;
+		const bool have = lane < segments_per_chunk && (segment + lane) * segment_length < length;
 		const uint64_t mine = have ? (uint64_t) position_anchors[segment + lane] : 0;
 		first_anchor = wave64::read_first_lane(mine);
 		later_anchors = (uint32_t) (mine - first_anchor);   // (a chunk is at most rows_per_chunk rows: kilobytes)
@@ -146,8 +176,14 @@ struct segment_cursor {
 __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, unsigned row)
 {
 	if (segment_length % row != 0) { return 1; }
-	uint64_t rows_per_segment = segment_length / row;
-	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / rows_per_segment;
+	const uint64_t rows_per_segment = segment_length / row;
+	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / (unsigned) rows_per_segment;   // (no 64-bit division: a wavefront's prologue is short)
+}
+
+/// wave-uniform a / b without the ~100-instruction 64-bit division when both fit 32 bits
+__device__ __forceinline__ uint64_t divide(uint64_t a, unsigned b)
+{
+	return (a >> 32) == 0 ? (uint64_t) ((uint32_t) a / b) : a / b;
 }
 
 /// Everything the fast path knows about a group of R full rows
@@ -194,7 +230,7 @@ struct row_group {
 			const unsigned last = num_chunks[k] == 0 ? 0 : num_chunks[k] - 1;
 			const unsigned mine = lane < last ? lane : (last < 64 ? last : 63);
 			const uintptr_t base = num_chunks[k] == 0 ? (reinterpret_cast<uintptr_t>(any_valid_address) & ~(uintptr_t) 15) : first_chunk[k];
-			chunks[k] = *reinterpret_cast<const chunk_t*>(base + 16 * (uintptr_t) mine);
+			chunks[k] = memory_access::load_global<chunk_t>(base + 16 * (uintptr_t) mine);
 		}
 	}
 	__device__ __forceinline__ void stage_into(uint32_t* stage, unsigned lane) const
@@ -204,7 +240,7 @@ struct row_group {
 			chunk_t* row_stage = reinterpret_cast<chunk_t*>(stage + k * staging_words);
 			row_stage[lane] = chunks[k];   // lanes past the last chunk write bytes nobody reads
 			if (num_chunks[k] > 64) {      // a 1024-byte row that starts unaligned: one more chunk (rare)
-				if (lane == 0) { row_stage[64] = *reinterpret_cast<const chunk_t*>(first_chunk[k] + 16 * (uintptr_t) 64); }
+				if (lane == 0) { row_stage[64] = memory_access::load_global<chunk_t>(first_chunk[k] + 16 * (uintptr_t) 64); }
 			}
 		}
 		wave64::lds_fence();
@@ -300,8 +336,8 @@ __device__ __forceinline__ uint64_t decompress_rows(
 		const unsigned head = (unsigned) (address - first_chunk);
 		const unsigned num_chunks = row_bytes[k] == 0 ? 0 : (head + row_bytes[k] + 15) / 16;   // <= 65
 		chunk_t* row_stage = reinterpret_cast<chunk_t*>(stage + k * staging_words);
-		if (lane < num_chunks) { row_stage[lane] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) lane); }
-		if (num_chunks > 64 && lane == 0) { row_stage[64] = *reinterpret_cast<const chunk_t*>(first_chunk + 16 * (uintptr_t) 64); }
+		if (lane < num_chunks) { row_stage[lane] = memory_access::load_global<chunk_t>(first_chunk + 16 * (uintptr_t) lane); }
+		if (num_chunks > 64 && lane == 0) { row_stage[64] = memory_access::load_global<chunk_t>(first_chunk + 16 * (uintptr_t) 64); }
 		offset[k] += head;
 		bytes_start += row_bytes[k];
 	}
@@ -336,6 +372,164 @@ __device__ __forceinline__ uint64_t decompress_rows(
 
 namespace detail {
 
+/// The WIDE path: the byte offsets of up to 64 size WORDS' worth of elements from ONE wave scan.
+///
+/// A lane takes a whole 32-bit word of size fields (2-bit fields, the documented typical case —
+/// discard_zero_bytes_variable.cuh:344-347 — 16 elements), so that a wavefront covers a "super-row" of up to
+/// 64 * per elements (all of a 1024-element segment) per step:
+///   1. lane l: word w0 + l; its byte count = per * min + the sum of its fields, all fields at once (SWAR: two masks,
+///      two shifts, a multiply);  ONE 64-lane DPP prefix sum of those (the row-wise path scans once per 64 * E elements);
+///   2. the super-row's output rows (64 lanes x E consecutive elements, one 16-byte store per lane, as everywhere): a
+///      lane fetches the word and the start of the lane that owns its elements (two ds_bpermute), adds the fields below
+///      its own (SWAR again) — and has offsets and sizes without a scan, a division or a size-word load per row;
+///   3. the super-row's compressed bytes — ONE contiguous range of at most 4 KiB, known from the scan's total — are staged
+///      with at most five coalesced 16-byte-per-lane loads (the row-wise path: one load, with its address arithmetic, per
+///      row) while the next super-row's size words are already in flight; elements are cut out of LDS as on the row-wise path.
+/// A segment may begin inside a word (field f0 of word w0, f0 a multiple of E): lane 0's fields below f0 are masked out.
+/// 64-bit containers of 1-, 2- or 4-bit fields are pairs of such words.  Needs: bits in {1, 2, 3, 4}; (32 / bits) % E == 0;
+/// 16-byte aligned rows (the caller checks).
+enum : unsigned {
+	wide_staging_bytes = 4096,                                   // of a super-row's compressed bytes (rows per step are limited to what fits)
+	wide_staging_words = (wide_staging_bytes + 16 + 16) / 4,     // + head misalignment + over-read slack for the aligned dword reads
+};
+
+template <unsigned Bits> __device__ __forceinline__ unsigned sum_of_fields(uint32_t x);
+template <> __device__ __forceinline__ unsigned sum_of_fields<1>(uint32_t x) { return __builtin_popcount(x); }
+template <> __device__ __forceinline__ unsigned sum_of_fields<2>(uint32_t x)
+{
+	x = (x & 0x33333333u) + ((x >> 2) & 0x33333333u);      // 8 nibbles, each <= 6
+	x = (x + (x >> 4)) & 0x0f0f0f0fu;                      // 4 bytes, each <= 12
+	return (x * 0x01010101u) >> 24;
+}
+template <> __device__ __forceinline__ unsigned sum_of_fields<4>(uint32_t x)
+{
+	x = (x & 0x0f0f0f0fu) + ((x >> 4) & 0x0f0f0f0fu);      // 4 bytes, each <= 30
+	return (x * 0x01010101u) >> 24;
+}
+
+__host__ __device__ inline bool wide_path_applies(unsigned bits, unsigned container_size, unsigned E)
+{
+	// (3-bit fields: two steps per 1024-element segment, no faster than the row-wise path; 2-byte elements, E = 8: 6 points slower)
+	if (!GIDDY_DZBV_WIDE || bits < 1 || bits > 4 || bits == 3 || E > 4) { return false; }
+	return (32 / bits) % E == 0;
+}
+
+/// `num_rows` full rows of one segment starting at element `pos`, byte `bytes_start` (both advanced).
+template <unsigned Bits, unsigned UncompressedSize>
+__device__ __forceinline__ void decompress_wide(
+	uint_t<UncompressedSize>* __restrict__ decompressed, const uint8_t* __restrict__ compressed_data,
+	const uint32_t* __restrict__ size_words, uint32_t* stage, unsigned lane, uint64_t& pos, unsigned num_rows, uint64_t& bytes_start,
+	unsigned min_size, const size_masks& masks)
+{
+	using namespace memory_access;
+	using U = uint_t<UncompressedSize>;
+	using chunk_t = typename chunk<16>::type;
+	constexpr unsigned E = 16 / UncompressedSize, row = 64 * E, per = 32 / Bits, field_mask = (1u << Bits) - 1;
+	constexpr unsigned rows_of_64_words = (64 * per) / row;
+	static_assert(per % E == 0 && rows_of_64_words >= 1, "a lane's E size fields share a word");
+
+	// rows per step: what 64 words hold, and what the staging area holds of the largest elements these fields can state
+	const unsigned largest = min_size + field_mask < UncompressedSize ? min_size + field_mask : UncompressedSize;
+	const unsigned rows_staged = largest == 0 ? rows_of_64_words : wide_staging_bytes / (row * largest);
+	const unsigned max_rows = rows_staged < rows_of_64_words ? rows_staged : rows_of_64_words;   // >= 4: a row is at most 1 KiB
+
+	uint64_t word_base = pos / per;
+	unsigned field_base = (unsigned) (pos - word_base * per);
+	auto rows_of_step = [&](unsigned first_field, unsigned rows_left) {
+		const unsigned available = (64 * per - first_field) / row, limit = available < max_rows ? available : max_rows;
+		return rows_left < limit ? rows_left : limit;
+	};
+	auto load_words = [&](uint64_t first_word, unsigned first_field, unsigned rows) {
+		const unsigned used = (first_field + rows * row + per - 1) / per;   // words holding those fields (<= 64)
+		return lane < used ? size_words[first_word + lane] : 0u;
+	};
+	unsigned R = rows_of_step(field_base, num_rows);
+	uint32_t word = load_words(word_base, field_base, R);
+
+	while (num_rows > 0) {
+		// ---- this super-row: R rows = fields [field_base, end_field) of words word_base ...; the next one's words are requested now ----
+		const unsigned end_field = field_base + R * row;
+		const uint64_t next_word_base = word_base + end_field / per;
+		const unsigned next_field_base = end_field % per, next_R = rows_of_step(next_field_base, num_rows - R);
+		uint32_t next_word = 0;
+		if (next_R > 0) { next_word = load_words(next_word_base, next_field_base, next_R); }
+
+		if (lane == 0) { word &= ~((1u << (field_base * Bits)) - 1u); }   // the segment's first field may be inside the word
+		const unsigned lane_bytes = (per - (lane == 0 ? field_base : 0u)) * min_size + sum_of_fields<Bits>(word);
+		const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
+		// where the lane's word WOULD begin if all of its fields counted: a field's offset = this + field * min + the fields below it
+		const unsigned start = inclusive - lane_bytes - (lane == 0 ? field_base * min_size : 0u);
+		// the super-row's bytes: up to the offset of field `end_field` (scalar arithmetic on two lanes' values)
+		const unsigned last_owner = end_field / per < 63 ? end_field / per : 63, past_field = end_field - last_owner * per;
+		const uint32_t last_word = wave64::read_lane(word, last_owner);
+		const unsigned super_row_bytes = wave64::read_lane(start, last_owner) + past_field * min_size
+			+ sum_of_fields<Bits>(past_field * Bits >= 32 ? last_word : last_word & ((1u << (past_field * Bits)) - 1u));
+
+		// ---- stage the byte range: exactly the 16-byte chunks that overlap it (nothing is read past the buffer's last chunk) ----
+		const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
+		const uintptr_t first_chunk = address & ~(uintptr_t) 15;
+		const unsigned head = (unsigned) (address - first_chunk);
+		const unsigned num_chunks = super_row_bytes == 0 ? 0 : (head + super_row_bytes + 15) / 16;   // <= wide_staging_bytes / 16 + 1
+		chunk_t* const staged = reinterpret_cast<chunk_t*>(stage);
+		constexpr unsigned pieces = wide_staging_bytes / 1024, ahead = GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT < pieces ? GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT : pieces;
+		chunk_t in_flight[ahead];
+		const unsigned last_chunk = num_chunks == 0 ? 0 : num_chunks - 1;
+		auto request = [&](unsigned piece) {   // (lanes past the end repeat the last chunk)
+			if (piece * 64 < num_chunks) {
+				const unsigned mine = piece * 64 + lane;
+				in_flight[piece % ahead] = load_global<chunk_t>(first_chunk + 16 * (uintptr_t) (mine < last_chunk ? mine : last_chunk));
+			}
+		};
+		#pragma unroll
+		for (unsigned piece = 0; piece < ahead; piece++) { request(piece); }   // requests first ...
+		#pragma unroll
+		for (unsigned piece = 0; piece < pieces; piece++) {                    // ... then into LDS as they arrive
+			if (piece * 64 < num_chunks) {
+				const unsigned mine = piece * 64 + lane;
+				staged[mine < last_chunk ? mine : last_chunk] = in_flight[piece % ahead];
+			}
+			if (piece + ahead < pieces) { request(piece + ahead); }
+		}
+		if (num_chunks > pieces * 64 && lane == 0) {   // a full staging area's worth that starts unaligned: one more chunk (rare)
+			staged[pieces * 64] = load_global<chunk_t>(first_chunk + 16 * (uintptr_t) (pieces * 64));
+		}
+		wave64::lds_fence();
+
+		// ---- rows: offsets and sizes from the owner's word and start; elements cut out of the staged range ----
+		U* out = decompressed + pos + (uint64_t) lane * E;
+		for (unsigned k = 0; k < R; k++) {
+			const unsigned g = field_base + k * row + lane * E, owner = g / per, field = g - owner * per;
+			const uint32_t owners_word = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) word);
+			const unsigned owners_start = (unsigned) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) start);
+			const unsigned shift = field * Bits;
+			unsigned at = head + owners_start + field * min_size + sum_of_fields<Bits>(owners_word & ((1u << shift) - 1u));
+			const uint32_t fields = owners_word >> shift;
+			group<U, E> values;
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				unsigned size = min_size + ((fields >> (j * Bits)) & field_mask);
+				if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+				const uint32_t* words = stage + (at >> 2);
+				values[j] = (U) cut<UncompressedSize>(words[0], words[1], UncompressedSize == 8 ? words[2] : 0u, at & 3, size, masks);
+				at += size;
+			}
+			store_group(out, values);
+			out += row;
+		}
+		wave64::lds_fence();   // the staging area is rewritten by the next step
+
+		// ---- on to the next super-row ----
+		pos += (uint64_t) R * row;
+		num_rows -= R;
+		bytes_start += super_row_bytes;
+		word_base = next_word_base; field_base = next_field_base; R = next_R; word = next_word;
+	}
+}
+
+} // namespace detail
+
+namespace detail {
+
 /// The fast path: `num_groups` groups of R full rows starting at element `rows_start` (advanced), software-pipelined
 /// two deep so that a wavefront never waits for two HBM round trips in a row (CDNA4 retires vector-memory operations
 /// in order — loads queue behind earlier stores): while group g is cut out of LDS and stored, group g+1's bytes and
@@ -356,7 +550,7 @@ __device__ __forceinline__ void decompress_full_groups(
 	group_t current, next;
 	container_type after_next[R];
 	// wave-uniform position of the next group's first size field
-	uint64_t container_base = rows_start / per;
+	uint64_t container_base = divide(rows_start, per);
 	unsigned field_base = (unsigned) (rows_start - container_base * per);
 	auto fetch_fields = [&](container_type (&fields)[R]) {
 		load_size_fields<UncompressedSize, ElementSizesContainerSize>(fields, packed_element_sizes, lane, container_base, field_base, bits, per, per_reciprocal);
@@ -391,7 +585,7 @@ __device__ __forceinline__ void decompress_full_groups(
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 // (scalar registers are capped so that eight wavefronts fit a SIMD: measured 3-5 % over what the allocator takes unasked)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) decompress(
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress(
 	uint_t<UncompressedSize>*  __restrict__  decompressed,
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>*
@@ -408,7 +602,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 	constexpr unsigned row = 64 * E;
 	constexpr unsigned R = detail::rows_in_flight;
 	using container_type = uint_t<ElementSizesContainerSize>;
-	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][R * detail::staging_words];
+	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][GIDDY_DZBV_WIDE && detail::wide_staging_words > R * detail::staging_words ? (unsigned) detail::wide_staging_words : R * detail::staging_words];
 
 	__shared__ detail::size_masks masks;
 	detail::fill(masks);
@@ -424,21 +618,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 	if (L == 0 || bits_per_element_size == 0) { return; }
 	const unsigned bits = bits_per_element_size;
 	const unsigned per = (8 * ElementSizesContainerSize) / bits;
-	const unsigned per_reciprocal = per == 1 ? 0u : (unsigned) ((((uint64_t) 1 << 32) + per - 1) / per);
+	const unsigned per_reciprocal = per == 1 ? 0u : 0xffffffffu / per + 1;   // ceil(2^32 / per)
 	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
 	const bool aligned_output = memory_access::is_aligned(decompressed, 16) && (L % E == 0);
 
 	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, row);
 	const uint64_t chunk_length = segments_per_chunk * L;
-	const uint64_t num_segments = (n + L - 1) / L;
-	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
 	const uint64_t group_elements = (uint64_t) R * row;
 
 	// (segments that are not whole rows are taken one per trip: their full groups of rows go the fast way, the tail the slow way)
 	const bool fast_path = packed && aligned_output;
+	const bool wide_path = fast_path && detail::wide_path_applies(bits, ElementSizesContainerSize, E) && segments_per_chunk == 1 && L < ((uint64_t) 1 << 31) * row;
 
-	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+	for (uint64_t c = wave; ; c += num_waves) {
 		const uint64_t chunk_start = c * chunk_length;
+		if (chunk_start >= n) { break; }
 		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
 		const uint64_t num_groups = fast_path ? (chunk_end - chunk_start) / group_elements : 0;
 		uint64_t rows_start = chunk_start;
@@ -448,6 +642,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 			// one anchored segment: full groups of rows on the fast path, then whatever is left — ragged tails,
 			// unaligned outputs, segment lengths that are not whole rows, size fields straddling containers
 			cursor.bytes_start = wave64::read_first_lane((uint64_t) position_anchors[c]);
+			if constexpr (E <= 4) if (wide_path) {
+				const uint32_t* size_words = reinterpret_cast<const uint32_t*>(packed_element_sizes);
+				const unsigned full_rows = (unsigned) ((chunk_end - chunk_start) / row);
+				auto wide = [&](auto field_bits) {
+					detail::decompress_wide<decltype(field_bits)::value, UncompressedSize>(decompressed, compressed_data, size_words, stage, lane,
+						rows_start, full_rows, cursor.bytes_start, min_represented_element_size, masks);
+				};
+				if (bits == 2) { wide(std::integral_constant<unsigned, 2>()); }
+				else if (bits == 4) { wide(std::integral_constant<unsigned, 4>()); }
+				else if (bits == 1) { wide(std::integral_constant<unsigned, 1>()); }
+			}
+			if (!wide_path)
 			detail::decompress_full_groups<false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, 0,
 				min_represented_element_size, bits, per, per_reciprocal, masks);
@@ -460,7 +666,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(94))) deco
 		else {
 			// a batch of short segments, each a whole number of rows: the groups of rows span segments
 			const uint32_t rows_per_segment = (uint32_t) (L / row);
-			cursor.start_at(position_anchors, c * segments_per_chunk, num_segments, (unsigned) segments_per_chunk, lane);
+			cursor.start_at(position_anchors, c * segments_per_chunk, L, n, (unsigned) segments_per_chunk, lane);
 			detail::decompress_full_groups<true, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, rows_per_segment,
 				min_represented_element_size, bits, per, per_reciprocal, masks);

@@ -225,6 +225,15 @@ __device__ __forceinline__ void store_group(T* __restrict__ p, const group<T, N>
 	}
 }
 
+/// a load from GLOBAL memory at an address held as an integer.  Dereferencing a pointer made from an integer is a
+/// FLAT load to the compiler — it counts against the LDS counter as well as the vector-memory one, so every wait for
+/// an LDS read becomes a wait for all loads in flight; naming the address space keeps the two apart.
+template <typename T>
+__device__ __forceinline__ T load_global(uintptr_t address)
+{
+	return *reinterpret_cast<const T __attribute__((address_space(1)))*>(address);
+}
+
 template <typename P>
 __device__ __forceinline__ bool is_aligned(const P* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
 
