@@ -10,7 +10,9 @@ dictionary, 2^30 elements on one MI355X.  `value` = decompressed GB/s of the who
 output bytes / max-over-ranks time), inputs resident in HBM when the timed region starts.  For N > 1
 (launched by torch.distributed.run, one rank per GPU) every rank decodes its own 2^30-element shard —
 columns shard by independent anchored segment ranges, there is no data-path collective — so scaling
-is "weak".
+is "weak".  BASELINE.json configs[3]/[4] (ONE RLE column of 2^30 / ONE DZB-variable column of 2^31 elements cut over the GPUs)
+are measured as stated — strong scaling, shards cut on the device by libgiddy_amd.sharding — under `sharded` at every N, and as the
+headline line with --scaling strong --workload NAME.
 
 The JSON line also carries
   roofline      algorithmic HBM bytes of one launch / that kernel's mean duration (HIP events on
@@ -48,12 +50,19 @@ def parse():
                    "point-to-point gather of every rank's decoded shard into one contiguous buffer on rank 0 (reported separately, never part of `value`)")
     p.add_argument("--gather-log2n", type=int, default=28, help="elements of each rank's decoded shard that are gathered")
     p.add_argument("--cpu-sample-log2", type=int, default=27)
+    p.add_argument("--scaling", choices=("weak", "strong"), default="weak", help="strong: the headline line is ONE column of 2^log2n elements "
+                   "(same seed on every rank) cut into rank shards on the device by libgiddy_amd.sharding — BASELINE.json configs[3]/[4] as stated; "
+                   "use with --workload run_length_encoding | run_position_encoding_relative | run_position_encoding_absolute | discard_zero_bytes_variable")
+    p.add_argument("--sharded", default="default", help="extra strong-scaling measurements appended to the line under `sharded` (every N, so that the "
+                   "driver's N = 1, 2, 4, 8 runs give the curve): default = run_length_encoding at 2^30 and discard_zero_bytes_variable at 2^31 elements "
+                   "(with the gather into rank 0) | none | comma list of workload[:log2n]")
     return p.parse_args()
 
 
-def make_workload(name, n, device):
+def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28):
+    """`cap`: elements of the workloads whose single-GPU BASELINE shape is a 2^28-element shard (DZB-variable, incidence bitmaps)"""
     import workloads as w
-    w.SEED_OFFSET = 1000 * int(os.environ.get("RANK", "0"))
+    w.SEED_OFFSET = 1000 * int(os.environ.get("RANK", "0")) if per_rank_seed else 0
     table = {
         "dictionary": lambda: w.Dictionary(n, device),
         "dictionary_zipf": lambda: w.Dictionary(n, device, zipf=True),
@@ -67,13 +76,13 @@ def make_workload(name, n, device):
         "run_length_encoding": lambda: w.RunLength(n, device),
         "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
         "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),
-        "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device),
-        "discard_zero_bytes_variable_3bit": lambda: w.DiscardZeroBytesVariable(min(n, 1 << 28), device, bits=3),
+        "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, cap), device),
+        "discard_zero_bytes_variable_3bit": lambda: w.DiscardZeroBytesVariable(min(n, cap), device, bits=3),
         "discard_zero_bytes_fixed": lambda: w.DiscardZeroBytesFixed(n, device),
         "model": lambda: w.Model(n, device),
         "model_fused_patches": lambda: w.ModelFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "discard_zero_bytes_fixed_fused_patches": lambda: w.DiscardZeroBytesFixedFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
-        "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, 1 << 28), device),
+        "incidence_bitmaps": lambda: w.IncidenceBitmaps(min(n, cap), device),
     }
     work = table[name]()
     work.workload_name = name
@@ -178,32 +187,100 @@ def cpu_baseline(work, sample, unit_bytes_label="decompressed GB/s"):
             "single_thread_value": round(results[1], 3), "cpu": cpu_model()}
 
 
-def time_gather(work, count, rank, world, device, barrier, repetitions=3):
-    """The single optional collective: every rank's first `count` decoded elements gathered into one
-    contiguous buffer on rank 0 by point-to-point RCCL transfers — each shard crosses one xGMI link once."""
+def time_gather(local, counts, rank, world, device, barrier, repetitions=3, expected=None):
+    """The single optional collective: rank r's decoded shard `local` (counts[r] elements) gathered into one
+    contiguous buffer on rank 0 by point-to-point RCCL transfers — each shard crosses one xGMI link once.  `expected`: on rank 0,
+    what the contiguous buffer must hold (strong scaling: the whole decoded column)."""
     import torch
     import torch.distributed as dist
     from libgiddy_amd.distributed import gather_decoded
-    local = work.output.view(-1)[:count]
-    out = torch.empty(world * count, dtype=local.dtype, device=device) if rank == 0 else None
+    total = sum(int(c) for c in counts)
+    out = torch.empty(total, dtype=local.dtype, device=device) if rank == 0 else None
     best = float("inf")
     synchronize = torch.cuda.synchronize if local.is_cuda else (lambda: None)   # (CPU tensors: the gloo test of this function)
     for repetition in range(repetitions + 1):   # the first one sets the connections up
         barrier(); synchronize()
         t0 = time.perf_counter()
-        gather_decoded(local, [count] * world, dst=0, out=out)
+        gather_decoded(local, counts, dst=0, out=out)
         synchronize(); barrier()
         elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
         if repetition > 0:
             best = min(best, float(elapsed[0]))
-    ok = True
+    report = {}
     if rank == 0:
-        ok = bool((out[:count] == local).all())   # own shard in place; the others' contents are theirs (different seeds)
-    inbound = (world - 1) * count * local.element_size()
-    return {"bytes_per_rank": count * local.element_size(), "ms": round(best * 1e3, 3), "inbound_GBps_at_root": round(inbound / best / 1e9, 1),
-            "links": world - 1, "own_shard_in_place": ok,
-            "note": "point-to-point receives from every peer (one xGMI link each, about 153 GB/s per link); not part of `value`"}
+        report["own_shard_in_place"] = bool((out[: int(counts[0])] == local).all())
+        if expected is not None:
+            report["gathered_equals_the_column"] = bool((out == expected.reshape(-1)).all())
+    inbound = (total - int(counts[0])) * local.element_size()
+    report.update({"bytes_per_rank": [int(c) * local.element_size() for c in counts] if len(set(int(c) for c in counts)) > 1 else int(counts[0]) * local.element_size(),
+                   "ms": round(best * 1e3, 3), "inbound_GBps_at_root": round(inbound / best / 1e9, 1), "links": world - 1,
+                   "note": "point-to-point receives from every peer (one xGMI link each, about 153 GB/s per link); not part of `value`"})
+    return report
+
+
+def all_reduce_u64_sum(value, world, device, backend):
+    """sum of 64-bit checksums over the ranks, wrapping — carried as 16-bit limbs so that no backend's integer addition can overflow"""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return value & ((1 << 64) - 1)
+    limbs = torch.tensor([(value >> (16 * i)) & 0xFFFF for i in range(4)], dtype=torch.int64, device=device if backend == "nccl" else "cpu")
+    dist.all_reduce(limbs, op=dist.ReduceOp.SUM)
+    return sum(int(limbs[i]) << (16 * i) for i in range(4)) & ((1 << 64) - 1)
+
+
+def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier, oracle, gather=False):
+    """BASELINE.json configs[3]/[4] as stated: ONE column of 2^log2n elements — the same seed on every rank — cut into `world`
+    segment-range shards ON THE DEVICE (libgiddy_amd.sharding: views of the big arrays, anchors rebased by a device subtraction), rank r
+    decodes shard r; no collective on the data path.  Checked: the shards' position-weighted checksums sum to the whole column's (decoded
+    by every rank by itself first), and rank 0 verifies the whole column against the oracle / the full-size identities."""
+    import torch
+    import torch.distributed as dist
+    import workloads as w
+    w.SEED_OFFSET = 0
+    stream = torch.cuda.current_stream().cuda_stream
+    whole = make_workload(name, 1 << log2n, device, per_rank_seed=False, cap=1 << log2n)
+    whole.run(stream)
+    if rank == 0:
+        whole.verify(oracle)
+    torch.cuda.synchronize()
+    column_checksum = w.checksum(whole.output)
+    whole.output.zero_()
+    shard = w.Sharded(whole, rank, world)
+    shard.run(stream)
+    torch.cuda.synchronize()
+    shards_checksum = all_reduce_u64_sum(w.checksum(shard.output, first_index=shard.start), world, device, backend)
+    assert shards_checksum == column_checksum, "%s: the shards' checksums (%x) do not sum to the column's (%x)" % (name, shards_checksum, column_checksum)
+    steps, warmup = args.steps, args.warmup
+    elapsed, launch_ms = timed_steps(shard, steps, warmup, barrier)
+    times = torch.tensor([elapsed if r == rank else 0.0 for r in range(world)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.SUM)
+    slowest = float(times.max())
+    counts = [0] * world
+    if world > 1:
+        dist.all_gather_object(counts, shard.n)
+    else:
+        counts = [shard.n]
+    entry = {"workload": name, "instantiation": whole.name, "elements_total": whole.n, "scaling": "strong",
+             "sharding": "libgiddy_amd.sharding on device tensors: %d segment-range shards of one column, rebased anchors, no collective" % world,
+             "decompressed_GBps": round(whole.decompressed_bytes * steps / slowest / 1e9, 1), "ms_per_step": round(slowest / steps * 1e3, 4),
+             "per_rank_ms_per_step": [round(float(t) / steps * 1e3, 4) for t in times], "per_rank_elements": [int(c) for c in counts],
+             "world_size_seen_by_the_process_group": dist.get_world_size() if world > 1 else 1,
+             "checksum": "%016x" % column_checksum, "shards_checksum_equals_column_checksum": True,
+             "this_rank_roofline": roofline(shard, launch_ms, None)}
+    if gather and world > 1:
+        expected = getattr(whole, "values", None) if rank == 0 else None   # (DZB-V keeps the column it compressed)
+        if backend == "nccl":
+            entry["gather"] = time_gather(shard.output, counts, rank, world, device, barrier, expected=expected)
+        else:   # (the one-GPU rehearsal: gloo moves host tensors)
+            entry["gather"] = time_gather(shard.output.cpu(), counts, rank, world, torch.device("cpu"), barrier, repetitions=1,
+                                          expected=expected.cpu() if expected is not None else None)
+            entry["gather"]["note"] = "REHEARSAL over gloo through host copies: checks the flow, says nothing about xGMI"
+    del shard, whole
+    torch.cuda.empty_cache()
+    return entry
 
 
 def main():
@@ -241,6 +318,23 @@ def main():
     from oracle import oracle
     n = 1 << args.log2n
 
+    if args.scaling == "strong":
+        # ---- one column cut over the ranks: BASELINE.json configs[3] / configs[4] as stated ------------
+        entry = strong_scaling_leg(args.workload, args.log2n, args, rank, world, device, backend, barrier, oracle, gather=args.gather)
+        line = {
+            "metric": "decompressed GB/s (whole job), %s, ONE column of 2^%d elements cut into %d segment-range shards" % (entry["instantiation"], args.log2n, world),
+            "value": entry["decompressed_GBps"], "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": entry["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64" if "variable" in args.workload else "u32", "data": "synthetic",
+            "config": {"workload": args.workload, "instantiation": entry["instantiation"], "elements_total": entry["elements_total"], "sharding": entry["sharding"]},
+            "roofline": entry.pop("this_rank_roofline"), "sharded": {args.workload: entry},
+        }
+        if rank == 0:
+            print(json.dumps(line))
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
     # ---- the headline workload ------------------------------------------------------------------
     work = make_workload(args.workload, n, device)
     work.run(torch.cuda.current_stream().cuda_stream)
@@ -267,7 +361,8 @@ def main():
     }
 
     if args.gather and world > 1:
-        line["gather"] = time_gather(work, min(n, 1 << args.gather_log2n), rank, world, device, barrier)
+        count = min(n, 1 << args.gather_log2n)
+        line["gather"] = time_gather(work.output.view(-1)[:count], [count] * world, rank, world, device, barrier)
 
     if rank == 0 and world == 1:
         ceiling = measured_copy_ceiling()
@@ -305,6 +400,19 @@ def main():
             del w
             torch.cuda.empty_cache()
         line["schemes"] = schemes_out
+
+    # ---- BASELINE.json configs[3] / configs[4] as stated: one column cut over the ranks (strong scaling), at every N ----
+    if args.sharded != "none":
+        wanted = [("run_length_encoding", 30, False), ("discard_zero_bytes_variable", 31, True)] if args.sharded == "default" else \
+                 [(item.split(":")[0], int(item.split(":")[1]) if ":" in item else args.log2n, args.gather) for item in args.sharded.split(",") if item]
+        if "work" in dir():
+            del work
+        torch.cuda.empty_cache()
+        line["sharded"] = {}
+        for name, log2_total, with_gather in wanted:
+            entry = strong_scaling_leg(name, min(log2_total, args.log2n + 1), args, rank, world, device, backend, barrier, oracle, gather=with_gather)
+            entry["roofline_rank0"] = entry.pop("this_rank_roofline")
+            line["sharded"][name] = entry
 
     if rank == 0:
         print(json.dumps(line))

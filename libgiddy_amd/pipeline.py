@@ -9,7 +9,7 @@ The kernels are the ones the device-resident path uses (libgiddy_amd.schemes); t
 buffers, streams, events and async copies only.
 
 Host fields: the dictionary a libgiddy_amd.formats writer returns, with the LARGE arrays replaced by
-pinned torch tensors (`pin(fields)` does that) so that their slices copy asynchronously; small arrays
+pinned torch tensors (`pin(fields)` does that, by name) so that their slices copy asynchronously; small arrays
 (anchors, dictionaries, model records) stay numpy and are rebased per chunk.
 """
 import numpy as np
@@ -17,14 +17,18 @@ import torch
 
 from . import schemes, sharding
 
-_LARGE = 1 << 16   # bytes from which a host array is worth pinning
+# the bulk arrays of the formats (everything else — anchors, dictionaries, model records — is small, is rebased per
+# chunk on the host and stays numpy)
+BULK_ARRAYS = ("compressed_input", "compressed_data", "packed_element_sizes", "run_data", "run_lengths", "run_start_positions")
 
 
 def pin(fields):
-    """numpy arrays of at least 64 KiB -> pinned torch tensors (same bits); everything else unchanged"""
+    """the bulk arrays of a column (BULK_ARRAYS) -> pinned torch tensors holding the same bits, so that their slices copy
+    asynchronously; everything else unchanged.  (Anchor arrays are NOT pinned whatever their size: a chunk's anchors are
+    rebased on the host.)"""
     out = {}
     for name, value in fields.items():
-        if isinstance(value, np.ndarray) and value.nbytes >= _LARGE:
+        if name in BULK_ARRAYS and isinstance(value, np.ndarray):
             out[name] = torch.from_numpy(np.ascontiguousarray(value)).pin_memory()
         else:
             out[name] = value
@@ -97,7 +101,9 @@ def _as_bytes(value):
 
 def decode_from_host(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **instantiation):
     """Decompress `host_fields` (see the module docstring) into the device tensor `out_dev`, `num_chunks` chunks of
-    whole segments pipelined over `depth` streams.  Returns the streams used; the caller synchronises them.
+    whole segments pipelined over `depth` streams.  Returns the streams used.  The side streams first wait for whatever
+    the caller's current stream has queued (an earlier kernel or fill on `out_dev`); the CALLER synchronises the returned
+    streams before reading `out_dev` and before reusing or freeing the host fields (the copies are asynchronous).
     `instantiation`: what the field dtypes do not say (model=..., num_dictionary_entries=..., relative=...)."""
     shard, launch = _SCHEMES[scheme]
     arrays = [k for k, v in host_fields.items() if isinstance(v, (torch.Tensor, np.ndarray))]
@@ -106,6 +112,8 @@ def decode_from_host(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **
         kw.setdefault("num_dictionary_entries", len(host_fields["dictionary_entries"]))
     flat_out = out_dev.view(-1)
     streams = [torch.cuda.Stream(device=out_dev.device) for _ in range(depth)]
+    for stream in streams:
+        stream.wait_stream(torch.cuda.current_stream(out_dev.device))   # work already queued on out_dev comes first
     staging = [dict() for _ in range(depth)]   # per slot: field name -> device byte buffer, grown on demand
     decoded = [None] * depth
     for chunk in range(num_chunks):
@@ -135,10 +143,13 @@ def decode_from_host(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **
 def dictionary_from_host(keys_host, entries_dev, out_dev, *, uncompressed_size=4, dictionary_index_size=1,
                          chunk_elements=1 << 26, depth=3):
     """The Dictionary special case with the dictionary already on the device: keys_host is a pinned CPU tensor of
-    keys.  Returns the streams used (the caller synchronises)."""
+    keys.  Returns the streams used; they wait for the caller's current stream first (the dictionary upload, earlier work
+    on `out_dev`), and the caller synchronises them before reading `out_dev` or reusing `keys_host`."""
     n = keys_host.numel()
     num_entries = entries_dev.numel()
-    streams = [torch.cuda.Stream() for _ in range(depth)]
+    streams = [torch.cuda.Stream(device=out_dev.device) for _ in range(depth)]
+    for stream in streams:
+        stream.wait_stream(torch.cuda.current_stream(out_dev.device))
     staging = [torch.empty(min(chunk_elements, n), dtype=keys_host.dtype, device=out_dev.device) for _ in range(depth)]
     ready = [None] * depth
     for i, lo in enumerate(range(0, n, chunk_elements)):

@@ -15,13 +15,45 @@ decodes output elements [start_g, end_g), a whole number of segments, from:
 There is NO exchange step during decode; the only collective is the optional gather of the decoded
 shards into one contiguous buffer (libgiddy_amd.distributed.gather_decoded).
 
-Everything here is host-side index arithmetic on numpy arrays (or anything sliceable): it returns
-`Shard(fields, start, stop)` where `fields` has the same keys as libgiddy_amd.formats' writers.
+Everything here is index arithmetic; the arrays may be numpy arrays, host (pinned) torch tensors or DEVICE
+torch tensors, in any mix: the big arrays of a shard are slices — views, nothing is copied — and the only
+new arrays are the rebased anchor slices (one small subtraction, done where the anchors live: a column that
+is resident on a GPU is cut without a host round trip; reading the two boundary anchors costs two scalar
+device-to-host copies).  Integer tensors stand for the unsigned bits they hold (torch has little unsigned
+arithmetic): subtraction wraps the same way.  Returns `Shard(fields, start, stop)`; `fields` has the keys of
+libgiddy_amd.formats' writers.
 """
 import math
 from collections import namedtuple
 
 import numpy as np
+
+
+def _is_tensor(a):
+    return type(a).__module__.partition(".")[0] == "torch"
+
+
+def _itemsize(a):
+    return a.element_size() if _is_tensor(a) else a.dtype.itemsize
+
+
+def _unsigned_at(a, i):
+    """a[i] as a Python int, the element's bits read as unsigned"""
+    if _is_tensor(a):
+        return int(a[i].item()) & ((1 << (8 * a.element_size())) - 1)
+    return int(a[i]) & ((1 << (8 * a.dtype.itemsize)) - 1)
+
+
+def _rebased(a, offset):
+    """a - offset in wrapping arithmetic of a's width (numpy: any integer dtype; torch: signed or unsigned integer tensors)"""
+    bits = 8 * _itemsize(a)
+    offset = int(offset) & ((1 << bits) - 1)
+    if _is_tensor(a):
+        import torch
+        signed = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[a.element_size()]
+        wrapped = offset - (1 << bits) if offset >= (1 << (bits - 1)) else offset
+        return (a.view(signed) - wrapped).view(a.dtype)
+    return a - a.dtype.type(offset if a.dtype.kind == "u" else (offset - (1 << bits) if offset >= (1 << (bits - 1)) else offset))
 
 Shard = namedtuple("Shard", ["fields", "start", "stop"])   # decodes output elements [start, stop)
 
@@ -88,17 +120,17 @@ def delta(fields, rank, world_size):
 def discard_zero_bytes_variable(fields, rank, world_size):
     n, L = int(fields["length"]), int(fields["segment_length"])
     bits = int(fields["bits_per_element_size"])
-    per = (8 * fields["packed_element_sizes"].dtype.itemsize) // bits
+    per = (8 * _itemsize(fields["packed_element_sizes"])) // bits
     granule = (L * per // math.gcd(L, per)) // L          # segments per lcm(L, per) elements
     s0, s1, lo, hi = _element_range(n, L, rank, world_size, granule)
     anchors = fields["position_anchors"]
     total_bytes = len(fields["compressed_data"])
-    b0 = int(anchors[s0]) if s0 < len(anchors) else total_bytes
-    b1 = int(anchors[s1]) if s1 < len(anchors) else total_bytes
+    b0 = _unsigned_at(anchors, s0) if s0 < len(anchors) else total_bytes
+    b1 = _unsigned_at(anchors, s1) if s1 < len(anchors) else total_bytes
     out = dict(fields)
     out["compressed_data"] = fields["compressed_data"][b0:b1]
     out["packed_element_sizes"] = fields["packed_element_sizes"][lo // per: -(-hi // per)]
-    out["position_anchors"] = (anchors[s0:s1] - anchors.dtype.type(b0)) if s1 > s0 else anchors[s0:s1]
+    out["position_anchors"] = _rebased(anchors[s0:s1], b0) if s1 > s0 else anchors[s0:s1]
     out["length"] = hi - lo
     return Shard(out, lo, hi)
 
@@ -108,10 +140,15 @@ def incidence_bitmaps(fields, rank, world_size, alignment_in_ints=2, granule_wor
     words, nb = int(fields["bitmap_length"]), int(fields["num_bitmaps"])
     aligned = -(-words // alignment_in_ints) * alignment_in_ints
     s0, s1, w0, w1 = _element_range(words, granule_words, rank, world_size)
-    bm = np.asarray(fields["incidence_bitmaps"]).reshape(nb, aligned)[:, w0:w1]
-    shard_aligned = -(-(w1 - w0) // alignment_in_ints) * alignment_in_ints
-    laid_out = np.zeros((nb, max(shard_aligned, 0)), dtype=bm.dtype)
-    laid_out[:, : w1 - w0] = bm
+    shard_aligned = max(-(-(w1 - w0) // alignment_in_ints) * alignment_in_ints, 0)
+    bitmaps = fields["incidence_bitmaps"]
+    if _is_tensor(bitmaps):
+        import torch
+        laid_out = torch.zeros((nb, shard_aligned), dtype=bitmaps.dtype, device=bitmaps.device)
+        laid_out[:, : w1 - w0] = bitmaps.reshape(nb, aligned)[:, w0:w1]
+    else:
+        laid_out = np.zeros((nb, shard_aligned), dtype=bitmaps.dtype)
+        laid_out[:, : w1 - w0] = np.asarray(bitmaps).reshape(nb, aligned)[:, w0:w1]
     out = dict(fields, incidence_bitmaps=laid_out.reshape(-1), bitmap_length=w1 - w0)
     return Shard(out, 32 * w0, 32 * w1)
 
@@ -124,12 +161,12 @@ def run_length_encoding(fields, rank, world_size):
     if s1 <= s0:
         empty = {k: (v[:0] if hasattr(v, "__len__") else v) for k, v in fields.items()}
         return Shard(dict(empty, length=0, num_segments=0, num_element_runs=0), lo, hi)
-    r0 = int(anchors[s0])
-    r1 = int(anchors[s1]) + 1 if s1 < len(anchors) else num_runs     # the run straddling the end is included
+    r0 = _unsigned_at(anchors, s0)
+    r1 = _unsigned_at(anchors, s1) + 1 if s1 < len(anchors) else num_runs     # the run straddling the end is included
     out = dict(fields)
     out["run_data"] = fields["run_data"][r0:r1]
     out["run_lengths"] = fields["run_lengths"][r0:r1]
-    out["position_anchors"] = anchors[s0:s1] - anchors.dtype.type(r0)
+    out["position_anchors"] = _rebased(anchors[s0:s1], r0)
     out["intra_run_anchor_offsets"] = fields["intra_run_anchor_offsets"][s0:s1]
     out["num_segments"] = s1 - s0
     out["num_element_runs"] = r1 - r0
@@ -145,17 +182,17 @@ def run_position_encoding(fields, rank, world_size, relative=True):
     if s1 <= s0:
         empty = {k: (v[:0] if hasattr(v, "__len__") else v) for k, v in fields.items()}
         return Shard(dict(empty, length=0, num_anchors=0, num_element_runs=0), lo, hi)
-    r0 = int(anchors[s0])
-    r1 = int(anchors[s1]) + 1 if s1 < len(anchors) else num_runs
+    r0 = _unsigned_at(anchors, s0)
+    r1 = _unsigned_at(anchors, s1) + 1 if s1 < len(anchors) else num_runs
     positions = fields["run_start_positions"][r0:r1]
     if not relative:
         # absolute positions are rebased to the shard; the first run may have started before the shard —
         # its (wrapped) position is never read (run_position_encoding.cuh:122,221)
-        positions = positions - positions.dtype.type(lo)
+        positions = _rebased(positions, lo)
     out = dict(fields)
     out["run_data"] = fields["run_data"][r0:r1]
     out["run_start_positions"] = positions
-    out["position_anchors"] = anchors[s0:s1] - anchors.dtype.type(r0)
+    out["position_anchors"] = _rebased(anchors[s0:s1], r0)
     out["num_anchors"] = s1 - s0
     out["num_element_runs"] = r1 - r0
     out["length"] = hi - lo
@@ -163,8 +200,21 @@ def run_position_encoding(fields, rank, world_size, relative=True):
 
 
 def patches(fields, start, stop):
-    """Naive patches whose target lies in the shard [start, stop), positions rebased to the shard."""
-    idx = np.asarray(fields["indices"])
+    """Naive patches whose target lies in the shard [start, stop), positions rebased to the shard.  ASCENDING positions
+    (what the fused decoders need anyway) are cut with two binary searches — views again; any other order is filtered."""
+    idx, data = fields["indices"], fields["data"]
+    n = len(idx)
+    if _is_tensor(idx):
+        import torch
+        wide = idx.to(torch.int64) & ((1 << (8 * idx.element_size())) - 1) if idx.element_size() < 8 else idx.view(torch.int64)
+        if n < 2 or bool((wide[1:] >= wide[:-1]).all()):
+            lo, hi = (int(x) for x in torch.searchsorted(wide, torch.tensor([start, stop], dtype=torch.int64, device=wide.device)))
+            return {"indices": _rebased(idx[lo:hi], start), "data": data[lo:hi], "data_length": hi - lo}
+        inside = (wide >= start) & (wide < stop)
+        return {"indices": _rebased(idx[inside], start), "data": data[inside], "data_length": int(inside.sum())}
+    idx = np.asarray(idx)
+    if n < 2 or bool((idx[1:] >= idx[:-1]).all()):
+        lo, hi = (int(x) for x in np.searchsorted(idx, [start, stop]))
+        return {"indices": _rebased(idx[lo:hi], start), "data": np.asarray(data)[lo:hi], "data_length": hi - lo}
     inside = (idx >= start) & (idx < stop)
-    return {"indices": (idx[inside] - idx.dtype.type(start)), "data": np.asarray(fields["data"])[inside],
-            "data_length": int(inside.sum())}
+    return {"indices": _rebased(idx[inside], start), "data": np.asarray(data)[inside], "data_length": int(inside.sum())}

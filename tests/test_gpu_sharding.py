@@ -104,3 +104,75 @@ def test_pipelined_decode_of_every_sharding_scheme_from_host(num_chunks, depth):
     check("frame_of_reference", f, oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, 4096, np.int32, "linear"), model="linear")
     small = (cases.rng(7).integers(0, 1 << 20, size=n)).astype(np.uint64)
     check("discard_zero_bytes_fixed", formats.discard_zero_bytes_fixed(small, np.uint32), small)
+
+
+def test_pipelined_decode_with_large_anchor_arrays():
+    """a column whose ANCHOR arrays are hundreds of KiB (2^22 elements in segments of 64): anchors stay host arrays whatever
+    their size and are rebased per chunk; only the bulk arrays are pinned (by name)"""
+    from libgiddy_amd import pipeline
+    n = 1 << 22
+
+    def check(scheme, fields, truth, **extra):
+        pinned = pipeline.pin(fields)
+        assert all(isinstance(pinned[k], np.ndarray) for k in fields if "anchor" in k)
+        assert all(isinstance(pinned[k], torch.Tensor) and pinned[k].is_pinned() for k in pipeline.BULK_ARRAYS if k in fields)
+        out = torch.zeros(len(truth), dtype={4: torch.int32, 8: torch.int64}[truth.dtype.itemsize], device="cuda")
+        out.fill_(-1)   # queued on the current stream: the pipeline's side streams must wait for it
+        for s in pipeline.decode_from_host(scheme, pinned, out, num_chunks=7, depth=3, **extra):
+            s.synchronize()
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
+
+    col = cases.runs_column(n, 8, np.uint32, seed=15)
+    f = formats.run_length_encoding(col, 64, np.uint16)
+    assert f["position_anchors"].nbytes >= 1 << 18
+    check("run_length_encoding", f, col)
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 2, seed=16)
+    f = formats.discard_zero_bytes_variable(col, 64, 1, 2, np.uint32, 8, element_sizes=sizes)
+    assert f["position_anchors"].nbytes >= 1 << 18
+    check("discard_zero_bytes_variable", f, col)
+    f, truth = cases.delta_case(n, 64, np.uint64, np.uint16, seed=17)
+    check("delta", f, truth)
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_device_resident_column_is_cut_without_a_host_round_trip(world):
+    """sharding.* on DEVICE tensors: the shard's big arrays are views of the column's, the rebased anchors are computed on
+    the device; every rank's shard decodes to its range of the column"""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    n = 1 << 20
+    signed = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+
+    def to_device(fields):
+        return {k: (torch.from_numpy(np.ascontiguousarray(v).view({1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}[v.dtype.itemsize])).cuda()
+                    if isinstance(v, np.ndarray) else v) for k, v in fields.items()}
+
+    def check(shard_fn, fields, truth, launch):
+        device_fields = to_device(fields)
+        out = torch.zeros(len(truth), dtype=signed[truth.dtype.itemsize], device="cuda")
+        for rank in range(world):
+            sh = shard_fn(device_fields, rank, world)
+            for k, v in sh.fields.items():
+                assert not isinstance(v, torch.Tensor) or v.is_cuda, k
+            if sh.stop > sh.start:
+                launch(out[sh.start:sh.stop], sh.fields)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (shard_fn.__name__, np.flatnonzero(got != truth)[:5])
+
+    col = cases.runs_column(n, 32, np.uint32, seed=21)
+    check(sharding.run_length_encoding, formats.run_length_encoding(col, 4096, np.uint16), col,
+          lambda out, s: schemes.run_length_encoding(out, s["run_data"], s["run_lengths"], s["position_anchors"], s["intra_run_anchor_offsets"],
+                                                     s["segment_length"], s["num_segments"], s["num_element_runs"], s["length"], stream=st))
+    check(lambda f, r_, w: sharding.run_position_encoding(f, r_, w, relative=False), formats.run_position_encoding(col, 4096, np.uint32, False), col,
+          lambda out, s: schemes.run_position_encoding(out, s["run_data"], s["run_start_positions"], s["position_anchors"], s["segment_length"],
+                                                       s["num_anchors"], s["num_element_runs"], s["length"], position_size=4, relative=False, stream=st))
+    colv, sizes = cases.dzbv_column(n, np.uint64, 1, 2, seed=22)
+    check(sharding.discard_zero_bytes_variable, formats.discard_zero_bytes_variable(colv, 1024, 1, 2, np.uint32, 8, element_sizes=sizes), colv,
+          lambda out, s: schemes.discard_zero_bytes_variable(out, s["compressed_data"], s["packed_element_sizes"], s["position_anchors"], s["segment_length"],
+                                                             s["length"], 1, 2, uncompressed_size=8, index_size=8, stream=st))
+    f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=23)
+    check(sharding.delta, f, truth,
+          lambda out, s: schemes.delta(out, s["compressed_input"], s["anchor_values"], s["length"], s["segment_length"], uncompressed_size=8, compressed_size=2, stream=st))

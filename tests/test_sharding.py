@@ -91,6 +91,58 @@ def test_shards_decode_to_the_column(world):
         assert (np.concatenate(pieces) == truth).all()
 
 
+def _as_tensors(fields):
+    """every array of a column as a torch tensor holding the same bits (signed dtypes: torch's unsigned ones lack arithmetic)"""
+    import torch
+    signed = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+    return {k: (torch.from_numpy(np.ascontiguousarray(v).view(signed[v.dtype.itemsize]).copy()) if isinstance(v, np.ndarray) and v.dtype.kind in "iu" and k != "model_coefficients" else v)
+            for k, v in fields.items()}
+
+
+def _as_arrays(fields, like):
+    return {k: (v.numpy().view(like[k].dtype) if hasattr(v, "numpy") else v) for k, v in fields.items()}
+
+
+@pytest.mark.parametrize("world", [2, 5])
+def test_shards_of_tensors_decode_to_the_column(world):
+    """the same cuts on torch tensors (what a device-resident column is): slices are views, anchors are rebased by a
+    wrapping tensor subtraction — bit-identical shards to the numpy cuts"""
+    for name, (fields, truth, shard_fn, dtype, kw) in _columns().items():
+        scheme = name.split("_")[0]
+        tensors = _as_tensors(fields)
+        covered = 0
+        for rank in range(world):
+            sh, reference = shard_fn(tensors, rank, world), shard_fn(fields, rank, world)
+            assert (sh.start, sh.stop) == (reference.start, reference.stop) and sh.start == covered
+            back = _as_arrays(sh.fields, fields)
+            for k, v in reference.fields.items():
+                if isinstance(v, np.ndarray):
+                    assert np.array_equal(np.asarray(back[k]).reshape(-1), v.reshape(-1)), (name, rank, k)
+            views = ("compressed_input", "compressed_data", "run_data", "run_lengths") + (("run_start_positions",) if kw.get("relative", True) else ())
+            for k in views:   # (absolute run positions are rebased to the shard: the one big array that is rewritten, 1/mean-run of the output)
+                if k in sh.fields and sh.stop > sh.start and hasattr(sh.fields[k], "untyped_storage"):
+                    assert sh.fields[k].untyped_storage().data_ptr() == tensors[k].untyped_storage().data_ptr(), (name, k, "a copy, not a view")
+            got = _decode(scheme, back, dtype, **kw)
+            assert (got == truth[sh.start:sh.stop]).all(), (name, world, rank)
+            covered = sh.stop
+        assert covered == len(truth), name
+
+
+def test_patch_partition_of_tensors():
+    import torch
+    n = 100000
+    p = cases.patch_case(n, 300, np.uint64, 4, seed=7)
+    t = {"indices": torch.from_numpy(p["indices"].view(np.int32).copy()), "data": torch.from_numpy(p["data"].view(np.int64).copy()), "data_length": 300}
+    shuffled = np.random.default_rng(1).permutation(300)
+    for start, stop in [(0, 25000), (25000, 70000), (70000, n)]:
+        want = sharding.patches(p, start, stop)
+        got = sharding.patches(t, start, stop)
+        assert got["data_length"] == want["data_length"]
+        assert (got["indices"].numpy().view(np.uint32) == want["indices"]).all() and (got["data"].numpy().view(np.uint64) == want["data"]).all()
+        unordered = sharding.patches({"indices": p["indices"][shuffled], "data": p["data"][shuffled], "data_length": 300}, start, stop)
+        assert sorted(unordered["indices"].tolist()) == want["indices"].tolist()
+
+
 def test_patch_partition():
     n = 100000
     p = cases.patch_case(n, 300, np.uint64, 4, seed=7)
@@ -136,14 +188,24 @@ def _worker(rank, world, port, results):
         gathered = distributed.gather_decoded(torch.from_numpy(local.view(np.int64).copy()), counts, dst=0)
         if rank == 0:
             results.put(("dzbv", bool((gathered.numpy().view(np.uint64) == colv).all())))
-        # bench.py's --gather leg (the timing harness around the same collective), on CPU tensors
+        # bench.py's gather leg (the timing harness around the same collective), on CPU tensors, uneven shards
         import bench
-
-        class Work:
-            output = torch.arange(5000, dtype=torch.int32) + 100000 * rank
-        report = bench.time_gather(Work, 4096, rank, world, torch.device("cpu"), dist.barrier, repetitions=1)
+        column = torch.arange(9000, dtype=torch.int32) * 7 + 3
+        cut = [0, 5000, 9000] if world == 2 else [9000 * r // world for r in range(world + 1)]
+        local_t = column[cut[rank]:cut[rank + 1]].clone()
+        report = bench.time_gather(local_t, [cut[r + 1] - cut[r] for r in range(world)], rank, world, torch.device("cpu"), dist.barrier,
+                                   repetitions=1, expected=column if rank == 0 else None)
         if rank == 0:
-            results.put(("bench_gather", report["own_shard_in_place"] and report["bytes_per_rank"] == 4096 * 4 and report["links"] == world - 1))
+            results.put(("bench_gather", report["own_shard_in_place"] and report["gathered_equals_the_column"] and report["links"] == world - 1))
+        # bench.py's strong-scaling check: shards of tensor columns (cut as on a device), position-weighted checksums summed over the ranks
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+        import workloads
+        tensors = _as_tensors(fields)
+        sh = sharding.run_length_encoding(tensors, rank, world)
+        decoded = torch.from_numpy(_decode("rle", _as_arrays(sh.fields, fields), np.uint32).view(np.int32).copy())
+        summed = bench.all_reduce_u64_sum(workloads.checksum(decoded, first_index=sh.start), world, torch.device("cpu"), "gloo")
+        if rank == 0:
+            results.put(("strong_checksum", summed == workloads.checksum(torch.from_numpy(col.view(np.int32).copy()))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -161,5 +223,5 @@ def test_gather_with_gloo(world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = dict(results.get(timeout=10) for _ in range(3))
-    assert got == {"rle": True, "dzbv": True, "bench_gather": True}
+    got = dict(results.get(timeout=10) for _ in range(4))
+    assert got == {"rle": True, "dzbv": True, "bench_gather": True, "strong_checksum": True}

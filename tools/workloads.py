@@ -13,7 +13,7 @@ workload exposes:
 import numpy as np
 import torch
 
-from libgiddy_amd import schemes
+from libgiddy_amd import schemes, sharding
 
 
 SEED_OFFSET = 0   # bench.py sets this to 1000 * rank so that every GPU decodes different data
@@ -28,6 +28,39 @@ def _gen(seed, device):
 def _np(t, dtype=None):
     a = t.detach().cpu().numpy()
     return a.view(dtype) if dtype is not None else a
+
+
+def checksum(t, first_index=0):
+    """position-weighted 64-bit checksum of a decoded (device) range: sum of element * (2 * global index + 1), wrapping —
+    the sum of the shards' checksums is the column's whatever the cut"""
+    total = 0
+    step = 1 << 27
+    flat = t.reshape(-1)
+    for lo in range(0, flat.numel(), step):
+        hi = min(flat.numel(), lo + step)
+        weights = 2 * torch.arange(first_index + lo, first_index + hi, device=t.device, dtype=torch.int64) + 1
+        total = (total + int((flat[lo:hi].to(torch.int64) * weights).sum())) & ((1 << 64) - 1)
+    return total
+
+
+class Sharded:
+    """Rank `rank` of `world`'s shard of a workload's column: cut from the device-resident arrays by libgiddy_amd.sharding (views
+    + rebased anchors, no host round trip), decoded into its range of the workload's output buffer."""
+
+    def __init__(self, work, rank, world):
+        self.whole, self.rank, self.world = work, rank, world
+        shard = work.shard_function(work.column_fields(), rank, world)
+        self.start, self.stop, self.fields = shard.start, shard.stop, shard.fields
+        self.n = self.stop - self.start
+        self.output = work.output[self.start:self.stop]
+        self.name, self.kernel = work.name, work.kernel
+        self.decompressed_bytes = self.output.numel() * self.output.element_size()
+        self.algorithmic_bytes = self.decompressed_bytes + sum(v.numel() * v.element_size() for v in self.fields.values() if isinstance(v, torch.Tensor))
+        self.config = work.launch_fields(self.output, self.fields, torch.cuda.current_stream().cuda_stream, None) if self.n else None
+
+    def run(self, stream):
+        if self.n:
+            self.whole.launch_fields(self.output, self.fields, stream, self.config)
 
 
 class Dictionary:
@@ -392,6 +425,16 @@ class RunLength:
     def run(self, stream):
         self._launch(stream, self.config)
 
+    def column_fields(self):
+        return {"run_data": self.run_data, "run_lengths": self.run_lengths, "position_anchors": self.anchors, "intra_run_anchor_offsets": self.intra,
+                "segment_length": self.L, "num_segments": self.num_segments, "num_element_runs": self.num_runs, "length": self.n}
+
+    shard_function = staticmethod(sharding.run_length_encoding)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.run_length_encoding(out, f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], f["segment_length"],
+                                           f["num_segments"], f["num_element_runs"], f["length"], stream=stream, launch_config=config)
+
     def _expected_slice(self, lo, hi):
         pos = torch.arange(lo, hi, device=self.output.device)
         return self.run_data[torch.searchsorted(self.starts, pos, right=True) - 1]
@@ -449,6 +492,18 @@ class RunPosition(RunLength):
                                              self.num_runs, self.n, position_size=2 if self.relative else 4,
                                              relative=self.relative, stream=stream, launch_config=config)
 
+    def column_fields(self):
+        return {"run_data": self.run_data, "run_start_positions": self.positions, "position_anchors": self.anchors, "segment_length": self.L,
+                "num_anchors": self.num_segments, "num_element_runs": self.num_runs, "length": self.n}
+
+    def shard_function(self, fields, rank, world):
+        return sharding.run_position_encoding(fields, rank, world, relative=self.relative)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.run_position_encoding(out, f["run_data"], f["run_start_positions"], f["position_anchors"], f["segment_length"], f["num_anchors"],
+                                             f["num_element_runs"], f["length"], position_size=2 if self.relative else 4, relative=self.relative,
+                                             stream=stream, launch_config=config)
+
     def verify(self, oracle, sample=1 << 22):
         torch.cuda.synchronize()
         n, L = self.n, self.L
@@ -484,31 +539,44 @@ class DiscardZeroBytesVariable:
     kernel = "variable_width::decompress"
 
     def __init__(self, n, device, seed=8, segment_length=1024, bits=2, min_size=1):
-        g = _gen(seed, device)
         self.n, self.L, self.bits, self.min_size = n, segment_length, bits, min_size
         self.name = "discard_zero_bytes::variable_width<8,8,4> (%d-bit sizes, %d..%d bytes)" % (bits, min_size, min(8, min_size + (1 << bits) - 1))
         per = 32 // bits
-        sizes = torch.randint(min_size, min_size + (1 << bits), (n,), dtype=torch.int64, generator=g, device=device).clamp_(max=8)
-        offsets = torch.cumsum(sizes, 0) - sizes
-        total = int(offsets[-1] + sizes[-1])
-        values = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, generator=g, device=device)
-        mask = torch.where(sizes >= 8, torch.full_like(sizes, -1), (torch.ones_like(sizes) << (8 * sizes)) - 1)
-        values = (values & mask) | (torch.ones_like(sizes) << (8 * (sizes - 1)).clamp_(min=0))
-        values = values & mask
-        self.values = values
-        # packed size fields, LSB first, `per` fields per 32-bit container
+        largest = min(8, min_size + (1 << bits) - 1)
         ncont = (n + per - 1) // per
-        fields = torch.zeros(ncont * per, dtype=torch.int64, device=device)
-        fields[:n] = sizes - min_size
-        shifts = torch.arange(per, device=device, dtype=torch.int64) * bits
-        self.packed = (fields.view(ncont, per) << shifts).sum(dim=1).to(torch.int32)
-        # compressed bytes: byte k of element i at offsets[i] + k for k < sizes[i]
-        data = torch.empty(total + 0, dtype=torch.uint8, device=device)
-        for k in range(min(8, min_size + (1 << bits) - 1)):
-            sel = sizes > k
-            data[(offsets[sel] + k)] = ((values[sel] >> (8 * k)) & 0xFF).to(torch.uint8)
-        self.data = data
-        self.anchors = offsets[torch.arange(0, n, segment_length, device=device)].contiguous()
+        block = (1 << 26) // (per * segment_length) * (per * segment_length) or per * segment_length   # whole containers and segments
+        # generated block by block (a 2^31-element column's temporaries would not fit otherwise): block b draws from generator (seed, b)
+        self.values = torch.empty(n, dtype=torch.int64, device=device)
+        self.packed = torch.empty(ncont, dtype=torch.int32, device=device)
+        self.anchors = torch.empty((n + segment_length - 1) // segment_length, dtype=torch.int64, device=device)
+        pieces, total = [], 0
+        for index, lo in enumerate(range(0, n, block)):
+            hi = min(n, lo + block)
+            g = _gen(seed + 7919 * index, device)
+            sizes = torch.randint(min_size, min_size + (1 << bits), (hi - lo,), dtype=torch.int64, generator=g, device=device).clamp_(max=8)
+            offsets = torch.cumsum(sizes, 0) - sizes
+            bytes_here = int(offsets[-1] + sizes[-1])
+            values = torch.randint(0, 1 << 62, (hi - lo,), dtype=torch.int64, generator=g, device=device)
+            mask = torch.where(sizes >= 8, torch.full_like(sizes, -1), (torch.ones_like(sizes) << (8 * sizes)) - 1)
+            values = ((values & mask) | (torch.ones_like(sizes) << (8 * (sizes - 1)).clamp_(min=0))) & mask   # exactly `size` significant bytes
+            self.values[lo:hi] = values
+            # packed size fields, LSB first, `per` fields per 32-bit container
+            containers = (hi - lo + per - 1) // per
+            fields = torch.zeros(containers * per, dtype=torch.int64, device=device)
+            fields[: hi - lo] = sizes - min_size
+            shifts = torch.arange(per, device=device, dtype=torch.int64) * bits
+            self.packed[lo // per: lo // per + containers] = (fields.view(containers, per) << shifts).sum(dim=1).to(torch.int32)
+            # compressed bytes: byte k of element i at offsets[i] + k for k < sizes[i]
+            data = torch.empty(bytes_here, dtype=torch.uint8, device=device)
+            for k in range(largest):
+                sel = sizes > k
+                data[(offsets[sel] + k)] = ((values[sel] >> (8 * k)) & 0xFF).to(torch.uint8)
+            pieces.append(data)
+            self.anchors[lo // segment_length: (hi + segment_length - 1) // segment_length] = offsets[::segment_length] + total
+            total += bytes_here
+            del sizes, offsets, values, mask, fields, data
+        self.data = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
+        del pieces
         self.output = torch.empty(n, dtype=torch.int64, device=device)
         self.total_bytes = total
         self.algorithmic_bytes = total + 4 * ncont + 8 * n + 8 * len(self.anchors)
@@ -521,6 +589,17 @@ class DiscardZeroBytesVariable:
 
     def run(self, stream):
         self._launch(stream, self.config)
+
+    # the column in the format writers' vocabulary (libgiddy_amd.formats), device-resident; how a shard of it is cut and launched
+    def column_fields(self):
+        return {"compressed_data": self.data, "packed_element_sizes": self.packed, "position_anchors": self.anchors, "segment_length": self.L,
+                "length": self.n, "min_represented_element_size": self.min_size, "bits_per_element_size": self.bits}
+
+    shard_function = staticmethod(sharding.discard_zero_bytes_variable)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.discard_zero_bytes_variable(out, f["compressed_data"], f["packed_element_sizes"], f["position_anchors"], f["segment_length"],
+                                                   f["length"], self.min_size, self.bits, stream=stream, launch_config=config)
 
     def verify(self, oracle, sample=1 << 21):
         torch.cuda.synchronize()
