@@ -73,7 +73,7 @@ def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28):
         "delta_fused_compressed_patches": lambda: w.DeltaFusedCompressedPatches(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "frame_of_reference_fused_patches": lambda: w.FrameOfReferenceFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
         "dictionary_fused_patches": lambda: w.DictionaryFused(n, device, patch_fraction=float(os.environ.get("PATCH_FRACTION", "0.001"))),
-        "run_length_encoding": lambda: w.RunLength(n, device),
+        "run_length_encoding": lambda: w.RunLength(n, device, mean_run=int(os.environ.get("MEAN_RUN", "32"))),
         "run_position_encoding_relative": lambda: w.RunPosition(n, device, relative=True),
         "run_position_encoding_absolute": lambda: w.RunPosition(n, device, relative=False),
         "discard_zero_bytes_variable": lambda: w.DiscardZeroBytesVariable(min(n, cap), device),
@@ -119,9 +119,11 @@ def timed_steps(work, steps, warmup, barrier):
 
 
 def roofline(work, mean_launch_ms, traffic):
+    """`traffic`: None, or (bytes, source) as committed_traffic returns"""
     achieved = work.algorithmic_bytes / (mean_launch_ms * 1e-3) / 1e9
+    traffic, traffic_source = traffic if isinstance(traffic, tuple) else (traffic, None)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": work.kernel, "algorithmic_bytes_per_launch": work.algorithmic_bytes,
             "mean_launch_ms": round(mean_launch_ms, 4)}
 
@@ -154,19 +156,29 @@ def cpu_model():
 
 
 def committed_traffic(kernel, algorithmic_bytes=None, workload=None):
-    """HBM bytes per launch from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json) — or None if there is
-    no measurement for this kernel AT THIS SIZE (the passes ran the default workloads: 2^30 elements, DZB-V 2^28)."""
+    """(HBM bytes per launch, where the number comes from) from the committed rocprofv3 --pmc passes (profiles/hbm_traffic.json;
+    PMC counters cannot be collected from inside the run).  The value is None — and the source says why — when there is no
+    measurement for this kernel AT THIS SIZE (the passes ran the default workloads: 2^30 elements, DZB-V 2^28), or when the
+    headers the kernel is compiled from have changed since the pass (tools/kernel_sources.py fingerprints them)."""
+    import kernel_sources
     path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    source = {"file": "profiles/hbm_traffic.json", "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, calibrated (tools/profile_round.sh)"}
     try:
         with open(path) as f:
             committed = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, dict(source, status="no committed measurement")
+    source.update(round=committed.get("round"), measured_at_commit=committed.get("measured_at_commit"))
     entry = committed.get("by_workload", {}).get(workload) or committed.get(kernel, {})
+    if not entry:
+        return None, dict(source, status="no measurement for this kernel")
     measured_for = entry.get("algorithmic_bytes_per_launch")
     if algorithmic_bytes is not None and measured_for and abs(measured_for - algorithmic_bytes) > 0.001 * algorithmic_bytes:
-        return None
-    return entry.get("hbm_bytes_per_launch")
+        return None, dict(source, status="measured at another size")
+    recorded, current = entry.get("kernel_sources_sha16"), kernel_sources.fingerprint(kernel)
+    if recorded != current:
+        return None, dict(source, status="stale: the kernel's headers changed since the pass (was %s, is %s)" % (recorded, current))
+    return entry.get("hbm_bytes_per_launch"), dict(source, status="current", kernel_sources_sha16=current)
 
 
 def cpu_baseline(work, sample, unit_bytes_label="decompressed GB/s"):

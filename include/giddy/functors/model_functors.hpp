@@ -1,11 +1,13 @@
 // Parametric sequence models used by Frame-of-Reference and Model decompression:
-//   cuda::functors::unary::parametric_model::{constant, linear, zero}<IndexSize, T>
+//   cuda::functors::unary::parametric_model::{constant, linear, zero}<IndexSize, T>, polynomial<IndexSize, T, N>
 // Interface (index_type, coefficients_type, operator()) and value semantics follow the reference's
 // src/cuda/model_functors.hpp:25-125:  constant -> c[0];  linear -> c[0] + c[1]*x with x an
 // uint_t<IndexSize> (so the arithmetic is unsigned and wraps) converted to T on return.
-// The reference's generic `polynomial` is not Σ c_k x^k (it starts from 1 and pre-multiplies the
-// power, model_functors.hpp:54-66) and no registered kernel uses it un-overridden, so it is not
-// offered here; `linear` and `constant` are stand-alone.
+// `polynomial` keeps the reference's value EXACTLY as written (model_functors.hpp:54-66) — which is not
+// Σ c_k x^k: it starts from 1 and multiplies the power up before it is used, 1 + Σ_k c_k x^(k+1), all in T —
+// because a caller who instantiates a kernel template with it (no wrapper is registered for it, in the reference
+// or here) gets that column from the reference.  `linear` and `constant` are stand-alone types (their names, not
+// their bases, are what factory keys embed).
 #pragma once
 #include "giddy/array.hpp"
 #include "giddy/util/integer.hpp"
@@ -29,6 +31,26 @@ struct function_t {
 	GIDDY_HD function_t(const coefficients_type& c) : model_coefficients(c) { }
 
 	const coefficients_type model_coefficients;
+};
+
+template <unsigned IndexSize, typename T, unsigned NumModelCoefficients>
+struct polynomial : public function_t<IndexSize, T, NumModelCoefficients> {
+	using parent = function_t<IndexSize, T, NumModelCoefficients>;
+	using typename parent::index_type;
+	using typename parent::coefficients_type;
+	using parent::model_coefficients;
+	GIDDY_HD polynomial(const coefficients_type& c) : parent(c) { }
+	GIDDY_HD T operator()(const index_type& x) const
+	{
+		T result = 1;
+		T power_of_x = 1;
+		#pragma unroll
+		for (unsigned k = 0; k < NumModelCoefficients; k++) {
+			power_of_x *= x;
+			result += model_coefficients[k] * power_of_x;
+		}
+		return result;
+	}
 };
 
 template <unsigned IndexSize, typename T>

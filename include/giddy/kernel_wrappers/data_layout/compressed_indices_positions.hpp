@@ -4,7 +4,8 @@
 // decoders (kernel_wrappers/decompression/patched/*.hpp) run it over their "patch_positions_scratch" when they are
 // handed compressed positions.  Argument-map keys: those of the compressed-indices scatter wrapper
 // (src/kernel_wrappers/data_layout/compressed_indices_scatter.cu:48-104) with "positions" in place of "target" and
-// "data_to_scatter".
+// "data_to_scatter"; optionally "unsupported_patch_count" (unsigned*, zeroed by the caller): incremented once per patch
+// of a run whose offset width is none of 8/16/32/64 bits — the scatter skips such runs, a plain array cannot say so.
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/data_layout/compressed_indices_scatter.hpp"
@@ -39,11 +40,13 @@ inline void enqueue_expansion(stream::id_t stream, uint_t<OutputIndexSize>* posi
 	auto anchors          = argument<const input_index_type*>(arguments, "scatter_position_anchors");
 	auto anchoring_period = argument<input_index_type>(arguments, "anchoring_period");
 	auto num_runs         = argument<input_index_type>(arguments, "num_scatter_position_runs");
+	// optional: a device counter (caller-zeroed) of the patches of runs whose offset width is none of 8/16/32/64 bits
+	auto unsupported      = optional_argument<native_word_t*>(arguments, "unsupported_patch_count").value_or(nullptr);
 	cuda::enqueue_launch(
 		reinterpret_cast<const void*>(expand_positions<OutputIndexSize, InputIndexSize, RunLengthSize>), stream,
 		launch_configuration(num_patches, anchoring_period),
 		positions, run_lengths, offset_sizes, baseline_values, offsets_start, offset_bytes, anchors,
-		anchoring_period, num_runs, num_patches);
+		anchoring_period, num_runs, num_patches, unsupported);
 }
 
 template <unsigned OutputIndexSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>

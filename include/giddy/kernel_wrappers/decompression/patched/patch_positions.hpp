@@ -4,7 +4,10 @@
 // column's IndexSize) — those positions expanded into the caller's "patch_positions_scratch" (num_patches entries)
 // by a small kernel enqueued just before the decoder on the same stream.  The expansion moves bytes proportional to
 // the PATCHES; what the fusion removes is the second pass and the scattered read-modify-write over the COLUMN.
-// Runs whose offset width is none of 8/16/32/64 bits (which the scatter skips) are not supported here.
+// PRECONDITIONS (not checked on the way): plain positions are ASCENDING (equal positions: the last one wins);
+// compressed positions hold no run whose offset width is none of 8/16/32/64 bits (the scatter skips such runs; here
+// the wavefront that meets one stops patching its chunk).  To find out, pass "unsupported_patch_count" (unsigned*,
+// zeroed): the expansion counts the patches of such runs there.
 #pragma once
 #include "giddy/kernel_wrappers/data_layout/compressed_indices_positions.hpp"
 

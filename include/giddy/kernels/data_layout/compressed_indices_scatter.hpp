@@ -143,9 +143,12 @@ __global__ void scatter(
 		});
 }
 
-/// The positions alone, as a plain array (positions[k] = where patch k goes; all-ones for the patches of a run whose
-/// offset width is none of 8/16/32/64 bits, which scatter() skips): what the fused decoders merge from
+/// The positions alone, as a plain array (positions[k] = where patch k goes): what the fused decoders merge from
 /// (kernel_wrappers/decompression/patched/*.hpp) — bytes proportional to the patches, not to the column.
+/// A run whose offset width is none of 8/16/32/64 bits — which scatter() skips, compressed_indices_scatter.cuh:105-122 —
+/// has NO plain-array equivalent: its patches are written as all-ones, which a fused decoder reads as "no more patches"
+/// (later patches of that wavefront's chunk are then not applied).  Such input is outside the fused wrappers' contract;
+/// `unsupported_patches` (may be null) counts the patches of such runs so that a caller can find out.
 template <unsigned OutputIndexSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>
 __global__ void expand_positions(
 	uint_t<OutputIndexSize>*        __restrict__  positions,
@@ -157,7 +160,8 @@ __global__ void expand_positions(
 	const uint_t<InputIndexSize>*   __restrict__  scatter_position_anchors,
 	uint_t<InputIndexSize>                        anchoring_period,
 	uint_t<InputIndexSize>                        num_output_position_runs,
-	size_type_by_index_size<InputIndexSize>       data_length)
+	size_type_by_index_size<InputIndexSize>       data_length,
+	native_word_t*                  __restrict__  unsupported_patches = nullptr)
 {
 	__shared__ detail::run_descriptor descriptors[detail::max_waves_per_block][64];
 	detail::for_each_patch<OutputIndexSize, InputIndexSize, RunLengthSize>(
@@ -166,6 +170,7 @@ __global__ void expand_positions(
 		anchoring_period, num_output_position_runs, data_length, descriptors[wave64::index_in_block() % detail::max_waves_per_block],
 		[&](uint64_t patch, uint_t<OutputIndexSize> position, bool representable) {
 			positions[patch] = representable ? position : (uint_t<OutputIndexSize>) ~(uint_t<OutputIndexSize>) 0;
+			if (!representable && unsupported_patches != nullptr) { atomicAdd(unsupported_patches, 1u); }
 		});
 }
 

@@ -141,7 +141,7 @@ struct row_t {
 		memory_access::group<U, E> values;
 		#pragma unroll
 		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
-		patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values);
+		if (row_start < end) { patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values); }   // (rows past the end: nothing to patch, and no walking into the next segment's patches)
 		if (p + E <= end) { memory_access::store_group(out + p, values); }
 		else {
 			#pragma unroll
@@ -340,12 +340,15 @@ __device__ __forceinline__ void block_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
-		patches.seek(start, lane);   // (every wavefront walks the segment's patches and keeps those in its own rows)
 		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * R * traits::row) {
 			const uint64_t mine = sweep_start + (uint64_t) w * R * traits::row;
 			row_t<UncompressedSize, CompressedSize> rows[R];
+			// a wavefront seeks to ITS rows of the sweep, the probes in flight with the rows' own loads (walking there from the
+			// segment's start costs a serial step per patch of every wavefront below, every sweep)
+			if (mine < end) { patches.begin_seek(mine, lane); }
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].load(in, mine + (uint64_t) k * traits::row, end, lane); }   // rows past `end` load zeros
+			if (mine < end) { patches.finish_seek(lane); }
 			U my_total = 0;
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].scan(); my_total += (U) rows[k].total; }

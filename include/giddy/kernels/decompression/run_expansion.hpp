@@ -34,6 +34,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
+#define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
+#endif
 #ifndef GIDDY_RUN_TILE_WORDS_PER_LANE
 #define GIDDY_RUN_TILE_WORDS_PER_LANE 2
 #endif
@@ -88,13 +91,22 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 ///    positions) are 1-2 bytes wide — 79.5 vs 75.9 % of peak for RLE <4,4,2> — and 12-15 points slower when they
 ///    are 4-8 bytes wide, so those are staged too.
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
+///
+/// DENSE tiles (run_length_encoding.hpp / run_position_encoding.hpp): when the first batch of run descriptors does not reach the
+/// end of the tile — mean runs below ~16 — the tile is CUT SHORT at what that batch covers (whole 128-byte pieces of output), so
+/// that a tile never needs a second, dependent batch of descriptors, and its run values — at most a batch's worth — always come
+/// from LDS: with runs of 2-4 elements the look-ups through L1/L2 miss (a tile's values are kilobytes, touched once), one
+/// dependent HBM round trip PER ROW of 256 outputs — RLE<4,4,2> at mean run 4: 37 % of peak before.  `dense_only`: staging exists
+/// for such tiles alone (the instantiations whose sparse tiles are faster through L1/L2).
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { enabled = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || RunDescriptorSize >= 4, bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
+	enum : unsigned { always = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || RunDescriptorSize >= 4, dense_only = !always, enabled = 1,
+		bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
 		allocated = capacity + 16 / ElementSize,   // (the permuting expansions read up to 11 bytes past a lane's first run)
 		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);
 		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)
-		with_descriptors = enabled && ElementSize >= 4 };
+		with_descriptors = (always || GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS) && ElementSize >= 4,
+		dense_granule = 128 / ElementSize };   // a tile that is cut short ends on a multiple of this many outputs
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].

@@ -56,8 +56,8 @@ __global__ void decompress(
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
 	using staging = value_staging<UncompressedSize, RunLengthSize>;
-	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::allocated : 1];
-	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
+	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[max_waves_per_block][staging::allocated];
+	uint_t<UncompressedSize>* staged = staged_values[wave64::index_in_block() % max_waves_per_block];   // (idle wavefronts never use it)
 
 	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256
 	// threads); in a larger workgroup the extra wavefronts sit idle — there is no barrier they could miss
@@ -88,9 +88,11 @@ __global__ void decompress(
 			if (through < run_limit) { run_limit = through; }
 		}
 
-		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
-			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
-			const bool need_carry = tile_start + tile_len < segment_end;
+		uint32_t tile_len = 0;
+		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
+			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
+			bool need_carry = tile_start + tile_len < segment_end;
+			bool dense = false;
 			clear(table, lane);
 
 			uint32_t running = 0;      // clamped lengths summed over earlier batches = start of this batch's first run
@@ -110,6 +112,13 @@ __global__ void decompress(
 					if (staging::with_descriptors && have[j] && k < staging::capacity) { staged[k] = run_data[first_run + k]; }
 				}
 				uint32_t inclusive = wave64::inclusive_sum(lane_total);
+				const uint32_t covered = wave64::read_last_lane(inclusive);
+				if (batch_base == 0 && covered < tile_len && first_run + runs_per_batch < run_limit) {
+					// a dense tile (run_expansion.hpp): it ends where this batch's runs end, on a whole 128-byte piece of output
+					// (no length was clamped: each is at most `covered`)
+					tile_len = covered / staging::dense_granule * staging::dense_granule;
+					need_carry = true; dense = true;
+				}
 				uint32_t start = running + inclusive - lane_total;
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
@@ -123,12 +132,17 @@ __global__ void decompress(
 					}
 					start += clamped[j];
 				}
-				running += wave64::read_last_lane(inclusive);
+				running += covered;
 				batch_base += runs_per_batch;
 			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize, staging::enabled, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			if (staging::dense_only && !dense) {
+				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+			}
+			else {
+				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			}
 
 			if (need_carry) {
 				uint64_t who = wave64::ballot(found);

@@ -59,8 +59,8 @@ __global__ void decompress(
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
 	using staging = value_staging<UncompressedSize, PositionOffsetSize>;
-	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[staging::enabled ? max_waves_per_block : 1][staging::enabled ? staging::allocated : 1];
-	uint_t<UncompressedSize>* staged = staging::enabled ? staged_values[wave64::index_in_block() % max_waves_per_block] : nullptr;   // (idle wavefronts never use it)
+	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[max_waves_per_block][staging::allocated];
+	uint_t<UncompressedSize>* staged = staged_values[wave64::index_in_block() % max_waves_per_block];   // (idle wavefronts never use it)
 
 	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256
 	// threads); in a larger workgroup the extra wavefronts sit idle — there is no barrier they could miss
@@ -90,10 +90,12 @@ __global__ void decompress(
 		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
 			? (uint64_t) position_anchors[s + lane] : ~(uint64_t) 0;
 
-		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_length) {
-			const uint32_t tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
-			const uint64_t tile_end = tile_start + tile_len;
-			const bool need_carry = tile_end < segment_end;
+		uint32_t tile_len = 0;
+		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
+			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
+			uint64_t tile_end = tile_start + tile_len;
+			bool need_carry = tile_end < segment_end;
+			bool dense = false;
 			clear(table, lane);
 			if (staging::with_descriptors && lane == 0) { staged[0] = run_data[first_run]; }
 
@@ -101,7 +103,7 @@ __global__ void decompress(
 			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= tile_end
 			bool reached_past_tile;
 			do {
-				bool past = false;
+				uint64_t starts[runs_per_lane]; bool starts_here[runs_per_lane];   // a candidate that starts inside this chunk
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					uint64_t r = batch_base + (uint64_t) lane * runs_per_lane + j;
@@ -117,7 +119,8 @@ __global__ void decompress(
 							if (probe < segments_per_chunk && anchor < r) { segment_in_chunk = probe; }
 						}
 					}
-					if (r > last_candidate) { past = true; continue; }
+					starts[j] = 0; starts_here[j] = false;
+					if (r > last_candidate) { continue; }
 					uint64_t position = run_start_positions[r];
 					// the runs' values travel with their positions (staged for the expansion; runs past the tile's last are harmless)
 					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = run_data[r]; }
@@ -127,17 +130,39 @@ __global__ void decompress(
 						start = segment_start + (uint64_t) segment_in_chunk * L + (position != 0 ? position : L);
 					}
 					// a run starting at/after the chunk's nominal end opens the NEXT chunk
-					bool starts_in_segment = start < nominal_end;
-					if (!starts_in_segment || start > tile_end) { past = true; continue; }
-					if (start > tile_start && start < tile_end) { mark(table, (uint32_t) (start - tile_start)); }
-					last_at_or_before_end = (uint32_t) (r - first_run) + 1;   // r increases with j
+					starts[j] = start; starts_here[j] = start < nominal_end;
+				}
+				if (batch_base == first_run + 1) {
+					// a dense tile (run_expansion.hpp): when every run of the first batch starts inside the tile, the tile ends where
+					// the batch's last run starts (on a whole 128-byte piece of output)
+					bool outside = false;
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) { outside = outside || !starts_here[j] || starts[j] >= tile_end; }
+					if (wave64::ballot(outside) == 0) {
+						const uint64_t last_start = wave64::read_last_lane(starts[runs_per_lane - 1]);
+						tile_len = (uint32_t) ((last_start - tile_start) / staging::dense_granule * staging::dense_granule);
+						tile_end = tile_start + tile_len;
+						need_carry = true; dense = true;
+					}
+				}
+				bool past = false;
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					if (!starts_here[j] || starts[j] > tile_end) { past = true; continue; }
+					if (starts[j] > tile_start && starts[j] < tile_end) { mark(table, (uint32_t) (starts[j] - tile_start)); }
+					last_at_or_before_end = (uint32_t) (batch_base + (uint64_t) lane * runs_per_lane + j - first_run) + 1;   // increases with j
 				}
 				reached_past_tile = wave64::ballot(past) != 0;
 				batch_base += runs_per_batch;
 			} while (!reached_past_tile);
 
 			const uint32_t marks = rank(table, lane);
-			expand<UncompressedSize, staging::enabled, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			if (staging::dense_only && !dense) {
+				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+			}
+			else {
+				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			}
 
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));

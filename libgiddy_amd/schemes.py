@@ -176,6 +176,8 @@ def _patch_arguments(patch_values, patch_positions, num_patches, value_code, ind
     if isinstance(patch_positions, dict):
         arguments.update(_compressed_position_arguments(patch_positions, index_size, index_size, index_size))
         arguments["patch_positions_scratch"] = r.pointer(patch_positions["patch_positions_scratch"], "u%d" % (8 * index_size))
+        if "unsupported_patch_count" in patch_positions:   # optional: a zeroed device counter of patches no plain position can stand for
+            arguments["unsupported_patch_count"] = r.pointer(patch_positions["unsupported_patch_count"], "u32")
     else:
         arguments["patch_positions"] = r.const_pointer(patch_positions, "u%d" % (8 * index_size))
     return arguments
@@ -381,6 +383,8 @@ def compressed_indices_positions(positions, compressed, input_data_length, *, ou
     launch = {"positions": r.pointer(positions, "u%d" % (8 * output_index_size)),
               "input_data_length": r.size_type_by_index_size(input_index_size)(input_data_length)}
     launch.update(_compressed_position_arguments(compressed, output_index_size, input_index_size, run_length_size))
+    if "unsupported_patch_count" in compressed:
+        launch["unsupported_patch_count"] = r.pointer(compressed["unsupported_patch_count"], "u32")
     return _run(key_compressed_indices_positions(output_index_size, input_index_size, run_length_size),
                 {"input_data_length": r.size_t(input_data_length), "anchoring_period": r.size_t(compressed["anchoring_period"])},
                 launch, stream, device, limits, launch_config)

@@ -10,12 +10,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgiddy_oracle.so")
+# GIDDY_ORACLE_LIBRARY_PATH selects another build of the same restatement (the sanitizer build, tests/test_sanitizers.py)
+_SO = os.environ.get("GIDDY_ORACLE_LIBRARY_PATH") or os.path.join(_HERE, "libgiddy_oracle.so")
 _lib = None
 
 
 def build(force=False):
     src = os.path.join(_HERE, "giddy_oracle.c")
+    if os.environ.get("GIDDY_ORACLE_LIBRARY_PATH"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-C", _HERE, "-s", "libgiddy_oracle.so"])
     return _SO

@@ -43,3 +43,16 @@ def test_reference_caller_runs(mode):
     result = subprocess.run([path], capture_output=True, text=True, timeout=120)
     assert result.returncode == 0, result.stdout + result.stderr
     assert "Unexpected value" not in result.stderr
+
+
+def test_polynomial_model_functor_through_the_kernel_templates():
+    """tests/cpp/polynomial_model.hip: model::decompress and frame_of_reference::decompress instantiated with the reference's generic
+    parametric_model::polynomial<4, int, 3> (model_functors.hpp:45-74; unregistered there and here), against the functor on the host"""
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import __graft_entry__ as entry
+    if not os.path.exists(entry.POLYNOMIAL_MODEL):
+        entry.build_cpp_test_tools()
+    result = subprocess.run([entry.POLYNOMIAL_MODEL], capture_output=True, text=True, timeout=120)
+    assert result.returncode == 0 and "polynomial_model OK" in result.stdout, result.stdout + result.stderr

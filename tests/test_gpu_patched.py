@@ -394,6 +394,17 @@ def test_expanded_positions_of_runs_the_scatter_skips_are_all_ones():
         c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"], c["scatter_position_anchors"], 256, 4)
     assert np.array_equal(got, expect)
     assert (got == 0xFFFFFFFF).sum() > 0 and (got != 0xFFFFFFFF).sum() > 0
+    # ... and a caller who passes "unsupported_patch_count" (a zeroed device counter) learns how many patches that is
+    import torch
+    counter = torch.zeros(1, dtype=torch.int32, device="cuda")
+    schemes.compressed_indices_positions(out, dict(on_device, unsupported_patch_count=counter), len(positions), stream=g.stream())
+    torch.cuda.synchronize()
+    assert int(counter[0]) == int((got == 0xFFFFFFFF).sum())
+    counter.zero_()
+    clean = {k: (g.dev(v) if isinstance(v, np.ndarray) else v) for k, v in formats.compressed_indices(positions, np.zeros(len(positions), np.uint8), 256).items()}
+    schemes.compressed_indices_positions(out, dict(clean, unsupported_patch_count=counter), len(positions), stream=g.stream())
+    torch.cuda.synchronize()
+    assert int(counter[0]) == 0 and np.array_equal(g.host(out, np.dtype("u4"), len(positions)), positions.astype(np.uint32))
 
 
 def test_fused_decoder_with_compressed_positions_is_graph_capturable():

@@ -6,7 +6,11 @@ MI355X_MICROARCH.md §HBM prescribes: units are KiB; FETCH_SIZE counts half of a
 import csv
 import json
 import os
+import subprocess
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import kernel_sources
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 RAW = os.path.join(ROOT, "gpurun_out", "prof")
@@ -102,7 +106,7 @@ def main():
         traffic[workload] = {"kernel": kernel, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
                              "hbm_read_bytes": int(read_bytes), "hbm_write_bytes": int(write_bytes),
                              "hbm_bytes_per_launch": int(total), "algorithmic_bytes_per_launch": algorithmic.get(workload),
-                             "dispatches_averaged": min(nf, nw)}
+                             "dispatches_averaged": min(nf, nw), "kernel_sources_sha16": kernel_sources.fingerprint(kernel)}
         ratio = total / algorithmic[workload] if algorithmic.get(workload) else float("nan")
         lines.append("| %s | %s | %.0f | %.0f | %.3f | %.3f | %.3f | %.3f |" % (
             workload, kernel, fetch, write, read_bytes / 1e9, write_bytes / 1e9, (algorithmic.get(workload) or 0) / 1e9, ratio))
@@ -110,7 +114,11 @@ def main():
     for workload, t in traffic.items():
         by_kernel.setdefault(t["kernel"], t)   # bench.py looks traffic up by kernel name (first workload wins)
     with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
-        json.dump({"round": ROUND, "read_correction": read_factor, "write_correction": write_factor,
+        try:
+            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+        except (OSError, subprocess.CalledProcessError):
+            commit = "unknown"
+        json.dump({"round": ROUND, "measured_at_commit": commit, "read_correction": read_factor, "write_correction": write_factor,
                    "by_workload": traffic, **by_kernel}, f, indent=1)
     with open(os.path.join(OUT, ROUND + "_pmc_hbm.md"), "w") as f:
         f.write("# HBM traffic per launch from rocprofv3 PMC passes (%s)\n\n" % ROUND)

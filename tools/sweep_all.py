@@ -297,6 +297,55 @@ def run_scatter(O, E, IS, n):
     return ms, p * (O + 2 * E), bool((expect == target).all())
 
 
+_compressed = {}
+
+
+def _compressed_positions(O, IS, RLS, n):
+    """ascending patch positions (0.1 % of the column; as many as the input index type can count) and their compressed-indices form
+    (libgiddy_amd.formats, a host loop: cached per index-size combination), on the device"""
+    key = (O, IS, RLS, n)
+    if key not in _compressed:
+        from libgiddy_amd import formats
+        g = gen(O + IS)
+        p = min(max(1, n // 1000), (1 << (8 * min(IS, RLS))) - 1 if min(IS, RLS) < 4 else n)
+        idx = torch.sort(torch.randperm(min(n, (1 << (8 * O)) - 1 if O < 8 else n), generator=g, device=DEV)[:p])[0]
+        c = formats.compressed_indices(idx.cpu().numpy().astype(np.uint64), np.zeros(0, np.uint8), 1024 if p > 4096 else 64,
+                                       output_index_size=O, input_index_size=IS, run_length_size=RLS)
+        on_device = {k: (torch.from_numpy(v.view({1: np.uint8, 2: np.int16, 4: np.int32, 8: np.int64}[v.dtype.itemsize])).to(DEV) if isinstance(v, np.ndarray) and v.size else v)
+                     for k, v in c.items() if k != "data_to_scatter"}
+        nbytes = sum(v.numel() * v.element_size() for v in on_device.values() if isinstance(v, torch.Tensor))
+        _compressed[key] = (idx, on_device, nbytes)
+    return _compressed[key]
+
+
+def run_cis(O, E, IS, RLS, n):
+    idx, c, position_bytes = _compressed_positions(O, IS, RLS, n)
+    p = len(idx)
+    val = rand_bits(p, E, gen(E))
+    target = torch.zeros(n, dtype=INT[E], device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (target, val, c["scatter_position_run_lengths"], c["scatter_position_run_individual_offset_sizes"], c["scatter_position_run_baseline_values"],
+            c["scatter_position_run_offsets_start_pos"], c["scatter_position_offset_bytes"], c["scatter_position_anchors"], c["anchoring_period"],
+            c["num_scatter_position_runs"], p)
+    kw = dict(output_index_size=O, element_size=E, input_index_size=IS, run_length_size=RLS, stream=st)
+    cfg = schemes.compressed_indices_scatter(*args, **kw)
+    ms = timeit(lambda: schemes.compressed_indices_scatter(*args, launch_config=cfg, **kw))
+    expect = torch.zeros(n, dtype=INT[E], device=DEV)
+    expect[idx] = val
+    return ms, position_bytes + 2 * p * E, bool((expect == target).all())
+
+
+def run_cis_positions(O, IS, RLS, n):
+    idx, c, position_bytes = _compressed_positions(O, IS, RLS, n)
+    p = len(idx)
+    out = torch.zeros(p, dtype=INT[O], device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    kw = dict(output_index_size=O, input_index_size=IS, run_length_size=RLS, stream=st)
+    cfg = schemes.compressed_indices_positions(out, c, p, **kw)
+    ms = timeit(lambda: schemes.compressed_indices_positions(out, c, p, launch_config=cfg, **kw))
+    return ms, position_bytes + p * O, bool((unsigned(out, O) == idx).all()) if O < 8 else bool((out == idx).all())
+
+
 def main():
     log2n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else 27
     n = 1 << log2n
@@ -329,8 +378,12 @@ def main():
                 I, U, P, RI = num(key); res = run_rpe(I, U, P, "true" in key, RI, n)
             elif key.startswith("scatter::kernel_t"):
                 O, E, IS = num(key)[:3]; res = run_scatter(O, E, IS, n)
+            elif key.startswith("scatter::compressed_indices::positions"):
+                O, IS, RLS = num(key); res = run_cis_positions(O, IS, RLS, n)
+            elif key.startswith("scatter::compressed_indices::kernel_t"):
+                O, E, IS, RLS = num(key); res = run_cis(O, E, IS, RLS, n)
             else:
-                continue   # compressed-indices scatter: covered by the parity tests, not swept here
+                continue
         except torch.OutOfMemoryError:
             print("%-110s skipped (memory)" % key); continue
         ms, nbytes, ok = res
