@@ -1,0 +1,343 @@
+// Kernel wrappers for the device-side COMPRESSORS (an extension — the reference has decompressors only): registered in the
+// same factory under keys "compression::<scheme>::kernel_t<...>", driven through the same three calls (and the same C ABI) as
+// the decompressors.  enqueue_launch() enqueues every phase of the compressor on the caller's stream; the launch configuration
+// that resolve_launch_configuration() returns is that of the first phase, and is otherwise not used (each phase sizes its own
+// grid from the column's length).  Common argument-map keys:
+//   "input"                    const uint_t<UncompressedSize>*   the column (device)
+//   "length"                   uint_t<IndexSize>
+//   "tile_totals"              uint64_t*   scratch, scratch_entries(length) entries (variable-rate schemes)
+//   "unrepresentable_count"    unsigned*   optional, caller-zeroed: elements the requested widths cannot hold
+// Outputs are named as the decompressors' inputs are (libgiddy_amd/formats.py).  Sizes the caller cannot know in advance
+// (bytes, runs, patches) are left in a device scalar it names ("total_bytes" / "num_element_runs" / "num_patches": uint64_t*).
+#pragma once
+#include "giddy/kernel_wrappers/common.hpp"
+#include "giddy/kernels/compression/discard_zero_bytes_variable.hpp"
+#include "giddy/kernels/compression/elementwise.hpp"
+#include "giddy/kernels/compression/patches.hpp"
+#include "giddy/kernels/compression/runs.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace compression {
+
+/// uint64 entries of "tile_totals" scratch enough for any compressor of a column of `length` elements
+inline size_t scratch_entries(size_t length) { return 2 * (util::div_rounding_up(length, (size_t) tile_elements) + 2) + 2; }
+
+inline launch_configuration_t elementwise_launch(uint64_t length)
+{
+	return tile_launch(util::div_rounding_up(length, (uint64_t) threads_per_block * 4));
+}
+
+// ---- Delta -------------------------------------------------------------------------------------------------------------
+namespace delta {
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned C>
+launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	if (argument<size_t>(extra_arguments, "segment_length") == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	return elementwise_launch(argument<size_t>(extra_arguments, "length"));
+}
+
+template <unsigned I, unsigned U, unsigned C>
+void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<uint_t<C>*>(arguments, "compressed_input"), argument<uint_t<U>*>(arguments, "anchor_values"),
+		argument<const uint_t<U>*>(arguments, "input"), (size_type) argument<uint_t<I>>(arguments, "length"),
+		(size_type) argument<uint_t<I>>(arguments, "segment_length"),
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, unsigned U, unsigned C>
+const device_function_t kernel_t<I, U, C>::get_device_function() const { return reinterpret_cast<const void*>(compress<I, U, C>); }
+
+} // namespace delta
+
+// ---- fixed-width discard-zero-bytes --------------------------------------------------------------------------------------
+namespace discard_zero_bytes {
+namespace fixed_width {
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned C>
+launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	return elementwise_launch(argument<size_t>(extra_arguments, "length"));
+}
+
+template <unsigned I, unsigned U, unsigned C>
+void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<uint_t<C>*>(arguments, "compressed_input"), argument<const uint_t<U>*>(arguments, "input"),
+		(size_type_by_index_size<I>) argument<uint_t<I>>(arguments, "length"),
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, unsigned U, unsigned C>
+const device_function_t kernel_t<I, U, C>::get_device_function() const { return reinterpret_cast<const void*>(compress<I, U, C>); }
+
+} // namespace fixed_width
+
+// ---- variable-width discard-zero-bytes -------------------------------------------------------------------------------------
+namespace variable_width {
+
+/// also: "compressed_data" uint8_t* (room for length * UncompressedSize bytes at worst), "packed_element_sizes", "position_anchors",
+/// "segment_length", "min_represented_element_size" (unsigned), "bits_per_element_size" (unsigned), "total_bytes" uint64_t* (optional)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned CS>
+launch_configuration_t kernel_t<I, U, CS>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	if (argument<size_t>(extra_arguments, "segment_length") == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), (size_t) tile_elements));
+}
+
+template <unsigned I, unsigned U, unsigned CS>
+void kernel_t<I, U, CS>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	auto input      = argument<const uint_t<U>*>(arguments, "input");
+	auto length     = (size_type) argument<uint_t<I>>(arguments, "length");
+	auto segment    = (size_type) argument<uint_t<I>>(arguments, "segment_length");
+	auto min_size   = argument<native_word_t>(arguments, "min_represented_element_size");
+	auto bits       = argument<native_word_t>(arguments, "bits_per_element_size");
+	auto totals     = argument<uint64_t*>(arguments, "tile_totals");
+	if (bits == 0 || bits > 8 * CS) { throw std::invalid_argument("The size fields must be between 1 bit and a container wide"); }
+	if (min_size > U) { throw std::invalid_argument("The minimum represented size exceeds the element size"); }
+	if (length == 0) { return; }
+	const uint64_t per = (8 * CS) / bits, num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) threads_per_block * per);
+	const auto config = tile_launch(num_tiles);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(count_bytes<I, U, CS>), stream, config, totals, input, length, min_size, bits);
+	enqueue_exclusive_offsets(stream, totals, num_tiles, optional_argument<uint64_t*>(arguments, "total_bytes").value_or(nullptr));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(compress<I, U, CS>), stream, config,
+		argument<uint8_t*>(arguments, "compressed_data"), argument<uint_t<CS>*>(arguments, "packed_element_sizes"),
+		argument<uint_t<I>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length, min_size, bits,
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, unsigned U, unsigned CS>
+const device_function_t kernel_t<I, U, CS>::get_device_function() const { return reinterpret_cast<const void*>(compress<I, U, CS>); }
+
+} // namespace variable_width
+} // namespace discard_zero_bytes
+
+// ---- Frame of Reference, a constant model per segment ----------------------------------------------------------------------
+namespace frame_of_reference {
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, typename U, typename C>
+launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
+	if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), segment_length));
+}
+
+template <unsigned I, typename U, typename C>
+void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<C*>(arguments, "compressed_input"), reinterpret_cast<cuda::array<int, 1>*>(argument<int*>(arguments, "segment_model_coefficients")),
+		argument<const U*>(arguments, "input"), (size_type) argument<uint_t<I>>(arguments, "length"),
+		(size_type) argument<uint_t<I>>(arguments, "segment_length"),
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, typename U, typename C>
+const device_function_t kernel_t<I, U, C>::get_device_function() const { return reinterpret_cast<const void*>(compress_with_constant_model<I, U, C>); }
+
+} // namespace frame_of_reference
+
+// ---- dictionary encoding ---------------------------------------------------------------------------------------------------
+namespace dictionary {
+
+/// "dictionary_entries" (sorted ascending, distinct), "num_dictionary_entries" (size_type of the key width)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned D>
+launch_configuration_t kernel_t<I, U, D>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	return elementwise_launch(argument<size_t>(extra_arguments, "length"));
+}
+
+template <unsigned I, unsigned U, unsigned D>
+void kernel_t<I, U, D>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<uint_t<D>*>(arguments, "compressed_input"), argument<const uint_t<U>*>(arguments, "input"),
+		argument<const uint_t<U>*>(arguments, "dictionary_entries"), (size_type_by_index_size<I>) argument<uint_t<I>>(arguments, "length"),
+		(size_type_by_index_size<D>) argument<size_type_by_index_size<D>>(arguments, "num_dictionary_entries"),
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, unsigned U, unsigned D>
+const device_function_t kernel_t<I, U, D>::get_device_function() const { return reinterpret_cast<const void*>(encode<I, U, D>); }
+
+} // namespace dictionary
+
+// ---- run-length and run-position encoding ------------------------------------------------------------------------------------
+namespace run_length_encoding {
+
+/// outputs "run_data", "run_lengths", "position_anchors", "intra_run_anchor_offsets" (room for `length` runs at worst),
+/// "num_element_runs" uint64_t* (device scalar, written); scratch "tile_totals" and "run_starts_scratch" (uint_t<IndexSize>*, `length` entries at worst)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = IndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned RL, unsigned RI>
+launch_configuration_t kernel_t<I, U, RL, RI>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	if (argument<size_t>(extra_arguments, "segment_length") == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), (size_t) tile_elements));
+}
+
+template <unsigned I, unsigned U, unsigned RL, unsigned RI>
+void kernel_t<I, U, RL, RI>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	auto input     = argument<const uint_t<U>*>(arguments, "input");
+	auto length    = (size_type) argument<uint_t<I>>(arguments, "length");
+	auto segment   = (size_type) argument<uint_t<I>>(arguments, "segment_length");
+	auto totals    = argument<uint64_t*>(arguments, "tile_totals");
+	auto starts    = argument<uint_t<I>*>(arguments, "run_starts_scratch");
+	auto num_runs  = argument<uint64_t*>(arguments, "num_element_runs");
+	if (length == 0) { return; }
+	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) tile_elements);
+	uint64_t* run_totals = totals + num_tiles + 2;   // the run-level pass's own scratch, behind the element-level one
+	const uint64_t max_run_length = ~(uint64_t) 0 >> (64 - 8 * RL);   // the largest value a length field holds
+	const auto config = tile_launch(num_tiles);
+	// element level: where the natural runs start
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_run_starts<I, U>), stream, config, totals, input, length);
+	enqueue_exclusive_offsets(stream, totals, num_tiles);   // totals[num_tiles] = the number of natural runs
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, I, false, RI>), stream, config,
+		starts, static_cast<uint_t<U>*>(nullptr), static_cast<uint_t<I>*>(nullptr), static_cast<uint_t<RI>*>(nullptr),
+		input, static_cast<const uint64_t*>(totals), segment, length);
+	// run level: runs longer than a length field holds are cut into pieces
+	const uint64_t* natural_runs = totals + num_tiles;
+	const uint64_t num_run_tiles = num_tiles;   // (at most `length` natural runs; tiles beyond their number count nothing)
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_pieces<I>), stream, config, run_totals, static_cast<const uint_t<I>*>(starts),
+		natural_runs, num_run_tiles, length, max_run_length);
+	enqueue_exclusive_offsets(stream, run_totals, num_run_tiles, num_runs);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_pieces<I, U, RL, RI>), stream, config,
+		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
+		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"),
+		input, static_cast<const uint_t<I>*>(starts), natural_runs, static_cast<const uint64_t*>(run_totals), num_run_tiles, segment, length, max_run_length);
+}
+
+template <unsigned I, unsigned U, unsigned RL, unsigned RI>
+const device_function_t kernel_t<I, U, RL, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::write_pieces<I, U, RL, RI>); }
+
+} // namespace run_length_encoding
+
+namespace run_position_encoding {
+
+/// outputs "run_data", "run_start_positions", "position_anchors", "num_element_runs" uint64_t*; scratch "tile_totals"
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = IndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
+launch_configuration_t kernel_t<I, U, P, R, RI>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
+	if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	if (R && P < 8 && (segment_length - 1) > (~(uint64_t) 0 >> (64 - 8 * (P < 8 ? P : 7)))) { throw std::invalid_argument("The segment is too long for relative positions of this width"); }
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), (size_t) tile_elements));
+}
+
+template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
+void kernel_t<I, U, P, R, RI>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	auto input   = argument<const uint_t<U>*>(arguments, "input");
+	auto length  = (size_type) argument<uint_t<I>>(arguments, "length");
+	auto segment = (size_type) argument<uint_t<I>>(arguments, "segment_length");
+	auto totals  = argument<uint64_t*>(arguments, "tile_totals");
+	if (length == 0) { return; }
+	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) tile_elements);
+	const auto config = tile_launch(num_tiles);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_run_starts<I, U>), stream, config, totals, input, length);
+	enqueue_exclusive_offsets(stream, totals, num_tiles, argument<uint64_t*>(arguments, "num_element_runs"));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>), stream, config,
+		static_cast<uint_t<I>*>(nullptr), argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
+		argument<uint_t<RI>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length);
+}
+
+template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
+const device_function_t kernel_t<I, U, P, R, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>); }
+
+} // namespace run_position_encoding
+
+// ---- patches: where a decoded column differs from the true one ---------------------------------------------------------------
+namespace patches {
+
+/// "decoded", "truth" (const uint_t<ElementSize>*), outputs "patch_positions" (ascending), "patch_values" (room for `length`
+/// at worst), "num_patches" uint64_t*; scratch "tile_totals"
+template <unsigned IndexSize, unsigned ElementSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned E>
+launch_configuration_t kernel_t<I, E>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), (size_t) tile_elements));
+}
+
+template <unsigned I, unsigned E>
+void kernel_t<I, E>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	auto decoded = argument<const uint_t<E>*>(arguments, "decoded");
+	auto truth   = argument<const uint_t<E>*>(arguments, "truth");
+	auto length  = (size_type) argument<uint_t<I>>(arguments, "length");
+	auto totals  = argument<uint64_t*>(arguments, "tile_totals");
+	if (length == 0) { return; }
+	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) tile_elements);
+	const auto config = tile_launch(num_tiles);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(count_differences<I, E>), stream, config, totals, decoded, truth, length);
+	enqueue_exclusive_offsets(stream, totals, num_tiles, argument<uint64_t*>(arguments, "num_patches"));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(write_differences<I, E>), stream, config,
+		argument<uint_t<I>*>(arguments, "patch_positions"), argument<uint_t<E>*>(arguments, "patch_values"), decoded, truth,
+		static_cast<const uint64_t*>(totals), length);
+}
+
+template <unsigned I, unsigned E>
+const device_function_t kernel_t<I, E>::get_device_function() const { return reinterpret_cast<const void*>(write_differences<I, E>); }
+
+} // namespace patches
+
+} // namespace compression
+} // namespace kernels
+} // namespace cuda

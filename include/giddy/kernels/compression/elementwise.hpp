@@ -1,0 +1,157 @@
+// The fixed-rate compressors: Delta, fixed-width discard-zero-bytes, Frame of Reference with a constant model per
+// segment, dictionary ENCODING against a given sorted dictionary.  One pass each; what cannot be represented in the
+// requested width is counted in `*unrepresentable` (caller-zeroed, may be null) and stored truncated.
+// Formats: libgiddy_amd/formats.py (delta, discard_zero_bytes_fixed, frame_of_reference(model="constant"), dictionary).
+#pragma once
+#include "giddy/array.hpp"
+#include "giddy/kernels/compression/common.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace compression {
+
+namespace delta {
+
+/// compressed[i] = input[i] - input[i - 1] (wrapping; compressed[0] = 0), anchor_values[s] = input[s * L - 1] (anchor_values[0] =
+/// input[0]): what decompression::delta::decompress turns back into `input` (delta.cuh:5-19: the anchor is the value BEFORE the segment)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void __launch_bounds__(threads_per_block) compress(
+	uint_t<CompressedSize>*          __restrict__  compressed_output,
+	uint_t<UncompressedSize>*        __restrict__  anchor_values,
+	const uint_t<UncompressedSize>*  __restrict__  input,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length,
+	native_word_t*                   __restrict__  unrepresentable)
+{
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	const uint64_t n = length, L = segment_length;
+	unsigned bad = 0;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t) gridDim.x * blockDim.x) {
+		const U previous = input[i == 0 ? 0 : i - 1];
+		const U difference = (U) (input[i] - previous);
+		compressed_output[i] = (C) difference;
+		if ((U) (C) difference != difference) { bad++; }
+		if (i % L == 0) { anchor_values[i / L] = previous; }
+	}
+	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
+}
+
+} // namespace delta
+
+namespace discard_zero_bytes {
+namespace fixed_width {
+
+/// compressed[i] = the low CompressedSize bytes of input[i]
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void __launch_bounds__(threads_per_block) compress(
+	uint_t<CompressedSize>*          __restrict__  compressed_output,
+	const uint_t<UncompressedSize>*  __restrict__  input,
+	size_type_by_index_size<IndexSize>             length,
+	native_word_t*                   __restrict__  unrepresentable)
+{
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	unsigned bad = 0;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (uint64_t) gridDim.x * blockDim.x) {
+		const U value = input[i];
+		compressed_output[i] = (C) value;
+		if ((U) (C) value != value) { bad++; }
+	}
+	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
+}
+
+} // namespace fixed_width
+} // namespace discard_zero_bytes
+
+namespace frame_of_reference {
+
+/// One workgroup per segment (segments at grid stride): the segment's reference value = the midpoint of its minimum and maximum
+/// (floor of the mean of the two, as formats.frame_of_reference(model="constant") has it), then the signed offsets from it.
+/// Uncompressed, Compressed: signed types, as in the decompressor's registrations (frame_of_reference.cu:132-142); coefficients int32.
+template <unsigned IndexSize, typename Uncompressed, typename Compressed>
+__global__ void __launch_bounds__(threads_per_block) compress_with_constant_model(
+	Compressed*          __restrict__  compressed_output,
+	cuda::array<int, 1>* __restrict__  segment_model_coefficients,
+	const Uncompressed*  __restrict__  input,
+	size_type_by_index_size<IndexSize> length,
+	size_type_by_index_size<IndexSize> segment_length,
+	native_word_t*       __restrict__  unrepresentable)
+{
+	__shared__ int64_t low[waves_per_block], high[waves_per_block];
+	const uint64_t n = length, L = segment_length, num_segments = (n + L - 1) / L;
+	unsigned bad = 0;
+	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+		const uint64_t start = s * L, end = start + L < n ? start + L : n;
+		int64_t lowest = INT64_MAX, highest = INT64_MIN;
+		for (uint64_t i = start + threadIdx.x; i < end; i += blockDim.x) {
+			const int64_t v = (int64_t) input[i];
+			lowest = v < lowest ? v : lowest; highest = v > highest ? v : highest;
+		}
+		#pragma unroll
+		for (int offset = 32; offset >= 1; offset >>= 1) {
+			const int64_t other_low = __shfl_xor(lowest, offset, 64), other_high = __shfl_xor(highest, offset, 64);
+			lowest = other_low < lowest ? other_low : lowest; highest = other_high > highest ? other_high : highest;
+		}
+		__syncthreads();
+		if (wave64::lane_id() == 0) { low[wave64::index_in_block()] = lowest; high[wave64::index_in_block()] = highest; }
+		__syncthreads();
+		for (unsigned w = 0; w < wave64::per_block() && w < waves_per_block; w++) {
+			lowest = low[w] < lowest ? low[w] : lowest; highest = high[w] > highest ? high[w] : highest;
+		}
+		const int reference = (int) ((lowest + highest) >> 1);   // floor((min + max) / 2), then narrowed to int32 as the writer does
+		if (threadIdx.x == 0) { segment_model_coefficients[s][0] = reference; }
+		for (uint64_t i = start + threadIdx.x; i < end; i += blockDim.x) {
+			const int64_t offset = (int64_t) input[i] - (int64_t) reference;
+			compressed_output[i] = (Compressed) offset;
+			if ((int64_t) (Compressed) offset != offset) { bad++; }
+		}
+	}
+	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
+}
+
+} // namespace frame_of_reference
+
+namespace dictionary {
+
+/// compressed[i] = the index of input[i] in `dictionary_entries`, which is SORTED ascending and distinct (what
+/// formats.dictionary builds with numpy.unique): a binary search per element.  A value that is not in the dictionary is counted
+/// in `*unrepresentable` and gets the index of the first entry not below it.
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+__global__ void __launch_bounds__(threads_per_block) encode(
+	uint_t<DictionaryIndexSize>*     __restrict__  compressed_output,
+	const uint_t<UncompressedSize>*  __restrict__  input,
+	const uint_t<UncompressedSize>*  __restrict__  dictionary_entries,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<DictionaryIndexSize>   num_dictionary_entries,
+	native_word_t*                   __restrict__  unrepresentable)
+{
+	using U = uint_t<UncompressedSize>;
+	enum : unsigned { staged_capacity = 16384 / sizeof(U) };   // dictionaries of up to 16 KiB are searched in LDS
+	__shared__ U staged[staged_capacity];
+	const uint64_t entries = num_dictionary_entries;
+	const U* table = dictionary_entries;
+	if (entries <= staged_capacity) {   // (workgroup-uniform)
+		for (unsigned i = threadIdx.x; i < entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
+		__syncthreads();
+		table = staged;
+	}
+	unsigned bad = 0;
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (uint64_t) gridDim.x * blockDim.x) {
+		const U value = input[i];
+		uint64_t lo = 0, hi = entries;   // first entry >= value
+		while (lo < hi) {
+			const uint64_t mid = (lo + hi) >> 1;
+			if (table[mid] < value) { lo = mid + 1; } else { hi = mid; }
+		}
+		compressed_output[i] = (uint_t<DictionaryIndexSize>) lo;
+		if (lo >= entries || table[lo] != value) { bad++; }
+	}
+	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
+}
+
+} // namespace dictionary
+
+} // namespace compression
+} // namespace kernels
+} // namespace cuda

@@ -1,0 +1,201 @@
+"""Device-side compressors: columns that are resident on the GPU put into the formats the decompression kernels read,
+without a host pass (an extension — the reference ships decompressors only, README.md:128-130 "Issue #3").
+
+Same signatures and the same output dictionaries as the numpy writers of libgiddy_amd.formats — the parity target: these
+functions' outputs equal that module's byte for byte (tests/test_gpu_compressors.py) — but inputs and outputs are torch
+tensors on the device, and all computing is done by the library's HIP kernels through the C ABI (factory keys
+"compression::<scheme>::kernel_t<...>", include/giddy/kernel_wrappers/compression/compressors.hpp).  torch allocates the
+output and scratch buffers and reads back the few scalars that size them (bytes, runs, patches) — plumbing only.
+Tensors stand for the unsigned bits they hold (torch has few unsigned dtypes): a uint64 column is an int64 tensor.
+"""
+import numpy as np
+import torch
+
+from . import registered as r
+from . import schemes
+
+_SIGNED = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
+_NAMES = {1: "signed char", 2: "short", 4: "int", 8: "long"}
+TILE = 4096                                   # elements per tile of the variable-rate compressors (compression/common.hpp)
+
+
+class Unrepresentable(ValueError):
+    """some elements do not fit the requested widths (formats.py raises ValueError for the same columns)"""
+
+
+def _size(x):
+    return np.dtype(x).itemsize if not isinstance(x, int) else x
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _scratch(n, device):
+    return torch.empty(2 * (-(-n // TILE) + 2) + 2, dtype=torch.int64, device=device)
+
+
+def _launch(key, resolve, launch, counter=None, what="elements"):
+    kernel = schemes.kernel(key)
+    config = kernel.resolve_launch_configuration(r.CURRENT_DEVICE, resolve)
+    kernel.enqueue_launch(_stream(), config, launch)
+    if counter is not None:
+        bad = int(counter[0])
+        if bad:
+            raise Unrepresentable("%d %s do not fit the requested widths" % (bad, what))
+
+
+def _counter(device):
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def delta(column, segment_length, compressed_dtype=np.uint16, index_size=4):
+    n, usize, csize = column.numel(), column.element_size(), _size(compressed_dtype)
+    out = {"compressed_input": torch.empty(n, dtype=_SIGNED[csize], device=column.device),
+           "anchor_values": torch.empty(-(-n // segment_length), dtype=column.dtype, device=column.device), "length": n, "segment_length": segment_length}
+    counter = _counter(column.device)
+    if n:
+        _launch("compression::delta::kernel_t<%du, %du, %du>" % (index_size, usize, csize),
+                {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
+                {"compressed_input": r.pointer(out["compressed_input"], "u%d" % (8 * csize)), "anchor_values": r.pointer(out["anchor_values"], "u%d" % (8 * usize)),
+                 "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
+                 "unrepresentable_count": r.pointer(counter, "u32")}, counter, "deltas")
+    return out
+
+
+def discard_zero_bytes_fixed(column, compressed_dtype, index_size=4):
+    n, usize, csize = column.numel(), column.element_size(), _size(compressed_dtype)
+    out = {"compressed_input": torch.empty(n, dtype=_SIGNED[csize], device=column.device), "length": n}
+    counter = _counter(column.device)
+    if n:
+        _launch("compression::discard_zero_bytes::fixed_width::kernel_t<%du, %du, %du>" % (index_size, usize, csize), {"length": r.size_t(n)},
+                {"compressed_input": r.pointer(out["compressed_input"], "u%d" % (8 * csize)), "input": r.const_pointer(column, "u%d" % (8 * usize)),
+                 "length": r.uint_t(index_size)(n), "unrepresentable_count": r.pointer(counter, "u32")}, counter)
+    return out
+
+
+def discard_zero_bytes_variable(column, segment_length, min_represented_element_size=1, bits_per_element_size=2, container_dtype=np.uint32, index_size=4):
+    n, usize, csize = column.numel(), column.element_size(), _size(container_dtype)
+    per = 8 * csize // bits_per_element_size
+    device = column.device
+    data = torch.empty(max(n * min(usize, min_represented_element_size + (1 << bits_per_element_size) - 1), 1), dtype=torch.uint8, device=device)
+    out = {"packed_element_sizes": torch.empty(-(-n // per), dtype=_SIGNED[csize], device=device),
+           "position_anchors": torch.empty(-(-n // segment_length), dtype=_SIGNED[index_size], device=device), "segment_length": segment_length, "length": n,
+           "min_represented_element_size": min_represented_element_size, "bits_per_element_size": bits_per_element_size}
+    counter, total = _counter(device), torch.zeros(1, dtype=torch.int64, device=device)
+    scratch = torch.empty(-(-n // (256 * per)) + 4, dtype=torch.int64, device=device)
+    if n:
+        _launch("compression::discard_zero_bytes::variable_width::kernel_t<%du, %du, %du>" % (index_size, usize, csize),
+                {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
+                {"compressed_data": r.pointer(data, "u8"), "packed_element_sizes": r.pointer(out["packed_element_sizes"], "u%d" % (8 * csize)),
+                 "position_anchors": r.pointer(out["position_anchors"], "u%d" % (8 * index_size)), "input": r.const_pointer(column, "u%d" % (8 * usize)),
+                 "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
+                 "min_represented_element_size": r.uint_t(4)(min_represented_element_size), "bits_per_element_size": r.uint_t(4)(bits_per_element_size),
+                 "tile_totals": r.pointer(scratch, "u64"), "total_bytes": r.pointer(total, "u64"), "unrepresentable_count": r.pointer(counter, "u32")}, counter)
+    out["compressed_data"] = data[: int(total[0])]
+    return out
+
+
+def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model="constant", index_size=4):
+    """a constant model per segment (the midpoint of the segment's extremes); `column`: a SIGNED tensor (int16 / int32)"""
+    if model != "constant":
+        raise NotImplementedError("the device-side writer fits constant models; formats.frame_of_reference fits lines with numpy.polyfit, in floating point")
+    n, usize, csize = column.numel(), column.element_size(), _size(compressed_dtype)
+    nseg = -(-n // segment_length)
+    out = {"compressed_input": torch.empty(n, dtype=_SIGNED[csize], device=column.device),
+           "segment_model_coefficients": torch.empty((nseg, 1), dtype=torch.int32, device=column.device), "length": n, "segment_length": segment_length}
+    counter = _counter(column.device)
+    if n:
+        _launch("compression::frame_of_reference::kernel_t<%du, %s, %s>" % (index_size, _NAMES[usize], _NAMES[csize]),
+                {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
+                {"compressed_input": r.pointer(out["compressed_input"], "i%d" % (8 * csize)), "segment_model_coefficients": r.pointer(out["segment_model_coefficients"], "i32"),
+                 "input": r.const_pointer(column, "i%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
+                 "unrepresentable_count": r.pointer(counter, "u32")}, counter, "offsets")
+    return out
+
+
+def dictionary(column, key_dtype=np.uint8, entries=None, index_size=4):
+    """`entries`: the dictionary, sorted ascending and distinct, on the device.  Not given: the column's distinct values, by
+    torch.unique over the column's unsigned order (the one step of this module the library's kernels do not do: a device-wide sort)."""
+    n, usize, ksize = column.numel(), column.element_size(), _size(key_dtype)
+    if entries is None:
+        if usize == 8:   # unsigned order of 64-bit values: flip the sign bit, sort signed, flip back
+            flipped = torch.unique(column ^ torch.iinfo(torch.int64).min)
+            entries = flipped ^ torch.iinfo(torch.int64).min
+        else:
+            wide = torch.unique(column.to(torch.int64) & ((1 << (8 * usize)) - 1))
+            entries = wide.to(_SIGNED[usize]) if usize < 4 else (wide - ((wide >> 31) << 32)).to(torch.int32)
+    if entries.numel() > (1 << (8 * ksize)):
+        raise Unrepresentable("too many distinct values for the key type")
+    out = {"compressed_input": torch.empty(n, dtype=_SIGNED[ksize], device=column.device), "dictionary_entries": entries, "length": n,
+           "num_dictionary_entries": entries.numel()}
+    counter = _counter(column.device)
+    if n:
+        _launch("compression::dictionary::kernel_t<%du, %du, %du>" % (index_size, usize, ksize), {"length": r.size_t(n)},
+                {"compressed_input": r.pointer(out["compressed_input"], "u%d" % (8 * ksize)), "input": r.const_pointer(column, "u%d" % (8 * usize)),
+                 "dictionary_entries": r.const_pointer(entries, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n),
+                 "num_dictionary_entries": r.size_type_by_index_size(ksize)(entries.numel()), "unrepresentable_count": r.pointer(counter, "u32")},
+                counter, "values (not in the dictionary)")
+    return out
+
+
+def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None):
+    """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case)"""
+    n, usize, lsize = column.numel(), column.element_size(), _size(run_length_dtype)
+    device = column.device
+    capacity = capacity or max(n, 1)
+    nseg = -(-n // segment_length)
+    buffers = {"run_data": torch.empty(capacity, dtype=column.dtype, device=device), "run_lengths": torch.empty(capacity, dtype=_SIGNED[lsize], device=device),
+               "position_anchors": torch.empty(nseg, dtype=_SIGNED[index_size], device=device), "intra_run_anchor_offsets": torch.empty(nseg, dtype=_SIGNED[lsize], device=device)}
+    runs = torch.zeros(1, dtype=torch.int64, device=device)
+    starts = torch.empty(capacity, dtype=_SIGNED[index_size], device=device)
+    if n:
+        _launch("compression::run_length_encoding::kernel_t<%du, %du, %du, %du>" % (index_size, usize, lsize, index_size),
+                {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
+                {"run_data": r.pointer(buffers["run_data"], "u%d" % (8 * usize)), "run_lengths": r.pointer(buffers["run_lengths"], "u%d" % (8 * lsize)),
+                 "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
+                 "intra_run_anchor_offsets": r.pointer(buffers["intra_run_anchor_offsets"], "u%d" % (8 * lsize)),
+                 "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "run_starts_scratch": r.pointer(starts, "u%d" % (8 * index_size)),
+                 "num_element_runs": r.pointer(runs, "u64")})
+    count = int(runs[0])
+    return {"run_data": buffers["run_data"][:count], "run_lengths": buffers["run_lengths"][:count], "position_anchors": buffers["position_anchors"],
+            "intra_run_anchor_offsets": buffers["intra_run_anchor_offsets"], "segment_length": segment_length, "num_segments": nseg,
+            "num_element_runs": count, "length": n}
+
+
+def run_position_encoding(column, segment_length, position_dtype=np.uint16, relative=True, index_size=4, capacity=None):
+    n, usize, psize = column.numel(), column.element_size(), _size(position_dtype)
+    device = column.device
+    capacity = capacity or max(n, 1)
+    nseg = -(-n // segment_length)
+    buffers = {"run_data": torch.empty(capacity, dtype=column.dtype, device=device), "run_start_positions": torch.empty(capacity, dtype=_SIGNED[psize], device=device),
+               "position_anchors": torch.empty(nseg, dtype=_SIGNED[index_size], device=device)}
+    runs = torch.zeros(1, dtype=torch.int64, device=device)
+    if n:
+        _launch("compression::run_position_encoding::kernel_t<%du, %du, %du, %s, %du>" % (index_size, usize, psize, "true" if relative else "false", index_size),
+                {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
+                {"run_data": r.pointer(buffers["run_data"], "u%d" % (8 * usize)), "run_start_positions": r.pointer(buffers["run_start_positions"], "u%d" % (8 * psize)),
+                 "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
+                 "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64")})
+    count = int(runs[0])
+    return {"run_data": buffers["run_data"][:count], "run_start_positions": buffers["run_start_positions"][:count], "position_anchors": buffers["position_anchors"],
+            "segment_length": segment_length, "num_anchors": nseg, "num_element_runs": count, "length": n}
+
+
+def patches(decoded, truth, index_size=4, capacity=None):
+    """positions (ascending) where `decoded` differs from `truth`, and the true values there"""
+    n, esize = truth.numel(), truth.element_size()
+    device = truth.device
+    capacity = capacity or max(n, 1)
+    positions = torch.empty(capacity, dtype=_SIGNED[index_size], device=device)
+    values = torch.empty(capacity, dtype=truth.dtype, device=device)
+    count = torch.zeros(1, dtype=torch.int64, device=device)
+    if n:
+        _launch("compression::patches::kernel_t<%du, %du>" % (index_size, esize), {"length": r.size_t(n)},
+                {"patch_positions": r.pointer(positions, "u%d" % (8 * index_size)), "patch_values": r.pointer(values, "u%d" % (8 * esize)),
+                 "decoded": r.const_pointer(decoded, "u%d" % (8 * esize)), "truth": r.const_pointer(truth, "u%d" % (8 * esize)),
+                 "length": r.uint_t(index_size)(n), "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_patches": r.pointer(count, "u64")})
+    k = int(count[0])
+    return {"indices": positions[:k], "data": values[:k], "data_length": k}

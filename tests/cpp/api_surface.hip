@@ -122,14 +122,16 @@ int main()
 	// ---- factory + type-erased path -----------------------------------------------------------------------------
 	{
 		auto& factory = registered::kernel_t::getSubclassFactory();
-		size_t reference_registrations = 0, fused_patch_extensions = 0, position_expansions = 0;
+		size_t reference_registrations = 0, fused_patch_extensions = 0, position_expansions = 0, compressors = 0;
 		for (const auto& entry : factory.getInsantiators()) {
-			(entry.first.find("::patched::") != std::string::npos ? fused_patch_extensions :
+			(entry.first.rfind("compression::", 0) == 0 ? compressors :
+			 entry.first.find("::patched::") != std::string::npos ? fused_patch_extensions :
 			 entry.first.find("::positions::") != std::string::npos ? position_expansions : reference_registrations)++;
 		}
 		CHECK(reference_registrations == 163);
 		CHECK(fused_patch_extensions == 12 + 20 + 8 + 5 + 12);
 		CHECK(position_expansions == 8);
+		CHECK(compressors == 91);
 		const char* key = "decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
 		CHECK(factory.canProduce(key));
 		auto k = registered::kernel_t::produceSubclass(key);

@@ -37,7 +37,10 @@ def test_factory_has_the_163_reference_registrations():
     # ... and so is the stand-alone expansion of compressed patch positions the fused wrappers use
     expansions = [k for k in all_keys if "::positions::" in k]
     assert sorted(expansions) == sorted(schemes.key_compressed_indices_positions(o, i) for o in (4, 8) for i in (1, 2, 4, 8))
-    keys = [k for k in all_keys if "::patched::" not in k and "::positions::" not in k]
+    # ... and the device-side compressors (the reference has none), under "compression::..."
+    compressors = [k for k in all_keys if k.startswith("compression::")]
+    assert len(compressors) == 91
+    keys = [k for k in all_keys if "::patched::" not in k and "::positions::" not in k and not k.startswith("compression::")]
     assert len(keys) == 163
     counts = {}
     for k in keys:

@@ -1,0 +1,199 @@
+"""-m gpu: the device-side compressors (libgiddy_amd.compressors -> C ABI -> HIP kernels under
+include/giddy/kernels/compression/) against the numpy format writers (libgiddy_amd.formats): every output array equal BYTE FOR
+BYTE, every size equal; then the round trip — what the library compressed, the library's decoders turn back into the column."""
+import numpy as np
+import pytest
+
+import cases
+from libgiddy_amd import formats
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+SIGNED = {1: np.int8, 2: np.int16, 4: np.int32, 8: np.int64}
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+
+
+def dev(a):
+    """numpy array -> device tensor holding the same bits (unsigned dtypes as the signed ones of their width)"""
+    a = np.ascontiguousarray(a)
+    return torch.from_numpy(a.view(SIGNED[a.dtype.itemsize]) if a.dtype.kind == "u" else a).cuda()
+
+
+def same(got, want, name):
+    assert set(want) - {"data_to_scatter"} <= set(got), (name, set(want) - set(got))
+    for key, expected in want.items():
+        if isinstance(expected, np.ndarray):
+            actual = got[key].cpu().numpy().reshape(-1)
+            assert actual.dtype.itemsize == expected.dtype.itemsize, (name, key, actual.dtype, expected.dtype)
+            actual = actual.view(expected.dtype)
+            assert actual.shape == expected.reshape(-1).shape, (name, key, actual.shape, expected.shape)
+            bad = np.flatnonzero(actual != expected.reshape(-1))
+            assert len(bad) == 0, (name, key, bad[:5], actual[bad[:5]], expected.reshape(-1)[bad[:5]])
+        else:
+            assert int(got[key]) == int(expected), (name, key, got[key], expected)
+
+
+SHAPES = [(1, 1), (1, 64), (100, 7), (4096, 4096), (4097, 1024), (70001, 1000), (300007, 4096), (1 << 20, 1 << 18)]
+
+
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
+@pytest.mark.parametrize("index_size", [4, 8])
+def test_delta(usize, csize, index_size):
+    from libgiddy_amd import compressors, schemes
+    ud = np.dtype("u%d" % usize)
+    for n, L in SHAPES:
+        rng = cases.rng(n + usize + csize)
+        steps = rng.integers(0, 1 << (8 * csize), size=n, dtype=np.uint64)
+        column = (np.cumsum(steps) + np.uint64(rng.integers(0, 1 << 20))).astype(ud)   # (wraps for narrow columns: deltas are modular)
+        want = formats.delta(column, L, np.dtype("u%d" % csize))
+        got = compressors.delta(dev(column), L, np.dtype("u%d" % csize), index_size=index_size)
+        same(got, want, ("delta", n, L))
+        out = torch.empty(n, dtype=got["anchor_values"].dtype, device="cuda")
+        schemes.delta(out, got["compressed_input"], got["anchor_values"], n, L, uncompressed_size=usize, compressed_size=csize, index_size=index_size,
+                      stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy().view(ud) == column).all()
+    with pytest.raises(compressors.Unrepresentable):
+        compressors.delta(dev(np.array([0, 1 << (8 * csize)], dtype=ud)), 2, np.dtype("u%d" % csize), index_size=index_size)
+
+
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 2), (8, 1), (8, 4)])
+def test_discard_zero_bytes_fixed(usize, csize):
+    from libgiddy_amd import compressors
+    for n in (1, 1000, 300007):
+        column = cases.rng(n).integers(0, 1 << (8 * csize), size=n, dtype=np.uint64).astype("u%d" % usize)
+        same(compressors.discard_zero_bytes_fixed(dev(column), np.dtype("u%d" % csize)), formats.discard_zero_bytes_fixed(column, np.dtype("u%d" % csize)), ("dzbf", n))
+    with pytest.raises(compressors.Unrepresentable):
+        compressors.discard_zero_bytes_fixed(dev(np.array([1 << (8 * csize)], dtype="u%d" % usize)), np.dtype("u%d" % csize))
+
+
+@pytest.mark.parametrize("index_size,usize,container", [(4, 2, 4), (4, 4, 4), (4, 8, 4), (8, 2, 4), (8, 4, 4), (8, 8, 4), (4, 2, 8), (4, 4, 8), (4, 8, 8)])
+@pytest.mark.parametrize("min_size,bits", [(1, 2), (1, 3), (0, 2), (2, 1), (0, 4)])
+def test_discard_zero_bytes_variable(index_size, usize, container, min_size, bits):
+    from libgiddy_amd import compressors, schemes
+    if min_size > usize:
+        pytest.skip("min size exceeds element width")
+    ud = np.dtype("u%d" % usize)
+    for n, L in [(1, 32), (1000, 64), (4096, 1024), (333333, 1024), (50, 7), (70000, 1000)]:
+        column, _ = cases.dzbv_column(n, ud, min_size, bits, seed=n + bits + usize)
+        want = formats.discard_zero_bytes_variable(column, L, min_size, bits, "u%d" % container, index_size)
+        got = compressors.discard_zero_bytes_variable(dev(column), L, min_size, bits, np.dtype("u%d" % container), index_size)
+        same(got, want, ("dzbv", n, L))
+        out = torch.empty(n, dtype=torch.from_numpy(np.zeros(1, SIGNED[usize])).dtype, device="cuda")
+        schemes.discard_zero_bytes_variable(out, got["compressed_data"], got["packed_element_sizes"], got["position_anchors"], L, n, min_size, bits,
+                                            uncompressed_size=usize, container_size=container, index_size=index_size, stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy().view(ud) == column).all()
+    if min_size + (1 << bits) - 1 < usize:   # a value needing more bytes than a field can state
+        with pytest.raises(compressors.Unrepresentable):
+            compressors.discard_zero_bytes_variable(dev(np.array([np.iinfo(ud).max], dtype=ud)), 4, min_size, bits, np.dtype("u%d" % container), index_size)
+
+
+@pytest.mark.parametrize("index_size,uncompressed,compressed", [(4, np.int16, np.int8), (4, np.int32, np.int8), (4, np.int32, np.int16), (8, np.int32, np.int16)])
+def test_frame_of_reference_constant_model(index_size, uncompressed, compressed):
+    from libgiddy_amd import compressors
+    for n, L in SHAPES:
+        rng = cases.rng(n + L)
+        info = np.iinfo(compressed)
+        base = rng.integers(-20000, 20000, size=-(-n // L)).repeat(L)[:n]
+        column = (base + rng.integers(info.min // 2, info.max // 2, size=n)).astype(uncompressed)
+        want = formats.frame_of_reference(column, L, compressed, "constant")
+        got = compressors.frame_of_reference(dev(column), L, compressed, "constant", index_size=index_size)
+        same(got, want, ("for", n, L))
+    with pytest.raises(compressors.Unrepresentable):
+        compressors.frame_of_reference(dev(np.array([np.iinfo(uncompressed).min // 2, np.iinfo(uncompressed).max // 2], dtype=uncompressed)), 2, compressed)
+
+
+@pytest.mark.parametrize("usize,ksize", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)])
+def test_dictionary(usize, ksize):
+    from libgiddy_amd import compressors
+    ud = np.dtype("u%d" % usize)
+    for n, distinct in [(1, 1), (1000, 7), (300007, min(256, 1 << (8 * min(usize, ksize)))), (1 << 20, min(40000, 1 << (8 * min(usize, ksize))))]:
+        rng = cases.rng(n + distinct)
+        pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=distinct, dtype=np.uint64, endpoint=True).astype(ud))
+        column = pool[rng.integers(0, len(pool), size=n)]
+        want = formats.dictionary(column, np.dtype("u%d" % ksize))
+        same(compressors.dictionary(dev(column), np.dtype("u%d" % ksize)), want, ("dictionary", n, distinct))                       # the dictionary found on the device
+        same(compressors.dictionary(dev(column), np.dtype("u%d" % ksize), entries=dev(want["dictionary_entries"])), want, ("dictionary, given", n))
+    if usize > 1:
+        with pytest.raises(compressors.Unrepresentable):
+            compressors.dictionary(dev(np.array([5, 6, 7], dtype=ud)), np.dtype("u%d" % ksize), entries=dev(np.array([5, 7], dtype=ud)))
+
+
+RUN_COLUMNS = [(1, 1, 1), (100, 7, 3), (4096, 4096, 32), (70001, 1000, 2), (300007, 4096, 32), (300007, 1024, 1000), (1 << 20, 4096, 5), (200000, 512, 70000)]
+
+
+@pytest.mark.parametrize("index_size,usize,lsize", [(4, 1, 1), (4, 1, 2), (4, 2, 2), (4, 4, 1), (4, 4, 2), (4, 4, 4), (4, 8, 2), (8, 4, 2), (8, 1, 8), (8, 8, 8)])
+def test_run_length_encoding(index_size, usize, lsize):
+    """... including runs longer than a length field holds, which the format cuts into pieces (formats._runs_of)"""
+    from libgiddy_amd import compressors, schemes
+    ud = np.dtype("u%d" % usize)
+    for n, L, mean_run in RUN_COLUMNS:
+        column = cases.runs_column(n, mean_run, ud, seed=n + mean_run)
+        want = formats.run_length_encoding(column, L, np.dtype("u%d" % lsize), index_size)
+        got = compressors.run_length_encoding(dev(column), L, np.dtype("u%d" % lsize), index_size)
+        same(got, want, ("rle", n, L, mean_run))
+        out = torch.empty(n, dtype=got["run_data"].dtype, device="cuda")
+        schemes.run_length_encoding(out, got["run_data"], got["run_lengths"], got["position_anchors"], got["intra_run_anchor_offsets"], L, got["num_segments"],
+                                    got["num_element_runs"], n, uncompressed_size=usize, run_length_size=lsize, index_size=index_size,
+                                    stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy().view(ud) == column).all(), ("rle round trip", n, L, mean_run)
+    # runs far longer than any narrow length field holds, segments beginning inside their pieces
+    column = np.repeat(np.array([5, 6, 5, 9, 200], dtype=ud), [70000, 1, 140001, 3, 66000])
+    for L in (64, 4096, 100000):
+        same(compressors.run_length_encoding(dev(column), L, np.dtype("u%d" % lsize), index_size), formats.run_length_encoding(column, L, np.dtype("u%d" % lsize), index_size),
+             ("rle, long runs", L))
+
+
+@pytest.mark.parametrize("index_size,usize,psize,relative", [(4, 1, 2, True), (4, 4, 2, True), (4, 8, 2, True), (8, 4, 2, True), (4, 2, 4, False), (4, 4, 4, False), (8, 4, 8, False)])
+def test_run_position_encoding(index_size, usize, psize, relative):
+    from libgiddy_amd import compressors, schemes
+    ud = np.dtype("u%d" % usize)
+    for n, L, mean_run in RUN_COLUMNS:
+        if relative and L > (1 << (8 * psize)):
+            continue
+        column = cases.runs_column(n, mean_run, ud, seed=n + mean_run + 1)
+        want = formats.run_position_encoding(column, L, np.dtype("u%d" % psize), relative, index_size)
+        got = compressors.run_position_encoding(dev(column), L, np.dtype("u%d" % psize), relative, index_size)
+        same(got, want, ("rpe", n, L, mean_run))
+        out = torch.empty(n, dtype=got["run_data"].dtype, device="cuda")
+        schemes.run_position_encoding(out, got["run_data"], got["run_start_positions"], got["position_anchors"], L, got["num_anchors"], got["num_element_runs"], n,
+                                      uncompressed_size=usize, position_size=psize, relative=relative, index_size=index_size, stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy().view(ud) == column).all(), ("rpe round trip", n, L, mean_run)
+
+
+@pytest.mark.parametrize("index_size,esize", [(4, 1), (4, 4), (4, 8), (8, 2), (8, 8)])
+def test_patches(index_size, esize):
+    from libgiddy_amd import compressors
+    ud = np.dtype("u%d" % esize)
+    for n, differing in [(1, 0), (1, 1), (5000, 50), (300007, 301), (1 << 20, 1 << 19)]:
+        rng = cases.rng(n + differing)
+        truth = rng.integers(0, np.iinfo(ud).max, size=n, dtype=np.uint64, endpoint=True).astype(ud)
+        decoded = truth.copy()
+        where = rng.choice(n, size=differing, replace=False)
+        decoded[where] = decoded[where] + ud.type(1)
+        same(compressors.patches(dev(decoded), dev(truth), index_size), formats.patches(decoded, truth, index_size), ("patches", n, differing))
+
+
+def test_a_column_goes_through_model_plus_patches_without_leaving_the_device():
+    """what the pieces are for: a nearly linear column -> Model decode of its fit -> patches found on the device -> fused Model + patches == the column"""
+    from libgiddy_amd import compressors, schemes
+    n = 1 << 20
+    rng = cases.rng(5)
+    column = (np.arange(n, dtype=np.int64) * 37 - 12345).astype(np.int32)
+    odd = rng.choice(n, size=1000, replace=False)
+    column[odd] += rng.integers(1, 100, size=1000).astype(np.int32)
+    truth = dev(column)
+    coefficients = np.array([-12345, 37], dtype=np.int32)
+    stream = torch.cuda.current_stream().cuda_stream
+    modelled = torch.empty(n, dtype=torch.int32, device="cuda")
+    schemes.model(modelled, coefficients, n, uncompressed_size=4, model="linear", stream=stream)
+    p = compressors.patches(modelled, truth)
+    assert p["data_length"] == 1000 and (p["indices"].cpu().numpy() == np.sort(odd)).all()
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    schemes.patched_model(out, coefficients, p["data"], p["indices"], n, p["data_length"], uncompressed_size=4, model="linear", stream=stream)
+    assert bool((out == truth).all())
