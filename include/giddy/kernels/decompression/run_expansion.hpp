@@ -34,6 +34,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_RESIDENT_BLOCKS_CAP
+#define GIDDY_RUN_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (0: no cap); DESIGN.md section 4
+#endif
 #ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
 #endif
