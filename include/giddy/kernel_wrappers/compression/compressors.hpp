@@ -13,6 +13,7 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/compression/discard_zero_bytes_variable.hpp"
 #include "giddy/kernels/compression/elementwise.hpp"
+#include "giddy/kernels/compression/incidence_bitmaps.hpp"
 #include "giddy/kernels/compression/patches.hpp"
 #include "giddy/kernels/compression/runs.hpp"
 
@@ -200,6 +201,38 @@ template <unsigned I, unsigned U, unsigned D>
 const device_function_t kernel_t<I, U, D>::get_device_function() const { return reinterpret_cast<const void*>(encode<I, U, D>); }
 
 } // namespace dictionary
+
+// ---- incidence bitmaps --------------------------------------------------------------------------------------------------------
+namespace incidence_bitmaps {
+
+/// "keys" const unsigned char* (the column's dictionary keys), "bitmap_length" (32-bit words), "num_bitmaps" (unsigned),
+/// output "incidence_bitmaps" unsigned* (num_bitmaps * round_up(bitmap_length, BitmapAlignmentInInts) words)
+template <unsigned IndexSize, unsigned BitmapAlignmentInInts>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned A>
+launch_configuration_t kernel_t<I, A>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), (size_t) 64 * waves_per_block));
+}
+
+template <unsigned I, unsigned A>
+void kernel_t<I, A>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	auto num_bitmaps = argument<native_word_t>(arguments, "num_bitmaps");
+	if (num_bitmaps > 256) { throw std::invalid_argument("At most 256 incidence bitmaps are supported"); }
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<standard_bit_container_t*>(arguments, "incidence_bitmaps"), argument<const uint8_t*>(arguments, "keys"),
+		(size_type_by_index_size<I>) argument<size_type_by_index_size<I>>(arguments, "bitmap_length"), num_bitmaps);
+}
+
+template <unsigned I, unsigned A>
+const device_function_t kernel_t<I, A>::get_device_function() const { return reinterpret_cast<const void*>(compress<I, A>); }
+
+} // namespace incidence_bitmaps
 
 // ---- run-length and run-position encoding ------------------------------------------------------------------------------------
 namespace run_length_encoding {

@@ -139,6 +139,30 @@ def dictionary(column, key_dtype=np.uint8, entries=None, index_size=4):
     return out
 
 
+def incidence_bitmaps(column, alignment_in_ints=2, use_dictionary=True, index_size=4):
+    """one bitmap per distinct value (at most 256); the column's length must be a multiple of 32"""
+    n = column.numel()
+    if n % 32:
+        raise ValueError("the kernel decodes whole 32-bit containers")
+    device = column.device
+    if use_dictionary:
+        encoded = dictionary(column, np.uint8, index_size=index_size)
+        entries, keys = encoded["dictionary_entries"], encoded["compressed_input"]
+    else:
+        if column.element_size() != 1:
+            raise ValueError("without a dictionary the values are the bitmap indices: one byte each")
+        count = (int(column.to(torch.int64).bitwise_and(255).max()) + 1) if n else 0
+        entries, keys = torch.arange(count, device=device).to(column.dtype), column
+    words, num_bitmaps = n // 32, entries.numel()
+    aligned = -(-words // alignment_in_ints) * alignment_in_ints
+    bitmaps = torch.empty(num_bitmaps * aligned, dtype=torch.int32, device=device)
+    if n:
+        _launch("compression::incidence_bitmaps::kernel_t<%du, %du>" % (index_size, alignment_in_ints), {"length": r.size_t(n)},
+                {"incidence_bitmaps": r.pointer(bitmaps, "u32"), "keys": r.const_pointer(keys, "u8"),
+                 "bitmap_length": r.size_type_by_index_size(index_size)(words), "num_bitmaps": r.uint_t(4)(num_bitmaps)})
+    return {"incidence_bitmaps": bitmaps, "dictionary_entries": entries, "bitmap_length": words, "num_bitmaps": num_bitmaps}
+
+
 def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None):
     """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case)"""
     n, usize, lsize = column.numel(), column.element_size(), _size(run_length_dtype)

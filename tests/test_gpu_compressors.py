@@ -179,6 +179,25 @@ def test_patches(index_size, esize):
         same(compressors.patches(dev(decoded), dev(truth), index_size), formats.patches(decoded, truth, index_size), ("patches", n, differing))
 
 
+@pytest.mark.parametrize("usize,use_dictionary", [(1, True), (2, True), (4, True), (8, True), (1, False)])
+def test_incidence_bitmaps(usize, use_dictionary):
+    from libgiddy_amd import compressors, schemes
+    ud = np.dtype("u%d" % usize)
+    for words, distinct in [(1, 1), (3, 2), (64, 16), (1001, 11), (32768, 256)]:
+        rng = cases.rng(words + distinct)
+        pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=distinct, dtype=np.uint64, endpoint=True).astype(ud)) if use_dictionary else np.arange(distinct, dtype=ud)
+        column = pool[rng.integers(0, len(pool), size=32 * words)]
+        if not use_dictionary:
+            column[-1] = distinct - 1   # (the writer sizes the bitmaps by the largest value)
+        want = formats.incidence_bitmaps(column, 2, use_dictionary)
+        got = compressors.incidence_bitmaps(dev(column), 2, use_dictionary)
+        same(got, want, ("incidence bitmaps", words, distinct))
+        out = torch.empty(32 * words, dtype=got["dictionary_entries"].dtype, device="cuda")
+        schemes.incidence_bitmaps(out, got["incidence_bitmaps"], got["dictionary_entries"], words, got["num_bitmaps"], uncompressed_size=usize, use_dictionary=use_dictionary,
+                                  stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy().view(ud) == column).all(), ("incidence bitmaps round trip", words, distinct)
+
+
 def test_a_column_goes_through_model_plus_patches_without_leaving_the_device():
     """what the pieces are for: a nearly linear column -> Model decode of its fit -> patches found on the device -> fused Model + patches == the column"""
     from libgiddy_amd import compressors, schemes

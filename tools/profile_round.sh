@@ -7,13 +7,14 @@ set -u
 cd "$GRAFT_REPO_ROOT"
 export TMPDIR=/tmp
 OUT=gpurun_out/prof
-rm -rf $OUT; mkdir -p $OUT
+if [ -z "${SKIP_PMC:-}" ]; then rm -rf $OUT; fi; mkdir -p $OUT; rm -rf $OUT/trace
 hipcc --offload-arch=gfx950 -O3 tools/pmc_calibrate.hip -o /tmp/pmc_calibrate
 # 1. kernel trace + stats of the bench command itself (ONLY_PMC=1 skips it)
 if [ -z "${ONLY_PMC:-}" ]; then
-rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --sharded none > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 fi
-# 2. PMC passes (separate runs); WORKLOADS="a b" overrides the list
+# 2. PMC passes (separate runs); WORKLOADS="a b" overrides the list; SKIP_PMC=1 keeps the passes of an earlier call
+if [ -n "${SKIP_PMC:-}" ]; then exit 0; fi
 WORKLOADS=${WORKLOADS:-dictionary frame_of_reference delta_patched run_length_encoding run_position_encoding_relative run_position_encoding_absolute discard_zero_bytes_variable discard_zero_bytes_variable_3bit discard_zero_bytes_fixed model incidence_bitmaps delta_fused_patches dictionary_fused_patches frame_of_reference_fused_patches delta_fused_compressed_patches model_fused_patches discard_zero_bytes_fixed_fused_patches}
 for counter in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $counter -d $OUT/pmc_$counter/calibrate -o cal --output-format csv -- /tmp/pmc_calibrate > $OUT/cal_$counter.log 2>&1
