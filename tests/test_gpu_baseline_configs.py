@@ -161,3 +161,46 @@ def test_run_positions_and_outputs_beyond_32_bits():
     schemes.run_position_encoding(out, values, starts, anchors, L, num_segments, num_runs, n, position_size=8, relative=False, index_size=8, run_index_size=8,
                                   stream=_stream())
     check()
+
+
+@pytest.mark.parametrize("scheme", ["delta", "run_length_encoding", "run_position_encoding", "discard_zero_bytes_variable", "dictionary"])
+def test_compress_then_decompress_at_full_size(scheme):
+    """the size-independent property the device-side compressors make available: decompress(compress(column)) == column, at the BASELINE
+    sizes (2^30 elements; DZB-variable 2^28), compressed ON THE DEVICE into the reference's formats and decoded by the kernels under test"""
+    import workloads as w
+    from libgiddy_amd import compressors, schemes
+    device, st = torch.device("cuda"), _stream()
+    n = 1 << (28 if scheme == "discard_zero_bytes_variable" else 30)
+    gen = torch.Generator(device=device); gen.manual_seed(77)
+    if scheme == "delta":
+        column = torch.cumsum(torch.randint(0, 65536, (n,), dtype=torch.int64, generator=gen, device=device), 0) + (1 << 40)
+        f = compressors.delta(column, 4096, np.uint16)
+        out = torch.empty_like(column)
+        schemes.delta(out, f["compressed_input"], f["anchor_values"], n, 4096, stream=st)
+    elif scheme in ("run_length_encoding", "run_position_encoding"):
+        lengths, starts, values = w._geometric_runs(n, 32, device, seed=41)
+        column = values[torch.searchsorted(starts, torch.arange(n, device=device), right=True) - 1]
+        del lengths, starts, values
+        out = torch.empty_like(column)
+        if scheme == "run_length_encoding":
+            f = compressors.run_length_encoding(column, 4096, np.uint16, capacity=n // 8)
+            schemes.run_length_encoding(out, f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], 4096, f["num_segments"], f["num_element_runs"], n, stream=st)
+        else:
+            f = compressors.run_position_encoding(column, 4096, np.uint16, True, capacity=n // 8)
+            schemes.run_position_encoding(out, f["run_data"], f["run_start_positions"], f["position_anchors"], 4096, f["num_anchors"], f["num_element_runs"], n, stream=st)
+        assert 30e6 < f["num_element_runs"] < 37e6
+    elif scheme == "discard_zero_bytes_variable":
+        sizes = torch.randint(1, 5, (n,), dtype=torch.int64, generator=gen, device=device)
+        column = torch.randint(0, 1 << 62, (n,), dtype=torch.int64, generator=gen, device=device) & ((torch.ones_like(sizes) << (8 * sizes)) - 1)
+        del sizes
+        f = compressors.discard_zero_bytes_variable(column, 1024, 1, 2, np.uint32, index_size=8)
+        out = torch.empty_like(column)
+        schemes.discard_zero_bytes_variable(out, f["compressed_data"], f["packed_element_sizes"], f["position_anchors"], 1024, n, 1, 2, stream=st)
+    else:
+        entries = torch.sort((torch.randperm(1 << 24, generator=gen, device=device)[:256] * 101 + 7).to(torch.int32))[0]
+        column = entries[torch.randint(0, 256, (n,), generator=gen, device=device)]
+        f = compressors.dictionary(column, np.uint8, entries=entries)
+        out = torch.empty_like(column)
+        schemes.dictionary(out, f["compressed_input"], f["dictionary_entries"], n, 256, stream=st)
+    torch.cuda.synchronize()
+    assert bool((out == column).all()), scheme
