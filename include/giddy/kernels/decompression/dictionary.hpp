@@ -142,7 +142,12 @@ __device__ __forceinline__ void decompress(
 			const uint64_t at = (uint64_t) i * blockDim.x + threadIdx.x;
 			if (at < num_dictionary_entries) { my_entries[i] = dictionary_entries[at]; }
 		}
-		bool staged_yet = false;   // (every thread gets here exactly once: the barrier inside is taken once by each)
+		// (Every thread gets here exactly once, so every wavefront takes the barrier inside exactly once — but from different call
+		// sites of the tile loop.  That relies on what s_barrier IS on CDNA — a count of arriving wavefronts, whatever their program
+		// counters — not on the textual convergence HIP's __syncthreads contract asks for; hoisting it in front of the loop costs the
+		// overlap this arrangement exists for.  If the workgroup is smaller than the launch parameters assumed — a caller's block-size
+		// limit — the test above fails and the plain staging loop below runs instead: correct, with several tiles per workgroup.)
+		bool staged_yet = false;
 		auto stage = [&]() {
 			if (staged_yet) { return; }
 			#pragma unroll

@@ -2,6 +2,7 @@
 (profiles/hbm_traffic.json) is only quoted by bench.py while the kernel it was taken on has not changed."""
 import hashlib
 import os
+import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 INCLUDE = os.path.join(ROOT, "include", "giddy")
@@ -24,11 +25,18 @@ def files_of(kernel):
     return sorted(set(SHARED + (own[0] if own else [])))
 
 
+def code_of(text):
+    """a header's text without comments and with white space collapsed: what the compiler sees of it, near enough"""
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    return re.sub(r"\s+", " ", text).strip()
+
+
 def fingerprint(kernel):
-    """sha256 (16 hex digits) over the headers `kernel` is compiled from"""
+    """sha256 (16 hex digits) over the CODE of the headers `kernel` is compiled from (comments and spacing do not count)"""
     h = hashlib.sha256()
     for name in files_of(kernel):
         path = os.path.join(INCLUDE, name)
         h.update(name.encode())
-        h.update(open(path, "rb").read() if os.path.exists(path) else b"(absent)")
+        h.update(code_of(open(path, encoding="utf-8").read()).encode() if os.path.exists(path) else b"(absent)")
     return h.hexdigest()[:16]

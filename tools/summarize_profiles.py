@@ -115,7 +115,8 @@ def main():
         by_kernel.setdefault(t["kernel"], t)   # bench.py looks traffic up by kernel name (first workload wins)
     with open(os.path.join(OUT, "hbm_traffic.json"), "w") as f:
         try:
-            commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
+            # (MEASURED_AT: the commit the passes ran on, when the summary is made later)
+            commit = os.environ.get("MEASURED_AT") or subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], text=True).strip()
         except (OSError, subprocess.CalledProcessError):
             commit = "unknown"
         json.dump({"round": ROUND, "measured_at_commit": commit, "read_correction": read_factor, "write_correction": write_factor,
