@@ -34,6 +34,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_DESCRIPTORS_PER_LANE
+#define GIDDY_RUN_DESCRIPTORS_PER_LANE 4
+#endif
 #ifndef GIDDY_RUN_RESIDENT_BLOCKS_CAP
 #define GIDDY_RUN_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (0: no cap); DESIGN.md section 4
 #endif
@@ -47,7 +50,7 @@ enum : unsigned {
 	words_per_lane      = GIDDY_RUN_TILE_WORDS_PER_LANE,
 	tile_words          = 64 * words_per_lane,     // 128
 	tile_length         = 32 * tile_words,         // 4096 outputs per tile
-	runs_per_lane       = 4,                       // run descriptors examined per lane per batch
+	runs_per_lane       = GIDDY_RUN_DESCRIPTORS_PER_LANE,   // run descriptors examined per lane per batch
 	runs_per_batch      = 64 * runs_per_lane,
 	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
 };

@@ -88,11 +88,18 @@ __global__ void decompress(
 			if (through < run_limit) { run_limit = through; }
 		}
 
+		// The NEXT tile's first batch of run lengths (and values) is requested before this tile's expansion stores anything: CDNA4
+		// retires vector-memory operations in order, so a load issued after a tile's stores is not back before they are
+		// acknowledged — a store drain on top of the load's own round trip, per tile (dense tiles, 1 KiB ... 4 KiB of output: the
+		// larger part of a wavefront's life).
+		uint_t<RunLengthSize> prefetched_lengths[runs_per_lane];
+		uint_t<UncompressedSize> prefetched_values[runs_per_lane];
+		bool prefetched = false, values_prefetched = false;   // (values: always where they travel with the descriptors; else after a dense tile)
 		uint32_t tile_len = 0;
 		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
 			bool need_carry = tile_start + tile_len < segment_end;
-			bool dense = false;
+			bool dense = false, values_staged = false;
 			clear(table, lane);
 
 			uint32_t running = 0;      // clamped lengths summed over earlier batches = start of this batch's first run
@@ -105,11 +112,13 @@ __global__ void decompress(
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					uint64_t k = batch_base + (uint64_t) lane * runs_per_lane + j;
 					have[j] = first_run + k < run_limit;
-					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) run_lengths[first_run + k]);
+					const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
+					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) (from_prefetch ? prefetched_lengths[j] : run_lengths[first_run + k]));
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
 					// the runs' values travel with their lengths (staged for the expansion; runs past the tile's last are harmless)
-					if (staging::with_descriptors && have[j] && k < staging::capacity) { staged[k] = run_data[first_run + k]; }
+					if (staging::with_descriptors && have[j] && k < staging::capacity) { staged[k] = from_prefetch ? prefetched_values[j] : run_data[first_run + k]; }
+					if (!staging::with_descriptors && from_prefetch && values_prefetched && have[j] && k < staging::capacity) { staged[k] = prefetched_values[j]; values_staged = true; }
 				}
 				uint32_t inclusive = wave64::inclusive_sum(lane_total);
 				const uint32_t covered = wave64::read_last_lane(inclusive);
@@ -136,22 +145,38 @@ __global__ void decompress(
 				batch_base += runs_per_batch;
 			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
 
-			const uint32_t marks = rank(table, lane);
-			if (staging::dense_only && !dense) {
-				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
-			}
-			else {
-				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
-			}
-
+			// where the next tile enters the runs — and its first batch, on its way before this tile stores
+			uint64_t next_first_run = first_run, next_left_in_first_run = left_in_first_run;
+			prefetched = false;
 			if (need_carry) {
 				uint64_t who = wave64::ballot(found);
 				if (who != 0) {
 					unsigned source = (unsigned) __builtin_ctzll(who);
-					first_run = wave64::read_lane(carried_run, source);
-					left_in_first_run = wave64::read_lane(carried_left, source);
+					next_first_run = wave64::read_lane(carried_run, source);
+					next_left_in_first_run = wave64::read_lane(carried_left, source);
 				}
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					const uint64_t r = next_first_run + (uint64_t) lane * runs_per_lane + j;
+					if (r < run_limit) {
+						prefetched_lengths[j] = run_lengths[r];
+						if (staging::with_descriptors || dense) { prefetched_values[j] = run_data[r]; }   // (after a dense tile, most likely another)
+					}
+				}
+				prefetched = true; values_prefetched = staging::with_descriptors || dense;
 			}
+
+			const uint32_t marks = rank(table, lane);
+			if (staging::dense_only && !dense) {
+				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
+			}
+			else if (!staging::with_descriptors && wave64::ballot(values_staged) != 0) {   // a dense tile whose values came with the prefetched lengths
+				expand<UncompressedSize, true, true>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			}
+			else {
+				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			}
+			first_run = next_first_run; left_in_first_run = next_left_in_first_run;
 		}
 	}
 }

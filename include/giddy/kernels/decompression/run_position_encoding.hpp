@@ -90,14 +90,20 @@ __global__ void decompress(
 		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
 			? (uint64_t) position_anchors[s + lane] : ~(uint64_t) 0;
 
+		// the NEXT tile's first batch of run positions (and values) is requested before this tile's expansion stores anything
+		// (run_length_encoding.hpp: loads issued after a tile's stores wait for those stores as well)
+		uint_t<PositionOffsetSize> prefetched_positions[runs_per_lane];
+		uint_t<UncompressedSize> prefetched_values[runs_per_lane], prefetched_first_value = 0;
+		bool prefetched = false, values_prefetched = false;
 		uint32_t tile_len = 0;
 		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
 			uint64_t tile_end = tile_start + tile_len;
 			bool need_carry = tile_end < segment_end;
-			bool dense = false;
+			bool dense = false, values_staged = false;
 			clear(table, lane);
-			if (staging::with_descriptors && lane == 0) { staged[0] = run_data[first_run]; }
+			if (staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
+			if (!staging::with_descriptors && prefetched && values_prefetched && lane == 0) { staged[0] = prefetched_first_value; }
 
 			uint64_t batch_base = first_run + 1;
 			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= tile_end
@@ -121,9 +127,11 @@ __global__ void decompress(
 					}
 					starts[j] = 0; starts_here[j] = false;
 					if (r > last_candidate) { continue; }
-					uint64_t position = run_start_positions[r];
+					const bool from_prefetch = prefetched && batch_base == first_run + 1;   // (wave-uniform)
+					uint64_t position = from_prefetch ? prefetched_positions[j] : run_start_positions[r];
 					// the runs' values travel with their positions (staged for the expansion; runs past the tile's last are harmless)
-					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = run_data[r]; }
+					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = from_prefetch ? prefetched_values[j] : run_data[r]; }
+					if (!staging::with_descriptors && from_prefetch && values_prefetched && r - first_run < staging::capacity) { staged[r - first_run] = prefetched_values[j]; values_staged = true; }
 					uint64_t start = position;
 					if (PositionsAreRelative) {
 						// ... and at relative position 0 it starts the NEXT segment
@@ -156,18 +164,36 @@ __global__ void decompress(
 				batch_base += runs_per_batch;
 			} while (!reached_past_tile);
 
+			// where the next tile enters the runs — and its first batch, on its way before this tile stores
+			uint64_t next_first_run = first_run;
+			prefetched = false;
+			if (need_carry) {
+				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
+				if (furthest != 0) { next_first_run = first_run + furthest - 1; }
+				const bool with_values = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
+				#pragma unroll
+				for (unsigned j = 0; j < runs_per_lane; j++) {
+					const uint64_t r = next_first_run + 1 + (uint64_t) lane * runs_per_lane + j;
+					if (r <= last_candidate) {
+						prefetched_positions[j] = run_start_positions[r];
+						if (with_values) { prefetched_values[j] = run_data[r]; }
+					}
+				}
+				if (with_values && lane == 0) { prefetched_first_value = run_data[next_first_run]; }
+				prefetched = true; values_prefetched = with_values;
+			}
+
 			const uint32_t marks = rank(table, lane);
 			if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
+			else if (!staging::with_descriptors && wave64::ballot(values_staged) != 0) {   // a dense tile whose values came with the prefetched positions
+				expand<UncompressedSize, true, true>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+			}
 			else {
 				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 			}
-
-			if (need_carry) {
-				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
-				if (furthest != 0) { first_run += furthest - 1; }
-			}
+			first_run = next_first_run;
 		}
 	}
 }

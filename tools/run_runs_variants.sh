@@ -14,6 +14,8 @@ for mean_run in (2, 4, 6, 8, 16, 32):
     show("rle<4,4,2> mean_run=%d" % mean_run, sw.run_rle(4, 4, 2, 4, n, 4096, mean_run))
 for mean_run in (4, 32):
     show("rpe<4,4,2,rel> mean_run=%d" % mean_run, sw.run_rpe(4, 4, 2, True, 4, n, 4096, mean_run))
-    show("rle<4,4,1> mean_run=%d" % mean_run, sw.run_rle(4, 4, 1, 4, n, 4096, mean_run))
+    show("rpe<4,4,4,abs> mean_run=%d" % mean_run, sw.run_rpe(4, 4, 4, False, 4, n, 4096, mean_run))
+    show("rle<4,8,2> mean_run=%d" % mean_run, sw.run_rle(4, 8, 2, 4, n, 4096, mean_run))
+    show("rle<4,2,2> mean_run=%d" % mean_run, sw.run_rle(4, 2, 2, 4, n, 4096, mean_run))
 PY
 done
