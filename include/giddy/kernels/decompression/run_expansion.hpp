@@ -34,6 +34,12 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_NONTEMPORAL_DESCRIPTORS
+#define GIDDY_RUN_NONTEMPORAL_DESCRIPTORS 0   // 1: run lengths / positions — read once — are loaded around the L1, which the run values' look-ups live in
+#endif
+#ifndef GIDDY_RUN_STAGE_WIDE_DESCRIPTORS
+#define GIDDY_RUN_STAGE_WIDE_DESCRIPTORS 1   // 4-byte values of kernels with 4-8-byte run descriptors go through LDS in every tile
+#endif
 #ifndef GIDDY_RUN_DESCRIPTORS_PER_LANE
 #define GIDDY_RUN_DESCRIPTORS_PER_LANE 4
 #endif
@@ -54,6 +60,13 @@ enum : unsigned {
 	runs_per_batch      = 64 * runs_per_lane,
 	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
 };
+
+/// a run descriptor (length or position): read once
+template <typename T>
+__device__ __forceinline__ T load_descriptor(const T* p)
+{
+	return GIDDY_RUN_NONTEMPORAL_DESCRIPTORS ? __builtin_nontemporal_load(p) : *p;
+}
 
 struct tile_entry {
 	uint32_t bits;         // bit j: a run starts at tile position 32*word + j   (position 0 is never marked)
@@ -106,7 +119,7 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 /// for such tiles alone (the instantiations whose sparse tiles are faster through L1/L2).
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { always = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || RunDescriptorSize >= 4, dense_only = !always, enabled = 1,
+	enum : unsigned { always = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || (GIDDY_RUN_STAGE_WIDE_DESCRIPTORS && RunDescriptorSize >= 4), dense_only = !always, enabled = 1,
 		bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
 		allocated = capacity + 16 / ElementSize,   // (the permuting expansions read up to 11 bytes past a lane's first run)
 		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);

@@ -113,7 +113,7 @@ __global__ void decompress(
 					uint64_t k = batch_base + (uint64_t) lane * runs_per_lane + j;
 					have[j] = first_run + k < run_limit;
 					const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
-					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) (from_prefetch ? prefetched_lengths[j] : run_lengths[first_run + k]));
+					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) (from_prefetch ? prefetched_lengths[j] : load_descriptor(run_lengths + first_run + k)));
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
 					// the runs' values travel with their lengths (staged for the expansion; runs past the tile's last are harmless)
@@ -159,7 +159,7 @@ __global__ void decompress(
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					const uint64_t r = next_first_run + (uint64_t) lane * runs_per_lane + j;
 					if (r < run_limit) {
-						prefetched_lengths[j] = run_lengths[r];
+						prefetched_lengths[j] = load_descriptor(run_lengths + r);
 						if (staging::with_descriptors || dense) { prefetched_values[j] = run_data[r]; }   // (after a dense tile, most likely another)
 					}
 				}

@@ -128,7 +128,7 @@ __global__ void decompress(
 					starts[j] = 0; starts_here[j] = false;
 					if (r > last_candidate) { continue; }
 					const bool from_prefetch = prefetched && batch_base == first_run + 1;   // (wave-uniform)
-					uint64_t position = from_prefetch ? prefetched_positions[j] : run_start_positions[r];
+					uint64_t position = from_prefetch ? prefetched_positions[j] : load_descriptor(run_start_positions + r);
 					// the runs' values travel with their positions (staged for the expansion; runs past the tile's last are harmless)
 					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = from_prefetch ? prefetched_values[j] : run_data[r]; }
 					if (!staging::with_descriptors && from_prefetch && values_prefetched && r - first_run < staging::capacity) { staged[r - first_run] = prefetched_values[j]; values_staged = true; }
@@ -175,7 +175,7 @@ __global__ void decompress(
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					const uint64_t r = next_first_run + 1 + (uint64_t) lane * runs_per_lane + j;
 					if (r <= last_candidate) {
-						prefetched_positions[j] = run_start_positions[r];
+						prefetched_positions[j] = load_descriptor(run_start_positions + r);
 						if (with_values) { prefetched_values[j] = run_data[r]; }
 					}
 				}
