@@ -34,6 +34,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_STAGED_LOOKUPS_TOGETHER
+#define GIDDY_RUN_STAGED_LOOKUPS_TOGETHER 1
+#endif
 #ifndef GIDDY_RUN_NONTEMPORAL_DESCRIPTORS
 #define GIDDY_RUN_NONTEMPORAL_DESCRIPTORS 0   // 1: run lengths / positions — read once — are loaded around the L1, which the run values' look-ups live in
 #endif
@@ -208,7 +211,8 @@ __device__ __forceinline__ void expand(
 		else if (use_staged) {
 			// one output dword (4 / ElementSize elements) at a time, so that at most that many ranks and looked-up
 			// values are alive at once (all 16 of a 1-byte column at once cost two wavefronts per SIMD of occupancy)
-			constexpr unsigned per_dword = 4 / (ElementSize > 4 ? 4 : ElementSize);
+			// (wide elements: a lane's 2 or 4 look-ups all at once — GIDDY_RUN_STAGED_LOOKUPS_TOGETHER — instead of one LDS round trip after the other)
+			constexpr unsigned per_dword = (GIDDY_RUN_STAGED_LOOKUPS_TOGETHER && ElementSize >= 4) ? E : 4 / (ElementSize > 4 ? 4 : ElementSize);
 			#pragma unroll
 			for (unsigned first = 0; first < E; first += per_dword) {
 				#pragma unroll
