@@ -54,7 +54,7 @@ def parse():
                    "(same seed on every rank) cut into rank shards on the device by libgiddy_amd.sharding — BASELINE.json configs[3]/[4] as stated; "
                    "use with --workload run_length_encoding | run_position_encoding_relative | run_position_encoding_absolute | discard_zero_bytes_variable")
     p.add_argument("--sharded", default="default", help="extra strong-scaling measurements appended to the line under `sharded` (every N, so that the "
-                   "driver's N = 1, 2, 4, 8 runs give the curve): default = run_length_encoding at 2^30 and discard_zero_bytes_variable at 2^31 elements "
+                   "driver's N = 1, 2, 4, 8 runs give the curve): default = run_length_encoding and run_position_encoding_relative at 2^30 and discard_zero_bytes_variable at 2^31 elements "
                    "(with the gather into rank 0) | none | comma list of workload[:log2n]")
     return p.parse_args()
 
@@ -415,7 +415,7 @@ def main():
 
     # ---- BASELINE.json configs[3] / configs[4] as stated: one column cut over the ranks (strong scaling), at every N ----
     if args.sharded != "none":
-        wanted = [("run_length_encoding", 30, False), ("discard_zero_bytes_variable", 31, True)] if args.sharded == "default" else \
+        wanted = [("run_length_encoding", 30, False), ("run_position_encoding_relative", 30, False), ("discard_zero_bytes_variable", 31, True)] if args.sharded == "default" else \
                  [(item.split(":")[0], int(item.split(":")[1]) if ":" in item else args.log2n, args.gather) for item in args.sharded.split(",") if item]
         if "work" in dir():
             del work

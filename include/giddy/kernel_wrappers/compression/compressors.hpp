@@ -12,6 +12,7 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/compression/discard_zero_bytes_variable.hpp"
+#include "giddy/kernels/compression/dictionary_construction.hpp"
 #include "giddy/kernels/compression/elementwise.hpp"
 #include "giddy/kernels/compression/incidence_bitmaps.hpp"
 #include "giddy/kernels/compression/patches.hpp"
@@ -200,6 +201,47 @@ void kernel_t<I, U, D>::enqueue_launch(stream::id_t stream, const launch_configu
 template <unsigned I, unsigned U, unsigned D>
 const device_function_t kernel_t<I, U, D>::get_device_function() const { return reinterpret_cast<const void*>(encode<I, U, D>); }
 
+} // namespace dictionary
+
+namespace dictionary {
+namespace construction {
+
+/// The column's distinct values, sorted ascending, for dictionaries of up to 65 536 entries.  Launch keys: "input", "length";
+/// output "dictionary_entries" uint_t<U>* (room for 65 536); scratch, ZEROED by the caller: "slot_states" unsigned* (2^18 entries),
+/// "status" unsigned* (2 entries: [0] = distinct values found — compare with the key width's limit —, [1] = entries written);
+/// scratch: "slot_values" uint64_t* (2^18 entries), "unsorted_entries" uint_t<U>* (65 536 entries)
+template <unsigned IndexSize, unsigned UncompressedSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, unsigned U>
+launch_configuration_t kernel_t<I, U>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	return elementwise_launch(argument<size_t>(extra_arguments, "length"));
+}
+
+template <unsigned I, unsigned U>
+void kernel_t<I, U>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	auto states   = argument<unsigned*>(arguments, "slot_states");
+	auto values   = argument<uint64_t*>(arguments, "slot_values");
+	auto status   = argument<unsigned*>(arguments, "status");
+	auto unsorted = argument<uint_t<U>*>(arguments, "unsorted_entries");
+	auto length   = (size_type_by_index_size<I>) argument<uint_t<I>>(arguments, "length");
+	if (length == 0) { return; }
+	cuda::kernel::enqueue_launch(*this, stream, launch_config, states, values, status, argument<const uint_t<U>*>(arguments, "input"), length);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(collect_distinct<U>), stream, launch_configuration_t(hash_slots / threads_per_block, threads_per_block),
+		unsorted, status, static_cast<const unsigned*>(states), static_cast<const uint64_t*>(values), (unsigned) max_entries);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(place_by_rank<U>), stream, launch_configuration_t(max_entries / threads_per_block, threads_per_block),
+		argument<uint_t<U>*>(arguments, "dictionary_entries"), static_cast<const uint_t<U>*>(unsorted), static_cast<const unsigned*>(status), (unsigned) max_entries);
+}
+
+template <unsigned I, unsigned U>
+const device_function_t kernel_t<I, U>::get_device_function() const { return reinterpret_cast<const void*>(insert_distinct<I, U>); }
+
+} // namespace construction
 } // namespace dictionary
 
 // ---- incidence bitmaps --------------------------------------------------------------------------------------------------------

@@ -1,0 +1,114 @@
+// Building a column's DICTIONARY on the device: its distinct values, sorted ascending — what numpy.unique gives
+// libgiddy_amd/formats.py::dictionary — for dictionaries of up to 65 536 entries (1- and 2-byte keys; wider keys mean a
+// device-wide sort of the column, which is not this library's business).  Three steps on the caller's stream:
+//   1. insert       every element into an open-addressing hash set in global memory (2^18 slots, caller-zeroed): a slot is claimed
+//                   by compare-and-swap on its state word, filled, then published; an element whose value is already there — all
+//                   but at most 65 536 of them — only reads.  A claimed-but-unpublished slot is retried on the NEXT trip of the
+//                   loop, never waited for inside one, so lanes of one wavefront cannot wait for each other.
+//   2. collect      the published slots' values, compacted into the entries array (their number through an atomic counter)
+//   3. sort         by rank: every entry counts the smaller ones (they are distinct) and goes to that position
+// `status[0]` = number of distinct values found (also when there are too many: the caller compares it with the key width's limit),
+// `status[1]` = entries collected.
+#pragma once
+#include "giddy/kernels/compression/common.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace compression {
+namespace dictionary {
+
+enum : unsigned { hash_slots = 1u << 18, max_entries = 1u << 16 };
+enum : unsigned { slot_empty = 0, slot_claimed = 1, slot_published = 2 };
+
+__device__ __forceinline__ unsigned hash_of(uint64_t v)
+{
+	v ^= v >> 33; v *= 0xff51afd7ed558ccdull; v ^= v >> 33; v *= 0xc4ceb9fe1a85ec53ull; v ^= v >> 33;
+	return (unsigned) v & (hash_slots - 1);
+}
+
+/// `slot_states` (hash_slots x unsigned, zeroed by the caller), `slot_values` (hash_slots x uint64), `status` (2 x unsigned, zeroed)
+template <unsigned IndexSize, unsigned UncompressedSize>
+__global__ void __launch_bounds__(threads_per_block) insert_distinct(
+	unsigned*                        __restrict__  slot_states,
+	uint64_t*                        __restrict__  slot_values,
+	unsigned*                        __restrict__  status,
+	const uint_t<UncompressedSize>*  __restrict__  input,
+	size_type_by_index_size<IndexSize>             length)
+{
+	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (uint64_t) gridDim.x * blockDim.x) {
+		const uint64_t value = (uint64_t) input[i];
+		unsigned slot = hash_of(value);
+		// the common case — the value is there already — through the ordinary cached loads: a published slot never changes, so a hit
+		// is a hit whatever the cache's age; anything else (a stale "empty", a neighbour's value) goes the careful way below
+		if (slot_states[slot] == slot_published && slot_values[slot] == value) { continue; }
+		for (unsigned trips = 0; trips < 64 * hash_slots; trips++) {   // (bounded: a full table — far too many distinct values — ends the search)
+			const unsigned state = __atomic_load_n(slot_states + slot, __ATOMIC_ACQUIRE);
+			if (state == slot_published) {
+				if (__atomic_load_n(slot_values + slot, __ATOMIC_RELAXED) == value) { break; }
+				slot = (slot + 1) & (hash_slots - 1);
+			}
+			else if (state == slot_empty) {
+				unsigned expected = slot_empty;
+				if (__atomic_compare_exchange_n(slot_states + slot, &expected, (unsigned) slot_claimed, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) {
+					__atomic_store_n(slot_values + slot, value, __ATOMIC_RELAXED);
+					__atomic_store_n(slot_states + slot, (unsigned) slot_published, __ATOMIC_RELEASE);
+					atomicAdd(status, 1u);
+					break;
+				}
+				// (lost the slot: look at it again on the next trip)
+			}
+			// (claimed, not yet published: again on the next trip — its owner does not wait for anybody)
+			if (__atomic_load_n(status, __ATOMIC_RELAXED) > max_entries) { break; }   // too many distinct values: give up
+		}
+	}
+}
+
+/// entries[k] = the k-th published slot's value (in no particular order); status[1] = their number (at most `capacity` are written)
+template <unsigned UncompressedSize>
+__global__ void __launch_bounds__(threads_per_block) collect_distinct(
+	uint_t<UncompressedSize>*  __restrict__  entries,
+	unsigned*                  __restrict__  status,
+	const unsigned*            __restrict__  slot_states,
+	const uint64_t*            __restrict__  slot_values,
+	unsigned                                 capacity)
+{
+	for (unsigned slot = blockIdx.x * blockDim.x + threadIdx.x; slot < hash_slots; slot += gridDim.x * blockDim.x) {
+		if (slot_states[slot] == slot_published) {
+			const unsigned k = atomicAdd(status + 1, 1u);
+			if (k < capacity) { entries[k] = (uint_t<UncompressedSize>) slot_values[slot]; }
+		}
+	}
+}
+
+/// sorted[rank of unsorted[i]] = unsorted[i], rank = the number of smaller entries (the entries are distinct, so the ranks are a
+/// permutation): count = min(status[1], capacity) entries, read from the device; every thread ranks one entry against all of them,
+/// which pass through LDS a tile at a time.  65 536 entries: 4.3 G comparisons, a fraction of a millisecond.
+template <unsigned UncompressedSize>
+__global__ void __launch_bounds__(threads_per_block) place_by_rank(
+	uint_t<UncompressedSize>*        __restrict__  sorted,
+	const uint_t<UncompressedSize>*  __restrict__  unsorted,
+	const unsigned*                  __restrict__  status,
+	unsigned                                       capacity)
+{
+	using U = uint_t<UncompressedSize>;
+	__shared__ U tile[threads_per_block];
+	const unsigned count = status[1] < capacity ? status[1] : capacity;
+	for (unsigned base = blockIdx.x * blockDim.x; base < count; base += gridDim.x * blockDim.x) {   // (workgroup-uniform bounds: the barriers are safe)
+		const unsigned i = base + threadIdx.x;
+		const U mine = i < count ? unsorted[i] : (U) 0;
+		unsigned rank = 0;
+		for (unsigned first = 0; first < count; first += blockDim.x) {
+			__syncthreads();
+			if (first + threadIdx.x < count) { tile[threadIdx.x] = unsorted[first + threadIdx.x]; }
+			__syncthreads();
+			const unsigned here = count - first < blockDim.x ? count - first : blockDim.x;
+			for (unsigned j = 0; j < here; j++) { rank += tile[j] < mine; }
+		}
+		if (i < count) { sorted[rank] = mine; }
+	}
+}
+
+} // namespace dictionary
+} // namespace compression
+} // namespace kernels
+} // namespace cuda

@@ -34,6 +34,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
 #define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
 #endif
+#ifndef GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE
+#define GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE 2   // element sizes from which the next tile's descriptors are requested ahead of the stores
+#endif
 #ifndef GIDDY_RUN_STAGED_LOOKUPS_TOGETHER
 #define GIDDY_RUN_STAGED_LOOKUPS_TOGETHER 1
 #endif

@@ -155,15 +155,17 @@ __global__ void decompress(
 					next_first_run = wave64::read_lane(carried_run, source);
 					next_left_in_first_run = wave64::read_lane(carried_left, source);
 				}
-				#pragma unroll
-				for (unsigned j = 0; j < runs_per_lane; j++) {
-					const uint64_t r = next_first_run + (uint64_t) lane * runs_per_lane + j;
-					if (r < run_limit) {
-						prefetched_lengths[j] = load_descriptor(run_lengths + r);
-						if (staging::with_descriptors || dense) { prefetched_values[j] = run_data[r]; }   // (after a dense tile, most likely another)
+				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint64_t r = next_first_run + (uint64_t) lane * runs_per_lane + j;
+						if (r < run_limit) {
+							prefetched_lengths[j] = load_descriptor(run_lengths + r);
+							if (staging::with_descriptors || dense) { prefetched_values[j] = run_data[r]; }   // (after a dense tile, most likely another)
+						}
 					}
+					prefetched = true; values_prefetched = staging::with_descriptors || dense;
 				}
-				prefetched = true; values_prefetched = staging::with_descriptors || dense;
 			}
 
 			const uint32_t marks = rank(table, lane);

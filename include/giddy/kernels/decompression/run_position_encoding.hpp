@@ -170,17 +170,19 @@ __global__ void decompress(
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
 				if (furthest != 0) { next_first_run = first_run + furthest - 1; }
-				const bool with_values = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
-				#pragma unroll
-				for (unsigned j = 0; j < runs_per_lane; j++) {
-					const uint64_t r = next_first_run + 1 + (uint64_t) lane * runs_per_lane + j;
-					if (r <= last_candidate) {
-						prefetched_positions[j] = load_descriptor(run_start_positions + r);
-						if (with_values) { prefetched_values[j] = run_data[r]; }
+				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+					const bool with_values = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint64_t r = next_first_run + 1 + (uint64_t) lane * runs_per_lane + j;
+						if (r <= last_candidate) {
+							prefetched_positions[j] = load_descriptor(run_start_positions + r);
+							if (with_values) { prefetched_values[j] = run_data[r]; }
+						}
 					}
+					if (with_values && lane == 0) { prefetched_first_value = run_data[next_first_run]; }
+					prefetched = true; values_prefetched = with_values;
 				}
-				if (with_values && lane == 0) { prefetched_first_value = run_data[next_first_run]; }
-				prefetched = true; values_prefetched = with_values;
 			}
 
 			const uint32_t marks = rank(table, lane);

@@ -114,17 +114,33 @@ def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model=
     return out
 
 
+def dictionary_entries(column, limit=1 << 16, index_size=4):
+    """the column's distinct values, sorted ascending (unsigned order) — numpy.unique on the device; at most `limit` <= 65 536 of them"""
+    n, usize = column.numel(), column.element_size()
+    device = column.device
+    states = torch.zeros(1 << 18, dtype=torch.int32, device=device)
+    status = torch.zeros(2, dtype=torch.int32, device=device)
+    values = torch.empty(1 << 18, dtype=torch.int64, device=device)
+    unsorted, entries = torch.empty(1 << 16, dtype=column.dtype, device=device), torch.empty(1 << 16, dtype=column.dtype, device=device)
+    if n:
+        _launch("compression::dictionary::construction::kernel_t<%du, %du>" % (index_size, usize), {"length": r.size_t(n)},
+                {"input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "dictionary_entries": r.pointer(entries, "u%d" % (8 * usize)),
+                 "slot_states": r.pointer(states, "u32"), "status": r.pointer(status, "u32"), "slot_values": r.pointer(values, "u64"),
+                 "unsorted_entries": r.pointer(unsorted, "u%d" % (8 * usize))})
+    found = int(status[0])
+    if found > limit:
+        raise Unrepresentable("too many distinct values for the key type")
+    return entries[:found]
+
+
 def dictionary(column, key_dtype=np.uint8, entries=None, index_size=4):
-    """`entries`: the dictionary, sorted ascending and distinct, on the device.  Not given: the column's distinct values, by
-    torch.unique over the column's unsigned order (the one step of this module the library's kernels do not do: a device-wide sort)."""
+    """`entries`: the dictionary, sorted ascending and distinct, on the device.  Not given: the column's distinct values, found and
+    sorted on the device (dictionary_entries()), for key types of 1 or 2 bytes."""
     n, usize, ksize = column.numel(), column.element_size(), _size(key_dtype)
     if entries is None:
-        if usize == 8:   # unsigned order of 64-bit values: flip the sign bit, sort signed, flip back
-            flipped = torch.unique(column ^ torch.iinfo(torch.int64).min)
-            entries = flipped ^ torch.iinfo(torch.int64).min
-        else:
-            wide = torch.unique(column.to(torch.int64) & ((1 << (8 * usize)) - 1))
-            entries = wide.to(_SIGNED[usize]) if usize < 4 else (wide - ((wide >> 31) << 32)).to(torch.int32)
+        if ksize > 2:
+            raise NotImplementedError("device-side dictionary construction holds up to 65 536 entries (1- and 2-byte keys): pass `entries`")
+        entries = dictionary_entries(column, limit=1 << (8 * ksize), index_size=index_size)
     if entries.numel() > (1 << (8 * ksize)):
         raise Unrepresentable("too many distinct values for the key type")
     out = {"compressed_input": torch.empty(n, dtype=_SIGNED[ksize], device=column.device), "dictionary_entries": entries, "length": n,

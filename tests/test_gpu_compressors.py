@@ -117,7 +117,8 @@ def test_dictionary(usize, ksize):
         pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=distinct, dtype=np.uint64, endpoint=True).astype(ud))
         column = pool[rng.integers(0, len(pool), size=n)]
         want = formats.dictionary(column, np.dtype("u%d" % ksize))
-        same(compressors.dictionary(dev(column), np.dtype("u%d" % ksize)), want, ("dictionary", n, distinct))                       # the dictionary found on the device
+        if ksize <= 2:   # the dictionary found and sorted on the device (hash set + rank sort: up to 65 536 entries)
+            same(compressors.dictionary(dev(column), np.dtype("u%d" % ksize)), want, ("dictionary", n, distinct))
         same(compressors.dictionary(dev(column), np.dtype("u%d" % ksize), entries=dev(want["dictionary_entries"])), want, ("dictionary, given", n))
     if usize > 1:
         with pytest.raises(compressors.Unrepresentable):
@@ -177,6 +178,25 @@ def test_patches(index_size, esize):
         where = rng.choice(n, size=differing, replace=False)
         decoded[where] = decoded[where] + ud.type(1)
         same(compressors.patches(dev(decoded), dev(truth), index_size), formats.patches(decoded, truth, index_size), ("patches", n, differing))
+
+
+@pytest.mark.parametrize("usize", [1, 2, 4, 8])
+def test_dictionary_construction(usize):
+    """the column's distinct values, sorted, found on the device: numpy.unique"""
+    from libgiddy_amd import compressors
+    ud = np.dtype("u%d" % usize)
+    for n, distinct in [(1, 1), (10, 3), (100000, 256), (1 << 20, 1000), (1 << 21, 65536), (300000, 40000)]:
+        distinct = min(distinct, 1 << (8 * usize))
+        rng = cases.rng(n + distinct + usize)
+        pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=distinct, dtype=np.uint64, endpoint=True).astype(ud))
+        column = pool[rng.integers(0, len(pool), size=n)]
+        got = compressors.dictionary_entries(dev(column)).cpu().numpy().view(ud)
+        assert np.array_equal(got, np.unique(column)), (usize, n, distinct, len(got))
+    if usize >= 4:
+        with pytest.raises(compressors.Unrepresentable):
+            compressors.dictionary_entries(dev(np.arange(70000, dtype=ud)))
+        with pytest.raises(compressors.Unrepresentable):
+            compressors.dictionary_entries(dev(np.arange(300, dtype=ud)), limit=256)
 
 
 @pytest.mark.parametrize("usize,use_dictionary", [(1, True), (2, True), (4, True), (8, True), (1, False)])

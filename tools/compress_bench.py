@@ -74,3 +74,7 @@ f, t = timed(lambda: compressors.dictionary(column, np.uint8, entries=torch.sort
 out = torch.empty_like(column)
 schemes.dictionary(out, f["compressed_input"], f["dictionary_entries"], n, 256, stream=st)
 report("dictionary<4,4,1> encoding, 256 entries", 4 * n, nbytes(f), t, bool((out == column).all()))
+f, t = timed(lambda: compressors.dictionary(column, np.uint8))
+out.zero_()
+schemes.dictionary(out, f["compressed_input"], f["dictionary_entries"], n, 256, stream=st)
+report("dictionary<4,4,1>: construction + encoding", 4 * n, nbytes(f), t, bool((out == column).all()) and f["num_dictionary_entries"] == 256)

@@ -353,6 +353,8 @@ def main():
     num = lambda s: [int(x) for x in re.findall(r"(\d+)u", s)]
     ctype = {"signed char": 1, "short": 2, "int": 4, "long": 8}
     for key in r.kernel_t.registered_keys():
+        if key.startswith("compression::"):
+            continue   # (the compressors: tools/compress_bench.py)
         torch.cuda.empty_cache()
         try:
             patched = "::patched::" in key   # the fused decompress-and-patch extensions: 0.1 % patches
