@@ -170,6 +170,38 @@ void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configu
 template <unsigned I, typename U, typename C>
 const device_function_t kernel_t<I, U, C>::get_device_function() const { return reinterpret_cast<const void*>(compress_with_constant_model<I, U, C>); }
 
+namespace linear {
+
+/// as frame_of_reference::kernel_t, with a fitted line per segment: "segment_model_coefficients" int* holds two values per segment
+template <unsigned IndexSize, typename Uncompressed, typename Compressed>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned I, typename U, typename C>
+launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
+	if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+	return tile_launch(util::div_rounding_up(argument<size_t>(extra_arguments, "length"), segment_length));
+}
+
+template <unsigned I, typename U, typename C>
+void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<C*>(arguments, "compressed_input"), reinterpret_cast<cuda::array<int, 2>*>(argument<int*>(arguments, "segment_model_coefficients")),
+		argument<const U*>(arguments, "input"), (size_type) argument<uint_t<I>>(arguments, "length"),
+		(size_type) argument<uint_t<I>>(arguments, "segment_length"),
+		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+}
+
+template <unsigned I, typename U, typename C>
+const device_function_t kernel_t<I, U, C>::get_device_function() const { return reinterpret_cast<const void*>(compress_with_linear_model<I, U, C>); }
+
+} // namespace linear
 } // namespace frame_of_reference
 
 // ---- dictionary encoding ---------------------------------------------------------------------------------------------------

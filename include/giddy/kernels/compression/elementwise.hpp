@@ -110,6 +110,80 @@ __global__ void __launch_bounds__(threads_per_block) compress_with_constant_mode
 	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
 }
 
+/// The same with a LINE per segment: c1 = the least-squares slope over x = 0 .. n-1 rounded to the nearest integer (ties to even) in
+/// exact integer arithmetic — (n Sxy - Sx Sy) / (n Sxx - Sx^2), 128-bit —, c0 = the midpoint of the residuals' extremes, offsets from
+/// c0 + c1 x: what formats.frame_of_reference(model="linear") writes.  One workgroup per segment, three passes over it.
+template <unsigned IndexSize, typename Uncompressed, typename Compressed>
+__global__ void __launch_bounds__(threads_per_block) compress_with_linear_model(
+	Compressed*          __restrict__  compressed_output,
+	cuda::array<int, 2>* __restrict__  segment_model_coefficients,
+	const Uncompressed*  __restrict__  input,
+	size_type_by_index_size<IndexSize> length,
+	size_type_by_index_size<IndexSize> segment_length,
+	native_word_t*       __restrict__  unrepresentable)
+{
+	__shared__ __int128 partial_xy[threads_per_block];
+	__shared__ int64_t partial_y[threads_per_block];
+	__shared__ int64_t low[waves_per_block], high[waves_per_block];
+	__shared__ int64_t slope_shared;
+	const uint64_t n = length, L = segment_length, num_segments = (n + L - 1) / L;
+	unsigned bad = 0;
+	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+		const uint64_t start = s * L, end = start + L < n ? start + L : n, count = end - start;
+		// 1. Sy and Sxy, exactly
+		__int128 sum_xy = 0; int64_t sum_y = 0;
+		for (uint64_t x = threadIdx.x; x < count; x += blockDim.x) {
+			const int64_t y = (int64_t) input[start + x];
+			sum_y += y; sum_xy += (__int128) y * (int64_t) x;
+		}
+		__syncthreads();
+		partial_xy[threadIdx.x] = sum_xy; partial_y[threadIdx.x] = sum_y;
+		__syncthreads();
+		if (threadIdx.x == 0) {
+			__int128 sxy = 0, sy = 0;
+			for (unsigned t = 0; t < blockDim.x && t < threads_per_block; t++) { sxy += partial_xy[t]; sy += partial_y[t]; }
+			int64_t slope = 0;
+			if (count >= 2) {
+				const __int128 c = (__int128) count, sx = c * (c - 1) / 2, sxx = (c - 1) * c * (2 * c - 1) / 6;
+				const __int128 numerator = c * sxy - sx * sy, denominator = c * sxx - sx * sx;   // denominator > 0
+				__int128 quotient = numerator / denominator, remainder = numerator % denominator;
+				if (remainder < 0) { quotient -= 1; remainder += denominator; }                    // floor division
+				if (2 * remainder > denominator || (2 * remainder == denominator && (quotient & 1) != 0)) { quotient += 1; }
+				slope = (int64_t) quotient;
+			}
+			slope_shared = slope;
+		}
+		__syncthreads();
+		const int64_t slope = slope_shared;
+		// 2. the residuals' extremes
+		int64_t lowest = INT64_MAX, highest = INT64_MIN;
+		for (uint64_t x = threadIdx.x; x < count; x += blockDim.x) {
+			const int64_t residual = (int64_t) input[start + x] - slope * (int64_t) x;
+			lowest = residual < lowest ? residual : lowest; highest = residual > highest ? residual : highest;
+		}
+		#pragma unroll
+		for (int offset = 32; offset >= 1; offset >>= 1) {
+			const int64_t other_low = __shfl_xor(lowest, offset, 64), other_high = __shfl_xor(highest, offset, 64);
+			lowest = other_low < lowest ? other_low : lowest; highest = other_high > highest ? other_high : highest;
+		}
+		if (wave64::lane_id() == 0) { low[wave64::index_in_block()] = lowest; high[wave64::index_in_block()] = highest; }
+		__syncthreads();
+		for (unsigned w = 0; w < wave64::per_block() && w < waves_per_block; w++) {
+			lowest = low[w] < lowest ? low[w] : lowest; highest = high[w] > highest ? high[w] : highest;
+		}
+		const int c0 = (int) ((lowest + highest) >> 1), c1 = (int) slope;   // (narrowed to int32 as the writer does)
+		if (threadIdx.x == 0) { segment_model_coefficients[s][0] = c0; segment_model_coefficients[s][1] = c1; }
+		// 3. offsets from the line
+		for (uint64_t x = threadIdx.x; x < count; x += blockDim.x) {
+			const int64_t offset = (int64_t) input[start + x] - ((int64_t) c0 + (int64_t) c1 * (int64_t) x);
+			compressed_output[start + x] = (Compressed) offset;
+			if ((int64_t) (Compressed) offset != offset) { bad++; }
+		}
+		__syncthreads();
+	}
+	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
+}
+
 } // namespace frame_of_reference
 
 namespace dictionary {

@@ -97,16 +97,18 @@ def discard_zero_bytes_variable(column, segment_length, min_represented_element_
 
 
 def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model="constant", index_size=4):
-    """a constant model per segment (the midpoint of the segment's extremes); `column`: a SIGNED tensor (int16 / int32)"""
-    if model != "constant":
-        raise NotImplementedError("the device-side writer fits constant models; formats.frame_of_reference fits lines with numpy.polyfit, in floating point")
+    """a constant model per segment (the midpoint of the segment's extremes) or a fitted line (exact least-squares slope, rounded; the
+    midpoint of the residuals); `column`: a SIGNED tensor (int16 / int32)"""
+    if model not in ("constant", "linear"):
+        raise ValueError(model)
     n, usize, csize = column.numel(), column.element_size(), _size(compressed_dtype)
     nseg = -(-n // segment_length)
+    dimension = 1 if model == "constant" else 2
     out = {"compressed_input": torch.empty(n, dtype=_SIGNED[csize], device=column.device),
-           "segment_model_coefficients": torch.empty((nseg, 1), dtype=torch.int32, device=column.device), "length": n, "segment_length": segment_length}
+           "segment_model_coefficients": torch.empty((nseg, dimension), dtype=torch.int32, device=column.device), "length": n, "segment_length": segment_length}
     counter = _counter(column.device)
     if n:
-        _launch("compression::frame_of_reference::kernel_t<%du, %s, %s>" % (index_size, _NAMES[usize], _NAMES[csize]),
+        _launch("compression::frame_of_reference::%skernel_t<%du, %s, %s>" % ("" if model == "constant" else "linear::", index_size, _NAMES[usize], _NAMES[csize]),
                 {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
                 {"compressed_input": r.pointer(out["compressed_input"], "i%d" % (8 * csize)), "segment_model_coefficients": r.pointer(out["segment_model_coefficients"], "i32"),
                  "input": r.const_pointer(column, "i%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),

@@ -42,6 +42,11 @@ static_block {
 	frame_of_reference::kernel_t<4, int, signed char>::registerInSubclassFactory();
 	frame_of_reference::kernel_t<4, int, short>::registerInSubclassFactory();
 	frame_of_reference::kernel_t<8, int, short>::registerInSubclassFactory();
+	// ... and with a fitted line per segment (the decompressor's linear-model tuples)
+	frame_of_reference::linear::kernel_t<4, short, signed char>::registerInSubclassFactory();
+	frame_of_reference::linear::kernel_t<4, int, signed char>::registerInSubclassFactory();
+	frame_of_reference::linear::kernel_t<4, int, short>::registerInSubclassFactory();
+	frame_of_reference::linear::kernel_t<8, int, short>::registerInSubclassFactory();
 	incidence_bitmaps::kernel_t<4, 2>::registerInSubclassFactory();   // <IndexSize, BitmapAlignmentInInts>
 	// run-length: <IndexSize, UncompressedSize, RunLengthSize, RunIndexSize>, the decompressor's 18 tuples
 	run_length_encoding::kernel_t<4, 1, 1>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 1, 2>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 1, 4>::registerInSubclassFactory();

@@ -36,10 +36,26 @@ def div_rounding_up(a, b):
 # ------------------------------------------------------------------------------------------------
 # Frame of reference  (src/kernels/decompression/frame_of_reference.cuh:19-33)
 # ------------------------------------------------------------------------------------------------
+def least_squares_slope(values):
+    """round-half-even of the least-squares slope of `values` over x = 0 .. n-1, in exact integer arithmetic (0 for fewer than 2 values)"""
+    n = len(values)
+    if n < 2:
+        return 0
+    sx, sxx = n * (n - 1) // 2, (n - 1) * n * (2 * n - 1) // 6
+    sy, sxy = sum(values), sum(x * v for x, v in enumerate(values))
+    numerator, denominator = n * sxy - sx * sy, n * sxx - sx * sx      # denominator > 0
+    quotient, remainder = divmod(numerator, denominator)                 # floor division: 0 <= remainder < denominator
+    if 2 * remainder > denominator or (2 * remainder == denominator and quotient % 2 != 0):
+        quotient += 1
+    return quotient
+
+
 def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model="constant"):
     """One model record per segment + a signed per-element offset.
 
-    constant: c0 = midpoint of the segment; linear: least-squares line rounded to integers
+    constant: c0 = midpoint of the segment; linear: the least-squares slope over x = 0 .. n-1, rounded to the
+    nearest integer (ties to even) in EXACT integer arithmetic — c1 = round((n Sxy - Sx Sy) / (n Sxx - Sx^2)) —
+    so that the device-side writer (libgiddy_amd.compressors) reproduces it bit for bit; c0 = midpoint of the residuals
     (coefficients are int32, as in every registered instantiation,
     src/kernel_wrappers/decompression/frame_of_reference.cu:132-142).
     """
@@ -60,9 +76,7 @@ def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model=
         coefs = np.zeros((nseg, 2), dtype=np.int32)
         for s in range(nseg):
             chunk = wide[s * segment_length:(s + 1) * segment_length]
-            x = np.arange(len(chunk), dtype=np.float64)
-            slope = 0.0 if len(chunk) < 2 else np.polyfit(x, chunk.astype(np.float64), 1)[0]
-            c1 = int(np.round(slope))
+            c1 = least_squares_slope([int(v) for v in chunk])
             resid = chunk - c1 * np.arange(len(chunk), dtype=np.int64)
             coefs[s] = (np.int32((int(resid.min()) + int(resid.max())) // 2), np.int32(c1))
         predicted = coefs[seg, 0].astype(np.int64) + coefs[seg, 1].astype(np.int64) * pos

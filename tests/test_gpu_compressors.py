@@ -108,6 +108,30 @@ def test_frame_of_reference_constant_model(index_size, uncompressed, compressed)
         compressors.frame_of_reference(dev(np.array([np.iinfo(uncompressed).min // 2, np.iinfo(uncompressed).max // 2], dtype=uncompressed)), 2, compressed)
 
 
+@pytest.mark.parametrize("index_size,uncompressed,compressed", [(4, np.int16, np.int8), (4, np.int32, np.int8), (4, np.int32, np.int16), (8, np.int32, np.int16)])
+def test_frame_of_reference_linear_model(index_size, uncompressed, compressed):
+    """a fitted line per segment: the exact least-squares slope (128-bit integer arithmetic on the device, Python integers in the writer), rounded half to even"""
+    from libgiddy_amd import compressors, schemes
+    for n, L in [(1, 4), (2, 4), (100, 8), (4096, 4096), (4097, 1024), (70001, 1000), (300007, 4096), (1 << 19, 1 << 18)]:
+        rng = cases.rng(n + L + 1)
+        info = np.iinfo(compressed)
+        segments = -(-n // L)
+        slopes = rng.integers(-3, 4, size=segments).repeat(L)[:n] if uncompressed == np.int16 else rng.integers(-40, 41, size=segments).repeat(L)[:n]
+        base = rng.integers(-2000, 2000, size=segments).repeat(L)[:n]
+        if uncompressed == np.int16 and L > 4096:
+            continue   # (a line over 2^18 positions leaves int16)
+        noise = rng.integers(info.min // 4, info.max // 4, size=n)
+        column = (base + slopes * (np.arange(n) % L) + noise).astype(uncompressed)
+        want = formats.frame_of_reference(column, L, compressed, "linear")
+        got = compressors.frame_of_reference(dev(column), L, compressed, "linear", index_size=index_size)
+        same(got, want, ("for linear", n, L))
+        out = torch.empty(n, dtype=torch.from_numpy(np.zeros(1, uncompressed)).dtype, device="cuda")
+        schemes.frame_of_reference(out, got["compressed_input"], got["segment_model_coefficients"], n, L, uncompressed_size=np.dtype(uncompressed).itemsize,
+                                   compressed_size=np.dtype(compressed).itemsize, model="linear", index_size=index_size, model_index_size=4,
+                                   stream=torch.cuda.current_stream().cuda_stream)
+        assert (out.cpu().numpy() == column).all(), ("for linear round trip", n, L)
+
+
 @pytest.mark.parametrize("usize,ksize", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)])
 def test_dictionary(usize, ksize):
     from libgiddy_amd import compressors
