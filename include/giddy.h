@@ -99,7 +99,7 @@ typedef struct giddy_launch_configuration_limits {
 #define GIDDY_CURRENT_DEVICE        (-2)
 
 /* ---- factory ---------------------------------------------------------------------------- */
-int          giddy_kernel_count(void);                 /* number of registered wrapper instantiations (the reference's 163 + 57 fused decompress-and-patch extensions + 8 expansions of compressed patch positions + 104 device-side compressors) */
+int          giddy_kernel_count(void);                 /* number of registered wrapper instantiations (the reference's 163 + 57 fused decompress-and-patch extensions + 8 expansions of compressed patch positions + 110 device-side compressors) */
 const char*  giddy_kernel_key(int index);              /* keys in lexicographic order; NULL if out of range */
 int          giddy_can_produce(const char* key);       /* 1 / 0 */
 int          giddy_produce(const char* key, giddy_kernel_t** kernel);

@@ -12,6 +12,7 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/compression/discard_zero_bytes_variable.hpp"
+#include "giddy/kernels/compression/compressed_indices.hpp"
 #include "giddy/kernels/compression/dictionary_construction.hpp"
 #include "giddy/kernels/compression/elementwise.hpp"
 #include "giddy/kernels/compression/incidence_bitmaps.hpp"
@@ -404,6 +405,54 @@ template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
 const device_function_t kernel_t<I, U, P, R, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>); }
 
 } // namespace run_position_encoding
+
+// ---- compressed patch positions -------------------------------------------------------------------------------------------------
+namespace compressed_indices {
+
+/// "positions" const uint_t<OutputIndexSize>* (ascending, distinct), "input_data_length", "anchoring_period"; outputs under the
+/// compressed-indices scatter's names (room: `input_data_length` runs and input_data_length * OutputIndexSize * 2 + 8 pool bytes at
+/// worst); "num_scatter_position_runs", "num_offset_bytes": uint64_t* device scalars; scratch "tile_totals": 2 * (blocks + 2) entries
+template <unsigned OutputIndexSize, unsigned InputIndexSize, unsigned RunLengthSize = InputIndexSize>
+class kernel_t : public cuda::registered::kernel_t {
+public:
+	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+};
+
+template <unsigned O, unsigned I, unsigned R>
+launch_configuration_t kernel_t<O, I, R>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
+{
+	auto n = argument<size_t>(extra_arguments, "input_data_length");
+	auto period = argument<size_t>(extra_arguments, "anchoring_period");
+	if (n == 0) { throw std::invalid_argument("Zero-length scatters not currently supported"); }
+	if (period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
+	return tile_launch(util::div_rounding_up(util::div_rounding_up(n, period), (size_t) threads_per_block));
+}
+
+template <unsigned O, unsigned I, unsigned R>
+void kernel_t<O, I, R>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+{
+	using size_type = size_type_by_index_size<I>;
+	auto positions = argument<const uint_t<O>*>(arguments, "positions");
+	auto n         = (size_type) argument<size_type>(arguments, "input_data_length");
+	auto period    = argument<uint_t<I>>(arguments, "anchoring_period");
+	auto totals    = argument<uint64_t*>(arguments, "tile_totals");
+	if (period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
+	const uint64_t blocks = util::div_rounding_up((uint64_t) n, (uint64_t) period);
+	uint64_t* block_runs = totals, * block_bytes = totals + blocks + 2;
+	cuda::enqueue_launch(reinterpret_cast<const void*>(count_runs<O, I, R>), stream, launch_config, block_runs, block_bytes, positions, n, period);
+	enqueue_exclusive_offsets(stream, block_runs, blocks, argument<uint64_t*>(arguments, "num_scatter_position_runs"));
+	enqueue_exclusive_offsets(stream, block_bytes, blocks, optional_argument<uint64_t*>(arguments, "num_offset_bytes").value_or(nullptr));
+	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+		argument<uint_t<R>*>(arguments, "scatter_position_run_lengths"), argument<unsigned char*>(arguments, "scatter_position_run_individual_offset_sizes"),
+		argument<uint_t<O>*>(arguments, "scatter_position_run_baseline_values"), argument<uint_t<I>*>(arguments, "scatter_position_run_offsets_start_pos"),
+		argument<unsigned char*>(arguments, "scatter_position_offset_bytes"), argument<uint_t<I>*>(arguments, "scatter_position_anchors"),
+		positions, static_cast<const uint64_t*>(block_runs), static_cast<const uint64_t*>(block_bytes), n, period);
+}
+
+template <unsigned O, unsigned I, unsigned R>
+const device_function_t kernel_t<O, I, R>::get_device_function() const { return reinterpret_cast<const void*>(write_runs<O, I, R>); }
+
+} // namespace compressed_indices
 
 // ---- patches: where a decoded column differs from the true one ---------------------------------------------------------------
 namespace patches {

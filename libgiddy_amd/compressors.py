@@ -241,3 +241,33 @@ def patches(decoded, truth, index_size=4, capacity=None):
                  "length": r.uint_t(index_size)(n), "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_patches": r.pointer(count, "u64")})
     k = int(count[0])
     return {"indices": positions[:k], "data": values[:k], "data_length": k}
+
+
+def compressed_indices(positions, anchoring_period, output_index_size=4, input_index_size=4, run_length_size=None):
+    """ascending, distinct patch positions (a device tensor of output_index_size-byte integers) -> the compressed-indices arrays the
+    compressed-indices scatter and the fused decoders take (without "data_to_scatter": the patch values are the caller's)"""
+    run_length_size = run_length_size or input_index_size
+    n = positions.numel()
+    if n == 0:
+        raise ValueError("zero-length scatters are rejected (compressed_indices_scatter.cuh:288-290)")
+    device = positions.device
+    O, I, R = output_index_size, input_index_size, run_length_size
+    blocks = -(-n // anchoring_period)
+    buffers = {"scatter_position_run_lengths": torch.empty(n, dtype=_SIGNED[R], device=device),
+               "scatter_position_run_individual_offset_sizes": torch.empty(n, dtype=torch.uint8, device=device),
+               "scatter_position_run_baseline_values": torch.empty(n, dtype=_SIGNED[O], device=device),
+               "scatter_position_run_offsets_start_pos": torch.empty(n, dtype=_SIGNED[I], device=device),
+               "scatter_position_offset_bytes": torch.empty(n * 2 * O + 8, dtype=torch.uint8, device=device),
+               "scatter_position_anchors": torch.empty(blocks, dtype=_SIGNED[I], device=device)}
+    sizes = torch.zeros(2, dtype=torch.int64, device=device)
+    scratch = torch.empty(2 * (blocks + 2), dtype=torch.int64, device=device)
+    launch = {name: r.pointer(t, "u8" if t.dtype == torch.uint8 else "u%d" % (8 * t.element_size())) for name, t in buffers.items()}
+    launch.update({"positions": r.const_pointer(positions, "u%d" % (8 * O)), "input_data_length": r.size_type_by_index_size(I)(n),
+                   "anchoring_period": r.uint_t(I)(anchoring_period), "tile_totals": r.pointer(scratch, "u64"),
+                   "num_scatter_position_runs": r.pointer(sizes[0:1], "u64"), "num_offset_bytes": r.pointer(sizes[1:2], "u64")})
+    _launch("compression::compressed_indices::kernel_t<%du, %du, %du>" % (O, I, R),
+            {"input_data_length": r.size_t(n), "anchoring_period": r.size_t(anchoring_period)}, launch)
+    runs, pool = int(sizes[0]), -(-int(sizes[1]) // 8) * 8
+    out = {name: (t if name == "scatter_position_anchors" else t[: pool if name == "scatter_position_offset_bytes" else runs]) for name, t in buffers.items()}
+    out.update({"anchoring_period": anchoring_period, "num_scatter_position_runs": runs, "input_data_length": n})
+    return out

@@ -48,6 +48,10 @@ static_block {
 	frame_of_reference::linear::kernel_t<4, int, short>::registerInSubclassFactory();
 	frame_of_reference::linear::kernel_t<8, int, short>::registerInSubclassFactory();
 	incidence_bitmaps::kernel_t<4, 2>::registerInSubclassFactory();   // <IndexSize, BitmapAlignmentInInts>
+	// compressed patch positions: <OutputIndexSize, InputIndexSize, RunLengthSize> (what the fused decoders and the position expansion take)
+	compressed_indices::kernel_t<4, 4>::registerInSubclassFactory(); compressed_indices::kernel_t<4, 8>::registerInSubclassFactory();
+	compressed_indices::kernel_t<8, 4>::registerInSubclassFactory(); compressed_indices::kernel_t<8, 8>::registerInSubclassFactory();
+	compressed_indices::kernel_t<4, 2>::registerInSubclassFactory(); compressed_indices::kernel_t<4, 1>::registerInSubclassFactory();
 	// run-length: <IndexSize, UncompressedSize, RunLengthSize, RunIndexSize>, the decompressor's 18 tuples
 	run_length_encoding::kernel_t<4, 1, 1>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 1, 2>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 1, 4>::registerInSubclassFactory();
 	run_length_encoding::kernel_t<4, 2, 1>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 2, 2>::registerInSubclassFactory(); run_length_encoding::kernel_t<4, 2, 4>::registerInSubclassFactory();

@@ -260,3 +260,32 @@ def test_a_column_goes_through_model_plus_patches_without_leaving_the_device():
     out = torch.empty(n, dtype=torch.int32, device="cuda")
     schemes.patched_model(out, coefficients, p["data"], p["indices"], n, p["data_length"], uncompressed_size=4, model="linear", stream=stream)
     assert bool((out == truth).all())
+
+
+@pytest.mark.parametrize("output_index_size,input_index_size", [(4, 4), (8, 8), (8, 4), (4, 8), (4, 2), (4, 1)])
+def test_compressed_patch_positions(output_index_size, input_index_size):
+    """the compressed-indices arrays written on the device == formats.compressed_indices, and a fused decoder takes them as they are"""
+    from libgiddy_amd import compressors, schemes
+    limit = (1 << (8 * input_index_size)) - 1 if input_index_size < 4 else 1 << 40
+    for n, period, span in [(1, 16, 100), (300, 64, 100000), (5000, 256, 1 << 24), (20000, 1024, 1 << 31), (100000, 1000, 1 << 20), (3000, 7, 1 << 33)]:
+        if n > limit or (span > (1 << 32) and output_index_size == 4):
+            continue
+        rng = cases.rng(n + period)
+        positions = np.unique(rng.integers(0, span, size=n * 2, dtype=np.uint64))[:n]
+        n_here = len(positions)
+        want = formats.compressed_indices(positions, np.zeros(0, np.uint8), period, output_index_size, input_index_size)
+        want.pop("data_to_scatter")
+        got = compressors.compressed_indices(dev(positions.astype("u%d" % output_index_size)), period, output_index_size, input_index_size)
+        same(got, want, ("compressed indices", n_here, period, span))
+    # ... straight into the fused Delta decoder
+    if (output_index_size, input_index_size) == (4, 4):
+        n, L = 1 << 18, 4096
+        f, truth = cases.delta_case(n, L, np.uint64, np.uint16, seed=9)
+        where = np.sort(cases.rng(10).choice(n, size=777, replace=False)).astype(np.uint32)
+        values = cases.rng(11).integers(0, 1 << 62, size=777, dtype=np.uint64)
+        compressed = compressors.compressed_indices(dev(where), 128)
+        compressed["patch_positions_scratch"] = torch.empty(777, dtype=torch.int32, device="cuda")
+        out = torch.empty(n, dtype=torch.int64, device="cuda")
+        schemes.patched_delta(out, dev(f["compressed_input"]), dev(f["anchor_values"]), dev(values), compressed, n, L, 777, stream=torch.cuda.current_stream().cuda_stream)
+        expect = truth.copy(); expect[where] = values
+        assert (out.cpu().numpy().view(np.uint64) == expect).all()
