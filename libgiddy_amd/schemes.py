@@ -140,14 +140,19 @@ def dictionary(decompressed, compressed_input, dictionary_entries, length, num_d
 
 
 def delta(decompressed, compressed_input, anchor_values, length, segment_length, *,
-          uncompressed_size=8, compressed_size=2, index_size=4, stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+          uncompressed_size=8, compressed_size=2, index_size=4, part_anchors_scratch=None,
+          stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
+    """`part_anchors_scratch` (an extension; a device buffer of ceil(length / 4096) + 1024 uncompressed-type entries): segments of 2^17 elements
+    or more are decoded in parts — a column that is ONE segment uses the whole GPU instead of one workgroup"""
+    launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
+              "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
+              "anchor_values": r.const_pointer(anchor_values, "u%d" % (8 * uncompressed_size)),
+              "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)}
+    if part_anchors_scratch is not None:
+        launch["part_anchors_scratch"] = r.pointer(part_anchors_scratch, "u%d" % (8 * uncompressed_size))
     return _run(
         key_delta(index_size, uncompressed_size, compressed_size),
-        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)},
-        {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
-         "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
-         "anchor_values": r.const_pointer(anchor_values, "u%d" % (8 * uncompressed_size)),
-         "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)},
+        {"length": r.size_t(length), "segment_length": r.size_t(segment_length)}, launch,
         stream, device, limits, launch_config)
 
 

@@ -109,3 +109,23 @@ def test_delta_and_rle_index_size_8_large_positions():
     schemes.delta(out, d, anchors, n, L, uncompressed_size=8, compressed_size=1, index_size=8, stream=g.stream())
     torch.cuda.synchronize()
     assert bool((out == pref).all())
+
+
+@pytest.mark.parametrize("usize,csize,index_size", [(8, 2, 4), (4, 1, 4), (8, 4, 8), (2, 1, 4)])
+def test_delta_with_very_long_segments_in_parts(usize, csize, index_size):
+    """the Delta wrapper's extension for long segments ("part_anchors_scratch"): segments of 2^17 elements or more are decoded in
+    parts — the parts' delta sums, the value before each part, then the ordinary decoder with the parts as its segments.  One giant
+    segment, several long ones, lengths that are not a multiple of the part, a ragged last segment, and a length no part divides
+    (which takes the ordinary path)"""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    for n, L in [(1 << 22, 1 << 22), ((1 << 22) + 12345, 1 << 22), (5 * (3 << 17) - 7, 3 << 17), (1 << 21, (1 << 17) + 4096), (600000, 200000), (1 << 20, 1 << 17)]:
+        f, truth = cases.delta_case(n, L, ud, cd, seed=n % 1000 + usize)
+        scratch = torch.zeros(n // 4096 + 1024, dtype={2: torch.int16, 4: torch.int32, 8: torch.int64}[usize], device="cuda")
+        out = g.dev_empty(n, ud)
+        schemes.delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), n, L, uncompressed_size=usize, compressed_size=csize, index_size=index_size,
+                      part_anchors_scratch=scratch, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != truth)
+        assert len(bad) == 0, (n, L, bad[:5], got[bad[:5]], truth[bad[:5]])

@@ -9,6 +9,8 @@ def show(name, res):
     print("%-50s %8.3f ms %8.1f GB/s %5.1f%% %s" % (name, ms, nbytes / ms / 1e6, nbytes / ms / 1e6 / 80, "ok" if ok else "MISMATCH"), flush=True)
 for L in (128, 256, 512, 1024, 2048, 4096, 16384, 32768, 1 << 16, 1 << 20, 1 << 24):
     show("delta<4,8,2> L=%d" % L, sw.run_delta(4, 8, 2, n, L))
+for L in (1 << 17, 1 << 20, 1 << 24, 1 << 28):
+    show("delta<4,8,2> L=%d, in parts (part_anchors_scratch)" % L, sw.run_delta(4, 8, 2, n, L, in_parts=True))
 for L in (256, 1024, 4096, 1 << 16):
     show("delta<4,4,1> L=%d" % L, sw.run_delta(4, 4, 1, n, L))
 for mean_run in (2, 4, 8, 32, 128, 1000, 20000):

@@ -97,7 +97,7 @@ def run_dictionary(I, U, D, n, patched=False, entries_n=None):
     return ms, (U + D) * n, ok
 
 
-def run_delta(I, U, C, n, L=4096, patched=False):
+def run_delta(I, U, C, n, L=4096, patched=False, in_parts=False):
     g = gen(U * 10 + C)
     d = rand_bits(n, C, g)
     du = unsigned(d, C)
@@ -107,6 +107,8 @@ def run_delta(I, U, C, n, L=4096, patched=False):
     out = torch.empty(n, dtype=INT[U], device=DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
+    if in_parts:   # the wrapper's extension for long segments
+        kw["part_anchors_scratch"] = torch.zeros(n // 4096 + 1024, dtype=INT[U], device=DEV)
     if patched:
         idx, pidx, pval = make_patches(n, U, I, U + C)
         cfg = schemes.patched_delta(out, d, anchors, pval, pidx, n, L, len(idx), **kw)
