@@ -68,6 +68,7 @@ __global__ void decompress(
 	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t L = segment_length, n = total_uncompressed_length, num_runs = num_element_runs;
+	using length_type = typename std::conditional<(RunLengthSize > 4), uint64_t, uint32_t>::type;   // what a run's length is computed with
 
 	// Short segments are taken several at a time: the runs of consecutive segments are consecutive too — anchors are
 	// only entry points — so k segments starting at segment s decode exactly like one segment of k * L outputs
@@ -81,7 +82,7 @@ __global__ void decompress(
 		const uint64_t chunk_outputs = segments_per_chunk * L;
 		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
 		uint64_t first_run = segment_position_anchors[s];
-		uint64_t left_in_first_run = (uint64_t) run_lengths[first_run] - segment_position_anchor_intra_run_offsets[s];
+		length_type left_in_first_run = (length_type) run_lengths[first_run] - (length_type) segment_position_anchor_intra_run_offsets[s];
 		uint64_t run_limit = num_runs;   // exclusive
 		if (s + segments_per_chunk < num_segments) {
 			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk] + 1;
@@ -96,33 +97,54 @@ __global__ void decompress(
 		uint_t<UncompressedSize> prefetched_values[runs_per_lane];
 		bool prefetched = false, values_prefetched = false;   // (values: always where they travel with the descriptors; else after a dense tile)
 		uint32_t tile_len = 0;
-		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
+		for (uint64_t tile_start = segment_start; tile_start < segment_end && first_run < run_limit; tile_start += tile_len) {
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
 			bool need_carry = tile_start + tile_len < segment_end;
 			bool dense = false, values_staged = false;
 			clear(table, lane);
 
+			// Runs are addressed RELATIVE to the tile's first run from here on (32 bits: a tile holds at most tile_length of them), and a
+			// batch's loads are unconditional — a lane past the last run re-reads that run and discards it — so that all of them are in
+			// flight together: no branch, no wait between one load and the next.
+			const uint32_t runs_from_here = run_limit - first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (run_limit - first_run);   // >= 1
+			const uint_t<RunLengthSize>* __restrict__ lengths_from_here = run_lengths + first_run;
+			const uint_t<UncompressedSize>* __restrict__ values_from_here = run_data + first_run;
 			uint32_t running = 0;      // clamped lengths summed over earlier batches = start of this batch's first run
-			uint64_t batch_base = 0;   // index (relative to first_run) of this batch's first run
-			bool found = false; uint64_t carried_run = 0, carried_left = 0;
+			uint32_t batch_base = 0;   // index (relative to first_run) of this batch's first run
+			uint32_t carried_run = ~0u; length_type carried_left = 0;   // the run that reaches past the tile's end, in the lane that holds it
 			do {
-				uint64_t lengths[runs_per_lane]; uint32_t clamped[runs_per_lane]; bool have[runs_per_lane];
+				length_type lengths[runs_per_lane]; uint32_t clamped[runs_per_lane]; bool have[runs_per_lane];
+				uint_t<UncompressedSize> values[runs_per_lane];
+				const uint32_t lane_base = batch_base + lane * runs_per_lane;
+				const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
+				const bool stage_prefetched = !staging::with_descriptors && from_prefetch && values_prefetched;   // a dense tile's successor
+				if (from_prefetch) {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) { lengths[j] = prefetched_lengths[j]; values[j] = prefetched_values[j]; }
+				}
+				else {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint32_t k = lane_base + j < runs_from_here ? lane_base + j : runs_from_here - 1;
+						lengths[j] = load_descriptor(lengths_from_here + k);
+						if (staging::with_descriptors) { values[j] = values_from_here[k]; }   // the runs' values travel with their lengths
+					}
+				}
 				uint32_t lane_total = 0;
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
-					uint64_t k = batch_base + (uint64_t) lane * runs_per_lane + j;
-					have[j] = first_run + k < run_limit;
-					const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
-					lengths[j] = !have[j] ? 0 : (k == 0 ? left_in_first_run : (uint64_t) (from_prefetch ? prefetched_lengths[j] : load_descriptor(run_lengths + first_run + k)));
+					have[j] = lane_base + j < runs_from_here;
+					if (!have[j]) { lengths[j] = 0; }
+					if (j == 0 && lane_base == 0) { lengths[0] = left_in_first_run; }
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
-					// the runs' values travel with their lengths (staged for the expansion; runs past the tile's last are harmless)
-					if (staging::with_descriptors && have[j] && k < staging::capacity) { staged[k] = from_prefetch ? prefetched_values[j] : run_data[first_run + k]; }
-					if (!staging::with_descriptors && from_prefetch && values_prefetched && have[j] && k < staging::capacity) { staged[k] = prefetched_values[j]; values_staged = true; }
+					// (staged for the expansion; runs past the tile's last are harmless)
+					if ((staging::with_descriptors || stage_prefetched) && have[j] && lane_base + j < staging::capacity) { staged[lane_base + j] = values[j]; }
 				}
+				values_staged = values_staged || stage_prefetched;
 				uint32_t inclusive = wave64::inclusive_sum(lane_total);
 				const uint32_t covered = wave64::read_last_lane(inclusive);
-				if (batch_base == 0 && covered < tile_len && first_run + runs_per_batch < run_limit) {
+				if (batch_base == 0 && covered < tile_len && covered >= staging::dense_granule && runs_from_here > runs_per_batch) {   // (lengths of 0 are not allowed: no empty tile)
 					// a dense tile (run_expansion.hpp): it ends where this batch's runs end, on a whole 128-byte piece of output
 					// (no length was clamped: each is at most `covered`)
 					tile_len = covered / staging::dense_granule * staging::dense_granule;
@@ -131,40 +153,40 @@ __global__ void decompress(
 				uint32_t start = running + inclusive - lane_total;
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
-					if (have[j]) {
-						if (start > 0 && start < tile_len) { mark(table, start); }
-						if (need_carry && start <= tile_len && lengths[j] > tile_len - start) {
-							found = true;
-							carried_run = first_run + batch_base + (uint64_t) lane * runs_per_lane + j;
-							carried_left = lengths[j] - (tile_len - start);
-						}
-					}
+					if (have[j] && start - 1u < tile_len - 1u) { mark(table, start); }   // 0 < start < tile_len
+					// (a run past the last has length 0 and reaches nowhere)
+					const bool reaches_past = need_carry && start <= tile_len && lengths[j] > (length_type) (tile_len - start);
+					carried_run = reaches_past ? lane_base + j : carried_run;
+					carried_left = reaches_past ? lengths[j] - (length_type) (tile_len - start) : carried_left;
 					start += clamped[j];
 				}
 				running += covered;
 				batch_base += runs_per_batch;
-			} while ((running < tile_len || (need_carry && running == tile_len)) && first_run + batch_base < run_limit);
+			} while ((running < tile_len || (need_carry && running == tile_len)) && batch_base < runs_from_here);
 
 			// where the next tile enters the runs — and its first batch, on its way before this tile stores
-			uint64_t next_first_run = first_run, next_left_in_first_run = left_in_first_run;
+			uint64_t next_first_run = first_run; length_type next_left_in_first_run = left_in_first_run;
 			prefetched = false;
 			if (need_carry) {
-				uint64_t who = wave64::ballot(found);
+				uint64_t who = wave64::ballot(carried_run != ~0u);
 				if (who != 0) {
 					unsigned source = (unsigned) __builtin_ctzll(who);
-					next_first_run = wave64::read_lane(carried_run, source);
+					next_first_run = first_run + wave64::read_lane(carried_run, source);
 					next_left_in_first_run = wave64::read_lane(carried_left, source);
 				}
 				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+					const uint32_t runs_from_there = run_limit - next_first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (run_limit - next_first_run);   // >= 1
+					uint32_t k[runs_per_lane];
 					#pragma unroll
 					for (unsigned j = 0; j < runs_per_lane; j++) {
-						const uint64_t r = next_first_run + (uint64_t) lane * runs_per_lane + j;
-						if (r < run_limit) {
-							prefetched_lengths[j] = load_descriptor(run_lengths + r);
-							if (staging::with_descriptors || dense) { prefetched_values[j] = run_data[r]; }   // (after a dense tile, most likely another)
-						}
+						k[j] = lane * runs_per_lane + j < runs_from_there ? lane * runs_per_lane + j : runs_from_there - 1;
+						prefetched_lengths[j] = load_descriptor(run_lengths + next_first_run + k[j]);
 					}
-					prefetched = true; values_prefetched = staging::with_descriptors || dense;
+					prefetched = true; values_prefetched = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
+					if (values_prefetched) {
+						#pragma unroll
+						for (unsigned j = 0; j < runs_per_lane; j++) { prefetched_values[j] = run_data[next_first_run + k[j]]; }
+					}
 				}
 			}
 
@@ -172,7 +194,7 @@ __global__ void decompress(
 			if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
-			else if (!staging::with_descriptors && wave64::ballot(values_staged) != 0) {   // a dense tile whose values came with the prefetched lengths
+			else if (!staging::with_descriptors && values_staged) {   // a dense tile whose values came with the prefetched lengths
 				expand<UncompressedSize, true, true>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 			}
 			else {

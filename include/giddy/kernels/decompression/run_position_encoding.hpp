@@ -96,69 +96,89 @@ __global__ void decompress(
 		uint_t<UncompressedSize> prefetched_values[runs_per_lane], prefetched_first_value = 0;
 		bool prefetched = false, values_prefetched = false;
 		uint32_t tile_len = 0;
-		for (uint64_t tile_start = segment_start; tile_start < segment_end; tile_start += tile_len) {
+		for (uint64_t tile_start = segment_start; tile_start < segment_end && first_run <= last_candidate; tile_start += tile_len) {
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
-			uint64_t tile_end = tile_start + tile_len;
-			bool need_carry = tile_end < segment_end;
+			bool need_carry = tile_start + tile_len < segment_end;
 			bool dense = false, values_staged = false;
 			clear(table, lane);
 			if (staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
 			if (!staging::with_descriptors && prefetched && values_prefetched && lane == 0) { staged[0] = prefetched_first_value; }
 
-			uint64_t batch_base = first_run + 1;
-			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= tile_end
+			// Candidates are addressed RELATIVE to the tile's first run from here on (candidate k is run first_run + 1 + k; 32 bits: a
+			// tile holds at most tile_length of them) and a batch's loads are unconditional — a lane past the last candidate re-reads
+			// that one and discards it — so that all of them are in flight together: no branch, no wait between one load and the next.
+			const uint32_t num_candidates = last_candidate - first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_candidate - first_run);
+			const uint_t<PositionOffsetSize>* __restrict__ positions_from_here = run_start_positions + first_run;
+			const uint_t<UncompressedSize>* __restrict__ values_from_here = run_data + first_run;
+			// a start is of interest up to the tile's end; one at/after the chunk's nominal end opens the NEXT chunk
+			const uint64_t reach = nominal_end - tile_start < tile_length + 1 ? nominal_end - tile_start : tile_length + 1;
+			uint32_t batch_base = 0;
+			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= the tile's end
 			bool reached_past_tile;
 			do {
-				uint64_t starts[runs_per_lane]; bool starts_here[runs_per_lane];   // a candidate that starts inside this chunk
+				uint_t<PositionOffsetSize> positions[runs_per_lane]; uint_t<UncompressedSize> values[runs_per_lane];
+				uint32_t offsets[runs_per_lane];   // of a candidate's start from the tile's; ~0: no such candidate, or it starts past the tile / the chunk
+				const uint32_t lane_base = batch_base + lane * runs_per_lane;
+				const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
+				const bool stage_prefetched = !staging::with_descriptors && from_prefetch && values_prefetched;   // a dense tile's successor
+				if (from_prefetch) {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) { positions[j] = prefetched_positions[j]; values[j] = prefetched_values[j]; }
+				}
+				else {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint32_t r = lane_base + j < num_candidates ? lane_base + j + 1 : num_candidates;   // (relative to first_run)
+						positions[j] = load_descriptor(positions_from_here + r);
+						if (staging::with_descriptors) { values[j] = values_from_here[r]; }   // the runs' values travel with their positions
+					}
+				}
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
-					uint64_t r = batch_base + (uint64_t) lane * runs_per_lane + j;
-					// Relative positions: run r lies in the chunk's segment i = #{j >= 1 : anchor_j < r} — a binary search over
-					// the anchors held one per lane.  (Done by every lane before any lane leaves the iteration: a shuffle
-					// cannot read from an inactive lane.)
-					unsigned segment_in_chunk = 0;
-					if (PositionsAreRelative && segments_per_chunk > 1) {   // wave-uniform
-						#pragma unroll
-						for (unsigned step = 16; step >= 1; step >>= 1) {
-							const unsigned probe = segment_in_chunk + step;
-							const uint64_t anchor = __shfl(chunk_anchor, (int) (probe < 64 ? probe : 63), 64);
-							if (probe < segments_per_chunk && anchor < r) { segment_in_chunk = probe; }
-						}
-					}
-					starts[j] = 0; starts_here[j] = false;
-					if (r > last_candidate) { continue; }
-					const bool from_prefetch = prefetched && batch_base == first_run + 1;   // (wave-uniform)
-					uint64_t position = from_prefetch ? prefetched_positions[j] : load_descriptor(run_start_positions + r);
-					// the runs' values travel with their positions (staged for the expansion; runs past the tile's last are harmless)
-					if (staging::with_descriptors && r - first_run < staging::capacity) { staged[r - first_run] = from_prefetch ? prefetched_values[j] : run_data[r]; }
-					if (!staging::with_descriptors && from_prefetch && values_prefetched && r - first_run < staging::capacity) { staged[r - first_run] = prefetched_values[j]; values_staged = true; }
-					uint64_t start = position;
+					const uint32_t k = lane_base + j;
+					const bool have = k < num_candidates;
+					uint64_t start = positions[j];
 					if (PositionsAreRelative) {
+						// Relative positions: the run lies in the chunk's segment i = #{j >= 1 : anchor_j < r} — a binary search over
+						// the anchors held one per lane
+						unsigned segment_in_chunk = 0;
+						if (segments_per_chunk > 1) {   // wave-uniform
+							const uint64_t r = first_run + 1 + k;
+							#pragma unroll
+							for (unsigned step = 16; step >= 1; step >>= 1) {
+								const unsigned probe = segment_in_chunk + step;
+								const uint64_t anchor = __shfl(chunk_anchor, (int) (probe < 64 ? probe : 63), 64);
+								if (probe < segments_per_chunk && anchor < r) { segment_in_chunk = probe; }
+							}
+						}
 						// ... and at relative position 0 it starts the NEXT segment
-						start = segment_start + (uint64_t) segment_in_chunk * L + (position != 0 ? position : L);
+						start = segment_start + (uint64_t) segment_in_chunk * L + (positions[j] != 0 ? (uint64_t) positions[j] : L);
 					}
-					// a run starting at/after the chunk's nominal end opens the NEXT chunk
-					starts[j] = start; starts_here[j] = start < nominal_end;
+					const uint64_t from_tile_start = start - tile_start;
+					offsets[j] = (have && from_tile_start < reach) ? (uint32_t) from_tile_start : ~0u;
+					// (staged for the expansion; runs past the tile's last are harmless)
+					if ((staging::with_descriptors || stage_prefetched) && have && k + 1 < staging::capacity) { staged[k + 1] = values[j]; }
 				}
-				if (batch_base == first_run + 1) {
+				values_staged = values_staged || stage_prefetched;
+				if (batch_base == 0) {
 					// a dense tile (run_expansion.hpp): when every run of the first batch starts inside the tile, the tile ends where
 					// the batch's last run starts (on a whole 128-byte piece of output)
 					bool outside = false;
 					#pragma unroll
-					for (unsigned j = 0; j < runs_per_lane; j++) { outside = outside || !starts_here[j] || starts[j] >= tile_end; }
-					if (wave64::ballot(outside) == 0) {
-						const uint64_t last_start = wave64::read_last_lane(starts[runs_per_lane - 1]);
-						tile_len = (uint32_t) ((last_start - tile_start) / staging::dense_granule * staging::dense_granule);
-						tile_end = tile_start + tile_len;
+					for (unsigned j = 0; j < runs_per_lane; j++) { outside = outside || offsets[j] >= tile_len; }
+					const uint32_t last_start = wave64::read_last_lane(offsets[runs_per_lane - 1]);
+					if (wave64::ballot(outside) == 0 && last_start >= staging::dense_granule) {   // (positions that do not increase: no empty tile)
+						tile_len = last_start / staging::dense_granule * staging::dense_granule;
 						need_carry = true; dense = true;
 					}
 				}
 				bool past = false;
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
-					if (!starts_here[j] || starts[j] > tile_end) { past = true; continue; }
-					if (starts[j] > tile_start && starts[j] < tile_end) { mark(table, (uint32_t) (starts[j] - tile_start)); }
-					last_at_or_before_end = (uint32_t) (batch_base + (uint64_t) lane * runs_per_lane + j - first_run) + 1;   // increases with j
+					const bool at_or_before_end = offsets[j] <= tile_len;
+					past = past || !at_or_before_end;
+					if (offsets[j] - 1u < tile_len - 1u) { mark(table, offsets[j]); }   // 0 < offset < tile_len
+					last_at_or_before_end = at_or_before_end ? lane_base + j + 2 : last_at_or_before_end;   // increases with j
 				}
 				reached_past_tile = wave64::ballot(past) != 0;
 				batch_base += runs_per_batch;
@@ -171,17 +191,19 @@ __global__ void decompress(
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
 				if (furthest != 0) { next_first_run = first_run + furthest - 1; }
 				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
-					const bool with_values = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
+					const uint32_t candidates_there = last_candidate - next_first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_candidate - next_first_run);
+					uint32_t r[runs_per_lane];
 					#pragma unroll
 					for (unsigned j = 0; j < runs_per_lane; j++) {
-						const uint64_t r = next_first_run + 1 + (uint64_t) lane * runs_per_lane + j;
-						if (r <= last_candidate) {
-							prefetched_positions[j] = load_descriptor(run_start_positions + r);
-							if (with_values) { prefetched_values[j] = run_data[r]; }
-						}
+						r[j] = lane * runs_per_lane + j < candidates_there ? lane * runs_per_lane + j + 1 : candidates_there;   // (relative to next_first_run)
+						prefetched_positions[j] = load_descriptor(run_start_positions + next_first_run + r[j]);
 					}
-					if (with_values && lane == 0) { prefetched_first_value = run_data[next_first_run]; }
-					prefetched = true; values_prefetched = with_values;
+					prefetched = true; values_prefetched = staging::with_descriptors || dense;   // (after a dense tile, most likely another)
+					if (values_prefetched) {
+						#pragma unroll
+						for (unsigned j = 0; j < runs_per_lane; j++) { prefetched_values[j] = run_data[next_first_run + r[j]]; }
+						prefetched_first_value = run_data[next_first_run];
+					}
 				}
 			}
 
@@ -189,7 +211,7 @@ __global__ void decompress(
 			if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
-			else if (!staging::with_descriptors && wave64::ballot(values_staged) != 0) {   // a dense tile whose values came with the prefetched positions
+			else if (!staging::with_descriptors && values_staged) {   // a dense tile whose values came with the prefetched positions
 				expand<UncompressedSize, true, true>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 			}
 			else {
