@@ -52,6 +52,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_RESIDENT_BLOCKS_CAP
 #define GIDDY_RUN_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (0: no cap); DESIGN.md section 4
 #endif
+#ifndef GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP
+#define GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP 4   // ... and for 32-bit values with 8-byte run descriptors (RPE <8,4,8,false,8>: 67 -> 73 %, RLE <8,4,8,8>: 70 -> 72 %; 4-byte descriptors: no cap is best)
+#endif
 #ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
 #endif
@@ -151,7 +154,14 @@ __device__ __forceinline__ void expand(
 	const bool aligned = is_aligned(out, 16);
 	const bool use_staged = Staged && staged != nullptr && num_runs_in_tile <= value_staging<ElementSize>::capacity;
 	if (use_staged && !AlreadyStaged) {
-		for (uint32_t i = lane; i < num_runs_in_tile; i += 64) { staged[i] = first_run_data[i]; }
+		// four loads per lane in flight at a time (unconditional: a lane past the last run re-reads that one), not one after the other
+		for (uint32_t base = lane; base < num_runs_in_tile + lane; base += 4 * 64) {
+			element_type fetched[4];
+			#pragma unroll
+			for (unsigned j = 0; j < 4; j++) { const uint32_t i = base + 64 * j; fetched[j] = first_run_data[i < num_runs_in_tile ? i : num_runs_in_tile - 1]; }
+			#pragma unroll
+			for (unsigned j = 0; j < 4; j++) { const uint32_t i = base + 64 * j; if (i < num_runs_in_tile) { staged[i] = fetched[j]; } }
+		}
 	}
 	if (use_staged) { wave64::lds_fence(); }
 

@@ -82,7 +82,10 @@ __global__ void decompress(
 		const uint64_t chunk_outputs = segments_per_chunk * L;
 		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
 		uint64_t first_run = segment_position_anchors[s];
-		length_type left_in_first_run = (length_type) run_lengths[first_run] - (length_type) segment_position_anchor_intra_run_offsets[s];
+		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
+		const length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s];
+		length_type left_in_first_run = 0;
+		bool entering = true;   // the chunk's first tile: the first run's length is not known yet
 		uint64_t run_limit = num_runs;   // exclusive
 		if (s + segments_per_chunk < num_segments) {
 			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk] + 1;
@@ -135,7 +138,7 @@ __global__ void decompress(
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					have[j] = lane_base + j < runs_from_here;
 					if (!have[j]) { lengths[j] = 0; }
-					if (j == 0 && lane_base == 0) { lengths[0] = left_in_first_run; }
+					if (j == 0 && lane_base == 0) { lengths[0] = entering ? lengths[0] - skipped_of_first_run : left_in_first_run; }
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
 					// (staged for the expansion; runs past the tile's last are harmless)
@@ -164,6 +167,7 @@ __global__ void decompress(
 				batch_base += runs_per_batch;
 			} while ((running < tile_len || (need_carry && running == tile_len)) && batch_base < runs_from_here);
 
+			entering = false;
 			// where the next tile enters the runs — and its first batch, on its way before this tile stores
 			uint64_t next_first_run = first_run; length_type next_left_in_first_run = left_in_first_run;
 			prefetched = false;
@@ -228,6 +232,7 @@ public:
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		// 32-bit values, narrow run lengths: 6 resident workgroups per CU are 3-7 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
 		if (UncompressedSize == 4 && RunLengthSize <= 2 && GIDDY_RUN_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_RESIDENT_BLOCKS_CAP; }
+		if (UncompressedSize == 4 && RunLengthSize == 8 && GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP; }
 	}
 
 	launch_config_resolution_params_t(

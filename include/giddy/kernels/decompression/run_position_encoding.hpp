@@ -245,6 +245,7 @@ public:
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		// 32-bit values, 16-bit positions: 6 resident workgroups per CU are 5-6 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
 		if (UncompressedSize == 4 && PositionOffsetSize <= 2 && GIDDY_RUN_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_RESIDENT_BLOCKS_CAP; }
+		if (UncompressedSize == 4 && PositionOffsetSize == 8 && GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP; }
 	}
 
 	launch_config_resolution_params_t(

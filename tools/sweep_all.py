@@ -19,6 +19,7 @@ import numpy as np
 import torch
 
 from libgiddy_amd import registered as r, schemes
+from workloads import output_buffer
 
 DEV = "cuda"
 INT = {1: torch.int8, 2: torch.int16, 4: torch.int32, 8: torch.int64}
@@ -82,7 +83,7 @@ def run_dictionary(I, U, D, n, patched=False, entries_n=None):
     entries_n = entries_n or min(1 << (8 * D), 4096 if D > 1 else 256)
     entries = rand_bits(entries_n, U, g)
     keys = rand_bits(n, D, g, high=entries_n)
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     if patched:
         idx, pidx, pval = make_patches(n, U, I, U + D)
@@ -104,7 +105,7 @@ def run_delta(I, U, C, n, L=4096, patched=False, in_parts=False):
     per_seg = du.view(n // L, L).sum(dim=1)
     anchors64 = (1 << 40) + torch.cumsum(per_seg, 0) - per_seg
     anchors = anchors64.to(INT[U])
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
     if in_parts:   # the wrapper's extension for long segments
@@ -125,7 +126,7 @@ def run_delta(I, U, C, n, L=4096, patched=False, in_parts=False):
 
 def run_dzb_fixed(I, U, C, n, patched=False):
     c = rand_bits(n, C, gen(U + C))
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, compressed_size=C, index_size=I, stream=st)
     if patched:
@@ -161,7 +162,7 @@ def run_dzb_variable(I, U, CS, n, L=1024, bits=2, min_size=1):
         sel = sizes > k
         data[offsets[sel] + k] = ((values[sel] >> (8 * k)) & 0xFF).to(torch.uint8)
     anchors = offsets[torch.arange(0, n, L, device=DEV)].to(INT[I]).contiguous()
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, container_size=CS, index_size=I, stream=st)
     cfg = schemes.discard_zero_bytes_variable(out, data, packed, anchors, L, n, min_size, bits, **kw)
@@ -177,7 +178,7 @@ def run_for(I, U, C, model, MI, n, L=4096, patched=False):
     coefs = torch.randint(-1000000, 1000000, (n // L, dim), dtype=torch.int32, generator=g, device=DEV)
     if dim == 2:
         coefs[:, 1] = torch.randint(-50, 50, (n // L,), dtype=torch.int32, generator=g, device=DEV)
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, compressed_size=C, model=model, index_size=I, model_index_size=MI, stream=st)
     if patched:
@@ -200,7 +201,7 @@ def run_for(I, U, C, model, MI, n, L=4096, patched=False):
 
 def run_model(I, U, model, n, patched=False):
     coefs = np.array([-12345, 37] if model == "linear" else [-4321], dtype="i%d" % U)
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, model=model, index_size=I, stream=st)
     if patched:
@@ -229,7 +230,7 @@ def run_ib(I, U, A, use_dict, n, nb=16):
     for b in range(nb):
         word = ((keys == b).view(words, 32).to(torch.int64) << shifts).sum(dim=1)
         bitmaps[b, :words] = torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     kw = dict(uncompressed_size=U, alignment_in_ints=A, use_dictionary=use_dict, index_size=I, stream=st)
     cfg = schemes.incidence_bitmaps(out, bitmaps.view(-1), entries, words, nb, **kw)
@@ -256,7 +257,7 @@ def run_rle(I, U, LS, RI, n, L=4096, mean_run=32):
     values = (torch.arange(count, device=DEV) * 2654435761 % (1 << min(8 * U, 62))).to(INT[U])
     seg = torch.arange(0, n, L, device=DEV)
     anchor = torch.searchsorted(starts, seg, right=True) - 1
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     args = (values, lengths.to(INT[LS]), anchor.to(INT[RI]), (seg - starts[anchor]).to(INT[LS]), L, len(seg), count, n)
     kw = dict(uncompressed_size=U, run_length_size=LS, index_size=I, run_index_size=RI, stream=st)
@@ -274,7 +275,7 @@ def run_rpe(I, U, P, relative, RI, n, L=4096, mean_run=32):
     seg = torch.arange(0, n, L, device=DEV)
     anchor = torch.searchsorted(starts, seg, right=True) - 1
     positions = (starts % L if relative else starts).to(INT[P])
-    out = torch.empty(n, dtype=INT[U], device=DEV)
+    out = output_buffer(n, INT[U], DEV)
     st = torch.cuda.current_stream().cuda_stream
     args = (values, positions, anchor.to(INT[RI]), L, len(seg), count, n)
     kw = dict(uncompressed_size=U, position_size=P, relative=relative, index_size=I, run_index_size=RI, stream=st)

@@ -19,6 +19,17 @@ from libgiddy_amd import schemes, sharding
 SEED_OFFSET = 0   # bench.py sets this to 1000 * rank so that every GPU decodes different data
 
 
+
+def output_buffer(n, dtype, device):
+    """an output of n elements on a 2 MiB boundary — where hipMalloc puts an allocation of this size.  torch's caching allocator may hand out any
+    512-byte offset inside a block it has cached, and the rate of some decoders depends on it (the run decoders lose 6 points
+    when the 64 KiB a workgroup writes lie across two 64 KiB pages — tools/alignment_probe.py)"""
+    size = torch.empty(0, dtype=dtype).element_size()
+    raw = torch.empty(n + (2 << 20) // size, dtype=dtype, device=device)
+    skip = (-raw.data_ptr() % (2 << 20)) // size
+    return raw[skip:skip + n]
+
+
 def _gen(seed, device):
     g = torch.Generator(device=device)
     g.manual_seed(seed + SEED_OFFSET)
@@ -78,7 +89,7 @@ class Dictionary:
             self.keys = torch.clamp((u ** (-1.0 / 0.2)).to(torch.int64) - 1, 0, 255).to(torch.uint8)
         else:
             self.keys = torch.randint(0, 256, (n,), dtype=torch.uint8, generator=g, device=device)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         self.algorithmic_bytes = 5 * n + 1024
         self.decompressed_bytes = 4 * n
         self.config = schemes.dictionary(self.output, self.keys, self.entries, n, 256, stream=torch.cuda.current_stream().cuda_stream)
@@ -121,7 +132,7 @@ class FrameOfReference:
         nseg = (n + segment_length - 1) // segment_length
         self.comp = torch.randint(-32768, 32768, (n,), dtype=torch.int16, generator=g, device=device)
         self.coefs = torch.randint(-1000000, 1000000, (nseg, 1), dtype=torch.int32, generator=g, device=device)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         self.algorithmic_bytes = 6 * n + 4 * nseg
         self.decompressed_bytes = 4 * n
         self.config = schemes.frame_of_reference(self.output, self.comp, self.coefs, n, segment_length,
@@ -213,7 +224,7 @@ class DeltaPatched:
         self.p = max(1, int(round(n * patch_fraction)))
         self.patch_idx = torch.sort(torch.randperm(n, generator=_gen(seed + 1, device), device=device)[: self.p])[0].to(torch.int32)
         self.patch_val = torch.randint(0, 1 << 62, (self.p,), dtype=torch.int64, generator=_gen(seed + 2, device), device=device)
-        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.output = output_buffer(n, torch.int64, device)
         self.algorithmic_bytes = 10 * n + 8 * nseg             # the dominant kernel (Delta) alone
         self.step_algorithmic_bytes = self.algorithmic_bytes + self.p * 20   # + patches: index, value, scattered store
         self.decompressed_bytes = 8 * n
@@ -413,7 +424,7 @@ class RunLength:
         self.run_lengths = lengths.to(torch.int16)
         self.anchors = anchor.to(torch.int32)
         self.intra = (seg_starts - starts[anchor]).to(torch.int16)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         self.algorithmic_bytes = 4 * n + 6 * self.num_runs + 6 * self.num_segments
         self.decompressed_bytes = 4 * n
         self.config = self._launch(torch.cuda.current_stream().cuda_stream, None)
@@ -481,7 +492,7 @@ class RunPosition(RunLength):
         self.run_data = values
         self.positions = (starts % segment_length).to(torch.int16) if relative else starts.to(torch.int32)
         self.anchors = (torch.searchsorted(starts, seg_starts, right=True) - 1).to(torch.int32)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         psize = 2 if relative else 4
         self.algorithmic_bytes = 4 * n + (4 + psize) * self.num_runs + 4 * self.num_segments
         self.decompressed_bytes = 4 * n
@@ -577,7 +588,7 @@ class DiscardZeroBytesVariable:
             del sizes, offsets, values, mask, fields, data
         self.data = torch.cat(pieces) if len(pieces) > 1 else pieces[0]
         del pieces
-        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.output = output_buffer(n, torch.int64, device)
         self.total_bytes = total
         self.algorithmic_bytes = total + 4 * ncont + 8 * n + 8 * len(self.anchors)
         self.decompressed_bytes = 8 * n
@@ -629,7 +640,7 @@ class DiscardZeroBytesFixed:
     def __init__(self, n, device, seed=9):
         self.n = n
         self.comp = torch.randint(-32768, 32768, (n,), dtype=torch.int16, generator=_gen(seed, device), device=device)
-        self.output = torch.empty(n, dtype=torch.int64, device=device)
+        self.output = output_buffer(n, torch.int64, device)
         self.algorithmic_bytes = 10 * n
         self.decompressed_bytes = 8 * n
         self.config = schemes.discard_zero_bytes_fixed(self.output, self.comp, n, uncompressed_size=8, compressed_size=2,
@@ -657,7 +668,7 @@ class Model:
     def __init__(self, n, device, seed=10):
         self.n = n
         self.coefs = np.array([-12345, 37], dtype=np.int32)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         self.algorithmic_bytes = 4 * n
         self.decompressed_bytes = 4 * n
         self.config = schemes.model(self.output, self.coefs, n, stream=torch.cuda.current_stream().cuda_stream)
@@ -760,7 +771,7 @@ class IncidenceBitmaps:
             word = (bits << shifts).sum(dim=1)
             bitmaps[b, :words] = torch.where(word >= (1 << 31), word - (1 << 32), word).to(torch.int32)
         self.bitmaps = bitmaps.view(-1)
-        self.output = torch.empty(n, dtype=torch.int32, device=device)
+        self.output = output_buffer(n, torch.int32, device)
         self.algorithmic_bytes = 4 * n + num_values * 4 * words
         self.decompressed_bytes = 4 * n
         self.config = schemes.incidence_bitmaps(self.output, self.bitmaps, self.entries, words, num_values,
