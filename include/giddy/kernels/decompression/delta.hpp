@@ -46,6 +46,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/on_device/sorted_patches.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -142,7 +143,7 @@ struct row_t {
 		#pragma unroll
 		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
 		if (row_start < end) { patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values); }   // (rows past the end: nothing to patch, and no walking into the next segment's patches)
-		if (p + E <= end) { memory_access::store_group(out + p, values); }
+		if (p + E <= end) { memory_access::store_group<memory_access::wide_output_policy<sizeof(U)>(GIDDY_DELTA_STORE_POLICY)>(out + p, values); }
 		else {
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) { if (p + j < end) { out[p + j] = values[j]; } }

@@ -93,7 +93,7 @@ __device__ __forceinline__ void translate(
 		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
 	}
 	else {
-		stream_tiles::transform<key_type, value_type>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
+		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY)>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
 	}
 }
 

@@ -118,7 +118,9 @@ __device__ __forceinline__ void decompress(
 			stream_tiles::nothing_to_do(), &chunk_staging);
 	}
 	else {
-		stream_tiles::transform<Compressed, Uncompressed, GIDDY_FOR_STEPS_PER_TILE>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
+		// (write-through stores where a segment's record is its one reference value: +1...2 points; with a line per segment -1...-4)
+		constexpr int stores = sizeof(coefficients_type) == sizeof(Uncompressed) ? memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_FOR_STORE_POLICY) : (int) memory_access::non_temporal;
+		stream_tiles::transform<Compressed, Uncompressed, GIDDY_FOR_STEPS_PER_TILE, stores>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
 	}
 }
 

@@ -32,7 +32,7 @@ __global__ void decompress(
 	using model_index_type = typename UnaryModelFunction::index_type;
 	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	UnaryModelFunction model(model_coefficients);
-	stream_tiles::generate<Uncompressed, false, GIDDY_MODEL_STEPS_PER_TILE>(decompressed, length,
+	stream_tiles::generate<Uncompressed, false, GIDDY_MODEL_STEPS_PER_TILE, memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_MODEL_STORE_POLICY)>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			#pragma unroll
 			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
@@ -100,7 +100,7 @@ __global__ void decompress_with_intervals(
 		}
 		else { interval = p / period; within = p - interval * period; }
 	};
-	stream_tiles::generate<Uncompressed, true, GIDDY_MODEL_STEPS_PER_TILE>(decompressed, length,
+	stream_tiles::generate<Uncompressed, true, GIDDY_MODEL_STEPS_PER_TILE, memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_MODEL_STORE_POLICY)>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
 			uint64_t interval, within;
 			split(first_position, interval, within);

@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include "giddy/common.hpp"
+#include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
 
 namespace cuda {
@@ -53,7 +54,7 @@ namespace run_expansion {
 #define GIDDY_RUN_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (0: no cap); DESIGN.md section 4
 #endif
 #ifndef GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP
-#define GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP 4   // ... and for 32-bit values with 8-byte run descriptors (RPE <8,4,8,false,8>: 67 -> 73 %, RLE <8,4,8,8>: 70 -> 72 %; 4-byte descriptors: no cap is best)
+#define GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP 0   // ... and for 32-bit values with 8-byte run descriptors: with nt stores 4 was best (RPE <8,4,8,false,8>: 67 -> 73 %); with write-through stores none (78 %)
 #endif
 #ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
@@ -142,7 +143,20 @@ struct value_staging {
 /// `num_runs_in_tile` = marks + 1.
 /// AlreadyStaged: the caller has put the tile's run values into `staged` itself (next to its own loads of the run
 /// descriptors, instead of one more dependent round trip here)
-template <unsigned ElementSize, bool Staged, bool AlreadyStaged = false>
+/// The cache policy of the stores of a tile that is expanded from STAGED values (no load between its stores, or after them; the look-up
+/// path loads between its stores and wants the quick acknowledgement of `nt`).  By measurement, every instantiation under both policies
+/// (2^30 outputs, mean run 32; write-through against nt): 1-byte elements -3...-8 points (a wavefront's whole tile is 4 KiB: the
+/// longer acknowledgement is most of its life), 2-byte +4...+7 (RPE with relative positions: -4), staged 4-byte +5...+7, 8-byte +4...+9
+/// (32-bit values with 8-byte descriptors: -11...-13 while held to 4 workgroups per CU, +5...+7 without that cap).
+template <unsigned ElementSize, unsigned RunDescriptorSize, bool RelativePositions = false>
+constexpr int staged_store_policy()
+{
+	return (ElementSize == 1 || (ElementSize == 2 && RelativePositions))
+		? (int) memory_access::non_temporal : (int) GIDDY_RUN_STAGED_STORE_POLICY;
+}
+
+/// StagedStores: memory_access::store_policy of the 16-byte stores when the tile's values are staged
+template <unsigned ElementSize, bool Staged, bool AlreadyStaged = false, int StagedStores = memory_access::non_temporal>
 __device__ __forceinline__ void expand(
 	uint_t<ElementSize>* __restrict__ out, uint32_t tile_len, const tile_entry* table,
 	const uint_t<ElementSize>* __restrict__ first_run_data, unsigned lane,
@@ -248,7 +262,11 @@ __device__ __forceinline__ void expand(
 				for (unsigned j = 1; j < E; j++) { values[j] = first_run_data[ranks[j]]; }
 			}
 		}
-		if (aligned && p + E <= tile_len) { store_group(out + p, values); }
+		if (aligned && p + E <= tile_len) {
+			// (a tile expanded from staged values issues no load between its stores, or after them: write-through stores)
+			if (use_staged) { store_group<StagedStores>(out + p, values); }
+			else { store_group(out + p, values); }
+		}
 		else {
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) { if (p + j < tile_len) { out[p + j] = values[j]; } }

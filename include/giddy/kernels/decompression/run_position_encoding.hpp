@@ -208,14 +208,15 @@ __global__ void decompress(
 			}
 
 			const uint32_t marks = rank(table, lane);
+			constexpr int staged_stores = staged_store_policy<UncompressedSize, PositionOffsetSize, PositionsAreRelative>();
 			if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
 			else if (!staging::with_descriptors && values_staged) {   // a dense tile whose values came with the prefetched positions
-				expand<UncompressedSize, true, true>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+				expand<UncompressedSize, true, true, staged_stores>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 			}
 			else {
-				expand<UncompressedSize, true, staging::with_descriptors>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
+				expand<UncompressedSize, true, staging::with_descriptors, staged_stores>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged, marks + 1);
 			}
 			first_run = next_first_run;
 		}

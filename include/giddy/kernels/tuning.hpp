@@ -26,3 +26,21 @@
 #ifndef GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK
 #define GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK 32  // fused Model: rows of 1 KiB a wavefront produces per seek (8 / 32 / 128 measured: 71-73 / 74-76 / 68-70 % at the best residency)
 #endif
+
+// Cache policy of the decoders' 16-byte output stores (memory_access::store_policy, wave64.hpp): 1 = `nt`, 2 = `sc1 nt` (write-through, the line
+// is dropped).  Per family, by measurement.
+#ifndef GIDDY_DICT_STORE_POLICY
+#define GIDDY_DICT_STORE_POLICY 2
+#endif
+#ifndef GIDDY_FOR_STORE_POLICY
+#define GIDDY_FOR_STORE_POLICY 2
+#endif
+#ifndef GIDDY_MODEL_STORE_POLICY
+#define GIDDY_MODEL_STORE_POLICY 2
+#endif
+#ifndef GIDDY_DELTA_STORE_POLICY
+#define GIDDY_DELTA_STORE_POLICY 2
+#endif
+#ifndef GIDDY_RUN_STAGED_STORE_POLICY
+#define GIDDY_RUN_STAGED_STORE_POLICY 2    // run decoders, tiles expanded from LDS-staged values (the look-up path loads between its stores: nt)
+#endif

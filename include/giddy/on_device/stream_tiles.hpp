@@ -46,7 +46,8 @@ __device__ __forceinline__ auto produce_with(ProduceGroup& produce_group, uint64
 /// `prepare(first_position)` -> a group's context (say, its segment's record): for a whole tile ALL the contexts are
 /// requested right behind the tile's input loads and before its first store — a load issued between two stores would
 /// have to wait for the earlier store (CDNA4 counts vector memory operations in order).
-template <typename In, typename Out, unsigned Steps = steps_per_tile, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
+/// `Stores`: memory_access::store_policy of the tile's 16-byte stores
+template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
 	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare())
@@ -77,7 +78,7 @@ __device__ __forceinline__ void transform(
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
 				group<Out, G> outputs;
 				produce_with(produce_group, g * G, inputs[k], outputs, contexts[k]);
-				store_group(out + g * G, outputs);
+				store_group<Stores>(out + g * G, outputs);
 				// narrow elements: G look-ups per step — keep the steps' work from being hoisted above one another
 				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
 				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
@@ -96,7 +97,7 @@ __device__ __forceinline__ void transform(
 			if (g >= num_groups) { continue; }
 			group<Out, G> outputs;
 			produce_with(produce_group, g * G, inputs[k], outputs, prepare(g * G));
-			store_group(out + g * G, outputs);
+			store_group<Stores>(out + g * G, outputs);
 		}
 	}
 
@@ -273,7 +274,7 @@ __device__ __forceinline__ void generate_and_patch(Out* __restrict__ out, uint64
 /// out[p] = produce(p): the same loop for a decoder with no input array (Model)
 /// ProduceAllFirst: a produce_group that loads from memory (a per-interval record) runs for all K steps of a whole tile
 /// before the tile's first store — a load issued between two stores would wait for the earlier store.
-template <typename Out, bool ProduceAllFirst = false, unsigned Steps = steps_per_tile, typename ProduceGroup, typename ProduceOne>
+template <typename Out, bool ProduceAllFirst = false, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, typename ProduceGroup, typename ProduceOne>
 __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one)
 {
 	using namespace memory_access;
@@ -288,7 +289,7 @@ __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, Prod
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) { produce_group((first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
 			#pragma unroll
-			for (unsigned k = 0; k < K; k++) { store_group(out + (first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
+			for (unsigned k = 0; k < K; k++) { store_group<Stores>(out + (first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
 			continue;
 		}
 		#pragma unroll
@@ -297,7 +298,7 @@ __device__ __forceinline__ void generate(Out* __restrict__ out, uint64_t n, Prod
 			if (g >= num_groups) { continue; }
 			group<Out, G> outputs;
 			produce_group(g * G, outputs);
-			store_group(out + g * G, outputs);
+			store_group<Stores>(out + g * G, outputs);
 		}
 	}
 	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;

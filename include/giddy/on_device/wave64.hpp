@@ -212,7 +212,18 @@ __device__ __forceinline__ group<T, N> load_group(const T* __restrict__ p)
 	return g;
 }
 
-template <bool NonTemporal = true, typename T, unsigned N>
+/// How a 16-byte store treats the caches.  `non_temporal` (`nt`): the line stays in the XCD's L2 marked for early eviction — the
+/// acknowledgement comes back soonest, which is what a wavefront wants that issues LOADS after its stores (the counter is in-order: the run
+/// decoders' look-ups through L1/L2).  `streaming` (`sc1 nt`): write-through, the line is dropped — for output that nobody reads again and
+/// wavefronts that only store from then on: measured +2.5 points for Delta, +4 for the staged run decoders, +1.5...2 for Dictionary / FOR,
+/// +1.2 for Model, and -5 for the look-up run decoders, -14 for DZB-fixed <4,8,2>, -1 for DZB-variable.
+enum store_policy : int { plain_store = 0, non_temporal = 1, streaming = 2 };
+
+/// the policy a decoder family asks for (kernels/tuning.hpp), for outputs of 4 bytes or more only: with 1- and 2-byte outputs a workgroup's
+/// tile is a quarter or half the bytes and the slower acknowledgement outweighs the gain (Dictionary <4,1,1>, <4,2,2>: -6 points; Delta <4,2,1>: -3)
+template <unsigned OutputSize> constexpr int wide_output_policy(int requested) { return OutputSize >= 4 ? requested : (int) non_temporal; }
+
+template <int Policy = non_temporal, typename T, unsigned N>
 __device__ __forceinline__ void store_group(T* __restrict__ p, const group<T, N>& g)
 {
 	constexpr unsigned bytes = N * sizeof(T);
@@ -220,7 +231,16 @@ __device__ __forceinline__ void store_group(T* __restrict__ p, const group<T, N>
 	using piece_t = typename chunk<piece>::type;
 	#pragma unroll
 	for (unsigned i = 0; i < bytes / piece; i++) {
-		if (NonTemporal) { __builtin_nontemporal_store(reinterpret_cast<const piece_t*>(&g)[i], reinterpret_cast<piece_t*>(p) + i); }
+		if constexpr (Policy == streaming && piece == 16) {
+			// (no builtin names this cache policy for a flat pointer.  The compiler does not count the store — which only makes its own
+			// waits stricter — and pads no hazard inside the string: a store of more than 8 bytes reads its data registers up to
+			// two states after issue, hence the s_nop before the compiler's next instruction may overwrite them)
+			typedef unsigned int four_words __attribute__((ext_vector_type(4)));
+			const four_words data = reinterpret_cast<const four_words*>(&g)[i];
+			piece_t* address = reinterpret_cast<piece_t*>(p) + i;
+			asm volatile("global_store_dwordx4 %0, %1, off sc1 nt\n\ts_nop 1" :: "v"(address), "v"(data) : "memory");
+		}
+		else if constexpr (Policy != plain_store) { __builtin_nontemporal_store(reinterpret_cast<const piece_t*>(&g)[i], reinterpret_cast<piece_t*>(p) + i); }
 		else { reinterpret_cast<piece_t*>(p)[i] = reinterpret_cast<const piece_t*>(&g)[i]; }
 	}
 }
