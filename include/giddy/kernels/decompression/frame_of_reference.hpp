@@ -39,6 +39,11 @@ enum : serialization_factor_t { DefaultSerializationFactor = 16 };
 
 namespace detail {
 
+/// 16-byte stores per lane per tile: 2 where 16-bit offsets become 32-bit values (measured: +2...+4 points against 4; 8-bit offsets lose 3...9 with 2)
+template <typename Uncompressed, typename Compressed>
+constexpr unsigned steps_per_tile() { return (sizeof(Uncompressed) == 4 && sizeof(Compressed) == 2 && GIDDY_FOR_STEPS_PER_TILE == 4) ? 2 : GIDDY_FOR_STEPS_PER_TILE; }
+
+
 template <unsigned IndexSize>
 __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotient, uint64_t& remainder)
 {
@@ -120,7 +125,7 @@ __device__ __forceinline__ void decompress(
 	else {
 		// (write-through stores where a segment's record is its one reference value: +1...2 points; with a line per segment -1...-4)
 		constexpr int stores = sizeof(coefficients_type) == sizeof(Uncompressed) ? memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_FOR_STORE_POLICY) : (int) memory_access::non_temporal;
-		stream_tiles::transform<Compressed, Uncompressed, GIDDY_FOR_STEPS_PER_TILE, stores>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
+		stream_tiles::transform<Compressed, Uncompressed, steps_per_tile<Uncompressed, Compressed>(), stores>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
 	}
 }
 
@@ -185,7 +190,7 @@ public:
 			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
 		}
 		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<Uncompressed>()
-			: stream_tiles::elements_per_thread_per_tile<Uncompressed, GIDDY_FOR_STEPS_PER_TILE>();
+			: stream_tiles::elements_per_thread_per_tile<Uncompressed, detail::steps_per_tile<Uncompressed, Compressed>()>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride
