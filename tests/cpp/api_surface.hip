@@ -48,7 +48,7 @@ int main()
 	{
 		ks::decompression::frame_of_reference::kernel_t<4, int32_t, int16_t, models::constant<4, int32_t>> k;
 		auto c = k.resolve_launch_configuration(props, attrs, (size_t) 1 << 20, (size_t) 4096);
-		CHECK(c.block_dimensions.x == 256 && c.grid_dimensions.x == (1u << 20) / (256 * 16));
+		CHECK(c.block_dimensions.x == 256 && c.grid_dimensions.x == (1u << 20) / (256 * 8));   // (16-bit offsets to 32-bit values: two 16-byte stores per lane per tile)
 		CHECK_THROWS(k.resolve_launch_configuration(props, attrs, (size_t) 100, (size_t) 0), std::invalid_argument);
 		CHECK_THROWS(k.resolve_launch_configuration(props, attrs, (size_t) 100, (size_t) 6), std::invalid_argument);
 	}

@@ -133,7 +133,7 @@ def test_reference_error_behaviour():
         k.resolve_launch_configuration(N, {"length": r.size_t(100), "segment_length": r.size_t(6)})
     # the reference cannot launch a single segment longer than a block (frame_of_reference.cuh:111-113); here it resolves
     c = k.resolve_launch_configuration(N, {"length": r.size_t(1 << 20), "segment_length": r.size_t(1 << 20)})
-    assert c.grid_dimensions[0] == (1 << 20) // (256 * 16)
+    assert c.grid_dimensions[0] == (1 << 20) // (256 * 8)   # 256 threads, two 16-byte stores (of 4 values) each per tile
     cis = schemes.kernel(schemes.key_compressed_indices_scatter(4, 4, 4))
     with pytest.raises(r.InvalidArgument, match="Zero-length scatters not currently supported"):
         cis.resolve_launch_configuration(N, {"input_data_length": r.size_t(0), "anchoring_period": r.size_t(1024)})
