@@ -97,6 +97,10 @@ __device__ __forceinline__ void translate(
 	}
 }
 
+#ifndef GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP
+#define GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 4-8-byte values and small dictionaries (0: no cap): with write-through stores 6-7 are 1.5-2.4 points faster than 8
+#endif
+
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
@@ -295,6 +299,7 @@ public:
 		// 1-byte values: 3 resident workgroups per CU are 3-5 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
 		if (UncompressedSize == 1 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 3u; }
 		if (UncompressedSize == 2 && dictionary_bytes <= 2048) { resident_blocks_per_multiprocessor_cap = 6u; }   // (+2..4 points)
+		if (cache && UncompressedSize >= 4 && dictionary_bytes <= 2048 && GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP; }
 		default_serialization_factor  = get_default_serialization_factor(cache);
 	}
 

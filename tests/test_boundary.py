@@ -88,7 +88,7 @@ def test_unknown_key_is_invalid_argument():
 def test_resolver_shapes():
     k = schemes.kernel(schemes.key_dictionary(4, 4, 1))
     c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 30)})
-    assert c.block_dimensions == (256, 1, 1) and c.grid_dimensions[0] == (1 << 30) // (256 * 16) and c.dynamic_shared_memory_size == 1024
+    assert c.block_dimensions == (256, 1, 1) and c.grid_dimensions[0] == (1 << 30) // (256 * 16) and c.dynamic_shared_memory_size == 26624   # (the 1 KiB dictionary, padded so that 6 workgroups share a CU's 160 KiB: the occupancy throttle)
     # a dictionary too large for LDS falls back to look-ups through the caches
     c = k.resolve_launch_configuration(N, {"num_dictionary_entries": r.size_t(1 << 20), "data_length": r.size_t(1 << 20)})
     assert c.dynamic_shared_memory_size == 0
@@ -166,4 +166,4 @@ def test_occupancy_throttle_is_an_lds_reservation_a_caller_can_refuse():
     assert refused.grid_dimensions == throttled.grid_dimensions and refused.block_dimensions == throttled.block_dimensions
     d = schemes.kernel(schemes.key_dictionary(4, 4, 1))
     config = d.resolve_launch_configuration(r.NOMINAL_MI355X, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 24)}, None)
-    assert config.dynamic_shared_memory_size == 1024
+    assert config.dynamic_shared_memory_size == 26624   # (1 KiB of dictionary + the occupancy throttle's padding: 6 workgroups per CU)
