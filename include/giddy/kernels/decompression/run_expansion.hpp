@@ -33,7 +33,7 @@ namespace run_expansion {
 #define GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST 2   // segments shorter than a tile are taken at least this many at a time
 #endif
 #ifndef GIDDY_RUN_STAGE_ALL_VALUES
-#define GIDDY_RUN_STAGE_ALL_VALUES 0   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (instead of L1/L2 gathers)
+#define GIDDY_RUN_STAGE_ALL_VALUES 1   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (0: sparse tiles gather them from L1/L2 — faster while stores were `nt`)
 #endif
 #ifndef GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE
 #define GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE 2   // element sizes from which the next tile's descriptors are requested ahead of the stores
@@ -116,9 +116,11 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 ///  * wide elements (8 bytes) have only 128 outputs per row, so a tile is 32 rows whose gathers, one dependent
 ///    L2 round trip each, serialise (measured at 2^30 outputs, run values beyond the last-level cache: 49 %
 ///    of peak with gathers).
-///  * 4-byte elements read through L1/L2 are 4 % faster than staged ones when the run descriptors (lengths or
-///    positions) are 1-2 bytes wide — 79.5 vs 75.9 % of peak for RLE <4,4,2> — and 12-15 points slower when they
-///    are 4-8 bytes wide, so those are staged too.
+///  * 4-byte elements: with `nt` stores the look-ups through L1/L2 were 4 points faster than staged values when the run
+///    descriptors (lengths or positions) are 1-2 bytes wide — 79.5 vs 75.9 % of peak for RLE <4,4,2> — and 12-15 points slower
+///    when they are 4-8 bytes wide.  A tile expanded from staged values issues no load between its stores, so its stores can be
+///    write-through (`staged_store_policy`), which the look-up path cannot afford; with that, staging wins for both (C4: RLE 84.7 ->
+///    85.6 %, mean run 6: 68 -> 72 %) and is what every instantiation does now (`GIDDY_RUN_STAGE_ALL_VALUES`).
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
 ///
 /// DENSE tiles (run_length_encoding.hpp / run_position_encoding.hpp): when the first batch of run descriptors does not reach the
