@@ -11,9 +11,9 @@
 //   2. mark: one LDS atomic-or per run start inside the tile                        — ds_or
 //   3. rank: popcount per word + one 64-lane DPP prefix sum -> runs before each word — 6 VALU steps
 //   4. expand: a lane owning E = 16/size consecutive outputs reads ONE {word, rank} pair (8-byte
-//      LDS read), derives its E ranks with masked popcounts, gathers run_data (L1/L2-resident:
-//      ~128 distinct values per tile; 1-2-byte columns look them up in a wave-private LDS copy
-//      instead) and issues one 16-byte store, contiguous across the wave.
+//      LDS read), derives its E ranks with masked popcounts, looks the run values up in a
+//      wave-private LDS copy of the tile's values (value_staging below) and issues one 16-byte
+//      store, contiguous across the wave.
 //
 // No __syncthreads anywhere: a wavefront's LDS traffic is ordered by wavefront-scope fences, so
 // wavefronts never wait for each other.  Work per output is constant, independent of run lengths.
