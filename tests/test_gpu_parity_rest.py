@@ -104,6 +104,14 @@ def _run_columns():
     yield "nine_per_16", np.repeat(np.arange(27000, dtype=np.uint32), np.tile([1, 1, 1, 1, 1, 1, 1, 1, 8], 3000))
     yield "short_mix", np.repeat(np.arange(30000, dtype=np.uint32), cases.rng(21).integers(1, 5, size=30000))
     yield "tileboundary", np.repeat(np.arange(6, dtype=np.uint32) + 9, [4096, 4096, 8192, 1, 4095, 12288])
+    # stretches of very short runs (dense tiles: cut where a batch of 256 run descriptors ends, values prefetched for the next tile) between
+    # stretches of long ones, so that segments of several tiles change from one kind of tile to the other and back
+    r = cases.rng(33)
+    lengths = np.concatenate([np.concatenate((r.integers(1, 4, size=int(r.integers(300, 3000))), r.integers(500, 5000, size=int(r.integers(2, 30))))) for _ in range(12)])
+    yield "density_changes", np.repeat(np.arange(len(lengths), dtype=np.uint32) * 7 + 1, lengths)
+    # a batch of 256 runs that ends exactly on the tile's end (the carry is found by one more batch), and one that ends on a whole piece of a dense tile
+    yield "sixteens", np.repeat(np.arange(5000, dtype=np.uint32), 16)
+    yield "eights", np.repeat(np.arange(9000, dtype=np.uint32), 8)
 
 
 RLE_TUPLES = [(4, u, l, 4) for l in (1, 2, 4) for u in (1, 2, 4, 8)] + [(8, 4, 1, 8), (8, 4, 2, 8), (8, 4, 4, 8), (8, 1, 8, 8), (8, 4, 8, 8), (8, 8, 8, 8)]
