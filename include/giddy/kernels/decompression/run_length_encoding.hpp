@@ -97,7 +97,7 @@ __global__ void decompress(
 		// acknowledged — a store drain on top of the load's own round trip, per tile (dense tiles, 1 KiB ... 4 KiB of output: the
 		// larger part of a wavefront's life).
 		uint_t<RunLengthSize> prefetched_lengths[runs_per_lane];
-		uint_t<UncompressedSize> prefetched_values[runs_per_lane];
+		uint_t<UncompressedSize> prefetched_values[runs_per_lane] = { };   // (read only where values_prefetched says they were loaded; never indeterminate)
 		bool prefetched = false, values_prefetched = false;   // (values: always where they travel with the descriptors; else after a dense tile)
 		uint32_t tile_len = 0;
 		for (uint64_t tile_start = segment_start; tile_start < segment_end && first_run < run_limit; tile_start += tile_len) {
@@ -117,7 +117,7 @@ __global__ void decompress(
 			uint32_t carried_run = ~0u; length_type carried_left = 0;   // the run that reaches past the tile's end, in the lane that holds it
 			do {
 				length_type lengths[runs_per_lane]; uint32_t clamped[runs_per_lane]; bool have[runs_per_lane];
-				uint_t<UncompressedSize> values[runs_per_lane];
+				uint_t<UncompressedSize> values[runs_per_lane] = { };
 				const uint32_t lane_base = batch_base + lane * runs_per_lane;
 				const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
 				const bool stage_prefetched = !staging::with_descriptors && from_prefetch && values_prefetched;   // a dense tile's successor

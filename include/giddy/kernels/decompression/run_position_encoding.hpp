@@ -93,7 +93,7 @@ __global__ void decompress(
 		// the NEXT tile's first batch of run positions (and values) is requested before this tile's expansion stores anything
 		// (run_length_encoding.hpp: loads issued after a tile's stores wait for those stores as well)
 		uint_t<PositionOffsetSize> prefetched_positions[runs_per_lane];
-		uint_t<UncompressedSize> prefetched_values[runs_per_lane], prefetched_first_value = 0;
+		uint_t<UncompressedSize> prefetched_values[runs_per_lane] = { }, prefetched_first_value = 0;
 		bool prefetched = false, values_prefetched = false;
 		uint32_t tile_len = 0;
 		for (uint64_t tile_start = segment_start; tile_start < segment_end && first_run <= last_candidate; tile_start += tile_len) {
@@ -116,7 +116,7 @@ __global__ void decompress(
 			uint32_t last_at_or_before_end = 0;   // 1 + (index relative to first_run) of the last run starting <= the tile's end
 			bool reached_past_tile;
 			do {
-				uint_t<PositionOffsetSize> positions[runs_per_lane]; uint_t<UncompressedSize> values[runs_per_lane];
+				uint_t<PositionOffsetSize> positions[runs_per_lane]; uint_t<UncompressedSize> values[runs_per_lane] = { };
 				uint32_t offsets[runs_per_lane];   // of a candidate's start from the tile's; ~0: no such candidate, or it starts past the tile / the chunk
 				const uint32_t lane_base = batch_base + lane * runs_per_lane;
 				const bool from_prefetch = prefetched && batch_base == 0;   // (wave-uniform)
