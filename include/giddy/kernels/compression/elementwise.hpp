@@ -201,26 +201,48 @@ __global__ void __launch_bounds__(threads_per_block) encode(
 	native_word_t*                   __restrict__  unrepresentable)
 {
 	using U = uint_t<UncompressedSize>;
+	using count_type = typename std::conditional<(DictionaryIndexSize > 4), uint64_t, uint32_t>::type;
 	enum : unsigned { staged_capacity = 16384 / sizeof(U) };   // dictionaries of up to 16 KiB are searched in LDS
 	__shared__ U staged[staged_capacity];
-	const uint64_t entries = num_dictionary_entries;
-	const U* table = dictionary_entries;
-	if (entries <= staged_capacity) {   // (workgroup-uniform)
+	const count_type entries = (count_type) num_dictionary_entries;
+	const bool in_lds = entries <= staged_capacity;   // (workgroup-uniform)
+	if (in_lds) {
 		for (unsigned i = threadIdx.x; i < entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();
-		table = staged;
 	}
-	unsigned bad = 0;
-	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (uint64_t) gridDim.x * blockDim.x) {
-		const U value = input[i];
-		uint64_t lo = 0, hi = entries;   // first entry >= value
-		while (lo < hi) {
-			const uint64_t mid = (lo + hi) >> 1;
-			if (table[mid] < value) { lo = mid + 1; } else { hi = mid; }
+	// the number of entries below `value`: every thread takes the same steps (no divergence), one look-up each; the two tables are
+	// searched by separate code so that the LDS one is read with LDS loads (through one generic pointer both would be flat loads)
+	auto entries_below = [entries](const auto* table, U value) {
+		count_type lo = 0, left = entries;
+		while (left > 1) {
+			const count_type half = left / 2;
+			lo += table[lo + half - 1] < value ? half : 0;
+			left -= half;
 		}
-		compressed_output[i] = (uint_t<DictionaryIndexSize>) lo;
-		if (lo >= entries || table[lo] != value) { bad++; }
+		if (left == 1 && table[lo] < value) { lo++; }
+		return lo;
+	};
+	unsigned bad = 0;
+	auto encode_one = [&](U value) {
+		count_type lo; bool found;
+		if (in_lds) { lo = entries_below(staged, value); found = lo < entries && staged[lo] == value; }
+		else { lo = entries_below(dictionary_entries, value); found = lo < entries && dictionary_entries[lo] == value; }
+		if (!found) { bad++; }
+		return (uint_t<DictionaryIndexSize>) lo;
+	};
+	// G = 16 / sizeof(U) elements per thread per step: one 16-byte load, one store of G keys (element-sized stores of 1-byte keys are 64 bytes per
+	// wavefront instruction)
+	constexpr unsigned G = 16 / sizeof(U);
+	const uint64_t n = length, global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x, num_threads = (uint64_t) gridDim.x * blockDim.x;
+	const uint64_t num_groups = (memory_access::is_aligned(input, 16) && memory_access::is_aligned(compressed_output, G * DictionaryIndexSize)) ? n / G : 0;
+	for (uint64_t g = global_thread; g < num_groups; g += num_threads) {
+		const memory_access::group<U, G> values = memory_access::load_group<U, G>(input + g * G);
+		memory_access::group<uint_t<DictionaryIndexSize>, G> keys;
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) { keys[j] = encode_one(values[j]); }
+		memory_access::store_group<memory_access::plain_store>(compressed_output + g * G, keys);
 	}
+	for (uint64_t i = num_groups * G + global_thread; i < n; i += num_threads) { compressed_output[i] = encode_one(input[i]); }
 	if (unrepresentable != nullptr && bad != 0) { atomicAdd(unrepresentable, bad); }
 }
 

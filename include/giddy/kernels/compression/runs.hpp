@@ -29,10 +29,12 @@ __global__ void __launch_bounds__(threads_per_block) count_run_starts(
 		uint64_t mine = 0;
 		if (first < n) {
 			uint_t<UncompressedSize> previous = first == 0 ? (uint_t<UncompressedSize>) ~input[0] : input[first - 1];
-			for (unsigned j = 0; j < elements_per_thread && first + j < n; j++) {
-				const uint_t<UncompressedSize> value = input[first + j];
-				mine += value != previous;
-				previous = value;
+			uint_t<UncompressedSize> values[elements_per_thread];
+			load_own_elements(values, input, first, n, previous);
+			#pragma unroll
+			for (unsigned j = 0; j < elements_per_thread; j++) {
+				mine += (first + j < n) && values[j] != previous;
+				previous = values[j];
 			}
 		}
 		const uint64_t total = block_sum(mine, table);
@@ -63,9 +65,9 @@ __global__ void __launch_bounds__(threads_per_block) write_run_starts(
 		if (first < n) {
 			previous = first == 0 ? (uint_t<UncompressedSize>) ~input[0] : input[first - 1];
 			uint_t<UncompressedSize> last = previous;
+			load_own_elements(values, input, first, n, previous);
 			#pragma unroll
 			for (unsigned j = 0; j < elements_per_thread; j++) {
-				values[j] = first + j < n ? input[first + j] : last;
 				mine += (first + j < n) && values[j] != last;
 				last = values[j];
 			}
