@@ -4,6 +4,11 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/decompression/discard_zero_bytes_variable.hpp"
 
+// output bytes per launch of a long column (see enqueue_launch)
+#ifndef GIDDY_DZBV_LAUNCH_BYTES
+#define GIDDY_DZBV_LAUNCH_BYTES (1ull << 30)
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -54,9 +59,32 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	auto min_represented_element_size = argument<element_size_t>(arguments, "min_represented_element_size");
 	auto bits_per_element_size        = argument<unsigned>(arguments, "bits_per_element_size");
 
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
-		decompressed, compressed_data, packed_element_sizes, position_anchors,
-		(size_type) segment_length, (size_type) length, min_represented_element_size, bits_per_element_size);
+	// A long launch loses its compact write front: workgroup b runs on XCD b % 8, the XCDs work through their eighths of the grid at
+	// paces that differ by some 10 %, and once their fronts are tens of MiB apart the memory system serves them at 65-70 % of the HBM peak
+	// instead of 81 % (profiles/r03_dzbv_xcd_drift_2p30.txt).  A launch boundary brings the fronts together again, so a long column
+	// is decoded as consecutive launches of about `GIDDY_DZBV_LAUNCH_BYTES` of output each (2^31 elements: 69 -> 78 %): whole
+	// segments, whole size containers and 16-byte aligned outputs per piece; the anchors are absolute, so compressed_data stays put.
+	const size_t n = length, L = segment_length;
+	const size_t per = bits_per_element_size == 0 ? 1 : (8 * ElementSizesContainerSize) / bits_per_element_size;
+	const size_t segments = L == 0 ? 0 : util::div_rounding_up(n, L);
+	const size_t pieces = std::max<size_t>(1, (n * UncompressedSize + (size_t) GIDDY_DZBV_LAUNCH_BYTES / 2) / (size_t) GIDDY_DZBV_LAUNCH_BYTES);
+	const size_t granule = std::max<size_t>(per, 1) * 16;
+	const size_t segments_per_piece = pieces <= 1 ? segments : util::round_up(util::div_rounding_up(segments, pieces), granule);
+	for (size_t first = 0; first < std::max<size_t>(segments, 1); first += std::max<size_t>(segments_per_piece, 1)) {
+		const size_t begin = first * L, end = std::min(n, (first + segments_per_piece) * L);
+		auto piece_config = launch_config;
+		if (begin != 0 || end != n) {
+			// a piece's own covering grid, within the grid the caller resolved for the column (which may be capped, or limited by the caller)
+			const size_t chunks = util::div_rounding_up(util::div_rounding_up(end - begin, L), (size_t) detail::segments_per_wave_chunk(L, 64 * (16 / UncompressedSize)));
+			const size_t wavefronts_per_block = std::max<size_t>(1, launch_config.block_dimensions.x / warp_size);
+			const size_t covering = util::div_rounding_up(chunks, std::min<size_t>(wavefronts_per_block, detail::max_waves_per_block));
+			piece_config.grid_dimensions.x = (grid_dimension_t) std::max<size_t>(1, std::min<size_t>(covering, launch_config.grid_dimensions.x));
+		}
+		cuda::kernel::enqueue_launch(*this, stream, piece_config,
+			decompressed + begin, compressed_data, packed_element_sizes + begin / per, position_anchors + first,
+			(size_type) segment_length, (size_type) (end - begin), min_represented_element_size, bits_per_element_size);
+		if (segments_per_piece == 0) { break; }
+	}
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>

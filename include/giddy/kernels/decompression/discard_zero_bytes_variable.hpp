@@ -66,15 +66,30 @@ using element_size_t = native_word_t;
 // wavefronts per SIMD the register allocator must leave room for; 0 = its own choice (65-67 vector registers, 7 wavefronts:
 // measured 1-3 points FASTER than forcing 64 registers, which turns scalar spills into extra vector work)
 #ifndef GIDDY_DZBV_WAVES_PER_SIMD
-#define GIDDY_DZBV_WAVES_PER_SIMD 0
+#define GIDDY_DZBV_WAVES_PER_SIMD 6
 #endif
 #if GIDDY_DZBV_WAVES_PER_SIMD > 0
 #define GIDDY_DZBV_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GIDDY_DZBV_WAVES_PER_SIMD)))
 #else
 #define GIDDY_DZBV_OCCUPANCY
 #endif
+// a wavefront's chunks within its workgroup's span: 1 = interleaved with the other wavefronts', 0 = consecutive
+#ifndef GIDDY_DZBV_INTERLEAVE_SPANS
+#define GIDDY_DZBV_INTERLEAVE_SPANS 1
+#endif
 #ifndef GIDDY_DZBV_SGPRS
-#define GIDDY_DZBV_SGPRS 94
+#define GIDDY_DZBV_SGPRS 102
+#endif
+// chunks (anchored segments, or batches of short ones) a wavefront takes when the column has plenty (launch_config_resolution_params_t)
+// cache policy of the 16-byte output stores on the fast paths (memory_access::store_policy): 1 = nt, 2 = sc1 nt (write-through)
+#ifndef GIDDY_DZBV_STORE_POLICY
+#define GIDDY_DZBV_STORE_POLICY 1
+#endif
+#ifndef GIDDY_DZBV_BUSY_FACTOR
+#define GIDDY_DZBV_BUSY_FACTOR 1024
+#endif
+#ifndef GIDDY_DZBV_CHUNKS_PER_WAVE
+#define GIDDY_DZBV_CHUNKS_PER_WAVE 1
 #endif
 
 namespace detail {
@@ -186,6 +201,12 @@ __device__ __forceinline__ uint64_t divide(uint64_t a, unsigned b)
 	return (a >> 32) == 0 ? (uint64_t) ((uint32_t) a / b) : a / b;
 }
 
+/// wave-uniform a / b, b > 0: 32-bit when both fit
+__device__ __forceinline__ uint64_t divide_any(uint64_t a, uint64_t b)
+{
+	return ((a | b) >> 32) == 0 ? (uint64_t) ((uint32_t) a / (uint32_t) b) : a / b;
+}
+
 /// Everything the fast path knows about a group of R full rows
 template <unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 struct row_group {
@@ -263,7 +284,7 @@ struct row_group {
 				values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size, masks);
 				at += size;
 			}
-			memory_access::store_group(decompressed + i0, values);
+			memory_access::store_group<GIDDY_DZBV_STORE_POLICY>(decompressed + i0, values);
 		}
 		wave64::lds_fence();   // the staging area may be rewritten after this
 	}
@@ -414,116 +435,218 @@ __host__ __device__ inline bool wide_path_applies(unsigned bits, unsigned contai
 	return (32 / bits) % E == 0;
 }
 
-/// `num_rows` full rows of one segment starting at element `pos`, byte `bytes_start` (both advanced).
-template <unsigned Bits, unsigned UncompressedSize>
+/// What a wavefront does next on the wide path: `rows` full rows — a "super-row", at most 64 size words' worth — of one segment.
+/// All wave-uniform.
+struct wide_step {
+	uint64_t pos;            // the first element
+	unsigned field_base;     // its size field within word pos / per
+	unsigned rows;
+	unsigned anchor_slot;    // the lane that holds the segment's anchor when the step begins a segment; no_anchor: the bytes follow the previous step's
+	enum : unsigned { no_anchor = ~0u };
+};
+
+/// The super-rows of a wavefront's segments, in order: segments first, first + stride, ... (`segments_left` of them), each
+/// cut into steps of what 64 words and the staging area hold.  A segment's ragged end (fewer elements than a row) is not planned.
+/// FullSteps: every step is 64 whole words (the caller checks) — the position just advances, no division, no row counts.
+template <unsigned Bits, unsigned UncompressedSize, bool FullSteps>
+struct wide_plan {
+	enum : unsigned { E = 16 / UncompressedSize, row = 64 * E, per = 32 / Bits, rows_of_64_words = (64 * per) / row };
+	uint64_t L, n, segment_start, between_segments, pos;   // pos: where the next step begins
+	unsigned segments_left, max_rows, rows_left, next_slot;
+
+	__device__ __forceinline__ void start(uint64_t first_segment, unsigned num_segments, unsigned stride, uint64_t L_, uint64_t n_, unsigned max_rows_)
+	{
+		L = L_; n = n_; segment_start = first_segment * L; between_segments = (uint64_t) stride * L; pos = segment_start;
+		segments_left = num_segments; max_rows = max_rows_; rows_left = 0; next_slot = 0;
+	}
+	__device__ __forceinline__ bool next(wide_step& s)
+	{
+		s.anchor_slot = wide_step::no_anchor;
+		while (rows_left == 0) {
+			if (segments_left == 0) { return false; }
+			if (next_slot != 0) { segment_start += between_segments; }
+			pos = segment_start;
+			if (FullSteps) { rows_left = (unsigned) (L / row); }   // (the caller keeps segment_length / row below 2^32)
+			else {
+				const uint64_t end = pos + L < n ? pos + L : n;
+				rows_left = (unsigned) ((end - pos) / row);
+			}
+			s.anchor_slot = next_slot++; segments_left--;
+		}
+		s.pos = pos;
+		if (FullSteps) { s.field_base = 0; s.rows = rows_of_64_words; }
+		else {
+			s.field_base = (unsigned) (pos % per);
+			const unsigned available = (64 * per - s.field_base) / row, limit = available < max_rows ? available : max_rows;
+			s.rows = rows_left < limit ? rows_left : limit;
+		}
+		pos += (uint64_t) s.rows * row; rows_left -= s.rows;
+		return true;
+	}
+};
+
+/// The wide path over a wavefront's segments, software-pipelined ACROSS super-rows and segments: while super-row t is cut out of
+/// LDS and stored, the bytes of super-row t+1 — requested BEFORE t's stores: CDNA4 returns vector-memory operations in order, a
+/// load issued behind stores waits for their acknowledgement — and the size words of super-row t+2 are in flight.  A wavefront
+/// that lives for one 1024-element segment pays anchor -> size words -> scan -> bytes -> stores as one dependent chain per 8 KiB
+/// of output (round 2: 64 % of its cycles waiting); one that takes several segments pays it once.
+///   FullSteps: every step is exactly 64 words from field 0 (segment_length a multiple of 64 * per, whole segments only,
+///   and the staging area holds them): the row loop is unrolled with a known number of stores, which is what lets the
+///   compiler's wait for the next step's bytes leave this step's stores in flight (with a store loop of unknown trip count
+///   its vmcnt bookkeeping falls back to waiting for the stores as well).
+/// Returns where it stopped (element and byte) so that the caller can finish a ragged end the slow way.
+template <unsigned Bits, unsigned IndexSize, unsigned UncompressedSize, bool FullSteps>
 __device__ __forceinline__ void decompress_wide(
 	uint_t<UncompressedSize>* __restrict__ decompressed, const uint8_t* __restrict__ compressed_data,
-	const uint32_t* __restrict__ size_words, uint32_t* stage, unsigned lane, uint64_t& pos, unsigned num_rows, uint64_t& bytes_start,
-	unsigned min_size, const size_masks& masks)
+	const uint32_t* __restrict__ size_words, const uint_t<IndexSize>* __restrict__ position_anchors,
+	uint32_t* stage, unsigned lane,
+	uint64_t first_segment, unsigned num_segments, unsigned segment_stride, uint64_t L, uint64_t n,
+	unsigned min_size, const size_masks& masks, uint64_t& pos_out, uint64_t& bytes_out)
 {
 	using namespace memory_access;
 	using U = uint_t<UncompressedSize>;
 	using chunk_t = typename chunk<16>::type;
 	constexpr unsigned E = 16 / UncompressedSize, row = 64 * E, per = 32 / Bits, field_mask = (1u << Bits) - 1;
 	constexpr unsigned rows_of_64_words = (64 * per) / row;
+	constexpr unsigned pieces = wide_staging_bytes / 1024;
 	static_assert(per % E == 0 && rows_of_64_words >= 1, "a lane's E size fields share a word");
 
 	// rows per step: what 64 words hold, and what the staging area holds of the largest elements these fields can state
 	const unsigned largest = min_size + field_mask < UncompressedSize ? min_size + field_mask : UncompressedSize;
 	const unsigned rows_staged = largest == 0 ? rows_of_64_words : wide_staging_bytes / (row * largest);
-	const unsigned max_rows = rows_staged < rows_of_64_words ? rows_staged : rows_of_64_words;   // >= 4: a row is at most 1 KiB
 
-	uint64_t word_base = pos / per;
-	unsigned field_base = (unsigned) (pos - word_base * per);
-	auto rows_of_step = [&](unsigned first_field, unsigned rows_left) {
-		const unsigned available = (64 * per - first_field) / row, limit = available < max_rows ? available : max_rows;
-		return rows_left < limit ? rows_left : limit;
+	wide_plan<Bits, UncompressedSize, FullSteps> plan;
+	plan.start(first_segment, num_segments, segment_stride, L, n, rows_staged < rows_of_64_words ? rows_staged : rows_of_64_words);   // (max_rows >= 4: a row is at most 1 KiB)
+
+	// all of the wavefront's anchors with one load (num_segments <= 64)
+	const uint64_t my_anchor = lane < num_segments ? (uint64_t) position_anchors[first_segment + (uint64_t) lane * segment_stride] : 0;
+
+	auto load_words = [&](const wide_step& s) {
+		if (FullSteps) { return size_words[s.pos / per + lane]; }
+		const unsigned used = (s.field_base + s.rows * row + per - 1) / per;   // words holding those fields (<= 64)
+		return lane < used ? size_words[s.pos / per + lane] : 0u;
 	};
-	auto load_words = [&](uint64_t first_word, unsigned first_field, unsigned rows) {
-		const unsigned used = (first_field + rows * row + per - 1) / per;   // words holding those fields (<= 64)
-		return lane < used ? size_words[first_word + lane] : 0u;
+
+	// a step's scan and byte range
+	struct located {
+		uint32_t word;           // the lane's size word (fields below the step's first masked out on lane 0)
+		unsigned start;          // where the lane's word WOULD begin in the staging area if all of its fields counted
+		unsigned total;          // bytes of the step (wave-uniform)
+		uintptr_t first_chunk;   // the 16-byte chunks overlapping the byte range (wave-uniform)
+		unsigned num_chunks;
 	};
-	unsigned R = rows_of_step(field_base, num_rows);
-	uint32_t word = load_words(word_base, field_base, R);
-
-	while (num_rows > 0) {
-		// ---- this super-row: R rows = fields [field_base, end_field) of words word_base ...; the next one's words are requested now ----
-		const unsigned end_field = field_base + R * row;
-		const uint64_t next_word_base = word_base + end_field / per;
-		const unsigned next_field_base = end_field % per, next_R = rows_of_step(next_field_base, num_rows - R);
-		uint32_t next_word = 0;
-		if (next_R > 0) { next_word = load_words(next_word_base, next_field_base, next_R); }
-
-		if (lane == 0) { word &= ~((1u << (field_base * Bits)) - 1u); }   // the segment's first field may be inside the word
+	uint64_t bytes_start = 0;
+	auto locate = [&](const wide_step& s, uint32_t word) {
+		located at;
+		if (s.anchor_slot != wide_step::no_anchor) { bytes_start = wave64::read_lane(my_anchor, s.anchor_slot); }
+		const unsigned field_base = FullSteps ? 0u : s.field_base;
+		if (!FullSteps && lane == 0) { word &= ~((1u << (field_base * Bits)) - 1u); }   // the segment's first field may be inside the word
 		const unsigned lane_bytes = (per - (lane == 0 ? field_base : 0u)) * min_size + sum_of_fields<Bits>(word);
 		const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
-		// where the lane's word WOULD begin if all of its fields counted: a field's offset = this + field * min + the fields below it
 		const unsigned start = inclusive - lane_bytes - (lane == 0 ? field_base * min_size : 0u);
-		// the super-row's bytes: up to the offset of field `end_field` (scalar arithmetic on two lanes' values)
-		const unsigned last_owner = end_field / per < 63 ? end_field / per : 63, past_field = end_field - last_owner * per;
-		const uint32_t last_word = wave64::read_lane(word, last_owner);
-		const unsigned super_row_bytes = wave64::read_lane(start, last_owner) + past_field * min_size
-			+ sum_of_fields<Bits>(past_field * Bits >= 32 ? last_word : last_word & ((1u << (past_field * Bits)) - 1u));
-
-		// ---- stage the byte range: exactly the 16-byte chunks that overlap it (nothing is read past the buffer's last chunk) ----
-		const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
-		const uintptr_t first_chunk = address & ~(uintptr_t) 15;
-		const unsigned head = (unsigned) (address - first_chunk);
-		const unsigned num_chunks = super_row_bytes == 0 ? 0 : (head + super_row_bytes + 15) / 16;   // <= wide_staging_bytes / 16 + 1
-		chunk_t* const staged = reinterpret_cast<chunk_t*>(stage);
-		constexpr unsigned pieces = wide_staging_bytes / 1024, ahead = GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT < pieces ? GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT : pieces;
-		chunk_t in_flight[ahead];
-		const unsigned last_chunk = num_chunks == 0 ? 0 : num_chunks - 1;
-		auto request = [&](unsigned piece) {   // (lanes past the end repeat the last chunk)
-			if (piece * 64 < num_chunks) {
-				const unsigned mine = piece * 64 + lane;
-				in_flight[piece % ahead] = load_global<chunk_t>(first_chunk + 16 * (uintptr_t) (mine < last_chunk ? mine : last_chunk));
-			}
-		};
-		#pragma unroll
-		for (unsigned piece = 0; piece < ahead; piece++) { request(piece); }   // requests first ...
-		#pragma unroll
-		for (unsigned piece = 0; piece < pieces; piece++) {                    // ... then into LDS as they arrive
-			if (piece * 64 < num_chunks) {
-				const unsigned mine = piece * 64 + lane;
-				staged[mine < last_chunk ? mine : last_chunk] = in_flight[piece % ahead];
-			}
-			if (piece + ahead < pieces) { request(piece + ahead); }
+		if (FullSteps) { at.total = wave64::read_last_lane(inclusive); }
+		else {
+			// up to the offset of field `end_field` (scalar arithmetic on two lanes' values)
+			const unsigned end_field = field_base + s.rows * row;
+			const unsigned last_owner = end_field / per < 63 ? end_field / per : 63, past_field = end_field - last_owner * per;
+			const uint32_t last_word = wave64::read_lane(word, last_owner);
+			at.total = wave64::read_lane(start, last_owner) + past_field * min_size
+				+ sum_of_fields<Bits>(past_field * Bits >= 32 ? last_word : last_word & ((1u << (past_field * Bits)) - 1u));
 		}
-		if (num_chunks > pieces * 64 && lane == 0) {   // a full staging area's worth that starts unaligned: one more chunk (rare)
-			staged[pieces * 64] = load_global<chunk_t>(first_chunk + 16 * (uintptr_t) (pieces * 64));
+		const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + bytes_start;
+		at.first_chunk = address & ~(uintptr_t) 15;
+		const unsigned head = (unsigned) (address - at.first_chunk);
+		at.num_chunks = at.total == 0 ? 0 : (head + at.total + 15) / 16;   // <= wide_staging_bytes / 16 + 1
+		at.word = word; at.start = start + head;
+		bytes_start += at.total;
+		return at;
+	};
+	// the byte range: exactly the 16-byte chunks that overlap it (nothing is read past the buffer's last chunk; lanes past the end repeat the last one)
+	auto request = [&](const located& at, chunk_t (&in_flight)[pieces]) {
+		const unsigned last_chunk = at.num_chunks == 0 ? 0 : at.num_chunks - 1;
+		#pragma unroll
+		for (unsigned piece = 0; piece < pieces; piece++) {
+			if (piece * 64 < at.num_chunks) {
+				const unsigned mine = piece * 64 + lane;
+				in_flight[piece] = load_global<chunk_t>(at.first_chunk + 16 * (uintptr_t) (mine < last_chunk ? mine : last_chunk));
+			}
+		}
+	};
+	chunk_t* const staged = reinterpret_cast<chunk_t*>(stage);
+	auto into_lds = [&](const located& at, const chunk_t (&in_flight)[pieces]) {
+		const unsigned last_chunk = at.num_chunks == 0 ? 0 : at.num_chunks - 1;
+		#pragma unroll
+		for (unsigned piece = 0; piece < pieces; piece++) {
+			if (piece * 64 < at.num_chunks) {
+				const unsigned mine = piece * 64 + lane;
+				staged[mine < last_chunk ? mine : last_chunk] = in_flight[piece];
+			}
+		}
+		if (at.num_chunks > pieces * 64 && lane == 0) {   // a full staging area's worth that starts unaligned: one more chunk (rare)
+			staged[pieces * 64] = load_global<chunk_t>(at.first_chunk + 16 * (uintptr_t) (pieces * 64));
 		}
 		wave64::lds_fence();
+	};
+	// one output row: offsets and sizes from the owner lane's word and start; elements cut out of the staged range
+	auto emit_row = [&](const located& at, unsigned field_base, unsigned k, U* out) {
+		const unsigned g = field_base + k * row + lane * E, owner = g / per, field = g - owner * per;
+		const uint32_t owners_word = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) at.word);
+		const unsigned owners_start = (unsigned) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) at.start);
+		const unsigned shift = field * Bits;
+		unsigned position = owners_start + field * min_size + sum_of_fields<Bits>(owners_word & ((1u << shift) - 1u));
+		const uint32_t fields = owners_word >> shift;
+		group<U, E> values;
+		#pragma unroll
+		for (unsigned j = 0; j < E; j++) {
+			unsigned size = min_size + ((fields >> (j * Bits)) & field_mask);
+			if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
+			const uint32_t* words = stage + (position >> 2);
+			values[j] = (U) cut<UncompressedSize>(words[0], words[1], UncompressedSize == 8 ? words[2] : 0u, position & 3, size, masks);
+			position += size;
+		}
+		store_group<GIDDY_DZBV_STORE_POLICY>(out + (uint64_t) k * row, values);
+	};
 
-		// ---- rows: offsets and sizes from the owner's word and start; elements cut out of the staged range ----
-		U* out = decompressed + pos + (uint64_t) lane * E;
-		for (unsigned k = 0; k < R; k++) {
-			const unsigned g = field_base + k * row + lane * E, owner = g / per, field = g - owner * per;
-			const uint32_t owners_word = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) word);
-			const unsigned owners_start = (unsigned) __builtin_amdgcn_ds_bpermute((int) (owner * 4), (int) start);
-			const unsigned shift = field * Bits;
-			unsigned at = head + owners_start + field * min_size + sum_of_fields<Bits>(owners_word & ((1u << shift) - 1u));
-			const uint32_t fields = owners_word >> shift;
-			group<U, E> values;
+	auto rows_of = [&](const wide_step& s, const located& at) {
+		U* out = decompressed + s.pos + (uint64_t) lane * E;
+		if (FullSteps) {
 			#pragma unroll
-			for (unsigned j = 0; j < E; j++) {
-				unsigned size = min_size + ((fields >> (j * Bits)) & field_mask);
-				if (size > UncompressedSize) { size = UncompressedSize; }   // precondition n_i <= sizeof(element); never read more
-				const uint32_t* words = stage + (at >> 2);
-				values[j] = (U) cut<UncompressedSize>(words[0], words[1], UncompressedSize == 8 ? words[2] : 0u, at & 3, size, masks);
-				at += size;
-			}
-			store_group(out, values);
-			out += row;
+			for (unsigned k = 0; k < rows_of_64_words; k++) { emit_row(at, 0, k, out); }
+		}
+		else {
+			for (unsigned k = 0; k < s.rows; k++) { emit_row(at, s.field_base, k, out); }
 		}
 		wave64::lds_fence();   // the staging area is rewritten by the next step
+#if defined(GIDDY_DZBV_STAMP_PROBE)
+		// (experiment: when was this step finished, and on which XCD — in place of the step's first element)
+		if (lane == 0) { decompressed[s.pos] = (U) ((__builtin_amdgcn_s_memrealtime() << 4) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15)); }
+#endif
+	};
 
-		// ---- on to the next super-row ----
-		pos += (uint64_t) R * row;
-		num_rows -= R;
-		bytes_start += super_row_bytes;
-		word_base = next_word_base; field_base = next_field_base; R = next_R; word = next_word;
+	// Step t's rows are cut out and stored between the REQUEST for step t+1's bytes and their arrival in LDS: in straight-line code the
+	// compiler's wait for those bytes is "all but the last <stores of step t>" — it leaves the stores in flight.  (Were the wait at a
+	// point that the prologue reaches too, it would be the stricter of the two paths' counts, i.e. wait for the stores.)
+	wide_step current, next, after;
+	if (!plan.next(current)) { return; }
+	uint32_t next_word = 0, after_word = 0;
+	located here = locate(current, load_words(current)), there;
+	bool have_next = plan.next(next);
+	next_word = load_words(have_next ? next : current);
+	chunk_t in_flight[pieces];
+	request(here, in_flight);
+	into_lds(here, in_flight);
+	while (have_next) {
+		const bool have_after = plan.next(after);
+		after_word = load_words(have_after ? after : next);    // size words of step t + 2 (unconditional: a branch here would make every later wait a wait for all loads)
+		there = locate(next, next_word);
+		request(there, in_flight);                             // bytes of step t + 1: before the stores of step t
+		rows_of(current, here);
+		into_lds(there, in_flight);
+		current = next; here = there; next = after; next_word = after_word; have_next = have_after;
 	}
+	rows_of(current, here);
+	pos_out = current.pos + (uint64_t) current.rows * row;
+	bytes_out = bytes_start;
 }
 
 } // namespace detail
@@ -583,9 +706,19 @@ __device__ __forceinline__ void decompress_full_groups(
 
 } // namespace detail
 
+namespace detail {
+
+template <unsigned UncompressedSize>
+struct block_storage {
+	enum : unsigned { R = rows_in_flight, words_per_wave = GIDDY_DZBV_WIDE && wide_staging_words > R * staging_words ? (unsigned) wide_staging_words : R * staging_words };
+	uint32_t staging[max_waves_per_block][words_per_wave];
+	size_masks masks;
+};
+
+/// What workgroup `block_index` of a grid of `blocks_in_grid` decodes.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-// (scalar registers are capped so that eight wavefronts fit a SIMD: measured 3-5 % over what the allocator takes unasked)
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress(
+__device__ __forceinline__ void decompress_as_block(
+	uint64_t block_index, uint64_t blocks_in_grid, uint32_t (&staging)[max_waves_per_block][block_storage<UncompressedSize>::words_per_wave], const size_masks& masks,
 	uint_t<UncompressedSize>*  __restrict__  decompressed,
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>*
@@ -596,24 +729,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 	element_size_t                           min_represented_element_size,
 	native_word_t                            bits_per_element_size)
 {
-	static_assert(ElementSizesContainerSize == 4 || ElementSizesContainerSize == 8,
-		"Only container types with 32 or 64 bits are currently supported");
 	constexpr unsigned E = 16 / UncompressedSize;
 	constexpr unsigned row = 64 * E;
 	constexpr unsigned R = detail::rows_in_flight;
 	using container_type = uint_t<ElementSizesContainerSize>;
-	__shared__ __attribute__((aligned(16))) uint32_t staging[detail::max_waves_per_block][GIDDY_DZBV_WIDE && detail::wide_staging_words > R * detail::staging_words ? (unsigned) detail::wide_staging_words : R * detail::staging_words];
-
-	__shared__ detail::size_masks masks;
-	detail::fill(masks);
 	// staging exists for max_waves_per_block wavefronts; in a larger workgroup the extra wavefronts sit idle
 	const unsigned working_waves = wave64::per_block() < detail::max_waves_per_block ? wave64::per_block() : detail::max_waves_per_block;
 	if (wave64::index_in_block() >= working_waves) { return; }
 	uint32_t* stage = staging[wave64::index_in_block()];
 
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
+	const uint64_t num_waves = blocks_in_grid * working_waves;
 	const uint64_t L = segment_length, n = length;
 	if (L == 0 || bits_per_element_size == 0) { return; }
 	const unsigned bits = bits_per_element_size;
@@ -630,9 +756,69 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 	const bool fast_path = packed && aligned_output;
 	const bool wide_path = fast_path && detail::wide_path_applies(bits, ElementSizesContainerSize, E) && segments_per_chunk == 1 && L < ((uint64_t) 1 << 31) * row;
 
-	for (uint64_t c = wave; ; c += num_waves) {
+	// Chunks (an anchored segment, or a batch of short ones) are handed out in SPANS: with K = ceil(chunks / wavefronts) — 1 when the
+	// grid covers the column — workgroup b owns chunks [b * w * K, (b + 1) * w * K), w wavefronts per workgroup, and its wavefront i
+	// takes b * w * K + i + j * w, j < K (interleaved, so that at every step the workgroup writes w consecutive chunks) or the K
+	// consecutive ones from b * w * K + i * K.  Every grid covers the column; a wavefront with several chunks can overlap their
+	// memory round trips (the wide path does), which a grid-stride walk — chunk c, then c + all the wavefronts — cannot.
+	const uint64_t total_chunks = detail::divide_any(n + chunk_length - 1, chunk_length);
+	const uint64_t K = detail::divide_any(total_chunks + num_waves - 1, num_waves);
+	const uint64_t block_first = block_index * working_waves * K;
+	const uint64_t block_limit = block_first + working_waves * K < total_chunks ? block_first + working_waves * K : total_chunks;
+	const unsigned stride = GIDDY_DZBV_INTERLEAVE_SPANS ? working_waves : 1u;
+	const uint64_t first_chunk = block_first + (GIDDY_DZBV_INTERLEAVE_SPANS ? (uint64_t) wave64::index_in_block() : wave64::index_in_block() * K);
+	const uint64_t span_limit = GIDDY_DZBV_INTERLEAVE_SPANS ? block_limit : (first_chunk + K < block_limit ? first_chunk + K : block_limit);
+	if (first_chunk >= span_limit) { return; }
+	const uint64_t my_chunks = detail::divide_any(span_limit - first_chunk + stride - 1, stride);
+
+	if constexpr (E <= 4) if (wide_path) {
+		// the wavefront's segments through one pipeline, up to 64 at a time (their anchors arrive with one load) when segments are whole
+		// rows; otherwise one at a time, each one's ragged end — fewer elements than a row — the slow way before the next begins
+		const uint32_t* size_words = reinterpret_cast<const uint32_t*>(packed_element_sizes);
+		auto wide = [&](auto field_bits) {
+			constexpr unsigned Bits = decltype(field_bits)::value, per_word = 32 / Bits, field_mask = (1u << Bits) - 1;
+			const unsigned largest = min_represented_element_size + field_mask < UncompressedSize ? min_represented_element_size + field_mask : UncompressedSize;
+			// (unrolled row loops of up to 8 rows: 16 — 1-bit fields, 8-byte elements — take 88 vector registers, and every path of the kernel pays for them)
+			constexpr bool unrolls = (64 * per_word) / row <= 8;
+			const bool full_steps = unrolls && L % (64 * per_word) == 0 && (largest == 0 || detail::wide_staging_bytes / (row * largest) >= (64 * per_word) / row);
+			const unsigned max_batch = L % row == 0 ? 64u : 1u;
+			for (uint64_t done = 0; done < my_chunks; ) {
+				const uint64_t segment = first_chunk + done * stride;
+				unsigned batch = my_chunks - done < max_batch ? (unsigned) (my_chunks - done) : max_batch;
+				uint64_t stopped_at = 0, bytes_at = 0;
+				// (the column's last segment may be incomplete: it is the last of some wavefront's, and goes through the general pipeline by itself)
+				const bool last_is_partial = (segment + (uint64_t) (batch - 1) * stride + 1) * L > n;
+				if (full_steps && !(last_is_partial && batch == 1)) {
+					if (last_is_partial) { batch--; }
+					if constexpr (unrolls) detail::decompress_wide<Bits, IndexSize, UncompressedSize, true>(decompressed, compressed_data, size_words, position_anchors, stage, lane,
+						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at);
+				}
+				else {
+					detail::decompress_wide<Bits, IndexSize, UncompressedSize, false>(decompressed, compressed_data, size_words, position_anchors, stage, lane,
+						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at);
+				}
+				done += batch;
+				const uint64_t last = segment + (uint64_t) (batch - 1) * stride, last_start = last * L, last_end = last_start + L < n ? last_start + L : n;
+				uint64_t tail = last_start + (last_end - last_start) / row * row;
+				if (tail < last_end) {
+					if (tail == last_start) { bytes_at = wave64::read_first_lane((uint64_t) position_anchors[last]); }   // (not one full row: nothing of it went through the pipeline)
+					for (; tail < last_end; tail += group_elements) {
+						bytes_at = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
+							decompressed, compressed_data, packed_element_sizes, stage, lane, tail, last_end, bytes_at,
+							min_represented_element_size, bits, per, masks);
+					}
+				}
+			}
+		};
+		if (bits == 2) { wide(std::integral_constant<unsigned, 2>()); }
+		else if (bits == 4) { wide(std::integral_constant<unsigned, 4>()); }
+		else if (bits == 1) { wide(std::integral_constant<unsigned, 1>()); }
+		return;
+	}
+
+	for (uint64_t j = 0; j < my_chunks; j++) {
+		const uint64_t c = first_chunk + j * stride;
 		const uint64_t chunk_start = c * chunk_length;
-		if (chunk_start >= n) { break; }
 		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
 		const uint64_t num_groups = fast_path ? (chunk_end - chunk_start) / group_elements : 0;
 		uint64_t rows_start = chunk_start;
@@ -642,18 +828,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 			// one anchored segment: full groups of rows on the fast path, then whatever is left — ragged tails,
 			// unaligned outputs, segment lengths that are not whole rows, size fields straddling containers
 			cursor.bytes_start = wave64::read_first_lane((uint64_t) position_anchors[c]);
-			if constexpr (E <= 4) if (wide_path) {
-				const uint32_t* size_words = reinterpret_cast<const uint32_t*>(packed_element_sizes);
-				const unsigned full_rows = (unsigned) ((chunk_end - chunk_start) / row);
-				auto wide = [&](auto field_bits) {
-					detail::decompress_wide<decltype(field_bits)::value, UncompressedSize>(decompressed, compressed_data, size_words, stage, lane,
-						rows_start, full_rows, cursor.bytes_start, min_represented_element_size, masks);
-				};
-				if (bits == 2) { wide(std::integral_constant<unsigned, 2>()); }
-				else if (bits == 4) { wide(std::integral_constant<unsigned, 4>()); }
-				else if (bits == 1) { wide(std::integral_constant<unsigned, 1>()); }
-			}
-			if (!wide_path)
 			detail::decompress_full_groups<false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, 0,
 				min_represented_element_size, bits, per, per_reciprocal, masks);
@@ -686,6 +860,28 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 	}
 }
 
+} // namespace detail
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress(
+	uint_t<UncompressedSize>*  __restrict__  decompressed,
+	const uint8_t*             __restrict__  compressed_data,
+	const uint_t<ElementSizesContainerSize>*
+	                           __restrict__  packed_element_sizes,
+	const uint_t<IndexSize>*   __restrict__  position_anchors,
+	size_type_by_index_size<IndexSize>       segment_length,
+	size_type_by_index_size<IndexSize>       length,
+	element_size_t                           min_represented_element_size,
+	native_word_t                            bits_per_element_size)
+{
+	static_assert(ElementSizesContainerSize == 4 || ElementSizesContainerSize == 8,
+		"Only container types with 32 or 64 bits are currently supported");
+	__shared__ __attribute__((aligned(16))) detail::block_storage<UncompressedSize> storage;
+	detail::fill(storage.masks);
+	detail::decompress_as_block<IndexSize, UncompressedSize, ElementSizesContainerSize>(blockIdx.x, gridDim.x, storage.staging, storage.masks,
+		decompressed, compressed_data, packed_element_sizes, position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
+}
+
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
 public:
@@ -697,13 +893,24 @@ public:
 	: parent(device_properties_, kernel_function_attributes_)
 	{
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
-		grid_construction_resolution  = warp;              // one wavefront per anchored segment
-		length                        = util::div_rounding_up(util::div_rounding_up(length_in_elements, segment_length),
+		grid_construction_resolution  = warp;              // a wavefront per span of anchored segments
+		const size_t chunks           = util::div_rounding_up(util::div_rounding_up(length_in_elements, segment_length),
 		                                    (size_t) detail::segments_per_wave_chunk(segment_length, 64 * (16 / UncompressedSize)));
-		serialization_option          = auto_maximized;    // (batches of short) segments at grid stride
+		length                        = util::div_rounding_up(chunks, chunks_per_wavefront(chunks, device_properties_));
+		serialization_option          = auto_maximized;    // spans of (batches of short) segments; the kernel covers the column with any grid
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
+		keep_gpu_busy_factor          = GIDDY_DZBV_BUSY_FACTOR;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
+	}
+
+	/// A wavefront that takes several chunks pays its prologue once and overlaps one chunk's loads with the previous one's stores
+	/// (the kernel's wide path) — as long as the column still gives every compute unit a dozen rounds of wavefronts.
+	static size_t chunks_per_wavefront(size_t chunks, const device::properties_t& device)
+	{
+		const size_t resident_wavefronts = (size_t) device.multiProcessorCount * 24;
+		size_t k = GIDDY_DZBV_CHUNKS_PER_WAVE;
+		while (k > 1 && chunks / k < 8 * resident_wavefronts) { k /= 2; }
+		return k < 1 ? 1 : k;
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_in_elements, size_t segment_length)

@@ -5,7 +5,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 import bench
 name = sys.argv[1]; log2n = int(sys.argv[2]) if len(sys.argv) > 2 else 30; steps = int(sys.argv[3]) if len(sys.argv) > 3 else 10
-w = bench.make_workload(name, 1 << log2n, torch.device("cuda", 0))
+w = bench.make_workload(name, 1 << log2n, torch.device("cuda", 0), cap=1 << log2n)
 w.run(torch.cuda.current_stream().cuda_stream)
 if os.environ.get("VERIFY", "1") == "1":
     from oracle import oracle
