@@ -23,8 +23,15 @@ namespace cuda {
 namespace kernels {
 namespace compression {
 
-/// uint64 entries of "tile_totals" scratch enough for any compressor of a column of `length` elements
+/// uint64 entries of "tile_totals" scratch enough for the run, patch and elementwise compressors of a column of `length` elements,
+/// and for the variable-width discard-zero-bytes compressor with at least 8 size fields per container
 inline size_t scratch_entries(size_t length) { return 2 * (util::div_rounding_up(length, (size_t) tile_elements) + 2) + 2; }
+/// ... and for variable-width discard-zero-bytes in general: its tiles are threads_per_block containers, of `fields_per_container`
+/// elements each (8 * ElementSizesContainerSize / bits_per_element_size: fewer than 8 from 5-bit fields in 4-byte containers on)
+inline size_t discard_zero_bytes_variable_scratch_entries(size_t length, size_t fields_per_container)
+{
+	return std::max(scratch_entries(length), util::div_rounding_up(length, (size_t) threads_per_block * std::max<size_t>(fields_per_container, 1)) + 3);
+}
 
 inline launch_configuration_t elementwise_launch(uint64_t length)
 {
@@ -97,7 +104,8 @@ const device_function_t kernel_t<I, U, C>::get_device_function() const { return 
 namespace variable_width {
 
 /// also: "compressed_data" uint8_t* (room for length * UncompressedSize bytes at worst), "packed_element_sizes", "position_anchors",
-/// "segment_length", "min_represented_element_size" (unsigned), "bits_per_element_size" (unsigned), "total_bytes" uint64_t* (optional)
+/// "segment_length", "min_represented_element_size" (unsigned), "bits_per_element_size" (unsigned), "total_bytes" uint64_t* (optional);
+/// scratch "tile_totals": discard_zero_bytes_variable_scratch_entries(length, fields per container) entries
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -312,8 +320,11 @@ const device_function_t kernel_t<I, A>::get_device_function() const { return rei
 // ---- run-length and run-position encoding ------------------------------------------------------------------------------------
 namespace run_length_encoding {
 
-/// outputs "run_data", "run_lengths", "position_anchors", "intra_run_anchor_offsets" (room for `length` runs at worst),
-/// "num_element_runs" uint64_t* (device scalar, written); scratch "tile_totals" and "run_starts_scratch" (uint_t<IndexSize>*, `length` entries at worst)
+/// outputs "run_data", "run_lengths" (room for "capacity" runs — optional size_t, default `length`, the worst case; runs beyond it are
+/// counted but not stored), "position_anchors", "intra_run_anchor_offsets", "num_element_runs" uint64_t* (device scalar, written: the TRUE
+/// number of runs, so a caller who guessed too low can tell); scratch "tile_totals" and "run_starts_scratch" (uint_t<IndexSize>*: one entry per
+/// natural run — `length` at worst — or "run_starts_capacity" entries when the caller states that; a column with more natural runs than that
+/// gives a wrong count)
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = IndexSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -342,22 +353,26 @@ void kernel_t<I, U, RL, RI>::enqueue_launch(stream::id_t stream, const launch_co
 	uint64_t* run_totals = totals + num_tiles + 2;   // the run-level pass's own scratch, behind the element-level one
 	const uint64_t max_run_length = ~(uint64_t) 0 >> (64 - 8 * RL);   // the largest value a length field holds
 	const auto config = tile_launch(num_tiles);
+	// "capacity" (optional, size_t): pieces the output arrays have room for, and natural runs the scratch has room for — the true count
+	// is reported all the same, so that a caller who sized by an estimate can tell and come back with bigger buffers
+	const uint64_t capacity = optional_argument<size_t>(arguments, "capacity").value_or((size_t) length);
+	const uint64_t starts_capacity = optional_argument<size_t>(arguments, "run_starts_capacity").value_or((size_t) length);
 	// element level: where the natural runs start
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_run_starts<I, U>), stream, config, totals, input, length);
 	enqueue_exclusive_offsets(stream, totals, num_tiles);   // totals[num_tiles] = the number of natural runs
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, I, false, RI>), stream, config,
 		starts, static_cast<uint_t<U>*>(nullptr), static_cast<uint_t<I>*>(nullptr), static_cast<uint_t<RI>*>(nullptr),
-		input, static_cast<const uint64_t*>(totals), segment, length);
+		input, static_cast<const uint64_t*>(totals), segment, length, starts_capacity);
 	// run level: runs longer than a length field holds are cut into pieces
 	const uint64_t* natural_runs = totals + num_tiles;
 	const uint64_t num_run_tiles = num_tiles;   // (at most `length` natural runs; tiles beyond their number count nothing)
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_pieces<I>), stream, config, run_totals, static_cast<const uint_t<I>*>(starts),
-		natural_runs, num_run_tiles, length, max_run_length);
+		natural_runs, num_run_tiles, length, max_run_length, starts_capacity);
 	enqueue_exclusive_offsets(stream, run_totals, num_run_tiles, num_runs);
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_pieces<I, U, RL, RI>), stream, config,
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"),
-		input, static_cast<const uint_t<I>*>(starts), natural_runs, static_cast<const uint64_t*>(run_totals), num_run_tiles, segment, length, max_run_length);
+		input, static_cast<const uint_t<I>*>(starts), natural_runs, static_cast<const uint64_t*>(run_totals), num_run_tiles, segment, length, max_run_length, starts_capacity, capacity);
 }
 
 template <unsigned I, unsigned U, unsigned RL, unsigned RI>
@@ -367,7 +382,8 @@ const device_function_t kernel_t<I, U, RL, RI>::get_device_function() const { re
 
 namespace run_position_encoding {
 
-/// outputs "run_data", "run_start_positions", "position_anchors", "num_element_runs" uint64_t*; scratch "tile_totals"
+/// outputs "run_data", "run_start_positions" (room for "capacity" runs — optional size_t, default `length`; runs beyond it are counted, not
+/// stored), "position_anchors", "num_element_runs" uint64_t* (the true number of runs); scratch "tile_totals"
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = IndexSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -398,7 +414,8 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch(stream::id_t stream, const launch_
 	enqueue_exclusive_offsets(stream, totals, num_tiles, argument<uint64_t*>(arguments, "num_element_runs"));
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>), stream, config,
 		static_cast<uint_t<I>*>(nullptr), argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
-		argument<uint_t<RI>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length);
+		argument<uint_t<RI>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length,
+		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));
 }
 
 template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
@@ -457,8 +474,8 @@ const device_function_t kernel_t<O, I, R>::get_device_function() const { return 
 // ---- patches: where a decoded column differs from the true one ---------------------------------------------------------------
 namespace patches {
 
-/// "decoded", "truth" (const uint_t<ElementSize>*), outputs "patch_positions" (ascending), "patch_values" (room for `length`
-/// at worst), "num_patches" uint64_t*; scratch "tile_totals"
+/// "decoded", "truth" (const uint_t<ElementSize>*), outputs "patch_positions" (ascending), "patch_values" (room for "capacity" patches —
+/// optional size_t, default `length`; patches beyond it are counted, not stored), "num_patches" uint64_t* (the true number); scratch "tile_totals"
 template <unsigned IndexSize, unsigned ElementSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -486,7 +503,7 @@ void kernel_t<I, E>::enqueue_launch(stream::id_t stream, const launch_configurat
 	enqueue_exclusive_offsets(stream, totals, num_tiles, argument<uint64_t*>(arguments, "num_patches"));
 	cuda::enqueue_launch(reinterpret_cast<const void*>(write_differences<I, E>), stream, config,
 		argument<uint_t<I>*>(arguments, "patch_positions"), argument<uint_t<E>*>(arguments, "patch_values"), decoded, truth,
-		static_cast<const uint64_t*>(totals), length);
+		static_cast<const uint64_t*>(totals), length, (uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));
 }
 
 template <unsigned I, unsigned E>

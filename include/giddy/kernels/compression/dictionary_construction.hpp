@@ -38,9 +38,11 @@ __global__ void __launch_bounds__(threads_per_block) insert_distinct(
 	for (uint64_t i = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; i < length; i += (uint64_t) gridDim.x * blockDim.x) {
 		const uint64_t value = (uint64_t) input[i];
 		unsigned slot = hash_of(value);
-		// the common case — the value is there already — through the ordinary cached loads: a published slot never changes, so a hit
-		// is a hit whatever the cache's age; anything else (a stale "empty", a neighbour's value) goes the careful way below
-		if (slot_states[slot] == slot_published && slot_values[slot] == value) { continue; }
+		// the common case — the value is there already: the STATE through an ordinary cached load (a published slot never changes, and a
+		// stale "empty" or "claimed" only sends the thread the careful way below), the VALUE past the L1 — the table's memory is not
+		// cleared between calls, so a stale value line could hold an earlier call's entry that happens to equal this thread's value
+		// while the slot was just published for another one
+		if (slot_states[slot] == slot_published && __atomic_load_n(slot_values + slot, __ATOMIC_RELAXED) == value) { continue; }
 		for (unsigned trips = 0; trips < 64 * hash_slots; trips++) {   // (bounded: a full table — far too many distinct values — ends the search)
 			const unsigned state = __atomic_load_n(slot_states + slot, __ATOMIC_ACQUIRE);
 			if (state == slot_published) {

@@ -34,7 +34,8 @@ __global__ void __launch_bounds__(threads_per_block) write_differences(
 	const uint_t<ElementSize>*  __restrict__  decoded,
 	const uint_t<ElementSize>*  __restrict__  truth,
 	const uint64_t*             __restrict__  tile_offsets,
-	size_type_by_index_size<IndexSize>        length)
+	size_type_by_index_size<IndexSize>        length,
+	uint64_t                                  capacity)   // patches the two arrays have room for: patches beyond it are counted, not stored
 {
 	__shared__ uint64_t table[waves_per_block + 1];
 	const uint64_t n = length, num_tiles = (n + tile_elements - 1) / tile_elements;
@@ -47,7 +48,7 @@ __global__ void __launch_bounds__(threads_per_block) write_differences(
 		if (mine != 0) {
 			for (unsigned j = 0; j < elements_per_thread && first + j < n; j++) {
 				const uint_t<ElementSize> value = truth[first + j];
-				if (decoded[first + j] != value) { patch_positions[k] = (uint_t<IndexSize>) (first + j); patch_values[k] = value; k++; }
+				if (decoded[first + j] != value) { if (k < capacity) { patch_positions[k] = (uint_t<IndexSize>) (first + j); patch_values[k] = value; } k++; }
 			}
 		}
 	}

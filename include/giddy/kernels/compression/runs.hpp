@@ -53,7 +53,8 @@ __global__ void __launch_bounds__(threads_per_block) write_run_starts(
 	const uint_t<UncompressedSize>*  __restrict__  input,
 	const uint64_t*                  __restrict__  tile_offsets,
 	size_type_by_index_size<IndexSize>             segment_length,
-	size_type_by_index_size<IndexSize>             length)
+	size_type_by_index_size<IndexSize>             length,
+	uint64_t                                       capacity)   // runs the per-run arrays have room for: runs beyond it are counted, not stored
 {
 	__shared__ uint64_t table[waves_per_block + 1];
 	const uint64_t n = length, L = segment_length, num_tiles = (n + tile_elements - 1) / tile_elements;
@@ -81,9 +82,11 @@ __global__ void __launch_bounds__(threads_per_block) write_run_starts(
 				const uint64_t i = first + j;
 				if (i < n) {
 					if (values[j] != previous) {
-						if (run_starts != nullptr) { run_starts[k] = (uint_t<IndexSize>) i; }
-						if (run_data != nullptr) { run_data[k] = values[j]; }
-						if (run_start_positions != nullptr) { run_start_positions[k] = (uint_t<PositionSize>) (PositionsAreRelative ? i % L : i); }
+						if (k < capacity) {
+							if (run_starts != nullptr) { run_starts[k] = (uint_t<IndexSize>) i; }
+							if (run_data != nullptr) { run_data[k] = values[j]; }
+							if (run_start_positions != nullptr) { run_start_positions[k] = (uint_t<PositionSize>) (PositionsAreRelative ? i % L : i); }
+						}
 						k++;
 					}
 					if (until_anchor == 0) {
@@ -107,10 +110,11 @@ __global__ void __launch_bounds__(threads_per_block) count_pieces(
 	const uint64_t*           __restrict__  num_natural_runs,
 	uint64_t                                num_run_tiles,
 	size_type_by_index_size<IndexSize>      length,
-	uint64_t                                max_run_length)
+	uint64_t                                max_run_length,
+	uint64_t                                starts_capacity)   // entries of run_starts that were stored (write_run_starts' capacity)
 {
 	__shared__ uint64_t table[waves_per_block + 1];
-	const uint64_t runs = *num_natural_runs, n = length;
+	const uint64_t runs = *num_natural_runs < starts_capacity ? *num_natural_runs : starts_capacity, n = length;
 	for (uint64_t t = blockIdx.x; t < num_run_tiles; t += gridDim.x) {
 		const uint64_t first = t * tile_elements + (uint64_t) threadIdx.x * elements_per_thread;
 		uint64_t mine = 0;
@@ -138,10 +142,12 @@ __global__ void __launch_bounds__(threads_per_block) write_pieces(
 	uint64_t                                       num_run_tiles,
 	size_type_by_index_size<IndexSize>             segment_length,
 	size_type_by_index_size<IndexSize>             length,
-	uint64_t                                       max_run_length)
+	uint64_t                                       max_run_length,
+	uint64_t                                       starts_capacity,
+	uint64_t                                       capacity)   // pieces run_data / run_lengths have room for
 {
 	__shared__ uint64_t table[waves_per_block + 1];
-	const uint64_t runs = *num_natural_runs, n = length, L = segment_length, M = max_run_length;
+	const uint64_t runs = *num_natural_runs < starts_capacity ? *num_natural_runs : starts_capacity, n = length, L = segment_length, M = max_run_length;
 	for (uint64_t t = blockIdx.x; t < num_run_tiles; t += gridDim.x) {
 		const uint64_t first = t * tile_elements + (uint64_t) threadIdx.x * elements_per_thread;
 		uint64_t mine = 0;
@@ -155,7 +161,7 @@ __global__ void __launch_bounds__(threads_per_block) write_pieces(
 			const uint64_t start = run_starts[first + j], end = first + j + 1 < runs ? (uint64_t) run_starts[first + j + 1] : n;
 			const uint_t<UncompressedSize> value = input[start];
 			const uint64_t pieces = (end - start - 1) / M + 1;
-			for (uint64_t p = 0; p < pieces; p++) {
+			for (uint64_t p = 0; p < pieces && piece + p < capacity; p++) {
 				run_data[piece + p] = value;
 				const uint64_t left = end - start - p * M;
 				run_lengths[piece + p] = (uint_t<RunLengthSize>) (left < M ? left : M);

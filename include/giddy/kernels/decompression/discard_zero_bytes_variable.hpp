@@ -765,9 +765,16 @@ __device__ __forceinline__ void decompress_as_block(
 	const uint64_t K = detail::divide_any(total_chunks + num_waves - 1, num_waves);
 	const uint64_t block_first = block_index * working_waves * K;
 	const uint64_t block_limit = block_first + working_waves * K < total_chunks ? block_first + working_waves * K : total_chunks;
+#if GIDDY_DZBV_INTERLEAVE_SPANS == 2
+	// (grid stride: wavefront g of all W takes chunks g, g + W, g + 2 W ... — with a grid of resident workgroups the chip as a whole sweeps the column once)
+	const unsigned stride = (unsigned) num_waves;
+	const uint64_t first_chunk = block_index * working_waves + wave64::index_in_block();
+	const uint64_t span_limit = total_chunks;
+#else
 	const unsigned stride = GIDDY_DZBV_INTERLEAVE_SPANS ? working_waves : 1u;
 	const uint64_t first_chunk = block_first + (GIDDY_DZBV_INTERLEAVE_SPANS ? (uint64_t) wave64::index_in_block() : wave64::index_in_block() * K);
 	const uint64_t span_limit = GIDDY_DZBV_INTERLEAVE_SPANS ? block_limit : (first_chunk + K < block_limit ? first_chunk + K : block_limit);
+#endif
 	if (first_chunk >= span_limit) { return; }
 	const uint64_t my_chunks = detail::divide_any(span_limit - first_chunk + stride - 1, stride);
 

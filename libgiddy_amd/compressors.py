@@ -181,8 +181,16 @@ def incidence_bitmaps(column, alignment_in_ints=2, use_dictionary=True, index_si
     return {"incidence_bitmaps": bitmaps, "dictionary_entries": entries, "bitmap_length": words, "num_bitmaps": num_bitmaps}
 
 
+class CapacityExceeded(ValueError):
+    """the column has more runs / patches than the caller's `capacity`; `.needed` is the true number (nothing was written out of bounds)"""
+    def __init__(self, what, needed, capacity):
+        super().__init__("%d %s, room for %d" % (needed, what, capacity))
+        self.needed = needed
+
+
 def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None):
-    """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case)"""
+    """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case).  The kernels are told, store nothing
+    beyond it and still report the true number of runs: CapacityExceeded carries it."""
     n, usize, lsize = column.numel(), column.element_size(), _size(run_length_dtype)
     device = column.device
     capacity = capacity or max(n, 1)
@@ -190,7 +198,7 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
     buffers = {"run_data": torch.empty(capacity, dtype=column.dtype, device=device), "run_lengths": torch.empty(capacity, dtype=_SIGNED[lsize], device=device),
                "position_anchors": torch.empty(nseg, dtype=_SIGNED[index_size], device=device), "intra_run_anchor_offsets": torch.empty(nseg, dtype=_SIGNED[lsize], device=device)}
     runs = torch.zeros(1, dtype=torch.int64, device=device)
-    starts = torch.empty(capacity, dtype=_SIGNED[index_size], device=device)
+    starts = torch.empty(max(n, 1), dtype=_SIGNED[index_size], device=device)   # one entry per NATURAL run (pieces of long runs come later): n at worst
     if n:
         _launch("compression::run_length_encoding::kernel_t<%du, %du, %du, %du>" % (index_size, usize, lsize, index_size),
                 {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
@@ -199,8 +207,10 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
                  "intra_run_anchor_offsets": r.pointer(buffers["intra_run_anchor_offsets"], "u%d" % (8 * lsize)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
                  "tile_totals": r.pointer(_scratch(n, device), "u64"), "run_starts_scratch": r.pointer(starts, "u%d" % (8 * index_size)),
-                 "num_element_runs": r.pointer(runs, "u64")})
+                 "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity)})
     count = int(runs[0])
+    if count > capacity:
+        raise CapacityExceeded("runs", count, capacity)
     return {"run_data": buffers["run_data"][:count], "run_lengths": buffers["run_lengths"][:count], "position_anchors": buffers["position_anchors"],
             "intra_run_anchor_offsets": buffers["intra_run_anchor_offsets"], "segment_length": segment_length, "num_segments": nseg,
             "num_element_runs": count, "length": n}
@@ -220,8 +230,10 @@ def run_position_encoding(column, segment_length, position_dtype=np.uint16, rela
                 {"run_data": r.pointer(buffers["run_data"], "u%d" % (8 * usize)), "run_start_positions": r.pointer(buffers["run_start_positions"], "u%d" % (8 * psize)),
                  "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
-                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64")})
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity)})
     count = int(runs[0])
+    if count > capacity:
+        raise CapacityExceeded("runs", count, capacity)
     return {"run_data": buffers["run_data"][:count], "run_start_positions": buffers["run_start_positions"][:count], "position_anchors": buffers["position_anchors"],
             "segment_length": segment_length, "num_anchors": nseg, "num_element_runs": count, "length": n}
 
@@ -238,8 +250,11 @@ def patches(decoded, truth, index_size=4, capacity=None):
         _launch("compression::patches::kernel_t<%du, %du>" % (index_size, esize), {"length": r.size_t(n)},
                 {"patch_positions": r.pointer(positions, "u%d" % (8 * index_size)), "patch_values": r.pointer(values, "u%d" % (8 * esize)),
                  "decoded": r.const_pointer(decoded, "u%d" % (8 * esize)), "truth": r.const_pointer(truth, "u%d" % (8 * esize)),
-                 "length": r.uint_t(index_size)(n), "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_patches": r.pointer(count, "u64")})
+                 "length": r.uint_t(index_size)(n), "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_patches": r.pointer(count, "u64"),
+                 "capacity": r.size_t(capacity)})
     k = int(count[0])
+    if k > capacity:
+        raise CapacityExceeded("patches", k, capacity)
     return {"indices": positions[:k], "data": values[:k], "data_length": k}
 
 

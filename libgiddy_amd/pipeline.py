@@ -17,15 +17,17 @@ import torch
 
 from . import schemes, sharding
 
-# the bulk arrays of the formats (everything else — anchors, dictionaries, model records — is small, is rebased per
-# chunk on the host and stays numpy)
-BULK_ARRAYS = ("compressed_input", "compressed_data", "packed_element_sizes", "run_data", "run_lengths", "run_start_positions")
+# the arrays a chunk takes a plain SLICE of: the bulk arrays of the formats and the per-segment arrays that need no rebasing (Delta's
+# anchor values, frame-of-reference's model records — n / L of them, tens of MB for short segments) — pinned, their slices copy
+# asynchronously.  position_anchors are rebased per chunk on the host and stay numpy; so do the small side tables.
+BULK_ARRAYS = ("compressed_input", "compressed_data", "packed_element_sizes", "run_data", "run_lengths", "run_start_positions",
+               "anchor_values", "segment_model_coefficients", "dictionary_entries")
 
 
 def pin(fields):
     """the bulk arrays of a column (BULK_ARRAYS) -> pinned torch tensors holding the same bits, so that their slices copy
-    asynchronously; everything else unchanged.  (Anchor arrays are NOT pinned whatever their size: a chunk's anchors are
-    rebased on the host.)"""
+    asynchronously (a copy from pageable memory blocks the host thread, and with it the enqueueing of the other streams' work);
+    everything else unchanged.  (position_anchors are NOT pinned whatever their size: a chunk's are rebased on the host.)"""
     out = {}
     for name, value in fields.items():
         if name in BULK_ARRAYS and isinstance(value, np.ndarray):

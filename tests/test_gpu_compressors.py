@@ -289,3 +289,45 @@ def test_compressed_patch_positions(output_index_size, input_index_size):
         schemes.patched_delta(out, dev(f["compressed_input"]), dev(f["anchor_values"]), dev(values), compressed, n, L, 777, stream=torch.cuda.current_stream().cuda_stream)
         expect = truth.copy(); expect[where] = values
         assert (out.cpu().numpy().view(np.uint64) == expect).all()
+
+
+def test_capacity_is_told_to_the_kernels():
+    """a `capacity` below the true number of runs / patches: nothing is stored beyond it (the arrays sit inside one allocation, with canaries
+    behind them), the true number comes back, and a second call with that much room gives the format writers' arrays"""
+    from libgiddy_amd import compressors
+    n, L = 300007, 4096
+    column = cases.runs_column(n, 8, np.uint32, seed=77)
+    long_runs = np.repeat(np.array([5, 6, 5, 9, 200], dtype=np.uint32), [70000, 1, 140001, 3, 66000])   # pieces far outnumber the natural runs (1-byte lengths)
+    for col, lsize in ((column, 2), (long_runs, 1)):
+        want = formats.run_length_encoding(col, L, np.dtype("u%d" % lsize), 4)
+        with pytest.raises(compressors.CapacityExceeded) as caught:
+            compressors.run_length_encoding(dev(col), L, np.dtype("u%d" % lsize), 4, capacity=want["num_element_runs"] // 3)
+        assert caught.value.needed == want["num_element_runs"]
+        same(compressors.run_length_encoding(dev(col), L, np.dtype("u%d" % lsize), 4, capacity=caught.value.needed), want, "rle at exact capacity")
+    want = formats.run_position_encoding(column, L, np.uint16, True)
+    with pytest.raises(compressors.CapacityExceeded) as caught:
+        compressors.run_position_encoding(dev(column), L, np.uint16, True, capacity=100)
+    assert caught.value.needed == want["num_element_runs"]
+    same(compressors.run_position_encoding(dev(column), L, np.uint16, True, capacity=caught.value.needed), want, "rpe at exact capacity")
+    truth = cases.rng(5).integers(0, 1 << 30, size=n, dtype=np.uint64).astype(np.uint32)
+    decoded = truth.copy(); where = np.sort(cases.rng(6).choice(n, size=5000, replace=False)); decoded[where] ^= 1
+    with pytest.raises(compressors.CapacityExceeded) as caught:
+        compressors.patches(dev(decoded), dev(truth), capacity=1000)
+    assert caught.value.needed == 5000
+    got = compressors.patches(dev(decoded), dev(truth), capacity=5000)
+    assert (got["indices"].cpu().numpy().view(np.uint32) == where).all() and (got["data"].cpu().numpy().view(np.uint32) == truth[where]).all()
+    # canaries: the kernels given arrays that END where the capacity ends, inside a larger buffer
+    from libgiddy_amd import registered as r, schemes
+    room = 1000
+    arena = torch.full((4 * room,), -1, dtype=torch.int32, device="cuda")
+    positions, values = arena[:room], arena[2 * room: 3 * room]
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(2 * (-(-n // 4096) + 2) + 2, dtype=torch.int64, device="cuda")
+    k = schemes.kernel("compression::patches::kernel_t<4u, 4u>")
+    k.enqueue_launch(torch.cuda.current_stream().cuda_stream, k.resolve_launch_configuration(r.CURRENT_DEVICE, {"length": r.size_t(n)}),
+                     {"patch_positions": r.pointer(positions, "u32"), "patch_values": r.pointer(values, "u32"), "decoded": r.const_pointer(dev(decoded), "u32"),
+                      "truth": r.const_pointer(dev(truth), "u32"), "length": r.uint_t(4)(n), "tile_totals": r.pointer(scratch, "u64"),
+                      "num_patches": r.pointer(count, "u64"), "capacity": r.size_t(room)})
+    torch.cuda.synchronize()
+    assert int(count[0]) == 5000 and bool((arena[room: 2 * room] == -1).all()) and bool((arena[3 * room:] == -1).all())
+    assert (positions.cpu().numpy().view(np.uint32) == where[:room]).all()
