@@ -71,6 +71,20 @@ enum : unsigned {
 	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
 };
 
+/// Which chunk a wavefront starts with, chosen by where the OUTPUT lies.  A workgroup's wavefronts write `working_waves` consecutive
+/// chunks; when those make up a power-of-two number of bytes — 4 x 16 KiB, a 64 KiB page, in configuration C4 — the grouping is
+/// shifted so that every workgroup's chunks lie in ONE naturally aligned window of that size wherever the column begins (measured
+/// with the static grouping, tools/alignment_probe.py: 85 % of the HBM peak on a 64 KiB boundary, 79 % displaced by 16 or 32 KiB —
+/// the displacement a pool allocator or a shard boundary gives).  Global wavefront g takes chunks g - shift, g - shift + W, ...; the
+/// `shift` wavefronts that would start below zero start one lap later, i.e. they take the column's last chunks.
+__device__ __forceinline__ uint64_t first_chunk_by_address(const void* output, uint64_t chunk_bytes, unsigned working_waves, uint64_t wave, uint64_t num_waves)
+{
+	const uint64_t group_bytes = chunk_bytes * working_waves;
+	if (chunk_bytes == 0 || (group_bytes & (group_bytes - 1)) != 0 || group_bytes > (1u << 20)) { return wave; }
+	const uint64_t shift = ((reinterpret_cast<uintptr_t>(output) & (group_bytes - 1)) / chunk_bytes) % working_waves;   // (chunk_bytes is a power of two as well)
+	return wave >= shift ? wave - shift : wave + num_waves - shift;
+}
+
 /// a run descriptor (length or position): read once
 template <typename T>
 __device__ __forceinline__ T load_descriptor(const T* p)
@@ -181,8 +195,12 @@ __device__ __forceinline__ void expand(
 	}
 	if (use_staged) { wave64::lds_fence(); }
 
-	for (uint32_t row_start = 0; row_start < tile_len; row_start += 64 * E) {
-		const uint32_t p = row_start + lane * E;
+	// Rows — one 16-byte store per lane, 1 KiB per wave instruction — begin on 512-byte boundaries of the OUTPUT, not of the tile: the
+	// first row is short by `pad` elements (its first lanes idle).  A tile that begins 128 or 256 bytes past such a boundary cost 7-9
+	// points with rows laid from the tile's start (every 512-byte block written by two instructions); 512 bytes on, nothing.
+	const uint32_t pad = aligned ? (uint32_t) ((reinterpret_cast<uintptr_t>(out) & 511u) / ElementSize) : 0u;
+	for (uint32_t row_start = 0; row_start < tile_len + pad; row_start += 64 * E) {
+		const uint32_t p = row_start + lane * E - pad;   // (wraps below zero for the first row's idle lanes)
 		if (p >= tile_len) { continue; }
 		const tile_entry entry = table[p >> 5];   // E divides 32: all E positions share the word
 		auto rank_of = [&](unsigned j) {

@@ -67,14 +67,32 @@ def segment_range(num_segments, rank, world_size, granule=1):
     return min(lo, num_segments), min(hi, num_segments)
 
 
+PAGE_BYTES = 64 * 1024   # shard boundaries fall on multiples of this many OUTPUT bytes where segments tile it (see page_granule)
+
+
+def page_granule(segment_length, output_itemsize, granule=1, page_bytes=None):
+    """Segments per shard-boundary granule so that a shard's output begins a whole number of 64 KiB pages into the column's: the
+    wave-per-segment decoders write a workgroup's four segments into one such page when the output is placed on a page boundary, and a
+    shard that begins 16 or 32 KiB into a page costs them 6 points ("where the output lies"; the kernels now also
+    regroup by address, this keeps shards from needing it).  Only where segments tile a page; `granule`: a granule the scheme needs
+    anyway (the result is a multiple of it)."""
+    page = PAGE_BYTES if page_bytes is None else page_bytes
+    segment_bytes = int(segment_length) * int(output_itemsize)
+    if segment_bytes <= 0 or page % segment_bytes != 0:
+        return granule
+    per_page = page // segment_bytes
+    return granule * per_page // math.gcd(granule, per_page)
+
+
 def _element_range(length, segment_length, rank, world_size, granule=1):
     num_segments = -(-length // segment_length)
     s0, s1 = segment_range(num_segments, rank, world_size, granule)
     return s0, s1, min(s0 * segment_length, length), min(s1 * segment_length, length)
 
 
-def elementwise(fields, rank, world_size, array_keys=("compressed_input",), granule=4096):
-    """Dictionary / DZB-fixed: split on multiples of `granule` elements; side tables are replicated."""
+def elementwise(fields, rank, world_size, array_keys=("compressed_input",), granule=PAGE_BYTES):
+    """Dictionary / DZB-fixed: split on multiples of `granule` elements (64 Ki: a whole number of 64 KiB output pages whatever the
+    element size); side tables are replicated."""
     n = int(fields["length"])
     s0, s1, lo, hi = _element_range(n, granule, rank, world_size)
     out = dict(fields)
@@ -84,9 +102,9 @@ def elementwise(fields, rank, world_size, array_keys=("compressed_input",), gran
     return Shard(out, lo, hi)
 
 
-def frame_of_reference(fields, rank, world_size):
+def frame_of_reference(fields, rank, world_size, output_itemsize=4):
     n, L = int(fields["length"]), int(fields["segment_length"])
-    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size, page_granule(L, output_itemsize))
     out = dict(fields)
     out["compressed_input"] = fields["compressed_input"][lo:hi]
     out["segment_model_coefficients"] = fields["segment_model_coefficients"][s0:s1]
@@ -109,7 +127,7 @@ def model(fields, rank, world_size, model="linear", granule=4096):
 
 def delta(fields, rank, world_size):
     n, L = int(fields["length"]), int(fields["segment_length"])
-    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size, page_granule(L, _itemsize(fields["anchor_values"])))
     out = dict(fields)
     out["compressed_input"] = fields["compressed_input"][lo:hi]
     out["anchor_values"] = fields["anchor_values"][s0:s1]
@@ -117,11 +135,12 @@ def delta(fields, rank, world_size):
     return Shard(out, lo, hi)
 
 
-def discard_zero_bytes_variable(fields, rank, world_size):
+def discard_zero_bytes_variable(fields, rank, world_size, output_itemsize=8):
     n, L = int(fields["length"]), int(fields["segment_length"])
     bits = int(fields["bits_per_element_size"])
     per = (8 * _itemsize(fields["packed_element_sizes"])) // bits
     granule = (L * per // math.gcd(L, per)) // L          # segments per lcm(L, per) elements
+    granule = page_granule(L, output_itemsize, granule)
     s0, s1, lo, hi = _element_range(n, L, rank, world_size, granule)
     anchors = fields["position_anchors"]
     total_bytes = len(fields["compressed_data"])
@@ -155,7 +174,7 @@ def incidence_bitmaps(fields, rank, world_size, alignment_in_ints=2, granule_wor
 
 def run_length_encoding(fields, rank, world_size):
     n, L = int(fields["length"]), int(fields["segment_length"])
-    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size, page_granule(L, _itemsize(fields["run_data"])))
     anchors = fields["position_anchors"]
     num_runs = int(fields["num_element_runs"])
     if s1 <= s0:
@@ -176,7 +195,7 @@ def run_length_encoding(fields, rank, world_size):
 
 def run_position_encoding(fields, rank, world_size, relative=True):
     n, L = int(fields["length"]), int(fields["segment_length"])
-    s0, s1, lo, hi = _element_range(n, L, rank, world_size)
+    s0, s1, lo, hi = _element_range(n, L, rank, world_size, page_granule(L, _itemsize(fields["run_data"])))
     anchors = fields["position_anchors"]
     num_runs = int(fields["num_element_runs"])
     if s1 <= s0:

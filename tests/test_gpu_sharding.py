@@ -107,14 +107,15 @@ def test_pipelined_decode_of_every_sharding_scheme_from_host(num_chunks, depth):
 
 
 def test_pipelined_decode_with_large_anchor_arrays():
-    """a column whose ANCHOR arrays are hundreds of KiB (2^22 elements in segments of 64): anchors stay host arrays whatever
-    their size and are rebased per chunk; only the bulk arrays are pinned (by name)"""
+    """a column whose ANCHOR arrays are hundreds of KiB (2^22 elements in segments of 64): position anchors — rebased per chunk on
+    the host — stay host arrays whatever their size; every array a chunk takes a plain slice of is pinned (by name: the bulk arrays,
+    and Delta's anchor VALUES and the model records, which need no rebasing)"""
     from libgiddy_amd import pipeline
     n = 1 << 22
 
     def check(scheme, fields, truth, **extra):
         pinned = pipeline.pin(fields)
-        assert all(isinstance(pinned[k], np.ndarray) for k in fields if "anchor" in k)
+        assert all(isinstance(pinned[k], np.ndarray) for k in fields if "position_anchor" in k)
         assert all(isinstance(pinned[k], torch.Tensor) and pinned[k].is_pinned() for k in pipeline.BULK_ARRAYS if k in fields)
         out = torch.zeros(len(truth), dtype={4: torch.int32, 8: torch.int64}[truth.dtype.itemsize], device="cuda")
         out.fill_(-1)   # queued on the current stream: the pipeline's side streams must wait for it
