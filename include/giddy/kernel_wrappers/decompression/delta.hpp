@@ -5,6 +5,7 @@
 #include "giddy/functors/functors.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 #include "giddy/kernels/reduction/scan.hpp"
+#include "giddy/stream_scratch.hpp"
 
 namespace cuda {
 namespace kernels {
@@ -14,6 +15,7 @@ namespace delta {
 namespace detail {
 
 enum : unsigned { long_segment_from = 1u << 17, longest_part = 1u << 16, shortest_part = 1u << 12 };
+enum : unsigned { chained_from_rows = 128 };   // segments of at least this many rows go by chained tiles (fewer: the wave and block paths)
 
 /// part_anchors[p] (holding the sum of part p's deltas on entry) = the value before part p: the segment's anchor + the sums of the
 /// segment's earlier parts.  A thread per segment (long segments are few).
@@ -87,6 +89,44 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
 	auto length            = argument<uint_t<IndexSize>>(arguments, "length");
 	auto segment_length    = argument<uint_t<IndexSize>>(arguments, "segment_length");
+
+	// Long segments — more rows than a wavefront takes by itself — as tiles of their own, chained by a decoupled look-back through
+	// per-tile states in stream-ordered scratch memory (kernels/decompression/delta.hpp, namespace chained): every tile a workgroup
+	// whatever the segment length, the deltas read once.  (GIDDY_DELTA_CHAINED_FROM in the environment: the segment length, in elements,
+	// from which this path is taken; 0 turns it off.)
+	{
+		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+		const uint64_t n = length, L = segment_length;
+		static const uint64_t chained_from = [] {
+			const char* v = std::getenv("GIDDY_DELTA_CHAINED_FROM");
+			return v ? (uint64_t) std::strtoull(v, nullptr, 10) : (uint64_t) detail::chained_from_rows * traits::row;
+		}();
+		const bool aligned = memory_access::is_aligned(decompressed, 16) && memory_access::is_aligned(compressed_input, 16);
+		const unsigned waves = chained::waves_per_tile_for<UncompressedSize, CompressedSize>(n, L);
+		// ... where they beat the block path (a workgroup of up to 16 wavefronts per segment): always when there are fewer segments than compute units,
+		// and for 64-bit values from 1-2-byte deltas from one tile per segment on (<4,8,2>, 2^28 elements, segments of 2^14 ...
+		// 2^20: 76 / 76 / 75 / 77 % against 75 / 70 / 69 / 66 %); 32-bit values and wide deltas keep the block path while it has enough
+		// segments (<4,4,1>: 88 % against 77-83 %)
+		const uint64_t num_segments = L == 0 ? 0 : util::div_rounding_up(n, L);
+		const bool preferred = num_segments < (uint64_t) detail::current_device_properties().multiProcessorCount || (UncompressedSize == 8 && CompressedSize <= 2);
+		const bool forced = std::getenv("GIDDY_DELTA_CHAINED_FROM") != nullptr;
+		if (chained_from != 0 && n > 0 && L >= chained_from && (preferred || forced) && L > (uint64_t) detail::rows_per_chunk * traits::row && aligned && waves != 0) {
+			using state_type = chained::tile_state<UncompressedSize>;
+			auto launch_tiles = [&](auto waves_constant) {
+				constexpr unsigned Waves = decltype(waves_constant)::value;
+				const uint64_t tiles = util::div_rounding_up(n, chained::tile_elements<UncompressedSize, CompressedSize, Waves>());
+				auto* states = static_cast<state_type*>(stream_scratch::take_zeroed(stream, tiles * sizeof(state_type)));
+				if (states == nullptr) { return false; }
+				launch_configuration_t tiles_config((grid_dimension_t) std::min<uint64_t>(tiles, 1u << 20), Waves * warp_size);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(chained::decompress<IndexSize, UncompressedSize, CompressedSize, Waves>), stream, tiles_config,
+					decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length, states);
+				stream_scratch::release(stream, states);
+				return true;
+			};
+			if (waves == 16 ? launch_tiles(std::integral_constant<unsigned, 16>()) : waves == 8 ? launch_tiles(std::integral_constant<unsigned, 8>())
+				: launch_tiles(std::integral_constant<unsigned, 4>())) { return; }
+		}
+	}
 
 	// An extension for columns with very long segments (a single un-anchored column is ONE segment: one workgroup's work, 8 % of the
 	// peak at 2^24 elements): given "part_anchors_scratch" — uncompressed_type*, ceil(length / 4096) + 1024 entries — segments of at least 2^17

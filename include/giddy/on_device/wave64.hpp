@@ -255,7 +255,7 @@ __device__ __forceinline__ T load_global(uintptr_t address)
 }
 
 template <typename P>
-__device__ __forceinline__ bool is_aligned(const P* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
+__host__ __device__ __forceinline__ bool is_aligned(const P* p, unsigned bytes) { return (reinterpret_cast<uintptr_t>(p) & (bytes - 1)) == 0; }
 
 } // namespace memory_access
 } // namespace cuda

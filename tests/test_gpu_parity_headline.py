@@ -117,7 +117,10 @@ DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]  # delta.cu:94-1
 @pytest.mark.parametrize("n,seglen", [
     (1, 1), (63, 7), (4096, 4096), (1000003, 4096), (300000, 512), (100000, 1), (50000, 100), (100, 1000),
     (1 << 20, 1 << 18), (3000000, 1 << 20), (70000, 65536 + 512), (12345, 1024),
-    (1000003, 1000), (300000, 3000), (500000, 5000), (200000, 136), (99999, 6)])   # not whole rows: ragged wave path / block path
+    (1000003, 1000), (300000, 3000), (500000, 5000), (200000, 136), (99999, 6),   # not whole rows: ragged wave path / block path
+    # long segments: tiles chained by look-back (whole tiles per segment, or one segment), 4 / 8 / 16 wavefronts per tile by chain length
+    (1 << 21, 16384), (1 << 21, 32768), ((1 << 21) + 12345, 65536), (5 << 20, 1 << 20), ((1 << 22) + 4096 * 3 + 8, 1 << 22),
+    (3000001, 3000001), (1 << 24, 1 << 24), ((1 << 24) + 999, 1 << 25)])
 def test_delta(usize, csize, index_size, n, seglen):
     schemes, r, g = _imports()
     ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
