@@ -115,12 +115,13 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 			auto launch_tiles = [&](auto waves_constant) {
 				constexpr unsigned Waves = decltype(waves_constant)::value;
 				const uint64_t tiles = util::div_rounding_up(n, chained::tile_elements<UncompressedSize, CompressedSize, Waves>());
-				auto* states = static_cast<state_type*>(stream_scratch::take_zeroed(stream, tiles * sizeof(state_type)));
-				if (states == nullptr) { return false; }
+				const auto scratch = stream_scratch::take_zeroed(stream, tiles * sizeof(state_type));
+				if (!scratch) { return false; }
+				auto* states = static_cast<state_type*>(scratch.memory);
 				launch_configuration_t tiles_config((grid_dimension_t) std::min<uint64_t>(tiles, 1u << 20), Waves * warp_size);
 				cuda::enqueue_launch(reinterpret_cast<const void*>(chained::decompress<IndexSize, UncompressedSize, CompressedSize, Waves>), stream, tiles_config,
 					decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length, states);
-				stream_scratch::release(stream, states);
+				stream_scratch::release(stream, scratch);
 				return true;
 			};
 			if (waves == 16 ? launch_tiles(std::integral_constant<unsigned, 16>()) : waves == 8 ? launch_tiles(std::integral_constant<unsigned, 8>())

@@ -3,6 +3,7 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/decompression/discard_zero_bytes_variable.hpp"
+#include "giddy/stream_scratch.hpp"
 
 // output bytes per launch of a long column (see enqueue_launch)
 #ifndef GIDDY_DZBV_LAUNCH_BYTES
@@ -14,6 +15,20 @@ namespace kernels {
 namespace decompression {
 namespace discard_zero_bytes {
 namespace variable_width {
+
+/// scratch for the finer anchors of long segments: taken on a stream, given back (stream-ordered) when the launches using it are enqueued
+struct fine_anchors_scratch {
+	stream::id_t stream; stream_scratch::block block; void* memory = nullptr;
+	explicit fine_anchors_scratch(stream::id_t stream_) : stream(stream_) { }
+	bool take(size_t bytes) { block = stream_scratch::take(stream, bytes); memory = block.memory; return memory != nullptr; }
+	~fine_anchors_scratch() { stream_scratch::release(stream, block); }
+};
+/// GIDDY_DZBV_FINE_ANCHORS=0 in the environment: long segments are decoded as they are (measurements)
+inline int fine_from_environment()
+{
+	static const int on = [] { const char* v = std::getenv("GIDDY_DZBV_FINE_ANCHORS"); return (v && v[0] == '0') ? 0 : 1; }();
+	return on;
+}
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize = sizeof(native_word_t)>
 class kernel_t : public cuda::registered::kernel_t {
@@ -64,6 +79,46 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	// instead of 81 % (profiles/r03_dzbv_xcd_drift_2p30.txt).  A launch boundary brings the fronts together again, so a long column
 	// is decoded as consecutive launches of about `GIDDY_DZBV_LAUNCH_BYTES` of output each (2^31 elements: 69 -> 78 %): whole
 	// segments, whole size containers and 16-byte aligned outputs per piece; the anchors are absolute, so compressed_data stays put.
+	// Long segments: anchors for every 1024 elements from the size fields (kernels/..., namespace fine), in stream-ordered scratch memory,
+	// then the decoder on segments of 1024 — where the wide path applies (1-, 2-, 4-bit fields; 4- and 8-byte elements).
+	fine_anchors_scratch fine_anchors(stream);
+	{
+		constexpr unsigned E = 16 / UncompressedSize;
+		const uint64_t n = length, L = segment_length;
+		const unsigned bits = bits_per_element_size;
+		if (E <= 4 && n > 0 && L > fine::sub && L % fine::sub == 0 && detail::wide_path_applies(bits, ElementSizesContainerSize, E)
+			&& (reinterpret_cast<uintptr_t>(decompressed) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_element_sizes) & 15) == 0 && fine_from_environment() != 0) {
+			const uint64_t subs = util::div_rounding_up(n, (uint64_t) fine::sub);
+			if (fine_anchors.take((subs + 1) * (sizeof(uint64_t) + sizeof(index_type)))) {
+				auto* totals = static_cast<uint64_t*>(fine_anchors.memory);
+				auto* anchors = reinterpret_cast<index_type*>(totals + subs + 1);
+				const auto* size_words = reinterpret_cast<const uint32_t*>(packed_element_sizes);
+				const unsigned min_size = min_represented_element_size;
+				auto with_bits = [&](auto bits_constant) {
+					constexpr unsigned Bits = decltype(bits_constant)::value;
+					if (L / fine::sub <= 64) {   // one launch: a wavefront per segment
+						const uint64_t segments = util::div_rounding_up(n, L);
+						cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_of_short_segments<Bits, IndexSize>), stream,
+							launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(subs, (uint64_t) 64 * fine::threads / 64 / 2), 1u << 16), fine::threads),
+							anchors, size_words, position_anchors, n, L, min_size);
+						return;
+					}
+					cuda::enqueue_launch(reinterpret_cast<const void*>(fine::totals<Bits>), stream,
+						launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(subs, (uint64_t) 64 * fine::threads / 64), 1u << 16), fine::threads),
+						totals, size_words, n, min_size);
+					const uint64_t blocks = util::div_rounding_up(n, L) * util::div_rounding_up(L / fine::sub, (uint64_t) fine::subs_per_block);
+					cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors<IndexSize>), stream,
+						launch_configuration_t((grid_dimension_t) std::min<uint64_t>(blocks, 1u << 16), fine::threads),
+						anchors, static_cast<const uint64_t*>(totals), position_anchors, n, L);
+				};
+				if (bits == 2) { with_bits(std::integral_constant<unsigned, 2>()); }
+				else if (bits == 4) { with_bits(std::integral_constant<unsigned, 4>()); }
+				else { with_bits(std::integral_constant<unsigned, 1>()); }
+				position_anchors = anchors;
+				segment_length = (index_type) fine::sub;
+			}
+		}
+	}
 	const size_t n = length, L = segment_length;
 	const size_t per = bits_per_element_size == 0 ? 1 : (8 * ElementSizesContainerSize) / bits_per_element_size;
 	const size_t segments = L == 0 ? 0 : util::div_rounding_up(n, L);
@@ -73,12 +128,13 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	for (size_t first = 0; first < std::max<size_t>(segments, 1); first += std::max<size_t>(segments_per_piece, 1)) {
 		const size_t begin = first * L, end = std::min(n, (first + segments_per_piece) * L);
 		auto piece_config = launch_config;
-		if (begin != 0 || end != n) {
+		const bool with_fine_anchors = fine_anchors.memory != nullptr;   // (then the caller's grid was resolved for other segments than the launch's)
+		if (begin != 0 || end != n || with_fine_anchors) {
 			// a piece's own covering grid, within the grid the caller resolved for the column (which may be capped, or limited by the caller)
 			const size_t chunks = util::div_rounding_up(util::div_rounding_up(end - begin, L), (size_t) detail::segments_per_wave_chunk(L, 64 * (16 / UncompressedSize)));
 			const size_t wavefronts_per_block = std::max<size_t>(1, launch_config.block_dimensions.x / warp_size);
 			const size_t covering = util::div_rounding_up(chunks, std::min<size_t>(wavefronts_per_block, detail::max_waves_per_block));
-			piece_config.grid_dimensions.x = (grid_dimension_t) std::max<size_t>(1, std::min<size_t>(covering, launch_config.grid_dimensions.x));
+			piece_config.grid_dimensions.x = (grid_dimension_t) std::max<size_t>(1, std::min<size_t>(covering, with_fine_anchors ? (size_t) 1 << 18 : (size_t) launch_config.grid_dimensions.x));
 		}
 		cuda::kernel::enqueue_launch(*this, stream, piece_config,
 			decompressed + begin, compressed_data, packed_element_sizes + begin / per, position_anchors + first,

@@ -889,6 +889,151 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 		decompressed, compressed_data, packed_element_sizes, position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
 }
 
+// ---- long segments: finer anchors from the size fields ----------------------------------------------------------------------
+//
+// A segment is a dependent chain — an element's bytes begin where its predecessor's end — and the decoder is at its best with one
+// 1024-element segment per wavefront and nothing carried from one to the next.  The byte offset of every
+// 1024th element follows from the SIZE FIELDS alone (1/32 of the column's bytes for 2-bit fields of 64-bit elements): the wrapper
+// has them summed per 1024 elements (`fine::totals`), scanned within each segment on top of the segment's anchor (`fine::anchors`),
+// and launches the decoder with a segment length of 1024 on those anchors.  Segments of 4096 / 65536 elements: 67 / 55-62 % of the
+// HBM peak before, the rate of 1024-element segments minus the pre-pass now.
+namespace fine {
+
+enum : unsigned { sub = 1024, subs_per_block = 4096, threads = 256 };
+
+/// Lane s: the bytes of elements [1024 (first + s), 1024 (first + s + 1)), for the 64 such pieces from `first` on — the size words of
+/// all 64 read as ONE contiguous stream of 16-byte-per-lane loads (2-bit fields: 16 KiB in 16 loads), each load's four words summed
+/// per lane (SWAR), the lanes that share a piece added up by a butterfly, the pieces' sums collected by lane.
+template <unsigned Bits>
+__device__ __forceinline__ uint32_t bytes_of_64_pieces(const uint32_t* __restrict__ size_words, uint64_t first, uint64_t length, unsigned min_size, unsigned lane)
+{
+	typedef uint32_t four_words __attribute__((ext_vector_type(4)));
+	constexpr unsigned per = 32 / Bits, words_per_piece = sub / per;              // 32 / 64 / 128 words
+	constexpr unsigned lanes_per_piece = words_per_piece / 4;                       // 8 / 16 / 32 lanes hold a piece's words
+	constexpr unsigned pieces_per_load = 64 / lanes_per_piece, loads = lanes_per_piece;   // 64 pieces in `loads` wave-wide loads
+	constexpr unsigned at_a_time = loads < 16 ? loads : 16;
+	const uint64_t first_word = first * words_per_piece;
+	const uint64_t num_words = (length + per - 1) / per;
+	uint32_t mine = 0;
+	#pragma unroll
+	for (unsigned c0 = 0; c0 < loads; c0 += at_a_time) {
+		uint32_t sums[at_a_time];
+		#pragma unroll
+		for (unsigned c = 0; c < at_a_time; c++) {
+			const uint64_t word = first_word + ((uint64_t) (c0 + c) * 64 + lane) * 4;
+			four_words w = { 0, 0, 0, 0 };
+			if (word + 4 <= num_words) { w = *reinterpret_cast<const four_words*>(size_words + word); }
+			else { for (unsigned j = 0; j < 4; j++) { if (word + j < num_words) { w[j] = size_words[word + j]; } } }
+			uint32_t sum = 0;
+			#pragma unroll
+			for (unsigned j = 0; j < 4; j++) {
+				const uint64_t element = (word + j) * per;
+				uint32_t fields = w[j];
+				unsigned valid = per;
+				if (element + per > length) { valid = element < length ? (unsigned) (length - element) : 0u; fields &= valid == 0 ? 0u : (valid * Bits >= 32 ? ~0u : (1u << (valid * Bits)) - 1u); }
+				// (sizes above the element's width are a breach of the format's precondition — the decoder clamps them; the sum assumes there are none)
+				sum += valid * min_size + detail::sum_of_fields<Bits>(fields);
+			}
+			sums[c] = sum;
+		}
+		#pragma unroll
+		for (unsigned c = 0; c < at_a_time; c++) {
+			uint32_t v = sums[c];
+			#pragma unroll
+			for (unsigned d = 1; d < lanes_per_piece; d <<= 1) { v += (uint32_t) __shfl_xor((int) v, (int) d, 64); }
+			// piece (c0 + c) * pieces_per_load + g is in lanes [g * lanes_per_piece, ...): lane s wants piece s
+			const uint32_t collected = (uint32_t) __shfl((int) v, (int) ((lane % pieces_per_load) * lanes_per_piece), 64);
+			if (lane / pieces_per_load == c0 + c) { mine = collected; }
+		}
+	}
+	return mine;
+}
+
+/// totals[k] = bytes of elements [1024 k, 1024 (k + 1)) — a wavefront per 64 of them
+template <unsigned Bits>
+__global__ void __launch_bounds__(threads) totals(
+	uint64_t* __restrict__ totals_out, const uint32_t* __restrict__ size_words, uint64_t length, unsigned min_size)
+{
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * (threads / 64) + wave64::index_in_block(), num_waves = (uint64_t) gridDim.x * (threads / 64);
+	const uint64_t num_subs = (length + sub - 1) / sub;
+	for (uint64_t k0 = wave * 64; k0 < num_subs; k0 += num_waves * 64) {
+		const uint32_t mine = bytes_of_64_pieces<Bits>(size_words, k0, length, min_size, lane);
+		if (k0 + lane < num_subs) { totals_out[k0 + lane] = mine; }
+	}
+}
+
+/// Segments of at most 64 x 1024 elements in ONE launch: a wavefront per 64 / (1024s per segment) whole segments — lane s ends up with
+/// the bytes of its 1024, one scan across the lanes, restarted at every segment's first lane on that segment's anchor.
+template <unsigned Bits, unsigned IndexSize>
+__global__ void __launch_bounds__(threads) anchors_of_short_segments(
+	uint_t<IndexSize>* __restrict__ anchors_out, const uint32_t* __restrict__ size_words, const uint_t<IndexSize>* __restrict__ position_anchors,
+	uint64_t length, uint64_t segment_length, unsigned min_size)
+{
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * (threads / 64) + wave64::index_in_block(), num_waves = (uint64_t) gridDim.x * (threads / 64);
+	const uint64_t num_subs = (length + sub - 1) / sub, num_segments = (length + segment_length - 1) / segment_length;
+	const unsigned subs_per_segment = (unsigned) (segment_length / sub);   // <= 64
+	const unsigned segments_per_wave = 64 / subs_per_segment, used_lanes = segments_per_wave * subs_per_segment;
+	for (uint64_t segment0 = wave * segments_per_wave; segment0 < num_segments; segment0 += num_waves * segments_per_wave) {
+		const uint64_t first = segment0 * subs_per_segment;
+		const uint32_t mine = bytes_of_64_pieces<Bits>(size_words, first, length, min_size, lane);
+		const unsigned segment_in_wave = lane / subs_per_segment, first_lane_of_segment = segment_in_wave * subs_per_segment;
+		const bool active = lane < used_lanes && segment0 + segment_in_wave < num_segments && first + lane < num_subs;
+		const uint64_t anchor = active ? (uint64_t) position_anchors[segment0 + segment_in_wave] : 0;
+		const uint64_t inclusive = wave64::inclusive_sum((uint64_t) mine);
+		const uint64_t exclusive = inclusive - mine;
+		const uint64_t at_segment_start = (uint64_t) __shfl((long long) exclusive, (int) (first_lane_of_segment < 64 ? first_lane_of_segment : 63), 64);
+		if (active) { anchors_out[first + lane] = (uint_t<IndexSize>) (anchor + exclusive - at_segment_start); }
+	}
+}
+
+/// anchors_out[k] = byte offset of element 1024 k: the anchor of its segment plus the totals of the segment's earlier 1024s.
+/// A workgroup per block of 4096 of a segment's 1024s: first the sum of the segment's blocks before its own, then a scan of its own.
+template <unsigned IndexSize>
+__global__ void __launch_bounds__(threads) anchors(
+	uint_t<IndexSize>* __restrict__ anchors_out, const uint64_t* __restrict__ totals_in, const uint_t<IndexSize>* __restrict__ position_anchors,
+	uint64_t length, uint64_t segment_length)
+{
+	__shared__ uint64_t partial[threads / 64 + 1];
+	const uint64_t subs_per_segment = segment_length / sub, num_subs = (length + sub - 1) / sub;
+	const uint64_t blocks_per_segment = (subs_per_segment + subs_per_block - 1) / subs_per_block;
+	const uint64_t num_segments = (length + segment_length - 1) / segment_length;
+	const unsigned lane = wave64::lane_id(), w = wave64::index_in_block();
+	for (uint64_t b = blockIdx.x; b < num_segments * blocks_per_segment; b += gridDim.x) {
+		const uint64_t segment = b / blocks_per_segment, block_in_segment = b % blocks_per_segment;
+		const uint64_t segment_first = segment * subs_per_segment;
+		const uint64_t first = segment_first + block_in_segment * subs_per_block;
+		const uint64_t limit_in_segment = segment_first + subs_per_segment < num_subs ? segment_first + subs_per_segment : num_subs;
+		const uint64_t end = first + subs_per_block < limit_in_segment ? first + subs_per_block : limit_in_segment;
+		// the segment's 1024s before this block
+		uint64_t before = 0;
+		for (uint64_t k = segment_first + threadIdx.x; k < first; k += threads) { before += totals_in[k]; }
+		for (unsigned d = 32; d > 0; d >>= 1) { before += (uint64_t) __shfl_xor((long long) before, (int) d, 64); }
+		if (lane == 0) { partial[w] = before; }
+		__syncthreads();
+		uint64_t running = (uint64_t) position_anchors[segment];
+		for (unsigned v = 0; v < threads / 64; v++) { running += partial[v]; }
+		__syncthreads();
+		// this block's: each thread a run of consecutive ones, a workgroup scan of the runs' sums
+		constexpr unsigned per_thread = subs_per_block / threads;   // 16
+		const uint64_t mine_first = first + (uint64_t) threadIdx.x * per_thread;
+		uint64_t values[per_thread], sum = 0;
+		#pragma unroll
+		for (unsigned j = 0; j < per_thread; j++) { values[j] = mine_first + j < end ? totals_in[mine_first + j] : 0; sum += values[j]; }
+		const uint64_t inclusive = wave64::inclusive_sum(sum);
+		if (lane == 63) { partial[w] = inclusive; }
+		__syncthreads();
+		uint64_t offset = running + inclusive - sum;
+		for (unsigned v = 0; v < w; v++) { offset += partial[v]; }
+		#pragma unroll
+		for (unsigned j = 0; j < per_thread; j++) { if (mine_first + j < end) { anchors_out[mine_first + j] = (uint_t<IndexSize>) offset; } offset += values[j]; }
+		__syncthreads();
+	}
+}
+
+} // namespace fine
+
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {
 public:

@@ -57,7 +57,12 @@ def test_dzb_variable(index_size, usize, container, min_size, bits):
     if min_size > usize:
         pytest.skip("min size exceeds element width")
     ud = np.dtype("u%d" % usize)
-    for n, seglen in [(1, 32), (1000, 64), (1024, 1024), (333333, 1024), (50, 7), (100000, 4096), (70000, 1000)]:
+    # (long segments that are whole 1024s: finer anchors from the size fields first — incl. a segment of more than 4096 x 1024 elements,
+    # a column that ends inside a 1024, one segment for the whole column)
+    shapes = [(1, 32), (1000, 64), (1024, 1024), (333333, 1024), (50, 7), (100000, 4096), (70000, 1000), (300000, 32768), (200000 + 77, 65536), (150000, 1 << 20)]
+    if (usize, bits, min_size) == (8, 2, 1):
+        shapes += [((5 << 20) + 3000, 5 << 20), (3 << 20, 1 << 20)]
+    for n, seglen in shapes:
         col, sizes = cases.dzbv_column(n, ud, min_size, bits, seed=n + bits + usize)
         f = formats.discard_zero_bytes_variable(col, seglen, min_size, bits, "u%d" % container, index_size, element_sizes=sizes)
         out = g.dev_empty(n, ud)
