@@ -59,10 +59,10 @@ def parse():
     return p.parse_args()
 
 
-def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28):
+def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28, seed_offset=None):
     """`cap`: elements of the workloads whose single-GPU BASELINE shape is a 2^28-element shard (DZB-variable, incidence bitmaps)"""
     import workloads as w
-    w.SEED_OFFSET = 1000 * int(os.environ.get("RANK", "0")) if per_rank_seed else 0
+    w.SEED_OFFSET = seed_offset if seed_offset is not None else (1000 * int(os.environ.get("RANK", "0")) if per_rank_seed else 0)
     table = {
         "dictionary": lambda: w.Dictionary(n, device),
         "dictionary_zipf": lambda: w.Dictionary(n, device, zipf=True),
@@ -89,33 +89,41 @@ def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28):
     return work
 
 
-def timed_steps(work, steps, warmup, barrier):
-    """EXACTLY `steps` timed passes between barrier+synchronize brackets.  The dominant kernel's launch
-    duration comes from a HIP event pair recorded around THAT launch on the launch stream (torch's current
-    stream, the one the kernels are enqueued on); a step with a second small kernel (Delta + patches) passes
-    the pair down so that only the decoder is bracketed."""
+def timed_steps(work, steps, warmup, barrier, per_step_events=True):
+    """EXACTLY `steps` timed passes between barrier+synchronize brackets.  The rank's wall time is read after its own synchronize() and
+    BEFORE the closing barrier (the barrier brackets the region; it is not part of any rank's time — a strong-scaled step is tens of
+    microseconds, a barrier as long).  The dominant kernel's launch duration comes from HIP events on the launch stream (torch's current
+    stream, the one the kernels are enqueued on): a pair around every launch by default — a step with a second small kernel (Delta +
+    patches) passes the pair down so that only the decoder is bracketed — or, `per_step_events=False`, ONE pair around the whole region
+    (no event between the steps: the mean then includes the gaps between launches, and short steps are not stretched by the events)."""
     import inspect
     import torch
     stream = torch.cuda.current_stream().cuda_stream
     brackets_itself = "around_dominant_kernel" in inspect.signature(work.run).parameters
     for _ in range(warmup):
         work.run(stream)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps if per_step_events else 1)]
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for begin, end in events:
-        if brackets_itself:
-            work.run(stream, around_dominant_kernel=(begin.record, end.record))
-        else:
-            begin.record()
+    if per_step_events:
+        for begin, end in events:
+            if brackets_itself:
+                work.run(stream, around_dominant_kernel=(begin.record, end.record))
+            else:
+                begin.record()
+                work.run(stream)
+                end.record()
+    else:
+        events[0][0].record()
+        for _ in range(steps):
             work.run(stream)
-            end.record()
+        events[0][1].record()
     torch.cuda.synchronize()
-    barrier()
     elapsed = time.perf_counter() - t0
+    barrier()
     per_launch_ms = [b.elapsed_time(e) for b, e in events]
-    return elapsed, sum(per_launch_ms) / len(per_launch_ms)
+    return elapsed, sum(per_launch_ms) / steps
 
 
 def roofline(work, mean_launch_ms, traffic):
@@ -231,6 +239,89 @@ def time_gather(local, counts, rank, world, device, barrier, repetitions=3, expe
     return report
 
 
+def placement_and_cache(name, work, n, device, steps):
+    """Two things a timing loop over one column on a 2 MiB boundary does not show (round-2 verdict):
+    the rate with the OUTPUT displaced (what a pool allocator or a shard boundary gives), and the rate when the compressed INPUT does
+    not come out of the 256 MiB Infinity Cache — a run column of 2^30 outputs is 200 MB of runs, which repeated launches find there:
+    three columns of different seeds are decoded in turn, into the same output."""
+    import torch
+    import workloads as w
+    stream = torch.cuda.current_stream().cuda_stream
+    out = {}
+    def frac(ms): return round(work.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    def timed(sequence):
+        for x in sequence[:2]: x.run(stream)
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); begin.record()
+        for x in sequence: x.run(stream)
+        end.record(); torch.cuda.synchronize()
+        return begin.elapsed_time(end) / len(sequence)
+    original, size = work.output, work.output.element_size()
+    big = torch.empty(n + (1 << 20), dtype=original.dtype, device=device)
+    for offset in (128, 32768):
+        work.output = big[offset // size: offset // size + n]
+        work.config = work._launch(stream, None) if hasattr(work, "_launch") else work.config
+        out["frac_output_at_+%d_bytes" % offset] = frac(timed([work] * steps))
+    work.output = original
+    del big
+    keep = w.SEED_OFFSET
+    others = []
+    for k in (1, 2):
+        other = make_workload(name, n, device, seed_offset=keep + 7777 * k)
+        other.output = original
+        others.append(other)
+    w.SEED_OFFSET = keep
+    out["frac_one_column_repeated"] = frac(timed([work] * steps))
+    out["frac_three_columns_in_turn"] = frac(timed([x for _ in range(steps) for x in [work] + others][: 3 * steps]))
+    del others
+    torch.cuda.empty_cache()
+    return out
+
+
+def time_gather_compressed(whole, shard, counts, rank, world, device, barrier, repetitions=3, expected=None, pieces=4, through_host=False):
+    """The same contiguous column on rank 0, the other way round (libgiddy_amd.distributed.gather_compressed): the peers send their
+    COMPRESSED shards, in pieces, and rank 0 decodes them into place while the next pieces arrive.  Reported beside `gather`, never
+    part of `value`."""
+    import torch
+    import torch.distributed as dist
+    from libgiddy_amd.distributed import gather_compressed
+    total = sum(int(c) for c in counts)
+    stream = lambda: torch.cuda.current_stream().cuda_stream
+    if through_host:   # (the one-GPU rehearsal: gloo moves host tensors; a piece goes up to the device, is decoded there and comes back)
+        repetitions = 1
+        out = torch.zeros(total, dtype=whole.output.dtype) if rank == 0 else None
+        fields = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in shard.fields.items()}
+        def decode(fs, view):
+            on_device = {k: (v.to(device) if torch.is_tensor(v) else v) for k, v in fs.items()}
+            decoded = torch.empty(view.numel(), dtype=view.dtype, device=device)
+            whole.launch_fields(decoded, on_device, stream(), None)
+            view.copy_(decoded.cpu())
+        where = torch.device("cpu")
+    else:
+        out = torch.zeros(total, dtype=whole.output.dtype, device=device) if rank == 0 else None
+        fields = shard.fields
+        decode = lambda fs, view: whole.launch_fields(view, fs, stream(), None)
+        where = device
+    best, moved = float("inf"), None
+    for repetition in range(repetitions + 1):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        moved = gather_compressed(fields, whole.shard_function, decode, out, counts, dst=0, pieces=pieces, device=where)
+        torch.cuda.synchronize()
+        elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=where)
+        barrier()
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+        if repetition > 0:
+            best = min(best, float(elapsed[0]))
+    report = {"ms": round(best * 1e3, 3), "pieces_per_shard": pieces,
+              "note": "peers send compressed shards point to point (one xGMI link each), rank 0 decodes the whole column; includes the decoding; not part of `value`"}
+    if rank == 0:
+        report.update({"bytes_received": moved[0], "bytes_a_decoded_gather_receives": moved[1]})
+        if expected is not None:
+            report["gathered_equals_the_column"] = bool((out.to(expected.device) == expected.reshape(-1)).all())
+    return report
+
+
 def all_reduce_u64_sum(value, world, device, backend):
     """sum of 64-bit checksums over the ranks, wrapping — carried as 16-bit limbs so that no backend's integer addition can overflow"""
     import torch
@@ -265,10 +356,13 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
     shards_checksum = all_reduce_u64_sum(w.checksum(shard.output, first_index=shard.start), world, device, backend)
     assert shards_checksum == column_checksum, "%s: the shards' checksums (%x) do not sum to the column's (%x)" % (name, shards_checksum, column_checksum)
     steps, warmup = args.steps, args.warmup
-    elapsed, launch_ms = timed_steps(shard, steps, warmup, barrier)
-    times = torch.tensor([elapsed if r == rank else 0.0 for r in range(world)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    elapsed, launch_ms = timed_steps(shard, steps, warmup, barrier, per_step_events=False)
+    # every rank's wall time (read before the closing barrier) and every rank's event-timed step, side by side
+    times = torch.tensor([[elapsed, launch_ms * 1e-3] if r == rank else [0.0, 0.0] for r in range(world)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(times, op=dist.ReduceOp.SUM)
+    event_ms = [round(float(x) * 1e3, 4) for x in times[:, 1]]
+    times = times[:, 0]
     slowest = float(times.max())
     counts = [0] * world
     if world > 1:
@@ -278,7 +372,9 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
     entry = {"workload": name, "instantiation": whole.name, "elements_total": whole.n, "scaling": "strong",
              "sharding": "libgiddy_amd.sharding on device tensors: %d segment-range shards of one column, rebased anchors, no collective" % world,
              "decompressed_GBps": round(whole.decompressed_bytes * steps / slowest / 1e9, 1), "ms_per_step": round(slowest / steps * 1e3, 4),
-             "per_rank_ms_per_step": [round(float(t) / steps * 1e3, 4) for t in times], "per_rank_elements": [int(c) for c in counts],
+             "per_rank_ms_per_step": [round(float(t) / steps * 1e3, 4) for t in times], "per_rank_event_ms_per_step": event_ms,
+             "timing": "wall: each rank's clock from after the opening barrier to after its own synchronize(), MAX over ranks; events: one HIP event pair around the rank's %d steps" % steps,
+             "per_rank_elements": [int(c) for c in counts],
              "world_size_seen_by_the_process_group": dist.get_world_size() if world > 1 else 1,
              "checksum": "%016x" % column_checksum, "shards_checksum_equals_column_checksum": True,
              "this_rank_roofline": roofline(shard, launch_ms, None)}
@@ -290,6 +386,9 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
             entry["gather"] = time_gather(shard.output.cpu(), counts, rank, world, torch.device("cpu"), barrier, repetitions=1,
                                           expected=expected.cpu() if expected is not None else None)
             entry["gather"]["note"] = "REHEARSAL over gloo through host copies: checks the flow, says nothing about xGMI"
+        entry["gather_compressed"] = time_gather_compressed(whole, shard, counts, rank, world, device, barrier, expected=expected, through_host=backend != "nccl")
+        if backend != "nccl":
+            entry["gather_compressed"]["note"] = "REHEARSAL over gloo through host copies: checks the flow, says nothing about xGMI"
     del shard, whole
     torch.cuda.empty_cache()
     return entry
@@ -406,6 +505,8 @@ def main():
                      "decompressed_GBps": round(w.decompressed_bytes * steps / el / 1e9, 1),
                      "ms_per_step": round(el / steps * 1e3, 4),
                      "roofline": roofline(w, launch_ms, committed_traffic(w.kernel, w.algorithmic_bytes, getattr(w, "workload_name", None))), "bit_exact": True}
+            if name in ("run_length_encoding", "run_position_encoding_absolute"):
+                entry["placement_and_cache"] = placement_and_cache(name, w, n, device, steps)
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
             schemes_out[name] = entry

@@ -40,3 +40,68 @@ def gather_decoded(local, counts, dst=0, group=None, out=None):
         for request in dist.batch_isend_irecv(ops):
             request.wait()
     return out if rank == dst else None
+
+
+# ---- move compressed, expand at the destination -------------------------------------------------------------------------------
+#
+# The library's premise (reference README.md:15-24) applied to xGMI: when ONE contiguous decoded column is wanted on rank `dst`,
+# the peers do not decode and ship 8 bytes per element — they ship their COMPRESSED shards (2.75 bytes per element for C5) and
+# `dst` decodes them into place.  Each peer's shard still crosses one link once; the root's inbound links carry 2.9 x less, and
+# the decoding (the root now decodes the whole column, 1 / world of it its own) overlaps the transfers: every peer cuts its
+# shard into `pieces` sub-shards with the scheme's own sharding function, piece k of ALL peers is one batch of point-to-point
+# receives (all links busy at once), and piece k is decoded while piece k + 1 arrives.
+
+def _describe(fields):
+    """what a receiver must know to take a shard's fields: (dtype, numel) per tensor, everything else as it is"""
+    return {k: (("tensor", str(v.dtype).replace("torch.", ""), int(v.numel())) if torch.is_tensor(v) else ("value", v)) for k, v in fields.items()}
+
+
+def _empty_like_description(description, device):
+    return {k: (torch.empty(d[2], dtype=getattr(torch, d[1]), device=device) if d[0] == "tensor" else d[1]) for k, d in description.items()}
+
+
+def gather_compressed(shard_fields, shard_function, decode, out, counts, dst=0, group=None, pieces=4, device=None):
+    """Rank r holds `shard_fields` — its shard of a column, as libgiddy_amd.sharding cut it, tensors where the arrays are — decoding to
+    counts[r] elements.  On `dst`, `out` (sum(counts) elements) receives the whole decoded column: `dst` decodes its own shard and every
+    peer's, whose compressed arrays arrive in `pieces` sub-shards (cut by `shard_function(fields, k, pieces)`).
+    `decode(fields, out_view)` enqueues the decoding of a (sub-)shard into its range of `out` (on the current stream, for device tensors).
+    Returns (bytes received by dst, bytes it would have received decoded) on `dst`, None elsewhere."""
+    rank = dist.get_rank(group)
+    world = dist.get_world_size(group)
+    offsets, total = shard_extents(counts)
+    if device is None:
+        device = out.device if out is not None else next(v.device for v in shard_fields.values() if torch.is_tensor(v))
+    mine = [shard_function(shard_fields, k, pieces) for k in range(pieces)]      # Shard(fields, start, stop) relative to my shard
+    described = [None] * world
+    dist.all_gather_object(described, [(_describe(s.fields), s.start, s.stop) for s in mine], group=group)
+    if rank != dst:
+        for s in mine:
+            ops = [dist.P2POp(dist.isend, v.contiguous(), dst, group) for v in s.fields.values() if torch.is_tensor(v) and v.numel() > 0]
+            if ops:
+                for request in dist.batch_isend_irecv(ops):
+                    request.wait()
+        return None
+    received = 0
+    def post(k):   # piece k of every peer: one batch — all links at once
+        arrived, ops = {}, []
+        for r in range(world):
+            if r == dst:
+                continue
+            description, start, stop = described[r][k]
+            arrived[r] = (_empty_like_description(description, device), start, stop)
+            ops += [dist.P2POp(dist.irecv, v, r, group) for v in arrived[r][0].values() if torch.is_tensor(v) and v.numel() > 0]
+        return arrived, (dist.batch_isend_irecv(ops) if ops else [])
+    in_flight = post(0)
+    for s in mine:    # my own shard meanwhile
+        if s.stop > s.start:
+            decode(s.fields, out[offsets[dst] + s.start: offsets[dst] + s.stop])
+    for k in range(pieces):
+        arrived, requests = in_flight
+        in_flight = post(k + 1) if k + 1 < pieces else None     # the next piece is on its way before this one is decoded
+        for request in requests:
+            request.wait()
+        for r, (fields, start, stop) in arrived.items():
+            received += sum(v.numel() * v.element_size() for v in fields.values() if torch.is_tensor(v))
+            if stop > start:
+                decode(fields, out[offsets[r] + start: offsets[r] + stop])
+    return received, (total - int(counts[dst])) * out.element_size()

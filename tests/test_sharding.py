@@ -188,6 +188,25 @@ def _worker(rank, world, port, results):
         gathered = distributed.gather_decoded(torch.from_numpy(local.view(np.int64).copy()), counts, dst=0)
         if rank == 0:
             results.put(("dzbv", bool((gathered.numpy().view(np.uint64) == colv).all())))
+        # ... and the same column gathered COMPRESSED: the peers' shards arrive in pieces, rank 0 decodes them into place
+        tensors_v = _as_tensors(f)
+        shv = sharding.discard_zero_bytes_variable(tensors_v, rank, world)
+        whole = torch.zeros(len(colv), dtype=torch.int64) if rank == 0 else None
+        def decode_into(fields, out_view):
+            out_view.copy_(torch.from_numpy(_decode("dzbv", _as_arrays(fields, f), np.uint64).view(np.int64).copy()))
+        moved = distributed.gather_compressed(shv.fields, sharding.discard_zero_bytes_variable, decode_into, whole, counts, dst=0, pieces=3)
+        if rank == 0:
+            results.put(("dzbv_compressed", bool((whole.numpy().view(np.uint64) == colv).all()) and 0 < moved[0] < moved[1]))
+        tensors_r = _as_tensors(fields)
+        shr = sharding.run_length_encoding(tensors_r, rank, world)
+        counts_r = [None] * world
+        dist.all_gather_object(counts_r, shr.stop - shr.start)
+        whole = torch.zeros(len(col), dtype=torch.int32) if rank == 0 else None
+        def decode_runs(fs, out_view):
+            out_view.copy_(torch.from_numpy(_decode("rle", _as_arrays(fs, fields), np.uint32).view(np.int32).copy()))
+        distributed.gather_compressed(shr.fields, sharding.run_length_encoding, decode_runs, whole, counts_r, dst=0, pieces=4)
+        if rank == 0:
+            results.put(("rle_compressed", bool((whole.numpy().view(np.uint32) == col).all())))
         # bench.py's gather leg (the timing harness around the same collective), on CPU tensors, uneven shards
         import bench
         column = torch.arange(9000, dtype=torch.int32) * 7 + 3
@@ -223,5 +242,5 @@ def test_gather_with_gloo(world):
     for p in procs:
         p.join(120)
         assert p.exitcode == 0
-    got = dict(results.get(timeout=10) for _ in range(4))
-    assert got == {"rle": True, "dzbv": True, "bench_gather": True, "strong_checksum": True}
+    got = dict(results.get(timeout=10) for _ in range(6))
+    assert got == {"rle": True, "dzbv": True, "dzbv_compressed": True, "rle_compressed": True, "bench_gather": True, "strong_checksum": True}
