@@ -123,6 +123,61 @@ int          giddy_enqueue_launch(
 
 const void*  giddy_device_function(const giddy_kernel_t* kernel);
 
+/* ---- a column cut into shards (GPUs of a node) or chunks (a host-to-device pipeline) ---------------------
+ * The reference has no multi-GPU or transfer layer (README.md:15-24 states the purpose — move compressed, expand on the
+ * device — and leaves the moving to the caller); these entry points are this library's own, over include/giddy/sharding.hpp
+ * (the same cuts as libgiddy_amd/sharding.py) and libgiddy_amd/csrc/wrappers/sharding.hip. */
+typedef enum giddy_scheme {
+	GIDDY_SCHEME_ELEMENTWISE = 1,                     /* Dictionary, fixed-width discard-zero-bytes */
+	GIDDY_SCHEME_FRAME_OF_REFERENCE,
+	GIDDY_SCHEME_DELTA,
+	GIDDY_SCHEME_DISCARD_ZERO_BYTES_VARIABLE,
+	GIDDY_SCHEME_RUN_LENGTH_ENCODING,
+	GIDDY_SCHEME_RUN_POSITION_ENCODING_RELATIVE,
+	GIDDY_SCHEME_RUN_POSITION_ENCODING_ABSOLUTE
+} giddy_scheme_t;
+
+/* what the cuts need to know of a column */
+typedef struct giddy_column_shape {
+	uint64_t     length;                  /* decoded elements */
+	uint64_t     segment_length;          /* elements per anchored segment (ignored: elementwise) */
+	uint32_t     output_itemsize;         /* bytes per decoded element */
+	uint32_t     bits_per_element_size;   /* variable-width discard-zero-bytes */
+	uint32_t     size_container_size;     /* ... bytes per container of size fields */
+	uint32_t     anchor_itemsize;         /* bytes per position anchor (variable-rate schemes) */
+	uint64_t     num_anchors;             /* entries of position_anchors */
+	uint64_t     num_units;               /* compressed_data bytes (discard-zero-bytes) / element runs (run encodings) */
+	const void*  position_anchors;        /* the column's anchors: two of them are read */
+	int32_t      anchors_on_device;       /* 1: position_anchors is device memory (two synchronous scalar copies) */
+	int32_t      reserved;
+} giddy_column_shape_t;
+
+/* cuda::sharding::shard_t: slices [first, end) per array, what to subtract from the shard's anchors / absolute positions */
+typedef struct giddy_shard {
+	uint64_t  first_segment, end_segment;                 /* per-segment arrays: anchors, anchor values, model records */
+	uint64_t  first_element, end_element;                 /* per-element arrays: compressed_input; the output */
+	uint64_t  first_unit, end_unit;                       /* compressed_data bytes / runs */
+	uint64_t  first_size_container, end_size_container;   /* packed_element_sizes */
+	uint64_t  anchor_bias, position_bias;
+} giddy_shard_t;
+
+int          giddy_shard(int scheme, const giddy_column_shape_t* shape, uint64_t rank, uint64_t world_size, giddy_shard_t* shard);
+
+/* out[i] = in[i] - bias (wrapping, `itemsize` 1, 2, 4 or 8 bytes per entry) on `hip_stream`: an anchor slice — or a slice of absolute
+ * run positions — rebased to its shard where it lies, on the device; out == in is allowed */
+int          giddy_enqueue_rebase(void* hip_stream, void* out, const void* in, uint64_t count, uint32_t itemsize, uint64_t bias);
+
+/* The host-to-device pipeline: the column — every array argument of `arguments` except "decompressed" a HOST pointer (pinned, for the
+ * copies to be asynchronous), "decompressed" a device pointer — is cut into `num_chunks` chunks (= shards), chunk c's slices are
+ * copied to the device on hip_streams[c % num_streams], its anchors rebased there, and it is decoded by the wrapper `key` names into its
+ * range of the output: the copy of chunk c + 1 overlaps the decoding of chunk c.  Scalars that state sizes ("length",
+ * "num_segments", "num_anchors", "num_element_runs", "total_uncompressed_length", "uncompressed_length") are set per chunk, the
+ * others and small side tables ("dictionary_entries": copied once per stream) passed on.  Nothing is synchronised: the caller waits on
+ * the streams.  `shape->position_anchors` must be the HOST array here. */
+int          giddy_decode_from_host(const char* key, int scheme, const giddy_column_shape_t* shape,
+                 const giddy_argument_t* arguments, size_t num_arguments,
+                 uint64_t num_chunks, void* const* hip_streams, size_t num_streams);
+
 /* ---- diagnostics -------------------------------------------------------------------------- */
 const char*  giddy_last_error(void);                   /* message of this thread's last failed call */
 const char*  giddy_version(void);

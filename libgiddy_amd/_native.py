@@ -36,8 +36,26 @@ class giddy_launch_configuration_limits(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "giddy_kernel_count", "giddy_kernel_key", "giddy_can_produce", "giddy_produce", "giddy_release",
     "giddy_resolve_launch_configuration", "giddy_enqueue_launch", "giddy_device_function",
+    "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host",
     "giddy_last_error", "giddy_version",
 )
+
+
+class giddy_column_shape(ctypes.Structure):
+    _fields_ = [("length", ctypes.c_uint64), ("segment_length", ctypes.c_uint64), ("output_itemsize", ctypes.c_uint32),
+                ("bits_per_element_size", ctypes.c_uint32), ("size_container_size", ctypes.c_uint32), ("anchor_itemsize", ctypes.c_uint32),
+                ("num_anchors", ctypes.c_uint64), ("num_units", ctypes.c_uint64), ("position_anchors", ctypes.c_void_p),
+                ("anchors_on_device", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
+class giddy_shard(ctypes.Structure):
+    _fields_ = [(name, ctypes.c_uint64) for name in (
+        "first_segment", "end_segment", "first_element", "end_element", "first_unit", "end_unit",
+        "first_size_container", "end_size_container", "anchor_bias", "position_bias")]
+
+
+SCHEMES = {"elementwise": 1, "frame_of_reference": 2, "delta": 3, "discard_zero_bytes_variable": 4, "run_length_encoding": 5,
+           "run_position_encoding_relative": 6, "run_position_encoding_absolute": 7}
 
 
 def _load():
@@ -61,6 +79,10 @@ def _load():
         ctypes.POINTER(giddy_argument), ctypes.c_size_t]
     lib.giddy_device_function.restype = ctypes.c_void_p
     lib.giddy_device_function.argtypes = [ctypes.c_void_p]
+    lib.giddy_shard.argtypes = [ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(giddy_shard)]
+    lib.giddy_enqueue_rebase.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
+    lib.giddy_decode_from_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.POINTER(giddy_argument), ctypes.c_size_t,
+                                           ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
     lib.giddy_last_error.restype = ctypes.c_char_p
     lib.giddy_version.restype = ctypes.c_char_p
     return lib

@@ -8,29 +8,17 @@
 #include <string>
 #include <vector>
 
-#include "giddy/array.hpp"
-#include "giddy/kernel_wrappers/registered_wrapper.hpp"
+#include "c_abi_internal.hpp"
 
-struct giddy_kernel {
-	std::unique_ptr<cuda::registered::kernel_t> wrapper;
-};
+namespace giddy_internal {
+
+std::string& last_error() { thread_local std::string message; return message; }
+
+} // namespace giddy_internal
 
 namespace {
 
-thread_local std::string last_error;
-
-template <typename F>
-int guarded(F&& f) noexcept
-{
-	try { f(); last_error.clear(); return GIDDY_SUCCESS; }
-	catch (const std::bad_any_cast& e)     { last_error = std::string("bad_any_cast: an argument does not hold the exact type the wrapper expects (") + e.what() + ")"; return GIDDY_BAD_ANY_CAST; }
-	catch (const std::out_of_range& e)     { last_error = std::string("out_of_range (missing argument?): ") + e.what(); return GIDDY_OUT_OF_RANGE; }
-	catch (const std::invalid_argument& e) { last_error = std::string("invalid_argument: ") + e.what(); return GIDDY_INVALID_ARGUMENT; }
-	catch (const std::logic_error& e)      { last_error = std::string("logic_error: ") + e.what(); return GIDDY_LOGIC_ERROR; }
-	catch (const cuda::runtime_error& e)   { last_error = std::string("HIP runtime error: ") + e.what(); return GIDDY_RUNTIME_ERROR; }
-	catch (const std::exception& e)        { last_error = std::string("exception: ") + e.what(); return GIDDY_UNKNOWN_ERROR; }
-	catch (...)                            { last_error = "unknown exception"; return GIDDY_UNKNOWN_ERROR; }
-}
+using giddy_internal::guarded;
 
 const std::vector<std::string>& sorted_keys()
 {
@@ -50,6 +38,10 @@ cuda::array<T, N> coefficients_from(const T* values)
 	for (size_t i = 0; i < N; i++) { a[i] = values[i]; }
 	return a;
 }
+
+} // namespace
+
+namespace giddy_internal {
 
 cuda::any to_any(const giddy_argument_t& a)
 {
@@ -101,6 +93,12 @@ cuda::kernel_t::arguments_type to_map(const giddy_argument_t* arguments, size_t 
 	}
 	return map;
 }
+
+} // namespace giddy_internal
+
+namespace {
+
+using giddy_internal::to_map;
 
 const giddy_kernel& checked(const giddy_kernel_t* kernel)
 {
@@ -194,7 +192,7 @@ const void* giddy_device_function(const giddy_kernel_t* kernel)
 	return (kernel != nullptr && kernel->wrapper) ? kernel->wrapper->get_device_function().ptr() : nullptr;
 }
 
-const char* giddy_last_error(void) { return last_error.c_str(); }
+const char* giddy_last_error(void) { return giddy_internal::last_error().c_str(); }
 
 const char* giddy_version(void) { return "libgiddy_amd 0.1 (gfx950)"; }
 

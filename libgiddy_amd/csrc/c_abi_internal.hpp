@@ -1,0 +1,37 @@
+// What the translation units behind include/giddy.h share: the exception-to-status guard, the thread's last error message and the
+// conversion of tagged C arguments into the wrappers' type-erased argument map.
+#pragma once
+#include "giddy.h"
+
+#include <any>
+#include <stdexcept>
+#include <string>
+
+#include "giddy/array.hpp"
+#include "giddy/kernel_wrappers/registered_wrapper.hpp"
+
+struct giddy_kernel {
+	std::unique_ptr<cuda::registered::kernel_t> wrapper;
+};
+
+namespace giddy_internal {
+
+std::string& last_error();   // this thread's
+cuda::any to_any(const giddy_argument_t& argument);
+cuda::kernel_t::arguments_type to_map(const giddy_argument_t* arguments, size_t count);
+
+template <typename F>
+int guarded(F&& f) noexcept
+{
+	std::string& message = last_error();
+	try { f(); message.clear(); return GIDDY_SUCCESS; }
+	catch (const std::bad_any_cast& e)     { message = std::string("bad_any_cast: an argument does not hold the exact type the wrapper expects (") + e.what() + ")"; return GIDDY_BAD_ANY_CAST; }
+	catch (const std::out_of_range& e)     { message = std::string("out_of_range (missing argument?): ") + e.what(); return GIDDY_OUT_OF_RANGE; }
+	catch (const std::invalid_argument& e) { message = std::string("invalid_argument: ") + e.what(); return GIDDY_INVALID_ARGUMENT; }
+	catch (const std::logic_error& e)      { message = std::string("logic_error: ") + e.what(); return GIDDY_LOGIC_ERROR; }
+	catch (const cuda::runtime_error& e)   { message = std::string("HIP runtime error: ") + e.what(); return GIDDY_RUNTIME_ERROR; }
+	catch (const std::exception& e)        { message = std::string("exception: ") + e.what(); return GIDDY_UNKNOWN_ERROR; }
+	catch (...)                            { message = "unknown exception"; return GIDDY_UNKNOWN_ERROR; }
+}
+
+} // namespace giddy_internal

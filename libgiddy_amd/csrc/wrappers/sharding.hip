@@ -1,0 +1,271 @@
+// giddy_shard / giddy_enqueue_rebase / giddy_decode_from_host (include/giddy.h): a column's cuts, the rebasing of a shard's anchors on
+// the device, and the chunked host-to-device pipeline, for callers of the C ABI.  The cuts are include/giddy/sharding.hpp's.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../c_abi_internal.hpp"
+#include "giddy/api/device.hpp"
+#include "giddy/kernels/data_layout/rebase.hpp"
+#include "giddy/sharding.hpp"
+#include "giddy/stream_scratch.hpp"
+
+namespace {
+
+using giddy_internal::guarded;
+
+uint64_t anchor_value(const giddy_column_shape_t& shape, uint64_t index)
+{
+	if (shape.position_anchors == nullptr) { throw std::invalid_argument("this scheme's cuts read the column's position_anchors: none given"); }
+	if (shape.anchor_itemsize != 1 && shape.anchor_itemsize != 2 && shape.anchor_itemsize != 4 && shape.anchor_itemsize != 8) { throw std::invalid_argument("anchors of 1, 2, 4 or 8 bytes"); }
+	uint64_t value = 0;
+	const char* at = static_cast<const char*>(shape.position_anchors) + index * shape.anchor_itemsize;
+	if (shape.anchors_on_device) { cuda::throw_if_error(hipMemcpy(&value, at, shape.anchor_itemsize, hipMemcpyDeviceToHost), "hipMemcpy (an anchor)"); }
+	else { std::memcpy(&value, at, shape.anchor_itemsize); }   // (little-endian host)
+	return value;
+}
+
+cuda::sharding::shard_t cut(int scheme, const giddy_column_shape_t& shape, uint64_t rank, uint64_t world_size)
+{
+	namespace sh = cuda::sharding;
+	auto at = [&](uint64_t i) { return anchor_value(shape, i); };
+	switch (scheme) {
+	case GIDDY_SCHEME_ELEMENTWISE:        return sh::elementwise(shape.length, rank, world_size);
+	case GIDDY_SCHEME_FRAME_OF_REFERENCE: return sh::frame_of_reference(shape.length, shape.segment_length, shape.output_itemsize, rank, world_size);
+	case GIDDY_SCHEME_DELTA:              return sh::delta(shape.length, shape.segment_length, shape.output_itemsize, rank, world_size);
+	case GIDDY_SCHEME_DISCARD_ZERO_BYTES_VARIABLE:
+		return sh::discard_zero_bytes_variable(shape.length, shape.segment_length, shape.bits_per_element_size, shape.size_container_size,
+			shape.output_itemsize, shape.num_anchors, shape.num_units, at, rank, world_size);
+	case GIDDY_SCHEME_RUN_LENGTH_ENCODING:
+		return sh::run_length_encoding(shape.length, shape.segment_length, shape.output_itemsize, shape.num_anchors, shape.num_units, at, rank, world_size);
+	case GIDDY_SCHEME_RUN_POSITION_ENCODING_RELATIVE:
+	case GIDDY_SCHEME_RUN_POSITION_ENCODING_ABSOLUTE:
+		return sh::run_position_encoding(shape.length, shape.segment_length, shape.output_itemsize, shape.num_anchors, shape.num_units,
+			scheme == GIDDY_SCHEME_RUN_POSITION_ENCODING_RELATIVE, at, rank, world_size);
+	default: throw std::invalid_argument("unknown giddy_scheme_t " + std::to_string(scheme));
+	}
+}
+
+void enqueue_rebase(hipStream_t stream, void* out, const void* in, uint64_t count, uint32_t itemsize, uint64_t bias)
+{
+	if (count == 0) { return; }
+	namespace rb = cuda::kernels::data_layout::rebase;
+	const cuda::launch_configuration_t config((cuda::grid_dimension_t) std::min<uint64_t>((count + 255) / 256, 4096), 256);
+	switch (itemsize) {
+	case 1: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase<1>), stream, config, static_cast<uint8_t*>(out), static_cast<const uint8_t*>(in), count, (uint8_t) bias); break;
+	case 2: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase<2>), stream, config, static_cast<uint16_t*>(out), static_cast<const uint16_t*>(in), count, (uint16_t) bias); break;
+	case 4: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase<4>), stream, config, static_cast<uint32_t*>(out), static_cast<const uint32_t*>(in), count, (uint32_t) bias); break;
+	case 8: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase<8>), stream, config, static_cast<uint64_t*>(out), static_cast<const uint64_t*>(in), count, (uint64_t) bias); break;
+	default: throw std::invalid_argument("entries of 1, 2, 4 or 8 bytes");
+	}
+}
+
+// ---- the pipeline ----------------------------------------------------------------------------------------------------------
+
+enum class sliced_by { nothing, elements, segments, units, size_containers, whole_table };
+
+/// how an array argument of a decompression wrapper is cut (by its name in the wrappers' argument maps — SURVEY.md section 8b)
+sliced_by slicing_of(const std::string& name)
+{
+	static const std::map<std::string, sliced_by> table = {
+		{ "compressed_input", sliced_by::elements },
+		{ "anchor_values", sliced_by::segments }, { "segment_model_coefficients", sliced_by::segments },
+		{ "position_anchors", sliced_by::segments }, { "intra_run_anchor_offsets", sliced_by::segments },
+		{ "segment_position_anchors", sliced_by::segments }, { "segment_position_anchor_intra_run_offsets", sliced_by::segments },
+		{ "compressed_data", sliced_by::units }, { "run_data", sliced_by::units }, { "run_lengths", sliced_by::units }, { "run_start_positions", sliced_by::units },
+		{ "packed_element_sizes", sliced_by::size_containers },
+		{ "dictionary_entries", sliced_by::whole_table },
+	};
+	auto found = table.find(name);
+	return found == table.end() ? sliced_by::nothing : found->second;
+}
+
+unsigned itemsize_of(int type)
+{
+	switch (type) {
+	case GIDDY_PTR_U8: case GIDDY_PTR_I8: case GIDDY_CPTR_U8: case GIDDY_CPTR_I8: return 1;
+	case GIDDY_PTR_U16: case GIDDY_PTR_I16: case GIDDY_CPTR_U16: case GIDDY_CPTR_I16: case GIDDY_CPTR_COEF_I16X1: return 2;
+	case GIDDY_PTR_U32: case GIDDY_PTR_I32: case GIDDY_CPTR_U32: case GIDDY_CPTR_I32: case GIDDY_CPTR_COEF_I16X2: case GIDDY_CPTR_COEF_I32X1: return 4;
+	case GIDDY_PTR_U64: case GIDDY_PTR_I64: case GIDDY_CPTR_U64: case GIDDY_CPTR_I64: case GIDDY_CPTR_COEF_I32X2: return 8;
+	default: return 0;   // not a pointer
+	}
+}
+
+bool is_scalar_count(const std::string& name, const cuda::sharding::shard_t& s, uint64_t& value)
+{
+	if (name == "length" || name == "total_uncompressed_length" || name == "uncompressed_length") { value = s.length(); return true; }
+	if (name == "num_segments" || name == "num_anchors") { value = s.segments.size(); return true; }
+	if (name == "num_element_runs") { value = s.units.size(); return true; }
+	return false;
+}
+
+void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& shape, const giddy_argument_t* arguments, size_t num_arguments,
+	uint64_t num_chunks, void* const* streams, size_t num_streams)
+{
+	if (key == nullptr || arguments == nullptr || streams == nullptr || num_streams == 0 || num_chunks == 0) { throw std::invalid_argument("null key / arguments / streams, or no chunks"); }
+	if (shape.anchors_on_device) { throw std::invalid_argument("the pipeline cuts a column that is in HOST memory: position_anchors on the host"); }
+	auto wrapper = cuda::registered::kernel_t::produceSubclass(key);
+	const auto properties = cuda::device::current::get().properties();
+	const auto attributes = wrapper->get_device_function().attributes();
+	hipStream_t first_stream = static_cast<hipStream_t>(streams[0]);
+
+	// what each argument is, worked out once
+	struct role { sliced_by how = sliced_by::nothing; unsigned itemsize = 0; bool anchors = false, positions = false, output = false, count = false; std::string name; };
+	std::vector<role> roles(num_arguments);
+	uint64_t dictionary_entries = 0;
+	for (size_t i = 0; i < num_arguments; i++) {
+		role& r = roles[i];
+		r.name = arguments[i].name ? arguments[i].name : "";
+		r.itemsize = itemsize_of(arguments[i].type);
+		r.how = r.itemsize ? slicing_of(r.name) : sliced_by::nothing;
+		r.anchors = r.name == "position_anchors" || r.name == "segment_position_anchors";
+		r.positions = r.name == "run_start_positions";
+		r.output = r.name == "decompressed";
+		if (r.name == "num_dictionary_entries") { dictionary_entries = arguments[i].value.u64; }
+	}
+	std::vector<cuda::sharding::shard_t> shards;
+	for (uint64_t c = 0; c < num_chunks; c++) { shards.push_back(cut(scheme, shape, c, num_chunks)); }
+
+	// The column's per-segment arrays (anchors, anchor values, model records: one entry per segment — small) and its side tables go to the
+	// device ONCE, whole, on the first stream; the anchors are rebased there chunk by chunk in one launch; the other streams wait for that.
+	// A chunk then costs a copy per BULK array and its launch — at 256 chunks the runtime's ~3 us per enqueued operation is what bounds the
+	// pipeline, not the link.
+	const uint64_t num_segments_total = shape.segment_length ? (shape.length + shape.segment_length - 1) / shape.segment_length : 0;
+	size_t whole_bytes = 256;
+	std::vector<size_t> whole_offset(num_arguments, 0);
+	for (size_t i = 0; i < num_arguments; i++) {
+		const role& r = roles[i];
+		size_t bytes = 0;
+		if (r.how == sliced_by::segments) { bytes = num_segments_total * r.itemsize; }
+		if (r.how == sliced_by::whole_table) { bytes = dictionary_entries * r.itemsize; }
+		whole_offset[i] = whole_bytes;
+		whole_bytes += (bytes + 255) / 256 * 256 + 256;
+	}
+	const size_t table_offset = whole_bytes;
+	whole_bytes += num_chunks * sizeof(cuda::kernels::data_layout::rebase::chunk_of_entries) + 256;
+	void* whole = nullptr;
+	cuda::throw_if_error(hipMallocAsync(&whole, whole_bytes, first_stream), "hipMallocAsync (a column's per-segment arrays)");
+	char* whole_base = static_cast<char*>(whole);
+	std::vector<cuda::kernels::data_layout::rebase::chunk_of_entries> table;
+	for (const auto& s : shards) { table.push_back({ s.segments.first, s.anchor_bias }); }
+	bool any_bias = false;
+	for (const auto& s : shards) { any_bias = any_bias || s.anchor_bias != 0; }
+	for (size_t i = 0; i < num_arguments; i++) {
+		const role& r = roles[i];
+		if (r.how != sliced_by::segments && r.how != sliced_by::whole_table) { continue; }
+		const size_t bytes = (r.how == sliced_by::segments ? num_segments_total : dictionary_entries) * r.itemsize;
+		if (bytes) { cuda::throw_if_error(hipMemcpyAsync(whole_base + whole_offset[i], arguments[i].value.pointer, bytes, hipMemcpyHostToDevice, first_stream), "hipMemcpyAsync (a per-segment array)"); }
+		if (r.anchors && any_bias && num_segments_total) {
+			// (the table is small and pageable: this copy returns when it has been staged, `table` may go out of scope afterwards)
+			cuda::throw_if_error(hipMemcpyAsync(whole_base + table_offset, table.data(), table.size() * sizeof(table[0]), hipMemcpyHostToDevice, first_stream), "hipMemcpyAsync (chunk table)");
+			namespace rb = cuda::kernels::data_layout::rebase;
+			const cuda::launch_configuration_t config((cuda::grid_dimension_t) std::min<uint64_t>((num_segments_total + 255) / 256, 4096), 256);
+			auto* chunks = reinterpret_cast<const rb::chunk_of_entries*>(whole_base + table_offset);
+			void* entries = whole_base + whole_offset[i];
+			switch (r.itemsize) {
+			case 1: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase_by_chunks<1>), first_stream, config, static_cast<uint8_t*>(entries), chunks, num_chunks, num_segments_total); break;
+			case 2: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase_by_chunks<2>), first_stream, config, static_cast<uint16_t*>(entries), chunks, num_chunks, num_segments_total); break;
+			case 4: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase_by_chunks<4>), first_stream, config, static_cast<uint32_t*>(entries), chunks, num_chunks, num_segments_total); break;
+			default: cuda::enqueue_launch(reinterpret_cast<const void*>(rb::rebase_by_chunks<8>), first_stream, config, static_cast<uint64_t*>(entries), chunks, num_chunks, num_segments_total); break;
+			}
+		}
+	}
+	hipEvent_t uploaded = nullptr;
+	cuda::throw_if_error(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming), "hipEventCreate");
+	cuda::throw_if_error(hipEventRecord(uploaded, first_stream), "hipEventRecord");
+	for (size_t k = 1; k < num_streams; k++) { cuda::throw_if_error(hipStreamWaitEvent(static_cast<hipStream_t>(streams[k]), uploaded, 0), "hipStreamWaitEvent"); }
+
+	std::vector<giddy_argument_t> chunk_arguments(arguments, arguments + num_arguments);
+	for (uint64_t c = 0; c < num_chunks; c++) {
+		const auto& shard = shards[c];
+		if (shard.length() == 0) { continue; }
+		hipStream_t stream = static_cast<hipStream_t>(streams[c % num_streams]);
+		// the chunk's slices of the bulk arrays, each 256-byte aligned within one block of the stream's scratch
+		size_t total = 0;
+		std::vector<size_t> offset(num_arguments, 0);
+		for (size_t i = 0; i < num_arguments; i++) {
+			const role& r = roles[i];
+			if (r.how != sliced_by::elements && r.how != sliced_by::units && r.how != sliced_by::size_containers) { continue; }
+			const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
+			offset[i] = total;
+			total += (slice.size() * r.itemsize + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of a slice's last chunk)
+		}
+		const auto block = cuda::stream_scratch::take(stream, std::max<size_t>(total, 256));
+		if (!block) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
+		char* base = static_cast<char*>(block.memory);
+		for (size_t i = 0; i < num_arguments; i++) {
+			const role& r = roles[i];
+			giddy_argument_t& a = chunk_arguments[i];
+			a = arguments[i];
+			if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
+				const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
+				const size_t bytes = slice.size() * r.itemsize;
+				if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offset[i], static_cast<const char*>(arguments[i].value.pointer) + slice.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a chunk's slice)"); }
+				a.value.pointer = base + offset[i];
+				if (r.positions && shard.position_bias != 0) { enqueue_rebase(stream, base + offset[i], base + offset[i], shard.units.size(), r.itemsize, shard.position_bias); }
+			}
+			else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; }
+			else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; }
+			else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; }
+			else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; } }
+		}
+		const auto map = giddy_internal::to_map(chunk_arguments.data(), chunk_arguments.size());
+		// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
+		auto resolution = map;
+		resolution["length"] = cuda::any((size_t) shard.length());
+		resolution["data_length"] = cuda::any((size_t) shard.length());
+		for (size_t i = 0; i < num_arguments; i++) {
+			if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
+				resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
+			}
+		}
+		const auto config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+		wrapper->enqueue_launch(stream, config, map);
+		cuda::stream_scratch::release(stream, block);
+	}
+	// the per-segment arrays are freed behind the last launch of every stream
+	for (size_t k = 1; k < num_streams; k++) {
+		hipEvent_t done = nullptr;
+		cuda::throw_if_error(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
+		cuda::throw_if_error(hipEventRecord(done, static_cast<hipStream_t>(streams[k])), "hipEventRecord");
+		cuda::throw_if_error(hipStreamWaitEvent(first_stream, done, 0), "hipStreamWaitEvent");
+		(void) hipEventDestroy(done);
+	}
+	(void) hipFreeAsync(whole, first_stream);
+	(void) hipEventDestroy(uploaded);
+}
+
+} // namespace
+
+extern "C" {
+
+int giddy_shard(int scheme, const giddy_column_shape_t* shape, uint64_t rank, uint64_t world_size, giddy_shard_t* shard)
+{
+	return guarded([&] {
+		if (shape == nullptr || shard == nullptr) { throw std::invalid_argument("null shape or output shard"); }
+		const auto s = cut(scheme, *shape, rank, world_size);
+		*shard = giddy_shard_t { s.segments.first, s.segments.end, s.elements.first, s.elements.end, s.units.first, s.units.end,
+			s.size_containers.first, s.size_containers.end, s.anchor_bias, s.position_bias };
+	});
+}
+
+int giddy_enqueue_rebase(void* hip_stream, void* out, const void* in, uint64_t count, uint32_t itemsize, uint64_t bias)
+{
+	return guarded([&] {
+		if (count != 0 && (out == nullptr || in == nullptr)) { throw std::invalid_argument("null array"); }
+		enqueue_rebase(static_cast<hipStream_t>(hip_stream), out, in, count, itemsize, bias);
+	});
+}
+
+int giddy_decode_from_host(const char* key, int scheme, const giddy_column_shape_t* shape, const giddy_argument_t* arguments, size_t num_arguments,
+	uint64_t num_chunks, void* const* hip_streams, size_t num_streams)
+{
+	return guarded([&] {
+		if (shape == nullptr) { throw std::invalid_argument("null shape"); }
+		decode_from_host(key, scheme, *shape, arguments, num_arguments, num_chunks, hip_streams, num_streams);
+	});
+}
+
+} // extern "C"

@@ -168,3 +168,70 @@ def dictionary_from_host(keys_host, entries_dev, out_dev, *, uncompressed_size=4
             ready[slot] = torch.cuda.Event()
             ready[slot].record(s)
     return streams
+
+
+# ---- the same pipeline in C++ behind the C ABI (giddy_decode_from_host) ---------------------------------------------------------
+#
+# The loop above spends ~60 us of Python per chunk (slicing, the anchors' rebasing, four or five copy_ calls, a ctypes launch): with
+# 256 chunks that, not the link, bounds it.  libgiddy_amd/csrc/wrappers/sharding.hip does the whole loop natively — the cuts of
+# include/giddy/sharding.hpp, hipMemcpyAsync of the chunk's slices into the stream's scratch block, the anchors rebased on the device,
+# the wrapper's launch — and this is its Python face: the column's arguments are built exactly as for an ordinary launch (the
+# scheme functions of libgiddy_amd.schemes, with HOST addresses), and handed over once.
+
+_NATIVE_SCHEMES = {"dictionary": "elementwise", "discard_zero_bytes_fixed": "elementwise", "frame_of_reference": "frame_of_reference",
+                   "delta": "delta", "discard_zero_bytes_variable": "discard_zero_bytes_variable", "run_length_encoding": "run_length_encoding"}
+
+
+def _captured_launch(launch, out, fields, kw):
+    """(factory key, launch arguments) of schemes' launch of `fields` — nothing is enqueued"""
+    captured = {}
+    original = schemes._run
+
+    def capture(key, resolve_arguments, launch_arguments, stream, device, limits, launch_config):
+        captured.update(key=key, launch=launch_arguments)
+        return None
+
+    schemes._run = capture
+    try:
+        launch(out, fields, 0, kw)
+    finally:
+        schemes._run = original
+    return captured["key"], captured["launch"]
+
+
+def decode_from_host_native(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **instantiation):
+    """decode_from_host, the chunk loop in C++ (include/giddy.h: giddy_decode_from_host).  Same contract: returns the streams used, which
+    first wait for the caller's current stream; the caller synchronises them."""
+    import ctypes
+    from . import _native as native, registered as r
+    _, launch = _SCHEMES[scheme]
+    arrays = [k for k, v in host_fields.items() if isinstance(v, (torch.Tensor, np.ndarray))]
+    kw = dict(instantiation, out_size=out_dev.element_size(), sizes={k: _itemsize(host_fields[k]) for k in arrays})
+    if scheme == "dictionary":
+        kw.setdefault("num_dictionary_entries", len(host_fields["dictionary_entries"]))
+    key, arguments = _captured_launch(launch, out_dev.view(-1), host_fields, kw)
+    array, keep = r._marshal(arguments)
+    shape = native.giddy_column_shape()
+    shape.length = int(host_fields["length"])
+    shape.segment_length = int(host_fields.get("segment_length", 0))
+    shape.output_itemsize = out_dev.element_size()
+    if scheme == "discard_zero_bytes_variable":
+        shape.bits_per_element_size = int(host_fields["bits_per_element_size"])
+        shape.size_container_size = _itemsize(host_fields["packed_element_sizes"])
+        shape.num_units = len(host_fields["compressed_data"])
+    if scheme in ("run_length_encoding", "run_position_encoding"):
+        shape.num_units = int(host_fields["num_element_runs"])
+    name = _NATIVE_SCHEMES.get(scheme) or ("run_position_encoding_relative" if instantiation.get("relative", True) else "run_position_encoding_absolute")
+    if "position_anchors" in host_fields:
+        anchors = host_fields["position_anchors"]
+        shape.position_anchors = anchors.data_ptr() if isinstance(anchors, torch.Tensor) else np.ascontiguousarray(anchors).ctypes.data
+        shape.anchor_itemsize = _itemsize(anchors)
+        shape.num_anchors = len(anchors)
+    streams = [torch.cuda.Stream(device=out_dev.device) for _ in range(depth)]
+    for stream in streams:
+        stream.wait_stream(torch.cuda.current_stream(out_dev.device))
+    handles = (ctypes.c_void_p * depth)(*[s.cuda_stream for s in streams])
+    status = native.lib.giddy_decode_from_host(key.encode(), native.SCHEMES[name], ctypes.byref(shape), array, len(arguments), num_chunks, handles, depth)
+    if status != 0:
+        raise RuntimeError(native.lib.giddy_last_error().decode())
+    return streams

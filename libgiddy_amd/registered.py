@@ -240,5 +240,5 @@ class kernel_t:
 
     def __del__(self):
         handle, self._handle = getattr(self, "_handle", None), None
-        if handle:
+        if handle and _native is not None and getattr(_native, "lib", None) is not None:   # (module globals are gone at interpreter exit)
             _native.lib.giddy_release(handle)

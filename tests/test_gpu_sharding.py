@@ -106,6 +106,57 @@ def test_pipelined_decode_of_every_sharding_scheme_from_host(num_chunks, depth):
     check("discard_zero_bytes_fixed", formats.discard_zero_bytes_fixed(small, np.uint32), small)
 
 
+@pytest.mark.parametrize("num_chunks,depth", [(1, 1), (5, 2), (64, 3)])
+def test_native_pipeline_decodes_every_sharding_scheme_from_host(num_chunks, depth):
+    """giddy_decode_from_host (the chunk loop in C++ behind the C ABI: cuts of include/giddy/sharding.hpp, slices copied into the stream's
+    scratch, anchors and absolute positions rebased ON THE DEVICE, the wrapper's launch) gives the column for every scheme"""
+    from libgiddy_amd import pipeline
+    n = 300000 + 77
+
+    def check(scheme, fields, truth, **extra):
+        out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
+        out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
+        for s in pipeline.decode_from_host_native(scheme, pipeline.pin(fields), out, num_chunks=num_chunks, depth=depth, **extra):
+            s.synchronize()
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
+
+    f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=3)
+    check("delta", f, truth)
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 3, seed=4)
+    check("discard_zero_bytes_variable", formats.discard_zero_bytes_variable(col, 1024, 1, 3, np.uint32, 8, element_sizes=sizes), col)
+    col = cases.runs_column(n, 32, np.uint32, seed=5)
+    check("run_length_encoding", formats.run_length_encoding(col, 4096, np.uint16), col)
+    check("run_position_encoding", formats.run_position_encoding(col, 4096, np.uint16, True), col, relative=True)
+    check("run_position_encoding", formats.run_position_encoding(col, 4096, np.uint32, False), col, relative=False)
+    f = cases.dictionary_case(n, 256, np.uint32, np.uint8, seed=2)
+    check("dictionary", dict(f, length=n), f["dictionary_entries"][f["compressed_input"].astype(np.int64)])
+    f = cases.for_case(n, 4096, np.int32, np.int16, "linear", seed=6)
+    from oracle import oracle
+    check("frame_of_reference", f, oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, 4096, np.int32, "linear"), model="linear")
+    small = (cases.rng(7).integers(0, 1 << 20, size=n)).astype(np.uint64)
+    check("discard_zero_bytes_fixed", formats.discard_zero_bytes_fixed(small, np.uint32), small)
+
+
+def test_rebase_on_the_device():
+    """giddy_enqueue_rebase: out[i] = in[i] - bias, wrapping in the entries' own width, in place or not, any count"""
+    import ctypes
+    from libgiddy_amd import _native as native
+    stream = torch.cuda.current_stream().cuda_stream
+    for dtype, np_dtype in ((torch.int8, np.uint8), (torch.int16, np.uint16), (torch.int32, np.uint32), (torch.int64, np.uint64)):
+        for count in (0, 1, 255, 100001):
+            host = cases.rng(count + 1).integers(0, 1 << (8 * np.dtype(np_dtype).itemsize - 1), size=count, dtype=np.uint64).astype(np_dtype)
+            bias = int(host[count // 2]) + 7 if count else 5
+            source = torch.from_numpy(host.view(np.dtype("i%d" % host.dtype.itemsize))).cuda()
+            target = torch.zeros_like(source)
+            assert native.lib.giddy_enqueue_rebase(stream, target.data_ptr(), source.data_ptr(), count, host.dtype.itemsize, bias) == 0, native.lib.giddy_last_error()
+            assert native.lib.giddy_enqueue_rebase(stream, source.data_ptr(), source.data_ptr(), count, host.dtype.itemsize, bias) == 0
+            torch.cuda.synchronize()
+            expect = host - np_dtype(bias & ((1 << (8 * host.dtype.itemsize)) - 1))
+            assert (target.cpu().numpy().view(np_dtype) == expect).all() and (source.cpu().numpy().view(np_dtype) == expect).all()
+    assert native.lib.giddy_enqueue_rebase(stream, 0, 0, 5, 4, 1) != 0 and native.lib.giddy_enqueue_rebase(stream, 8, 8, 5, 3, 1) != 0
+
+
 def test_pipelined_decode_with_large_anchor_arrays():
     """a column whose ANCHOR arrays are hundreds of KiB (2^22 elements in segments of 64): position anchors — rebased per chunk on
     the host — stay host arrays whatever their size; every array a chunk takes a plain slice of is pinned (by name: the bulk arrays,
