@@ -59,6 +59,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
 #endif
+#ifndef GIDDY_RUN_GROUPS
+#define GIDDY_RUN_GROUPS 1   // chunks of many runs take their descriptors and values from LDS, a group of 512 runs at a time (run_groups below)
+#endif
 #ifndef GIDDY_RUN_TILE_WORDS_PER_LANE
 #define GIDDY_RUN_TILE_WORDS_PER_LANE 2
 #endif
@@ -152,6 +155,22 @@ struct value_staging {
 		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)
 		with_descriptors = (always || GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS) && ElementSize >= 4,
 		dense_granule = 128 / ElementSize };   // a tile that is cut short ends on a multiple of this many outputs
+};
+
+/// Groups of runs (run_length_encoding.hpp, run_position_encoding.hpp): for chunks of many runs the descriptors and values of up to
+/// `group_runs` consecutive runs are brought into LDS by three coalesced 16-byte-per-lane loads, and the chunk's tiles are decoded
+/// from there.  4-byte values with 1-2-byte descriptors (the value area of value_staging holds 512 of them; a group begins on a
+/// multiple of 8 runs so that its loads are 16-byte aligned, and overlaps its predecessor by `overlap` runs: a tile that is cut at a
+/// group's end hands over at most a 128-byte piece of output — 32 runs of one element at worst — before that end).
+template <unsigned ElementSize, unsigned RunDescriptorSize>
+struct run_groups {
+	enum : unsigned {
+		enabled = GIDDY_RUN_GROUPS && ElementSize == 4 && RunDescriptorSize == 2,
+		lengths_per_lane = 16 / RunDescriptorSize, values_per_lane = 16 / ElementSize,
+		group_runs = 64 * lengths_per_lane,                           // 512: one 16-byte load per lane of descriptors
+		value_loads = (group_runs + 64 * values_per_lane - 1) / (64 * values_per_lane),   // 2 loads per lane of values
+		allocated = group_runs + 8, overlap = 48 };
+	static_assert(!enabled || group_runs <= value_staging<ElementSize, RunDescriptorSize>::capacity, "a group's values fit the value staging area");
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].

@@ -58,6 +58,13 @@ __global__ void decompress(
 	using staging = value_staging<UncompressedSize, RunLengthSize>;
 	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[max_waves_per_block][staging::allocated];
 	uint_t<UncompressedSize>* staged = staged_values[wave64::index_in_block() % max_waves_per_block];   // (idle wavefronts never use it)
+	// Chunks of MANY runs (mean runs below ~16): the chunk's run lengths and values come in GROUPS of up to `group_runs` runs — three
+	// coalesced 16-byte-per-lane loads, the next group's requested as soon as the current one is in LDS — and the tiles take their
+	// descriptors from LDS: no memory round trip between one tile and the next (each tile used to wait for its own batch of descriptors,
+	// requested only once the tile before it had been scanned: at mean runs of 2-4 a wavefront spent three quarters of its life waiting).
+	using groups = run_groups<UncompressedSize, RunLengthSize>;
+	__shared__ alignas(16) uint_t<RunLengthSize> group_lengths_storage[groups::enabled ? max_waves_per_block : 1][groups::enabled ? groups::allocated : 1];
+	uint_t<RunLengthSize>* group_lengths = group_lengths_storage[groups::enabled ? wave64::index_in_block() % max_waves_per_block : 0];
 
 	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256
 	// threads); in a larger workgroup the extra wavefronts sit idle — there is no barrier they could miss
@@ -84,7 +91,7 @@ __global__ void decompress(
 		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
 		uint64_t first_run = segment_position_anchors[s];
 		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
-		const length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s];
+		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s];
 		length_type left_in_first_run = 0;
 		bool entering = true;   // the chunk's first tile: the first run's length is not known yet
 		uint64_t run_limit = num_runs;   // exclusive
@@ -92,6 +99,35 @@ __global__ void decompress(
 			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk] + 1;
 			if (through < run_limit) { run_limit = through; }
 		}
+
+		// groups of runs through LDS (see above) when the chunk has more runs than one batch and the arrays allow 16-byte loads
+		typedef uint32_t sixteen_bytes __attribute__((ext_vector_type(4)));
+		const bool use_groups = groups::enabled && run_limit - first_run > runs_per_batch
+			&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
+		uint64_t group_base = 0, group_end = 0;            // runs [group_base, group_end) are in LDS (group_base a multiple of 8)
+		uint64_t next_group_base = ~(uint64_t) 0;          // the group that is on its way (none: ~0)
+		sixteen_bytes coming_lengths = { 0, 0, 0, 0 }, coming_values[groups::value_loads] = { };
+		auto request_group = [&](uint64_t base) {          // base: a multiple of 8, below run_limit
+			next_group_base = base;
+			const uint64_t mine = base + (uint64_t) lane * groups::lengths_per_lane;
+			if (mine < num_runs) { coming_lengths = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(run_lengths + mine)); }
+			#pragma unroll
+			for (unsigned v = 0; v < groups::value_loads; v++) {
+				const uint64_t value = base + (uint64_t) v * 64 * groups::values_per_lane + (uint64_t) lane * groups::values_per_lane;
+				if (value < num_runs && value < base + groups::group_runs) { coming_values[v] = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(run_data + value)); }
+			}
+		};
+		auto take_group = [&]() {                          // what request_group asked for -> LDS; the following group is requested
+			reinterpret_cast<sixteen_bytes*>(group_lengths)[lane] = coming_lengths;
+			#pragma unroll
+			for (unsigned v = 0; v < groups::value_loads; v++) { reinterpret_cast<sixteen_bytes*>(staged)[v * 64 + lane] = coming_values[v]; }
+			group_base = next_group_base;
+			group_end = group_base + groups::group_runs < run_limit ? group_base + groups::group_runs : run_limit;
+			next_group_base = ~(uint64_t) 0;
+			wave64::lds_fence();
+			if (group_end < run_limit) { request_group((group_end - groups::overlap) / 8 * 8); }
+		};
+		if (use_groups) { request_group(first_run / 8 * 8); take_group(); }
 
 		// The NEXT tile's first batch of run lengths (and values) is requested before this tile's expansion stores anything: CDNA4
 		// retires vector-memory operations in order, so a load issued after a tile's stores is not back before they are
@@ -105,12 +141,17 @@ __global__ void decompress(
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
 			bool need_carry = tile_start + tile_len < segment_end;
 			bool dense = false, values_staged = false;
+			if (use_groups && next_group_base <= first_run) { take_group(); }   // (the tile before ended at the old group's end: see the cut below)
 			clear(table, lane);
 
 			// Runs are addressed RELATIVE to the tile's first run from here on (32 bits: a tile holds at most tile_length of them), and a
 			// batch's loads are unconditional — a lane past the last run re-reads that run and discards it — so that all of them are in
 			// flight together: no branch, no wait between one load and the next.
-			const uint32_t runs_from_here = run_limit - first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (run_limit - first_run);   // >= 1
+			// (groups: a tile sees the runs that are in LDS — and one batch of them at most while the chunk has runs beyond the group, so that a
+			// tile which they do not fill is cut short where dense tiles are: after its first batch, before anything is marked)
+			const uint64_t visible_limit = !use_groups ? run_limit : (group_end < run_limit && first_run + runs_per_batch < group_end ? first_run + runs_per_batch : group_end);
+			const uint32_t runs_from_here = visible_limit - first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (visible_limit - first_run);   // >= 1
+			const uint_t<RunLengthSize>* staged_lengths_from_here = group_lengths + (first_run - group_base);
 			const uint_t<RunLengthSize>* __restrict__ lengths_from_here = run_lengths + first_run;
 			const uint_t<UncompressedSize>* __restrict__ values_from_here = run_data + first_run;
 			uint32_t running = 0;      // clamped lengths summed over earlier batches = start of this batch's first run
@@ -125,6 +166,13 @@ __global__ void decompress(
 				if (from_prefetch) {
 					#pragma unroll
 					for (unsigned j = 0; j < runs_per_lane; j++) { lengths[j] = prefetched_lengths[j]; values[j] = prefetched_values[j]; }
+				}
+				else if (use_groups) {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint32_t k = lane_base + j < runs_from_here ? lane_base + j : runs_from_here - 1;
+						lengths[j] = staged_lengths_from_here[k];   // (the values are in LDS already, at the same offsets)
+					}
 				}
 				else {
 					#pragma unroll
@@ -143,12 +191,12 @@ __global__ void decompress(
 					clamped[j] = lengths[j] > tile_len ? tile_len + 1 : (uint32_t) lengths[j];   // tile_len + 1: "starts past the tile"
 					lane_total += clamped[j];
 					// (staged for the expansion; runs past the tile's last are harmless)
-					if ((staging::with_descriptors || stage_prefetched) && have[j] && lane_base + j < staging::capacity) { staged[lane_base + j] = values[j]; }
+					if (!use_groups && (staging::with_descriptors || stage_prefetched) && have[j] && lane_base + j < staging::capacity) { staged[lane_base + j] = values[j]; }
 				}
 				values_staged = values_staged || stage_prefetched;
 				uint32_t inclusive = wave64::inclusive_sum(lane_total);
 				const uint32_t covered = wave64::read_last_lane(inclusive);
-				if (batch_base == 0 && covered < tile_len && covered >= staging::dense_granule && runs_from_here > runs_per_batch) {   // (lengths of 0 are not allowed: no empty tile)
+				if (batch_base == 0 && covered < tile_len && covered >= staging::dense_granule && (use_groups ? visible_limit < run_limit : runs_from_here > runs_per_batch)) {   // (lengths of 0 are not allowed: no empty tile)
 					// a dense tile (run_expansion.hpp): it ends where this batch's runs end, on a whole 128-byte piece of output
 					// (no length was clamped: each is at most `covered`)
 					tile_len = covered / staging::dense_granule * staging::dense_granule;
@@ -179,7 +227,13 @@ __global__ void decompress(
 					next_first_run = first_run + wave64::read_lane(carried_run, source);
 					next_left_in_first_run = wave64::read_lane(carried_left, source);
 				}
-				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+				else if (use_groups) {
+					// the tile ends exactly where the runs it could see end: the next one begins with the first run it could not see, whole
+					// (its length arrives with that tile's first batch, as a chunk's first run's does)
+					next_first_run = first_run + runs_from_here;
+					entering = true; skipped_of_first_run = 0;
+				}
+				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
 					const uint32_t runs_from_there = run_limit - next_first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (run_limit - next_first_run);   // >= 1
 					uint32_t k[runs_per_lane];
 					#pragma unroll
@@ -197,7 +251,10 @@ __global__ void decompress(
 
 			const uint32_t marks = rank(table, lane);
 			constexpr int staged_stores = staged_store_policy<UncompressedSize, RunLengthSize, false>();
-			if (staging::dense_only && !dense) {
+			if (use_groups) {   // the tile's values are in LDS, at the group's offsets
+				expand<UncompressedSize, true, true, staged_stores>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged + (first_run - group_base), marks + 1);
+			}
+			else if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
 			else if (!staging::with_descriptors && values_staged) {   // a dense tile whose values came with the prefetched lengths
