@@ -165,12 +165,42 @@ struct value_staging {
 template <unsigned ElementSize, unsigned RunDescriptorSize>
 struct run_groups {
 	enum : unsigned {
-		enabled = GIDDY_RUN_GROUPS && ElementSize == 4 && RunDescriptorSize == 2,
-		lengths_per_lane = 16 / RunDescriptorSize, values_per_lane = 16 / ElementSize,
-		group_runs = 64 * lengths_per_lane,                           // 512: one 16-byte load per lane of descriptors
-		value_loads = (group_runs + 64 * values_per_lane - 1) / (64 * values_per_lane),   // 2 loads per lane of values
+		enabled = GIDDY_RUN_GROUPS && ElementSize == 4 && (RunDescriptorSize == 2 || RunDescriptorSize == 4),
+		group_runs = 512,
+		descriptors_per_lane = 16 / RunDescriptorSize, values_per_lane = 16 / ElementSize,
+		descriptor_loads = (group_runs + 64 * descriptors_per_lane - 1) / (64 * descriptors_per_lane),   // 1 or 2 loads per lane of descriptors
+		value_loads = (group_runs + 64 * values_per_lane - 1) / (64 * values_per_lane),                 // 2 loads per lane of values
 		allocated = group_runs + 8, overlap = 48 };
 	static_assert(!enabled || group_runs <= value_staging<ElementSize, RunDescriptorSize>::capacity, "a group's values fit the value staging area");
+	typedef uint32_t sixteen_bytes __attribute__((ext_vector_type(4)));
+
+	/// a group on its way from memory (registers), and in LDS
+	struct in_flight { sixteen_bytes descriptors[descriptor_loads], values[value_loads]; };
+
+	/// the group of runs [base, base + group_runs) requested (base: a multiple of 8; only 16-byte pieces that hold a run below `num_runs` are read)
+	__device__ static __forceinline__ void request(in_flight& coming, const uint_t<RunDescriptorSize>* __restrict__ descriptors,
+		const uint_t<ElementSize>* __restrict__ values, uint64_t base, uint64_t num_runs, unsigned lane)
+	{
+		#pragma unroll
+		for (unsigned v = 0; v < descriptor_loads; v++) {
+			const uint64_t run = base + (uint64_t) (v * 64 + lane) * descriptors_per_lane;
+			if (run < num_runs && run < base + group_runs) { coming.descriptors[v] = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(descriptors + run)); }
+		}
+		#pragma unroll
+		for (unsigned v = 0; v < value_loads; v++) {
+			const uint64_t run = base + (uint64_t) (v * 64 + lane) * values_per_lane;
+			if (run < num_runs && run < base + group_runs) { coming.values[v] = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(values + run)); }
+		}
+	}
+	/// ... and put into LDS (entry i of either area: run base + i)
+	__device__ static __forceinline__ void into_lds(const in_flight& coming, uint_t<RunDescriptorSize>* staged_descriptors, uint_t<ElementSize>* staged_values, unsigned lane)
+	{
+		#pragma unroll
+		for (unsigned v = 0; v < descriptor_loads; v++) { reinterpret_cast<sixteen_bytes*>(staged_descriptors)[v * 64 + lane] = coming.descriptors[v]; }
+		#pragma unroll
+		for (unsigned v = 0; v < value_loads; v++) { reinterpret_cast<sixteen_bytes*>(staged_values)[v * 64 + lane] = coming.values[v]; }
+		wave64::lds_fence();
+	}
 };
 
 /// Writes tile outputs [0, tile_len) at `out`; values are first_run_data[rank(position)].

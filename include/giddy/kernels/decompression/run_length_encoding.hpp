@@ -101,30 +101,20 @@ __global__ void decompress(
 		}
 
 		// groups of runs through LDS (see above) when the chunk has more runs than one batch and the arrays allow 16-byte loads
-		typedef uint32_t sixteen_bytes __attribute__((ext_vector_type(4)));
 		const bool use_groups = groups::enabled && run_limit - first_run > runs_per_batch
 			&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
 		uint64_t group_base = 0, group_end = 0;            // runs [group_base, group_end) are in LDS (group_base a multiple of 8)
 		uint64_t next_group_base = ~(uint64_t) 0;          // the group that is on its way (none: ~0)
-		sixteen_bytes coming_lengths = { 0, 0, 0, 0 }, coming_values[groups::value_loads] = { };
+		typename groups::in_flight coming = { };
 		auto request_group = [&](uint64_t base) {          // base: a multiple of 8, below run_limit
 			next_group_base = base;
-			const uint64_t mine = base + (uint64_t) lane * groups::lengths_per_lane;
-			if (mine < num_runs) { coming_lengths = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(run_lengths + mine)); }
-			#pragma unroll
-			for (unsigned v = 0; v < groups::value_loads; v++) {
-				const uint64_t value = base + (uint64_t) v * 64 * groups::values_per_lane + (uint64_t) lane * groups::values_per_lane;
-				if (value < num_runs && value < base + groups::group_runs) { coming_values[v] = memory_access::load_global<sixteen_bytes>(reinterpret_cast<uintptr_t>(run_data + value)); }
-			}
+			groups::request(coming, run_lengths, run_data, base, num_runs, lane);
 		};
 		auto take_group = [&]() {                          // what request_group asked for -> LDS; the following group is requested
-			reinterpret_cast<sixteen_bytes*>(group_lengths)[lane] = coming_lengths;
-			#pragma unroll
-			for (unsigned v = 0; v < groups::value_loads; v++) { reinterpret_cast<sixteen_bytes*>(staged)[v * 64 + lane] = coming_values[v]; }
+			groups::into_lds(coming, group_lengths, staged, lane);
 			group_base = next_group_base;
 			group_end = group_base + groups::group_runs < run_limit ? group_base + groups::group_runs : run_limit;
 			next_group_base = ~(uint64_t) 0;
-			wave64::lds_fence();
 			if (group_end < run_limit) { request_group((group_end - groups::overlap) / 8 * 8); }
 		};
 		if (use_groups) { request_group(first_run / 8 * 8); take_group(); }

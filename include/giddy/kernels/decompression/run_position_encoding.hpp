@@ -61,6 +61,10 @@ __global__ void decompress(
 	using staging = value_staging<UncompressedSize, PositionOffsetSize>;
 	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[max_waves_per_block][staging::allocated];
 	uint_t<UncompressedSize>* staged = staged_values[wave64::index_in_block() % max_waves_per_block];   // (idle wavefronts never use it)
+	// chunks of many runs: positions and values in GROUPS of 512 runs through LDS (run_expansion.hpp: run_groups; run_length_encoding.hpp)
+	using groups = run_groups<UncompressedSize, PositionOffsetSize>;
+	__shared__ alignas(16) uint_t<PositionOffsetSize> group_positions_storage[groups::enabled ? max_waves_per_block : 1][groups::enabled ? groups::allocated : 1];
+	uint_t<PositionOffsetSize>* group_positions = group_positions_storage[groups::enabled ? wave64::index_in_block() % max_waves_per_block : 0];
 
 	// LDS is provisioned for max_waves_per_block wavefronts (the launch parameters cap the workgroup at 256
 	// threads); in a larger workgroup the extra wavefronts sit idle — there is no barrier they could miss
@@ -91,6 +95,22 @@ __global__ void decompress(
 		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
 			? (uint64_t) position_anchors[s + lane] : ~(uint64_t) 0;
 
+		// groups of runs through LDS when the chunk has more runs than one batch and the arrays allow 16-byte loads
+		const uint64_t run_limit = last_candidate + 1;   // (exclusive: the runs this chunk may look at)
+		const bool use_groups = groups::enabled && last_candidate - first_run > runs_per_batch
+			&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
+		uint64_t group_base = 0, group_end = 0, next_group_base = ~(uint64_t) 0;   // runs [group_base, group_end) are in LDS; the group on its way
+		typename groups::in_flight coming = { };
+		auto request_group = [&](uint64_t base) { next_group_base = base; groups::request(coming, run_start_positions, run_data, base, num_runs, lane); };
+		auto take_group = [&]() {
+			groups::into_lds(coming, group_positions, staged, lane);
+			group_base = next_group_base;
+			group_end = group_base + groups::group_runs < run_limit ? group_base + groups::group_runs : run_limit;
+			next_group_base = ~(uint64_t) 0;
+			if (group_end < run_limit) { request_group((group_end - groups::overlap) / 8 * 8); }
+		};
+		if (use_groups) { request_group(first_run / 8 * 8); take_group(); }
+
 		// the NEXT tile's first batch of run positions (and values) is requested before this tile's expansion stores anything
 		// (run_length_encoding.hpp: loads issued after a tile's stores wait for those stores as well)
 		uint_t<PositionOffsetSize> prefetched_positions[runs_per_lane];
@@ -101,14 +121,21 @@ __global__ void decompress(
 			tile_len = (uint32_t) ((segment_end - tile_start < tile_length) ? segment_end - tile_start : tile_length);
 			bool need_carry = tile_start + tile_len < segment_end;
 			bool dense = false, values_staged = false;
+			if (use_groups && next_group_base <= first_run) { take_group(); }   // (the tile before was cut at the old group's end)
 			clear(table, lane);
-			if (staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
+			if (!use_groups && staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
 			if (!staging::with_descriptors && prefetched && values_prefetched && lane == 0) { staged[0] = prefetched_first_value; }
 
 			// Candidates are addressed RELATIVE to the tile's first run from here on (candidate k is run first_run + 1 + k; 32 bits: a
 			// tile holds at most tile_length of them) and a batch's loads are unconditional — a lane past the last candidate re-reads
 			// that one and discards it — so that all of them are in flight together: no branch, no wait between one load and the next.
-			const uint32_t num_candidates = last_candidate - first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_candidate - first_run);
+			// (groups: a tile sees the candidates that are in LDS, and one batch of them at most while there are runs beyond what it sees — it
+			// is then cut short at the last start it saw, as a dense tile is)
+			const uint64_t last_visible = !use_groups ? last_candidate
+				: (group_end <= last_candidate && first_run + runs_per_batch < group_end - 1 ? first_run + runs_per_batch : (group_end - 1 < last_candidate ? group_end - 1 : last_candidate));
+			const bool more_beyond = last_visible < last_candidate;
+			const uint32_t num_candidates = last_visible - first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_visible - first_run);
+			const uint_t<PositionOffsetSize>* staged_positions_from_here = group_positions + (first_run - group_base);
 			const uint_t<PositionOffsetSize>* __restrict__ positions_from_here = run_start_positions + first_run;
 			const uint_t<UncompressedSize>* __restrict__ values_from_here = run_data + first_run;
 			// a start is of interest up to the tile's end; one at/after the chunk's nominal end opens the NEXT chunk
@@ -125,6 +152,13 @@ __global__ void decompress(
 				if (from_prefetch) {
 					#pragma unroll
 					for (unsigned j = 0; j < runs_per_lane; j++) { positions[j] = prefetched_positions[j]; values[j] = prefetched_values[j]; }
+				}
+				else if (use_groups) {
+					#pragma unroll
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const uint32_t r = lane_base + j < num_candidates ? lane_base + j + 1 : num_candidates;   // (relative to first_run)
+						positions[j] = staged_positions_from_here[r];   // (the values are in LDS already, at the same offsets)
+					}
 				}
 				else {
 					#pragma unroll
@@ -158,17 +192,23 @@ __global__ void decompress(
 					const uint64_t from_tile_start = start - tile_start;
 					offsets[j] = (have && from_tile_start < reach) ? (uint32_t) from_tile_start : ~0u;
 					// (staged for the expansion; runs past the tile's last are harmless)
-					if ((staging::with_descriptors || stage_prefetched) && have && k + 1 < staging::capacity) { staged[k + 1] = values[j]; }
+					if (!use_groups && (staging::with_descriptors || stage_prefetched) && have && k + 1 < staging::capacity) { staged[k + 1] = values[j]; }
 				}
 				values_staged = values_staged || stage_prefetched;
 				if (batch_base == 0) {
 					// a dense tile (run_expansion.hpp): when every run of the first batch starts inside the tile, the tile ends where
 					// the batch's last run starts (on a whole 128-byte piece of output)
 					bool outside = false;
+					uint32_t furthest_inside = 0;
 					#pragma unroll
-					for (unsigned j = 0; j < runs_per_lane; j++) { outside = outside || offsets[j] >= tile_len; }
-					const uint32_t last_start = wave64::read_last_lane(offsets[runs_per_lane - 1]);
-					if (wave64::ballot(outside) == 0 && last_start >= staging::dense_granule) {   // (positions that do not increase: no empty tile)
+					for (unsigned j = 0; j < runs_per_lane; j++) {
+						const bool visible = lane_base + j < num_candidates;
+						// (groups: the candidates the tile cannot see are neither inside nor outside — if all it sees start inside and there are more, it is cut)
+						outside = outside || (offsets[j] >= tile_len && (!more_beyond || visible));
+						furthest_inside = (visible && offsets[j] < tile_len && offsets[j] > furthest_inside) ? offsets[j] : furthest_inside;
+					}
+					const uint32_t last_start = more_beyond ? wave64::read_last_lane(wave64::inclusive_max(furthest_inside)) : wave64::read_last_lane(offsets[runs_per_lane - 1]);
+					if (wave64::ballot(outside) == 0 && last_start >= staging::dense_granule && last_start < tile_len) {   // (positions that do not increase: no empty tile)
 						tile_len = last_start / staging::dense_granule * staging::dense_granule;
 						need_carry = true; dense = true;
 					}
@@ -191,7 +231,7 @@ __global__ void decompress(
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
 				if (furthest != 0) { next_first_run = first_run + furthest - 1; }
-				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
 					const uint32_t candidates_there = last_candidate - next_first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_candidate - next_first_run);
 					uint32_t r[runs_per_lane];
 					#pragma unroll
@@ -210,7 +250,10 @@ __global__ void decompress(
 
 			const uint32_t marks = rank(table, lane);
 			constexpr int staged_stores = staged_store_policy<UncompressedSize, PositionOffsetSize, PositionsAreRelative>();
-			if (staging::dense_only && !dense) {
+			if (use_groups) {   // the tile's values are in LDS, at the group's offsets
+				expand<UncompressedSize, true, true, staged_stores>(decompressed + tile_start, tile_len, table, run_data + first_run, lane, staged + (first_run - group_base), marks + 1);
+			}
+			else if (staging::dense_only && !dense) {
 				expand<UncompressedSize, false>(decompressed + tile_start, tile_len, table, run_data + first_run, lane);
 			}
 			else if (!staging::with_descriptors && values_staged) {   // a dense tile whose values came with the prefetched positions
