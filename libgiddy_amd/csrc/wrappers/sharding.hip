@@ -1,6 +1,7 @@
 // giddy_shard / giddy_enqueue_rebase / giddy_decode_from_host (include/giddy.h): a column's cuts, the rebasing of a shard's anchors on
 // the device, and the chunked host-to-device pipeline, for callers of the C ABI.  The cuts are include/giddy/sharding.hpp's.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -145,11 +146,27 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 	}
 	const size_t table_offset = whole_bytes;
 	whole_bytes += num_chunks * sizeof(cuda::kernels::data_layout::rebase::chunk_of_entries) + 256;
-	void* whole = nullptr;
-	cuda::throw_if_error(hipMallocAsync(&whole, whole_bytes, first_stream), "hipMallocAsync (a column's per-segment arrays)");
+	// (the first stream's second kept block: it lives until every stream's last launch of this call — the next call on this stream is ordered
+	// behind those, see the end of this function)
+	const auto whole_block = cuda::stream_scratch::take(first_stream, whole_bytes, 1);
+	if (!whole_block) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a column's per-segment arrays"); }
+	void* whole = whole_block.memory;
 	char* whole_base = static_cast<char*>(whole);
-	std::vector<cuda::kernels::data_layout::rebase::chunk_of_entries> table;
-	for (const auto& s : shards) { table.push_back({ s.segments.first, s.anchor_bias }); }
+	// (the chunk table travels from PINNED memory that outlives this call — an asynchronous copy out of pageable memory may still be reading
+	// it when this function has returned: one buffer per host thread, reused once the previous call's copy out of it is known to be done)
+	using chunk_entry = cuda::kernels::data_layout::rebase::chunk_of_entries;
+	struct pinned_table { chunk_entry* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; };
+	static thread_local pinned_table pinned;
+	if (pinned.copied != nullptr) { cuda::throw_if_error(hipEventSynchronize(pinned.copied), "hipEventSynchronize"); }
+	else { cuda::throw_if_error(hipEventCreateWithFlags(&pinned.copied, hipEventDisableTiming), "hipEventCreate"); }
+	if (pinned.capacity < num_chunks) {
+		if (pinned.memory != nullptr) { (void) hipHostFree(pinned.memory); pinned.memory = nullptr; pinned.capacity = 0; }
+		const size_t capacity = std::max<size_t>(2 * num_chunks, 1024);
+		cuda::throw_if_error(hipHostMalloc(reinterpret_cast<void**>(&pinned.memory), capacity * sizeof(chunk_entry), hipHostMallocDefault), "hipHostMalloc (chunk table)");
+		pinned.capacity = capacity;
+	}
+	chunk_entry* table = pinned.memory;
+	for (uint64_t c = 0; c < num_chunks; c++) { table[c] = chunk_entry { shards[c].segments.first, shards[c].anchor_bias }; }
 	bool any_bias = false;
 	for (const auto& s : shards) { any_bias = any_bias || s.anchor_bias != 0; }
 	for (size_t i = 0; i < num_arguments; i++) {
@@ -158,8 +175,7 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		const size_t bytes = (r.how == sliced_by::segments ? num_segments_total : dictionary_entries) * r.itemsize;
 		if (bytes) { cuda::throw_if_error(hipMemcpyAsync(whole_base + whole_offset[i], arguments[i].value.pointer, bytes, hipMemcpyHostToDevice, first_stream), "hipMemcpyAsync (a per-segment array)"); }
 		if (r.anchors && any_bias && num_segments_total) {
-			// (the table is small and pageable: this copy returns when it has been staged, `table` may go out of scope afterwards)
-			cuda::throw_if_error(hipMemcpyAsync(whole_base + table_offset, table.data(), table.size() * sizeof(table[0]), hipMemcpyHostToDevice, first_stream), "hipMemcpyAsync (chunk table)");
+			cuda::throw_if_error(hipMemcpyAsync(whole_base + table_offset, table, num_chunks * sizeof(chunk_entry), hipMemcpyHostToDevice, first_stream), "hipMemcpyAsync (chunk table)");
 			namespace rb = cuda::kernels::data_layout::rebase;
 			const cuda::launch_configuration_t config((cuda::grid_dimension_t) std::min<uint64_t>((num_segments_total + 255) / 256, 4096), 256);
 			auto* chunks = reinterpret_cast<const rb::chunk_of_entries*>(whole_base + table_offset);
@@ -172,6 +188,7 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 			}
 		}
 	}
+	cuda::throw_if_error(hipEventRecord(pinned.copied, first_stream), "hipEventRecord");
 	hipEvent_t uploaded = nullptr;
 	cuda::throw_if_error(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming), "hipEventCreate");
 	cuda::throw_if_error(hipEventRecord(uploaded, first_stream), "hipEventRecord");
@@ -225,7 +242,8 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		wrapper->enqueue_launch(stream, config, map);
 		cuda::stream_scratch::release(stream, block);
 	}
-	// the per-segment arrays are freed behind the last launch of every stream
+	// the first stream runs on only when every stream has made its last launch of this call: whatever is enqueued on it next — the next
+	// call's uploads into the same kept block among them — comes after all of this call's readers of the per-segment arrays
 	for (size_t k = 1; k < num_streams; k++) {
 		hipEvent_t done = nullptr;
 		cuda::throw_if_error(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
@@ -233,7 +251,7 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		cuda::throw_if_error(hipStreamWaitEvent(first_stream, done, 0), "hipStreamWaitEvent");
 		(void) hipEventDestroy(done);
 	}
-	(void) hipFreeAsync(whole, first_stream);
+	cuda::stream_scratch::release(first_stream, whole_block);
 	(void) hipEventDestroy(uploaded);
 }
 

@@ -201,7 +201,9 @@ def _captured_launch(launch, out, fields, kw):
 
 def decode_from_host_native(scheme, host_fields, out_dev, *, num_chunks=16, depth=3, **instantiation):
     """decode_from_host, the chunk loop in C++ (include/giddy.h: giddy_decode_from_host).  Same contract: returns the streams used, which
-    first wait for the caller's current stream; the caller synchronises them."""
+    first wait for the caller's current stream; the caller synchronises them — and KEEPS `host_fields` ALIVE until then: these copies are
+    plain hipMemcpyAsync calls that torch's pinned-memory cache knows nothing about (a pinned tensor that dies early may be unmapped or
+    handed to someone else while the DMA still reads it)."""
     import ctypes
     from . import _native as native, registered as r
     _, launch = _SCHEMES[scheme]

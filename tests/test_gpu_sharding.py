@@ -116,8 +116,10 @@ def test_native_pipeline_decodes_every_sharding_scheme_from_host(num_chunks, dep
     def check(scheme, fields, truth, **extra):
         out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
         out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
-        for s in pipeline.decode_from_host_native(scheme, pipeline.pin(fields), out, num_chunks=num_chunks, depth=depth, **extra):
+        pinned = pipeline.pin(fields)   # (kept until the streams are done: the copies out of it are asynchronous, and unlike torch's own copy_ they
+        for s in pipeline.decode_from_host_native(scheme, pinned, out, num_chunks=num_chunks, depth=depth, **extra):   # are unknown to torch's pinned-memory cache)
             s.synchronize()
+        del pinned
         got = out.cpu().numpy().view(truth.dtype)
         assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
 
