@@ -38,6 +38,11 @@ KERNELS = {  # workload -> (substring of the kernel name, algorithmic bytes per 
 }
 
 
+# decoder launches per step: variable-width discard-zero-bytes decodes a 2 GiB column as two consecutive launches of ~1 GiB of output
+# (kernel_wrappers/decompression/discard_zero_bytes_variable.hpp); the traffic is reported per STEP, as bench.py's algorithmic bytes are
+LAUNCHES_PER_STEP = {"discard_zero_bytes_variable": 2, "discard_zero_bytes_variable_3bit": 2}
+
+
 def mean_counter(path, kernel_substring):
     values = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substring in r["Kernel_Name"]]
     return (sum(values) / len(values), len(values)) if values else (None, 0)
@@ -59,7 +64,7 @@ def main():
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "TimedRegionCalls", "TimedRegionAverageNs"])
         for r in ours:
             d = durations_by_kernel.get(r["Name"], [])
-            timed = d[-20:] if "dictionary" in r["Name"] else d[-10:]
+            timed = d[-20:] if "dictionary" in r["Name"] else (d[-20:] if "variable_width" in r["Name"] else d[-10:])   # (DZB-V: two launches per step)
             w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
                         len(timed), "%.1f" % (sum(timed) / max(len(timed), 1))])
     bench_line = open(os.path.join(RAW, "bench_under_rocprof.json")).read().strip().splitlines()[-1]
@@ -100,8 +105,9 @@ def main():
             continue
         if fetch is None or write is None:
             continue
-        read_bytes = fetch * 1024 * read_factor
-        write_bytes = write * 1024 * write_factor
+        per_step = LAUNCHES_PER_STEP.get(workload, 1)
+        read_bytes = fetch * 1024 * read_factor * per_step
+        write_bytes = write * 1024 * write_factor * per_step
         total = read_bytes + write_bytes
         traffic[workload] = {"kernel": kernel, "fetch_size_kib_raw": fetch, "write_size_kib_raw": write,
                              "hbm_read_bytes": int(read_bytes), "hbm_write_bytes": int(write_bytes),
