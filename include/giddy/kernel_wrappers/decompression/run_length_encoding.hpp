@@ -3,6 +3,8 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/decompression/run_length_encoding.hpp"
+#include "giddy/kernels/decompression/run_anchors.hpp"
+#include "giddy/stream_scratch.hpp"
 
 namespace cuda {
 namespace kernels {
@@ -62,6 +64,38 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	auto num_element_runs         = argument<run_index_size_type>(arguments, "num_element_runs");
 	auto uncompressed_length      = argument<size_type>(arguments, "length");
 
+	// Long segments: entry points for every `fine::sub`-th output first — sums of every 64 run lengths, scanned, searched per finer
+	// anchor —, then the decoder on segments of fine::sub (kernels/decompression/run_anchors.hpp).
+	namespace fine = run_expansion::fine;
+	const uint64_t n = uncompressed_length, L = segment_length, runs = num_element_runs;
+	stream_scratch::lease scratch(stream);
+	// (the pass over the lengths costs 2 x their bytes: at mean runs below 8 it only pays where segments are so long that the chip is not filled)
+	const bool worth_it = runs != 0 && (n / runs >= 8 || L >= 16 * (uint64_t) fine::sub);
+	if (n > 0 && runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && worth_it && memory_access::is_aligned(run_lengths, 16)) {
+		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
+		const uint64_t tiles = util::div_rounding_up(runs, (uint64_t) fine::runs_per_tile), blocks = util::div_rounding_up(runs, (uint64_t) fine::runs_per_block);
+		const size_t anchors_at = (tiles + blocks) * sizeof(uint64_t), offsets_at = util::round_up(anchors_at + num_fine * sizeof(run_index_type), (size_t) 16);
+		if (num_fine <= std::numeric_limits<size_type>::max() && scratch.take(offsets_at + num_fine * sizeof(run_length_type))) {
+			auto* tile_starts = static_cast<uint64_t*>(scratch.memory());
+			auto* block_totals = tile_starts + tiles;
+			auto* finer_anchors = reinterpret_cast<run_index_type*>(static_cast<char*>(scratch.memory()) + anchors_at);
+			auto* finer_offsets = reinterpret_cast<run_length_type*>(static_cast<char*>(scratch.memory()) + offsets_at);
+			const launch_configuration_t per_block((grid_dimension_t) std::min<uint64_t>(blocks, 1u << 16), fine::threads);
+			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::sum_run_lengths<RunLengthSize>), stream, per_block, tile_starts, block_totals, run_lengths, runs);
+			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::scan_tiles<>), stream, per_block, tile_starts, static_cast<const uint64_t*>(block_totals), runs);
+			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_from_sums<RunLengthSize, RunIndexSize>), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) fine::threads), 1u << 16), fine::threads),
+				finer_anchors, finer_offsets, static_cast<const uint64_t*>(tile_starts), run_lengths, position_anchors, intra_run_anchor_offsets,
+				L, (uint64_t) num_segments, runs, n);
+			auto config = launch_config;
+			const size_t wavefronts_per_block = std::max<size_t>(1, std::min<size_t>(launch_config.block_dimensions.x / warp_size, run_expansion::max_waves_per_block));
+			config.grid_dimensions.x = (grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) wavefronts_per_block), 1u << 20);
+			cuda::kernel::enqueue_launch(*this, stream, config,
+				decompressed, run_data, run_lengths, static_cast<const run_index_type*>(finer_anchors), static_cast<const run_length_type*>(finer_offsets),
+				(size_type) fine::sub, (size_type) num_fine, num_element_runs, uncompressed_length);
+			return;
+		}
+	}
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
 		segment_length, num_segments, num_element_runs, uncompressed_length);

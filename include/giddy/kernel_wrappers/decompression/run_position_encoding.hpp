@@ -3,6 +3,10 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/decompression/run_position_encoding.hpp"
+#include "giddy/kernels/decompression/run_anchors.hpp"
+#include "giddy/stream_scratch.hpp"
+
+#include <cstdlib>
 
 namespace cuda {
 namespace kernels {
@@ -61,6 +65,35 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	auto num_element_runs            = argument<run_index_size_type>(arguments, "num_element_runs");
 	auto uncompressed_length         = argument<uncompressed_index_size_type>(arguments, "length");
 
+	// Long segments: the run covering every `fine::sub`-th output first (a binary search per finer anchor), then the decoder on
+	// segments of fine::sub (kernels/decompression/run_anchors.hpp) — L = 65 536: 65 -> 8x %, L = 2^20: 26 -> 8x % of the HBM peak.
+	namespace fine = run_expansion::fine;
+	const uint64_t n = uncompressed_length, L = uncompressed_segment_length;
+	stream_scratch::lease scratch(stream);
+	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
+		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
+		if (num_fine <= std::numeric_limits<run_index_size_type>::max() && scratch.take(num_fine * sizeof(run_index_type))) {
+			auto* finer_anchors = static_cast<run_index_type*>(scratch.memory());
+			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_by_search<PositionOffsetSize, PositionsAreRelative, RunIndexSize>), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) fine::threads), 1u << 16), fine::threads),
+				finer_anchors, run_start_positions, position_anchors, L, (uint64_t) num_anchors, (uint64_t) num_element_runs, n);
+			auto config = launch_config;
+			const size_t wavefronts_per_block = std::max<size_t>(1, std::min<size_t>(launch_config.block_dimensions.x / warp_size, run_expansion::max_waves_per_block));
+			config.grid_dimensions.x = (grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) wavefronts_per_block), 1u << 20);
+			if (PositionsAreRelative) {
+				cuda::enqueue_launch(reinterpret_cast<const void*>(
+					decompress_relative_with_finer_anchors<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, RunIndexSize>), stream, config,
+					decompressed, run_data, run_start_positions, static_cast<const run_index_type*>(finer_anchors),
+					(uint64_t) fine::sub, L, (run_index_size_type) num_fine, num_element_runs, uncompressed_length);
+			}
+			else {
+				cuda::kernel::enqueue_launch(*this, stream, config,
+					decompressed, run_data, run_start_positions, static_cast<const run_index_type*>(finer_anchors),
+					(position_offset_size_type) fine::sub, (run_index_size_type) num_fine, num_element_runs, uncompressed_length);
+			}
+			return;
+		}
+	}
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, run_data, run_start_positions, position_anchors,
 		uncompressed_segment_length, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);

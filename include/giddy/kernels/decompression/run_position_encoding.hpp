@@ -43,13 +43,20 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 
 } // namespace detail
 
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
-__global__ void decompress(
+namespace detail {
+
+/// The kernel's body.  `position_period`: what RELATIVE positions are relative to — the start of the last multiple of it at or
+/// before the run; the anchoring period, except when the wrapper has put finer anchors into long segments (run_anchors.hpp: the
+/// anchors then come every `anchoring_period`, a divisor of it and at least a tile long, while the positions still count from
+/// the starts of the segments the column was compressed in).
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize>
+__device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*          __restrict__  decompressed,
 	const uint_t<UncompressedSize>*    __restrict__  run_data,
 	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
 	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
-	size_type_by_index_size<PositionOffsetSize>      anchoring_period,
+	uint64_t                                         anchoring_period,
+	uint64_t                                         position_period,
 	size_type_by_index_size<RunIndexSize>            num_anchors,
 	size_type_by_index_size<RunIndexSize>            num_element_runs,
 	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
@@ -88,6 +95,7 @@ __global__ void decompress(
 		if (segment_start >= n) { break; }
 		const uint64_t nominal_end = segment_start + segments_per_chunk * L;   // where the first segment after this chunk starts
 		const uint64_t segment_end = nominal_end < n ? nominal_end : n;
+		const uint64_t positions_origin = position_period == L ? segment_start : segment_start / position_period * position_period;
 		uint64_t first_run = position_anchors[s];
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
 		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk] : num_runs - 1;
@@ -187,7 +195,7 @@ __global__ void decompress(
 							}
 						}
 						// ... and at relative position 0 it starts the NEXT segment
-						start = segment_start + (uint64_t) segment_in_chunk * L + (positions[j] != 0 ? (uint64_t) positions[j] : L);
+						start = positions_origin + (uint64_t) segment_in_chunk * L + (positions[j] != 0 ? (uint64_t) positions[j] : position_period);
 					}
 					const uint64_t from_tile_start = start - tile_start;
 					offsets[j] = (have && from_tile_start < reach) ? (uint32_t) from_tile_start : ~0u;
@@ -265,6 +273,40 @@ __global__ void decompress(
 			first_run = next_first_run;
 		}
 	}
+}
+
+} // namespace detail
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
+	size_type_by_index_size<PositionOffsetSize>      anchoring_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>(
+		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
+}
+
+/// The same decoder over anchors finer than the segments the relative positions count from (the wrapper's launch for long segments)
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress_relative_with_finer_anchors(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  finer_anchors,
+	uint64_t                                         anchoring_period,
+	uint64_t                                         position_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, true, RunIndexSize>(
+		decompressed, run_data, run_start_positions, finer_anchors, anchoring_period, position_period, num_anchors, num_element_runs, uncompressed_length);
 }
 
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>

@@ -112,5 +112,17 @@ inline void release(stream::id_t stream, const block& b)
 	if (found != c.entries.end() && found->second.memory == b.memory) { found->second.leased = false; }
 }
 
+/// take() ... release() as a scope: what a wrapper's enqueue_launch holds while it enqueues the launches that use the block
+struct lease {
+	stream::id_t stream;
+	block taken;
+	explicit lease(stream::id_t stream_) : stream(stream_) { }
+	lease(const lease&) = delete;
+	lease& operator=(const lease&) = delete;
+	bool take(size_t bytes) { taken = stream_scratch::take(stream, bytes); return taken.memory != nullptr; }
+	void* memory() const { return taken.memory; }
+	~lease() { release(stream, taken); }
+};
+
 } // namespace stream_scratch
 } // namespace cuda

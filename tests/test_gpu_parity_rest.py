@@ -129,7 +129,8 @@ def test_rle(index_size, usize, lsize, run_index_size):
     for name, col in _run_columns():
         col = col.astype(np.uint64).astype(ud)
         n = len(col)
-        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512):   # (the short ones: several segments per wavefront trip)
+        # (the short ones: several segments per wavefront trip; 16384 and up: finer anchors first — kernels/decompression/run_anchors.hpp)
+        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20):
             f = formats.run_length_encoding(col, seglen, "u%d" % lsize, run_index_size)
             expect = oracle.run_length_encoding(f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], seglen, n)
             assert (expect == col).all()
@@ -154,7 +155,9 @@ def test_rpe(index_size, usize, psize, relative):
     for name, col in _run_columns():
         col = col.astype(np.uint64).astype(ud)
         n = len(col)
-        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512):   # (the short ones: several segments per wavefront trip)
+        # (the short ones: several segments per wavefront trip; 16384 and up: finer anchors first — kernels/decompression/run_anchors.hpp)
+        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20):
+            if relative and seglen > 1 << (8 * psize): continue   # (relative positions must fit their type)
             f = formats.run_position_encoding(col, seglen, "u%d" % psize, relative, index_size)
             expect = oracle.run_position_encoding(f["run_data"], f["run_start_positions"], f["position_anchors"], seglen, n, relative)
             assert (expect == col).all()
