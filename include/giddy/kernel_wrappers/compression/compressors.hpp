@@ -322,9 +322,8 @@ namespace run_length_encoding {
 
 /// outputs "run_data", "run_lengths" (room for "capacity" runs — optional size_t, default `length`, the worst case; runs beyond it are
 /// counted but not stored), "position_anchors", "intra_run_anchor_offsets", "num_element_runs" uint64_t* (device scalar, written: the TRUE
-/// number of runs, so a caller who guessed too low can tell); scratch "tile_totals" and "run_starts_scratch" (uint_t<IndexSize>*: one entry per
-/// natural run — `length` at worst — or "run_starts_capacity" entries when the caller states that; a column with more natural runs than that
-/// gives a wrong count)
+/// number of runs, so a caller who guessed too low can tell); scratch "tile_totals" (scratch_entries(length) entries).  ONE launch:
+/// kernels/compression/runs.hpp, one_pass::encode_run_lengths.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = IndexSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -346,37 +345,23 @@ void kernel_t<I, U, RL, RI>::enqueue_launch(stream::id_t stream, const launch_co
 	auto length    = (size_type) argument<uint_t<I>>(arguments, "length");
 	auto segment   = (size_type) argument<uint_t<I>>(arguments, "segment_length");
 	auto totals    = argument<uint64_t*>(arguments, "tile_totals");
-	auto starts    = argument<uint_t<I>*>(arguments, "run_starts_scratch");
 	auto num_runs  = argument<uint64_t*>(arguments, "num_element_runs");
 	if (length == 0) { return; }
-	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) tile_elements);
-	uint64_t* run_totals = totals + num_tiles + 2;   // the run-level pass's own scratch, behind the element-level one
+	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once; "run_starts_scratch" is not used any more
+	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
 	const uint64_t max_run_length = ~(uint64_t) 0 >> (64 - 8 * RL);   // the largest value a length field holds
-	const auto config = tile_launch(num_tiles);
-	// "capacity" (optional, size_t): pieces the output arrays have room for, and natural runs the scratch has room for — the true count
-	// is reported all the same, so that a caller who sized by an estimate can tell and come back with bigger buffers
+	// "capacity" (optional, size_t): pieces the output arrays have room for — the true count is reported all the same, so that a caller
+	// who sized by an estimate can tell and come back with bigger buffers
 	const uint64_t capacity = optional_argument<size_t>(arguments, "capacity").value_or((size_t) length);
-	const uint64_t starts_capacity = optional_argument<size_t>(arguments, "run_starts_capacity").value_or((size_t) length);
-	// element level: where the natural runs start
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_run_starts<I, U>), stream, config, totals, input, length);
-	enqueue_exclusive_offsets(stream, totals, num_tiles);   // totals[num_tiles] = the number of natural runs
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, I, false, RI>), stream, config,
-		starts, static_cast<uint_t<U>*>(nullptr), static_cast<uint_t<I>*>(nullptr), static_cast<uint_t<RI>*>(nullptr),
-		input, static_cast<const uint64_t*>(totals), segment, length, starts_capacity);
-	// run level: runs longer than a length field holds are cut into pieces
-	const uint64_t* natural_runs = totals + num_tiles;
-	const uint64_t num_run_tiles = num_tiles;   // (at most `length` natural runs; tiles beyond their number count nothing)
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_pieces<I>), stream, config, run_totals, static_cast<const uint_t<I>*>(starts),
-		natural_runs, num_run_tiles, length, max_run_length, starts_capacity);
-	enqueue_exclusive_offsets(stream, run_totals, num_run_tiles, num_runs);
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_pieces<I, U, RL, RI>), stream, config,
+	enqueue_zero(stream, totals, 2 * num_tiles * sizeof(uint64_t));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>), stream, tile_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
-		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"),
-		input, static_cast<const uint_t<I>*>(starts), natural_runs, static_cast<const uint64_t*>(run_totals), num_run_tiles, segment, length, max_run_length, starts_capacity, capacity);
+		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"), num_runs,
+		input, totals, totals + num_tiles, segment, length, max_run_length, capacity);
 }
 
 template <unsigned I, unsigned U, unsigned RL, unsigned RI>
-const device_function_t kernel_t<I, U, RL, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::write_pieces<I, U, RL, RI>); }
+const device_function_t kernel_t<I, U, RL, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>); }
 
 } // namespace run_length_encoding
 
@@ -408,18 +393,17 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch(stream::id_t stream, const launch_
 	auto segment = (size_type) argument<uint_t<I>>(arguments, "segment_length");
 	auto totals  = argument<uint64_t*>(arguments, "tile_totals");
 	if (length == 0) { return; }
-	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) tile_elements);
-	const auto config = tile_launch(num_tiles);
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::count_run_starts<I, U>), stream, config, totals, input, length);
-	enqueue_exclusive_offsets(stream, totals, num_tiles, argument<uint64_t*>(arguments, "num_element_runs"));
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>), stream, config,
-		static_cast<uint_t<I>*>(nullptr), argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
-		argument<uint_t<RI>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length,
+	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once
+	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
+	enqueue_zero(stream, totals, num_tiles * sizeof(uint64_t));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, tile_launch(num_tiles),
+		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
+		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint64_t*>(arguments, "num_element_runs"), input, totals, segment, length,
 		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));
 }
 
 template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
-const device_function_t kernel_t<I, U, P, R, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::write_run_starts<I, U, P, R, RI>); }
+const device_function_t kernel_t<I, U, P, R, RI>::get_device_function() const { return reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>); }
 
 } // namespace run_position_encoding
 

@@ -1,0 +1,116 @@
+// One pass instead of three for the compressors whose output position depends on everything before it (compression/common.hpp
+// describes the three: count per tile, offsets, write — the column read twice).  Tiles are CHAINED: a workgroup counts what its
+// tile emits, publishes that total, adds up the published totals of the tiles before it — back to the nearest tile that already
+// knows its own inclusive prefix ("decoupled look-back") — publishes its own prefix and writes.  The column is read once.
+//
+// A tile's state is one 8-byte word, {value << 2 | flag}, written and read with single relaxed agent-scope atomic accesses: it
+// validates itself, no fence is needed, and nothing else is communicated between workgroups.  The states must be ZERO when the
+// kernel starts (the wrappers enqueue a memset of the caller's `tile_totals` scratch).
+//
+// Progress: tile t waits only for tiles before it, and the hardware dispatches a launch's workgroups in index order on every XCD (a
+// kernel's grid strides keep that order) — the smallest unfinished tile's workgroup is therefore always resident and never waits
+// for anything that has not been dispatched.  (The decoders' chained tiles for long Delta segments rest on the same fact.)
+// Handing tiles out by an atomic ticket instead — so that a tile's predecessors really started before it, whichever XCD lags —
+// was measured and is slower (run-position encoding, 2^28 elements: 0.67 ms against 0.50): the ticket is one more round trip on
+// every workgroup's critical path.
+//
+// How far back: a probe reads 256 states (4 per lane of ONE wavefront) and takes about a microsecond; the nearest published prefix
+// is as many tiles back as started during one look-back, so tiles must start slower than ~256 per microsecond chip-wide for the
+// look-back to stay a probe or two long — 4096-element tiles of a 32-bit column at 4 TB/s start 250 per microsecond: the run
+// finders take tiles of 8192.
+#pragma once
+#include "giddy/kernels/compression/common.hpp"
+
+namespace cuda {
+namespace kernels {
+namespace compression {
+namespace chained {
+
+enum : uint64_t { nothing = 0, aggregate = 1, inclusive = 2, flag_mask = 3 };
+
+__device__ __forceinline__ void publish(uint64_t* states, uint64_t tile, uint64_t value, uint64_t flag)
+{
+	__hip_atomic_store(states + tile, (value << 2) | flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__device__ __forceinline__ uint64_t peek(const uint64_t* states, uint64_t tile)
+{
+	return __hip_atomic_load(states + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+/// The sum of the totals of tiles [0, tile), into every lane — called by all 64 lanes of ONE wavefront, after the tile's own
+/// total was published.
+__device__ __forceinline__ uint64_t sum_before(const uint64_t* states, uint64_t tile)
+{
+	constexpr unsigned per_lane = 4, window = 64 * per_lane;
+	const unsigned lane = wave64::lane_id();
+	uint64_t sum = 0, end = tile;   // tiles [0, end) are still to be added
+	// First wait for the tile right before — ONE word, the same for all lanes: the tiles before it were dispatched earlier and have
+	// said their part by then, nearly always.  (A thousand resident workgroups that each poll a window of sixteen cache lines of the
+	// same few kilobytes swamp the memory channel those lie in: a poll took tens of microseconds.)
+	while ((peek(states, tile - 1) & flag_mask) == nothing) { __builtin_amdgcn_s_sleep(8); }
+	while (end > 0) {
+		// entry i of the window is tile end - 1 - i; before the column's first tile: an inclusive prefix of 0
+		uint64_t words[per_lane];
+		#pragma unroll
+		for (unsigned j = 0; j < per_lane; j++) {
+			const uint64_t i = lane * per_lane + j;
+			words[j] = i < end ? peek(states, end - 1 - i) : (uint64_t) inclusive;
+		}
+		unsigned my_prefix = per_lane, my_nothing = per_lane;   // the nearest of mine that is a prefix / not there yet
+		#pragma unroll
+		for (int j = per_lane - 1; j >= 0; j--) {
+			if ((words[j] & flag_mask) == inclusive) { my_prefix = (unsigned) j; }
+			if ((words[j] & flag_mask) == nothing) { my_nothing = (unsigned) j; }
+		}
+		const uint64_t with_prefix = wave64::ballot(my_prefix < per_lane), with_nothing = wave64::ballot(my_nothing < per_lane);
+		unsigned first_prefix = window, first_nothing = window;
+		if (with_prefix != 0) { const unsigned l = (unsigned) __builtin_ctzll(with_prefix); first_prefix = l * per_lane + wave64::read_lane(my_prefix, l); }
+		if (with_nothing != 0) { const unsigned l = (unsigned) __builtin_ctzll(with_nothing); first_nothing = l * per_lane + wave64::read_lane(my_nothing, l); }
+		const bool reached_a_prefix = first_prefix < first_nothing;
+		const unsigned usable = reached_a_prefix ? first_prefix + 1 : first_nothing;   // entries [0, usable) count
+		if (usable == 0) {   // the nearest tile has not said anything yet: wait for that one word
+			while ((peek(states, end - 1) & flag_mask) == nothing) { __builtin_amdgcn_s_sleep(8); }
+			continue;
+		}
+		uint64_t mine = 0;
+		#pragma unroll
+		for (unsigned j = 0; j < per_lane; j++) { if (lane * per_lane + j < usable) { mine += words[j] >> 2; } }
+		sum += wave64::read_last_lane(wave64::inclusive_sum(mine));
+		if (reached_a_prefix) { break; }
+		end -= usable;
+	}
+	return sum;
+}
+
+/// What every chained tile does between counting and writing.  EVERY thread of the workgroup calls it (barriers inside) with the
+/// tile's total; returns the sum of the totals of the tiles before `tile`.  `slot`: a uint64_t of LDS.  The last tile stores the
+/// grand total to `grand_total` (if not null).
+__device__ __forceinline__ uint64_t exclusive_base(uint64_t* states, uint64_t tile, uint64_t num_tiles, uint64_t tile_total, uint64_t* slot, uint64_t* grand_total)
+{
+#ifdef GIDDY_CHAINED_TIMING_WITHOUT_THE_CHAIN   // (measurements only: what the kernels cost without waiting for each other — wrong output)
+	return 0;
+#endif
+	if (wave64::index_in_block() == 0) {
+		const bool first_lane = wave64::lane_id() == 0;
+		uint64_t base = 0;
+		if (tile != 0) {
+			if (first_lane) { publish(states, tile, tile_total, aggregate); }
+			base = sum_before(states, tile);
+		}
+		if (first_lane) {
+			publish(states, tile, base + tile_total, inclusive);
+			*slot = base;
+			if (tile + 1 == num_tiles && grand_total != nullptr) { *grand_total = base + tile_total; }
+		}
+	}
+	__syncthreads();
+	const uint64_t base = *slot;
+	__syncthreads();   // (the slot is free for the workgroup's next tile)
+	return base;
+}
+
+} // namespace chained
+} // namespace compression
+} // namespace kernels
+} // namespace cuda

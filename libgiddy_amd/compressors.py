@@ -31,8 +31,13 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+LAST_SCRATCH = None   # (the last scratch block handed to a kernel: development probes look at what a debug build left there)
+
+
 def _scratch(n, device):
-    return torch.empty(2 * (-(-n // TILE) + 2) + 2, dtype=torch.int64, device=device)
+    global LAST_SCRATCH
+    LAST_SCRATCH = torch.empty(2 * (-(-n // TILE) + 2) + 2, dtype=torch.int64, device=device)
+    return LAST_SCRATCH
 
 
 def _launch(key, resolve, launch, counter=None, what="elements"):
@@ -198,7 +203,6 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
     buffers = {"run_data": torch.empty(capacity, dtype=column.dtype, device=device), "run_lengths": torch.empty(capacity, dtype=_SIGNED[lsize], device=device),
                "position_anchors": torch.empty(nseg, dtype=_SIGNED[index_size], device=device), "intra_run_anchor_offsets": torch.empty(nseg, dtype=_SIGNED[lsize], device=device)}
     runs = torch.zeros(1, dtype=torch.int64, device=device)
-    starts = torch.empty(max(n, 1), dtype=_SIGNED[index_size], device=device)   # one entry per NATURAL run (pieces of long runs come later): n at worst
     if n:
         _launch("compression::run_length_encoding::kernel_t<%du, %du, %du, %du>" % (index_size, usize, lsize, index_size),
                 {"length": r.size_t(n), "segment_length": r.size_t(segment_length)},
@@ -206,7 +210,7 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
                  "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
                  "intra_run_anchor_offsets": r.pointer(buffers["intra_run_anchor_offsets"], "u%d" % (8 * lsize)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
-                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "run_starts_scratch": r.pointer(starts, "u%d" % (8 * index_size)),
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"),
                  "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity)})
     count = int(runs[0])
     if count > capacity:
