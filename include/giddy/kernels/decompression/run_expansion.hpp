@@ -59,6 +59,12 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
 #endif
+#ifndef GIDDY_RUN_ROW_PADDING
+#define GIDDY_RUN_ROW_PADDING 1   // rows of a tile begin on 512-byte boundaries of the output (expand)
+#endif
+#ifndef GIDDY_RUN_CHUNKS_BY_ADDRESS
+#define GIDDY_RUN_CHUNKS_BY_ADDRESS 1   // a workgroup's chunks share an aligned window of the output (first_chunk_by_address)
+#endif
 #ifndef GIDDY_RUN_GROUPS
 #define GIDDY_RUN_GROUPS 1   // chunks of many runs take their descriptors and values from LDS, a group of 512 runs at a time (run_groups below)
 #endif
@@ -83,8 +89,10 @@ enum : unsigned {
 __device__ __forceinline__ uint64_t first_chunk_by_address(const void* output, uint64_t chunk_bytes, unsigned working_waves, uint64_t wave, uint64_t num_waves)
 {
 	const uint64_t group_bytes = chunk_bytes * working_waves;
-	if (chunk_bytes == 0 || (group_bytes & (group_bytes - 1)) != 0 || group_bytes > (1u << 20)) { return wave; }
-	const uint64_t shift = ((reinterpret_cast<uintptr_t>(output) & (group_bytes - 1)) / chunk_bytes) % working_waves;   // (chunk_bytes is a power of two as well)
+	if (!GIDDY_RUN_CHUNKS_BY_ADDRESS || chunk_bytes == 0 || (group_bytes & (group_bytes - 1)) != 0 || group_bytes > (1u << 20)) { return wave; }
+	// (chunk_bytes and working_waves are powers of two as well: shifts and masks — two 64-bit divisions here cost the one- and two-byte
+	// columns, whose wavefronts live for a 4 KiB tile, 5 to 15 points: profiles/r03_sweep_all_instantiations.txt against its successor)
+	const uint64_t shift = ((reinterpret_cast<uintptr_t>(output) & (group_bytes - 1)) >> __builtin_ctzll(chunk_bytes)) & (working_waves - 1);
 	return wave >= shift ? wave - shift : wave + num_waves - shift;
 }
 
@@ -247,7 +255,9 @@ __device__ __forceinline__ void expand(
 	// Rows — one 16-byte store per lane, 1 KiB per wave instruction — begin on 512-byte boundaries of the OUTPUT, not of the tile: the
 	// first row is short by `pad` elements (its first lanes idle).  A tile that begins 128 or 256 bytes past such a boundary cost 7-9
 	// points with rows laid from the tile's start (every 512-byte block written by two instructions); 512 bytes on, nothing.
-	const uint32_t pad = aligned ? (uint32_t) ((reinterpret_cast<uintptr_t>(out) & 511u) / ElementSize) : 0u;
+	// (4- and 8-byte elements: for 1- and 2-byte columns — 16 and 8 outputs per lane, tiles of 4 and 8 KiB — the bookkeeping costs 1-3 points even where
+	// the pad is 0, and a displaced output was never their problem)
+	const uint32_t pad = (GIDDY_RUN_ROW_PADDING && ElementSize >= 4 && aligned) ? (uint32_t) ((reinterpret_cast<uintptr_t>(out) & 511u) / ElementSize) : 0u;
 	for (uint32_t row_start = 0; row_start < tile_len + pad; row_start += 64 * E) {
 		const uint32_t p = row_start + lane * E - pad;   // (wraps below zero for the first row's idle lanes)
 		if (p >= tile_len) { continue; }

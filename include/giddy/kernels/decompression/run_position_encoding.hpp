@@ -88,7 +88,8 @@ __device__ __forceinline__ void decompress(
 	// segment: a run's segment within the chunk is found by searching the chunk's anchors (one per lane).
 	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, PositionsAreRelative);
 	const uint64_t num_chunks = ((uint64_t) num_anchors + segments_per_chunk - 1) / segments_per_chunk;
-	const uint64_t my_first_chunk = first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves);
+	// (4- and 8-byte elements only: narrow columns lose 2-4 points to it even with the output on a page boundary — 41-repetition A/B)
+	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
 	for (uint64_t c = my_first_chunk; c < num_chunks; c += num_waves) {
 		const uint64_t s = c * segments_per_chunk;
 		const uint64_t segment_start = s * L;

@@ -83,6 +83,12 @@ __device__ __forceinline__ void transform(
 				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
 				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
 			}
+#if defined(GIDDY_STREAM_STAMP_PROBE)
+			// (experiment: when was this tile finished, and on which XCD — in place of the tile's first 8 bytes of output; tools/stream_stamp_probe.py)
+			if (threadIdx.x == 0) {
+				*reinterpret_cast<uint64_t*>(out + tile * groups_per_tile * G) = (__builtin_amdgcn_s_memrealtime() << 4) | (__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) & 15);
+			}
+#endif
 			continue;
 		}
 		#pragma unroll

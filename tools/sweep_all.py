@@ -46,7 +46,7 @@ def unsigned(t, size):
     return t.to(torch.int64) & BITS[size] if size < 8 else t
 
 
-def timeit(fn, reps=7):
+def timeit(fn, reps=int(os.environ.get("SWEEP_REPS", "7"))):
     fn(); fn()
     torch.cuda.synchronize()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
