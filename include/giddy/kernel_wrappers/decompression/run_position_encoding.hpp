@@ -69,6 +69,11 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	// segments of fine::sub (kernels/decompression/run_anchors.hpp) — L = 65 536: 65 -> 8x %, L = 2^20: 26 -> 8x % of the HBM peak.
 	namespace fine = run_expansion::fine;
 	const uint64_t n = uncompressed_length, L = uncompressed_segment_length;
+	// 32-bit positions, mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/.../run_position_encoding.hpp)
+	const bool sparse = PositionOffsetSize == 4 && UncompressedSize == 4 && num_element_runs != 0 && n / num_element_runs >= 16;
+	const void* const decoder = sparse
+		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
+		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);
 	stream_scratch::lease scratch(stream);
 	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
@@ -87,14 +92,14 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 					(uint64_t) fine::sub, L, (run_index_size_type) num_fine, num_element_runs, uncompressed_length);
 			}
 			else {
-				cuda::kernel::enqueue_launch(*this, stream, config,
+				cuda::enqueue_launch(decoder, stream, config,
 					decompressed, run_data, run_start_positions, static_cast<const run_index_type*>(finer_anchors),
 					(position_offset_size_type) fine::sub, (run_index_size_type) num_fine, num_element_runs, uncompressed_length);
 			}
 			return;
 		}
 	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+	cuda::enqueue_launch(decoder, stream, launch_config,
 		decompressed, run_data, run_start_positions, position_anchors,
 		uncompressed_segment_length, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);
 }

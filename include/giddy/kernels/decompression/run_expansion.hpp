@@ -170,10 +170,10 @@ struct value_staging {
 /// from there.  4-byte values with 1-2-byte descriptors (the value area of value_staging holds 512 of them; a group begins on a
 /// multiple of 8 runs so that its loads are 16-byte aligned, and overlaps its predecessor by `overlap` runs: a tile that is cut at a
 /// group's end hands over at most a 128-byte piece of output — 32 runs of one element at worst — before that end).
-template <unsigned ElementSize, unsigned RunDescriptorSize>
+template <unsigned ElementSize, unsigned RunDescriptorSize, bool Allowed = true>
 struct run_groups {
 	enum : unsigned {
-		enabled = GIDDY_RUN_GROUPS && ElementSize == 4 && (RunDescriptorSize == 2 || RunDescriptorSize == 4),
+		enabled = Allowed && GIDDY_RUN_GROUPS && ElementSize == 4 && (RunDescriptorSize == 2 || RunDescriptorSize == 4),
 		group_runs = 512,
 		descriptors_per_lane = 16 / RunDescriptorSize, values_per_lane = 16 / ElementSize,
 		descriptor_loads = (group_runs + 64 * descriptors_per_lane - 1) / (64 * descriptors_per_lane),   // 1 or 2 loads per lane of descriptors

@@ -49,7 +49,7 @@ namespace detail {
 /// before the run; the anchoring period, except when the wrapper has put finer anchors into long segments (run_anchors.hpp: the
 /// anchors then come every `anchoring_period`, a divisor of it and at least a tile long, while the positions still count from
 /// the starts of the segments the column was compressed in).
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize>
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups = true>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*          __restrict__  decompressed,
 	const uint_t<UncompressedSize>*    __restrict__  run_data,
@@ -69,7 +69,7 @@ __device__ __forceinline__ void decompress(
 	__shared__ alignas(16) uint_t<UncompressedSize> staged_values[max_waves_per_block][staging::allocated];
 	uint_t<UncompressedSize>* staged = staged_values[wave64::index_in_block() % max_waves_per_block];   // (idle wavefronts never use it)
 	// chunks of many runs: positions and values in GROUPS of 512 runs through LDS (run_expansion.hpp: run_groups; run_length_encoding.hpp)
-	using groups = run_groups<UncompressedSize, PositionOffsetSize>;
+	using groups = run_groups<UncompressedSize, PositionOffsetSize, WithGroups>;
 	__shared__ alignas(16) uint_t<PositionOffsetSize> group_positions_storage[groups::enabled ? max_waves_per_block : 1][groups::enabled ? groups::allocated : 1];
 	uint_t<PositionOffsetSize>* group_positions = group_positions_storage[groups::enabled ? wave64::index_in_block() % max_waves_per_block : 0];
 
@@ -290,6 +290,24 @@ __global__ void decompress(
 	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
 {
 	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>(
+		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
+}
+
+/// The same decoder without the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — 17 registers and 8 KiB of
+/// LDS lighter, which is worth 6 points to 32-bit ABSOLUTE positions at mean runs of 32 (one resident wavefront per SIMD more); the
+/// wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough runs for a group anyway.
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress_sparse_runs(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
+	size_type_by_index_size<PositionOffsetSize>      anchoring_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false>(
 		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
 }
 
