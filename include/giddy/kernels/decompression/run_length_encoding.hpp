@@ -31,9 +31,14 @@ namespace run_length_encoding {
 namespace detail {
 
 /// segments a wavefront takes per trip around its outer loop: as many short ones as fill one tile
-__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length)
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, unsigned element_size = 4)
 {
-	if (segment_length >= run_expansion::tile_length) { return 1; }
+	// (1-byte columns: a tile is 4 KiB of output, and a wavefront that lives for one of them spends its life on its first loads — several
+	// segments in a row, entered once: GIDDY_RUN_NARROW_CHUNK_BYTES of output per trip)
+	if (segment_length >= run_expansion::tile_length) {
+		const uint64_t fit = element_size == 1 ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length : 1;
+		return fit > 1 ? fit : 1;
+	}
 	// (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile — 52 -> 66 % at 3000)
 	uint64_t fit = run_expansion::tile_length / segment_length;
 	return fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST ? GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST : fit;
@@ -80,7 +85,7 @@ __global__ void decompress(
 	// Short segments are taken several at a time: the runs of consecutive segments are consecutive too — anchors are
 	// only entry points — so k segments starting at segment s decode exactly like one segment of k * L outputs
 	// entered at anchor s.  (A wavefront pays four dependent memory round trips per entry point.)
-	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L);
+	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, UncompressedSize);
 	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
 	// (4- and 8-byte elements only: narrow columns lose 2-4 points to it even with the output on a page boundary — 41-repetition A/B)
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
@@ -275,7 +280,7 @@ public:
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		grid_construction_resolution  = warp;                // one wavefront per anchored segment
 		length                        = util::div_rounding_up(util::div_rounding_up(uncompressed_length, segment_length),
-		                                    (size_t) detail::segments_per_wave_chunk(segment_length));
+		                                    (size_t) detail::segments_per_wave_chunk(segment_length, UncompressedSize));
 		serialization_option          = auto_maximized;      // (batches of short) segments at grid stride
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;

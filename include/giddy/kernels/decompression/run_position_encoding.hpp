@@ -33,9 +33,12 @@ namespace detail {
 
 /// segments a wavefront takes per trip around its outer loop: as many short ones as fill one tile — with relative
 /// positions at most 32, the reach of the search over the chunk's anchors
-__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, bool positions_are_relative)
+__host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, bool positions_are_relative, unsigned element_size = 4)
 {
-	if (segment_length >= run_expansion::tile_length) { return 1; }
+	if (segment_length >= run_expansion::tile_length) {   // (1-byte columns: run_length_encoding.hpp)
+		const uint64_t fit = element_size == 1 ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length : 1;
+		return fit > 1 ? fit : 1;
+	}
 	uint64_t fit = run_expansion::tile_length / segment_length;
 	if (fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST) { fit = GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST; }   // (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile)
 	return (positions_are_relative && fit > 32) ? 32 : fit;
@@ -86,7 +89,7 @@ __device__ __forceinline__ void decompress(
 	// Short segments are taken a tile's worth at a time — the runs of consecutive segments are consecutive, so k segments
 	// entered at the first one's anchor decode like one segment of k * L outputs.  Relative positions restart in every
 	// segment: a run's segment within the chunk is found by searching the chunk's anchors (one per lane).
-	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, PositionsAreRelative);
+	const uint64_t segments_per_chunk = detail::segments_per_wave_chunk(L, PositionsAreRelative, UncompressedSize);
 	const uint64_t num_chunks = ((uint64_t) num_anchors + segments_per_chunk - 1) / segments_per_chunk;
 	// (4- and 8-byte elements only: narrow columns lose 2-4 points to it even with the output on a page boundary — 41-repetition A/B)
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
@@ -344,7 +347,7 @@ public:
 		if (position_anchoring_period == 0) { throw std::invalid_argument("The anchoring period must be a positive number"); }
 		grid_construction_resolution  = warp;                // one wavefront per anchored segment
 		length                        = util::div_rounding_up(uncompressed_length, position_anchoring_period);
-		length = util::div_rounding_up(length, (size_t) detail::segments_per_wave_chunk(position_anchoring_period, PositionsAreRelative));   // batches of short segments
+		length = util::div_rounding_up(length, (size_t) detail::segments_per_wave_chunk(position_anchoring_period, PositionsAreRelative, UncompressedSize));   // batches of short segments
 		serialization_option          = auto_maximized;
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
