@@ -281,15 +281,13 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		// fields, four rows to a word
 		uint64_t before_rows[S::groups] = { };
 		uint32_t carry = 0;   // (wave-uniform: the last start in the rows before)
-		#pragma nounroll
+		#pragma unroll
 		for (unsigned r = 0; r < S::rows; r++) {
 			const uint32_t mine = (uint32_t) ((starts >> (r * S::E)) & S::row_mask);
 			const uint32_t my_last = mine == 0 ? 0 : wave * wave_elements + r * S::row_elements + lane * S::E + (31 - __builtin_clz(mine)) + 1;
 			const uint32_t through_me = wave64::inclusive_max(my_last);
 			const uint32_t lanes_before = wave64::shift_up_by_one(through_me, 0u);
-			const uint64_t field = (uint64_t) (lanes_before > carry ? lanes_before : carry) << (16 * (r % 4));
-			#pragma unroll
-			for (unsigned g = 0; g < S::groups; g++) { before_rows[g] |= r / 4 == g ? field : 0; }
+			before_rows[r / 4] |= (uint64_t) (lanes_before > carry ? lanes_before : carry) << (16 * (r % 4));
 			const uint32_t of_row = wave64::read_last_lane(through_me);
 			carry = of_row > carry ? of_row : carry;
 		}
@@ -340,6 +338,10 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			const uint64_t distance = pos < n ? pos - run_start : 0;
 			return (offset_type) (distance < M ? distance : distance % M);
 		};
+		// (wave-uniform: can a piece fill up among this wavefront's elements at all?  Not if even the run that reaches into it — begun at or after
+		// the last start known before the wavefront — stays shorter than M to the wavefront's end: then no row needs its offset here)
+		const uint64_t start_before_wave = waves_before != 0 ? tile_begin + waves_before - 1 : start_before_tile;
+		const bool a_piece_may_fill_up = wave_base + wave_elements - start_before_wave >= M;
 		mask_t ends = 0;
 		#pragma nounroll
 		for (unsigned r = 0; r < S::rows; r++) {
@@ -349,7 +351,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			const uint32_t first_bit_of_next_lane = __shfl_down(row_bits & 1u, 1, 64);
 			const uint32_t first_bit_of_next_row = r + 1 < S::rows ? wave64::read_first_lane((uint32_t) ((starts >> ((r + 1 < S::rows ? r + 1 : r) * S::E)) & 1u)) : (uint32_t) run_starts_after_wave;
 			const bool next_starts_after_row = (lane == 63 ? first_bit_of_next_row : first_bit_of_next_lane) != 0;
-			offset_type offset = offset_at_row(r);
+			offset_type offset = a_piece_may_fill_up ? offset_at_row(r) : 0;
 			uint32_t row_ends = 0;
 			if (pos + S::E < n && (uint64_t) offset + S::E <= (uint64_t) last_offset) {
 				// no piece can fill up among these elements and the column goes on after them: a piece ends where the next element starts a run
