@@ -167,6 +167,14 @@ int          giddy_shard(int scheme, const giddy_column_shape_t* shape, uint64_t
  * run positions — rebased to its shard where it lies, on the device; out == in is allowed */
 int          giddy_enqueue_rebase(void* hip_stream, void* out, const void* in, uint64_t count, uint32_t itemsize, uint64_t bias);
 
+/* One process, every device of a node (examples/src/sharded_decode_on_all_devices.hip): the DECODED shards — shard i: `bytes[i]` bytes at
+ * `shards[i]` on device `devices[i]`, written by work enqueued on `hip_streams[i]` — into one contiguous buffer at `destination` on
+ * `root_device`, shard after shard.  Each shard's copy is enqueued on its own stream (it crosses its xGMI link once, behind its decode);
+ * `root_stream` (a stream of the root device) then waits for all of them: work enqueued on it afterwards sees the whole column.  The
+ * counterpart of libgiddy_amd.distributed.gather_decoded (one process per GPU, RCCL) for callers who drive all devices themselves. */
+int          giddy_enqueue_gather_on_node(void* destination, int root_device, void* root_stream, const void* const* shards, const int* devices,
+                                          void* const* hip_streams, const uint64_t* bytes, size_t num_shards);
+
 /* The host-to-device pipeline: the column — every array argument of `arguments` except "decompressed" a HOST pointer (pinned, for the
  * copies to be asynchronous), "decompressed" a device pointer — is cut into `num_chunks` chunks (= shards), chunk c's slices are
  * copied to the device on hip_streams[c % num_streams], its anchors rebased there, and it is decoded by the wrapper `key` names into its

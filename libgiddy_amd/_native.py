@@ -36,7 +36,7 @@ class giddy_launch_configuration_limits(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "giddy_kernel_count", "giddy_kernel_key", "giddy_can_produce", "giddy_produce", "giddy_release",
     "giddy_resolve_launch_configuration", "giddy_enqueue_launch", "giddy_device_function",
-    "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host",
+    "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host", "giddy_enqueue_gather_on_node",
     "giddy_last_error", "giddy_version",
 )
 
@@ -79,6 +79,9 @@ def _load():
         ctypes.POINTER(giddy_argument), ctypes.c_size_t]
     lib.giddy_device_function.restype = ctypes.c_void_p
     lib.giddy_device_function.argtypes = [ctypes.c_void_p]
+    lib.giddy_enqueue_gather_on_node.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
+                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
+    lib.giddy_enqueue_gather_on_node.restype = ctypes.c_int
     lib.giddy_shard.argtypes = [ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(giddy_shard)]
     lib.giddy_enqueue_rebase.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
     lib.giddy_decode_from_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.POINTER(giddy_argument), ctypes.c_size_t,

@@ -277,6 +277,34 @@ int giddy_enqueue_rebase(void* hip_stream, void* out, const void* in, uint64_t c
 	});
 }
 
+int giddy_enqueue_gather_on_node(void* destination, int root_device, void* root_stream, const void* const* shards, const int* devices,
+	void* const* hip_streams, const uint64_t* bytes, size_t num_shards)
+{
+	return guarded([&] {
+		if (num_shards != 0 && (destination == nullptr || shards == nullptr || devices == nullptr || hip_streams == nullptr || bytes == nullptr)) { throw std::invalid_argument("null array"); }
+		int current = 0;
+		cuda::throw_if_error(hipGetDevice(&current), "hipGetDevice");
+		char* at = static_cast<char*>(destination);
+		for (size_t i = 0; i < num_shards; i++) {
+			if (bytes[i] != 0) {
+				if (shards[i] == nullptr) { throw std::invalid_argument("null shard"); }
+				cuda::throw_if_error(hipSetDevice(devices[i]), "hipSetDevice (a shard's device)");
+				const auto stream = static_cast<hipStream_t>(hip_streams[i]);
+				cuda::throw_if_error(hipMemcpyPeerAsync(at, root_device, shards[i], devices[i], bytes[i], stream), "hipMemcpyPeerAsync (a decoded shard to the root)");
+				// the root's stream waits for this copy
+				hipEvent_t copied;
+				cuda::throw_if_error(hipEventCreateWithFlags(&copied, hipEventDisableTiming), "hipEventCreateWithFlags");
+				hipError_t status = hipEventRecord(copied, stream);
+				if (status == hipSuccess) { status = hipStreamWaitEvent(static_cast<hipStream_t>(root_stream), copied, 0); }
+				(void) hipEventDestroy(copied);   // (released once the record has completed)
+				cuda::throw_if_error(status, "ordering the root's stream behind a shard's copy");
+			}
+			at += bytes[i];
+		}
+		cuda::throw_if_error(hipSetDevice(current), "hipSetDevice (back)");
+	});
+}
+
 int giddy_decode_from_host(const char* key, int scheme, const giddy_column_shape_t* shape, const giddy_argument_t* arguments, size_t num_arguments,
 	uint64_t num_chunks, void* const* hip_streams, size_t num_streams)
 {

@@ -75,6 +75,47 @@ def test_pipelined_decode_from_pinned_host_memory():
     assert bool((out == entries[keys_host.cuda().long()]).all())
 
 
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mean_run", [3, 40, 3000])
+def test_sharded_run_columns_in_long_segments(world, mean_run):
+    """Shards of run-encoded columns whose segments are long enough for the decoders' finer anchors (kernels/decompression/run_anchors.hpp):
+    a shard's run arrays begin mid-run and its anchors are rebased — the pre-pass must only ever take differences within a segment."""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    n, L = 1500000, 1 << 16
+    col = cases.runs_column(n, mean_run, np.uint32, seed=50 + mean_run)
+    for L in (1 << 16, 1 << 18):
+        f = formats.run_length_encoding(col, L, np.uint16)
+        pieces = []
+        for rank in range(world):
+            sh = sharding.run_length_encoding(f, rank, world)
+            count = sh.stop - sh.start
+            out = g.dev_empty(count, np.uint32)
+            s = sh.fields
+            if count:
+                schemes.run_length_encoding(out, g.dev(s["run_data"]), g.dev(s["run_lengths"]), g.dev(s["position_anchors"]), g.dev(s["intra_run_anchor_offsets"]),
+                                            L, s["num_segments"], s["num_element_runs"], s["length"], stream=st)
+            pieces.append(g.host(out, np.uint32, count))
+        got = np.concatenate(pieces)
+        assert (got == col).all(), ("rle", L, np.flatnonzero(got != col)[:5])
+        for relative, pd in ((True, np.uint16), (False, np.uint32)):
+            if relative and L > 1 << 16: continue
+            f = formats.run_position_encoding(col, L, pd, relative)
+            pieces = []
+            for rank in range(world):
+                sh = sharding.run_position_encoding(f, rank, world, relative=relative)
+                count = sh.stop - sh.start
+                out = g.dev_empty(count, np.uint32)
+                s = sh.fields
+                if count:
+                    schemes.run_position_encoding(out, g.dev(s["run_data"]), g.dev(s["run_start_positions"]), g.dev(s["position_anchors"]), L, s["num_anchors"],
+                                                  s["num_element_runs"], s["length"], position_size=np.dtype(pd).itemsize, relative=relative, stream=st)
+                pieces.append(g.host(out, np.uint32, count))
+            got = np.concatenate(pieces)
+            assert (got == col).all(), ("rpe", relative, L, np.flatnonzero(got != col)[:5])
+
+
 @pytest.mark.parametrize("num_chunks,depth", [(1, 1), (5, 2), (16, 3)])
 def test_pipelined_decode_of_every_sharding_scheme_from_host(num_chunks, depth):
     """libgiddy_amd.pipeline.decode_from_host: chunk = shard (anchors rebased on the host), copies and decodes overlapped
@@ -230,3 +271,30 @@ def test_device_resident_column_is_cut_without_a_host_round_trip(world):
     f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=23)
     check(sharding.delta, f, truth,
           lambda out, s: schemes.delta(out, s["compressed_input"], s["anchor_values"], s["length"], s["segment_length"], uncompressed_size=8, compressed_size=2, stream=st))
+
+
+def test_gather_on_node_through_the_c_abi():
+    """giddy_enqueue_gather_on_node with every "device" being device 0 (one GPU per box here): three decoded shards, each behind work on its own
+    stream, land shard after shard in one buffer that the root's stream sees whole."""
+    import ctypes
+    from libgiddy_amd import _native
+    lib = _native.lib
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    root = torch.cuda.Stream()
+    counts = [1000003, 0, 777]
+    shards = []
+    for k, (count, stream) in enumerate(zip(counts, streams)):
+        with torch.cuda.stream(stream):
+            shards.append(torch.arange(count, dtype=torch.int64, device="cuda") * (k + 3) + k)   # ("decoding" on the shard's stream)
+    out = torch.empty(sum(counts), dtype=torch.int64, device="cuda")
+    pointers = (ctypes.c_void_p * 3)(*[s.data_ptr() if s.numel() else None for s in shards])
+    devices = (ctypes.c_int * 3)(0, 0, 0)
+    handles = (ctypes.c_void_p * 3)(*[s.cuda_stream for s in streams])
+    sizes = (ctypes.c_uint64 * 3)(*[8 * c for c in counts])
+    status = lib.giddy_enqueue_gather_on_node(out.data_ptr(), 0, root.cuda_stream, pointers, devices, handles, sizes, 3)
+    assert status == 0, _native.last_error()
+    with torch.cuda.stream(root):
+        total = out.sum()   # (enqueued on the root's stream: behind all three copies)
+    root.synchronize()
+    expect = torch.cat(shards)
+    assert bool((out == expect).all()) and int(total) == int(expect.sum())
