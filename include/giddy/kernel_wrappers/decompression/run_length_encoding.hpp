@@ -68,6 +68,11 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	// anchor —, then the decoder on segments of fine::sub (kernels/decompression/run_anchors.hpp).
 	namespace fine = run_expansion::fine;
 	const uint64_t n = uncompressed_length, L = segment_length, runs = num_element_runs;
+	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_length_encoding.hpp)
+	const bool sparse = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16;
+	const void* const decoder = sparse
+		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
+		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>);
 	stream_scratch::lease scratch(stream);
 	// (the pass over the lengths costs 2 x their bytes: at mean runs below 8 it only pays where segments are so long that the chip is not filled)
 	const bool worth_it = runs != 0 && (n / runs >= 8 || L >= 16 * (uint64_t) fine::sub);
@@ -90,13 +95,13 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 			auto config = launch_config;
 			const size_t wavefronts_per_block = std::max<size_t>(1, std::min<size_t>(launch_config.block_dimensions.x / warp_size, run_expansion::max_waves_per_block));
 			config.grid_dimensions.x = (grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) wavefronts_per_block), 1u << 20);
-			cuda::kernel::enqueue_launch(*this, stream, config,
+			cuda::enqueue_launch(decoder, stream, config,
 				decompressed, run_data, run_lengths, static_cast<const run_index_type*>(finer_anchors), static_cast<const run_length_type*>(finer_offsets),
 				(size_type) fine::sub, (size_type) num_fine, num_element_runs, uncompressed_length);
 			return;
 		}
 	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+	cuda::enqueue_launch(decoder, stream, launch_config,
 		decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
 		segment_length, num_segments, num_element_runs, uncompressed_length);
 }

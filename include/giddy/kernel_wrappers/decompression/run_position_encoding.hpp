@@ -69,8 +69,8 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	// segments of fine::sub (kernels/decompression/run_anchors.hpp) — L = 65 536: 65 -> 8x %, L = 2^20: 26 -> 8x % of the HBM peak.
 	namespace fine = run_expansion::fine;
 	const uint64_t n = uncompressed_length, L = uncompressed_segment_length;
-	// 32-bit positions, mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/.../run_position_encoding.hpp)
-	const bool sparse = PositionOffsetSize == 4 && UncompressedSize == 4 && num_element_runs != 0 && n / num_element_runs >= 16;
+	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_position_encoding.hpp)
+	const bool sparse = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && n / num_element_runs >= 16;
 	const void* const decoder = sparse
 		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
 		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);

@@ -46,8 +46,14 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 
 } // namespace detail
 
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
-__global__ void decompress(
+namespace detail {
+
+/// The kernel's body.  `WithGroups`: with the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — without it the kernel
+/// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity
+/// Cache it is 10 points faster at mean runs of 32 (the wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough
+/// runs for a group anyway).
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups>
+__device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*             __restrict__  decompressed,
 	const uint_t<UncompressedSize>*       __restrict__  run_data,
 	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
@@ -67,7 +73,7 @@ __global__ void decompress(
 	// coalesced 16-byte-per-lane loads, the next group's requested as soon as the current one is in LDS — and the tiles take their
 	// descriptors from LDS: no memory round trip between one tile and the next (each tile used to wait for its own batch of descriptors,
 	// requested only once the tile before it had been scanned: at mean runs of 2-4 a wavefront spent three quarters of its life waiting).
-	using groups = run_groups<UncompressedSize, RunLengthSize>;
+	using groups = run_groups<UncompressedSize, RunLengthSize, WithGroups>;
 	__shared__ alignas(16) uint_t<RunLengthSize> group_lengths_storage[groups::enabled ? max_waves_per_block : 1][groups::enabled ? groups::allocated : 1];
 	uint_t<RunLengthSize>* group_lengths = group_lengths_storage[groups::enabled ? wave64::index_in_block() % max_waves_per_block : 0];
 
@@ -262,6 +268,41 @@ __global__ void decompress(
 			first_run = next_first_run; left_in_first_run = next_left_in_first_run;
 		}
 	}
+}
+
+} // namespace detail
+
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress(
+	uint_t<UncompressedSize>*             __restrict__  decompressed,
+	const uint_t<UncompressedSize>*       __restrict__  run_data,
+	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*           __restrict__  segment_position_anchors,
+	const uint_t<RunLengthSize>*          __restrict__  segment_position_anchor_intra_run_offsets,
+	size_type_by_index_size<UncompressedIndexSize>      segment_length,
+	size_type_by_index_size<UncompressedIndexSize>      num_segments,
+	size_type_by_index_size<RunIndexSize>               num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true>(decompressed, run_data, run_lengths,
+		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
+}
+
+/// ... without the groups-of-runs path (detail::decompress): the wrapper's launch for columns of mean runs of 16 or more
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress_sparse_runs(
+	uint_t<UncompressedSize>*             __restrict__  decompressed,
+	const uint_t<UncompressedSize>*       __restrict__  run_data,
+	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*           __restrict__  segment_position_anchors,
+	const uint_t<RunLengthSize>*          __restrict__  segment_position_anchor_intra_run_offsets,
+	size_type_by_index_size<UncompressedIndexSize>      segment_length,
+	size_type_by_index_size<UncompressedIndexSize>      num_segments,
+	size_type_by_index_size<RunIndexSize>               num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
+		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
 }
 
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>

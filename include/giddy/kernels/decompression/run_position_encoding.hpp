@@ -296,8 +296,9 @@ __global__ void decompress(
 		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
 }
 
-/// The same decoder without the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — 17 registers and 8 KiB of
-/// LDS lighter, which is worth 6 points to 32-bit ABSOLUTE positions at mean runs of 32 (one resident wavefront per SIMD more); the
+/// The same decoder without the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — 15-17 registers and 4-8 KiB of
+/// LDS lighter, and its waits are not the stricter of two paths': at mean runs of 32 with the compressed input NOT in the Infinity Cache it is
+/// 9-12 points faster (16-bit relative positions 62 -> 74 %, 32-bit absolute 67 -> 76 %), with the input cached 3 points slower or 6 faster; the
 /// wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough runs for a group anyway.
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
 __global__ void decompress_sparse_runs(
