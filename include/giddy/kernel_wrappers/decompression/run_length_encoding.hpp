@@ -6,6 +6,10 @@
 #include "giddy/kernels/decompression/run_anchors.hpp"
 #include "giddy/stream_scratch.hpp"
 
+#ifndef GIDDY_RUN_DENSE_KERNEL
+#define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -70,8 +74,11 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	const uint64_t n = uncompressed_length, L = segment_length, runs = num_element_runs;
 	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_length_encoding.hpp)
 	const bool sparse = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16;
+	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && !sparse
+		&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse
 		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
+		: dense ? reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
 		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>);
 	stream_scratch::lease scratch(stream);
 	// (the pass over the lengths costs 2 x their bytes: at mean runs below 8 it only pays where segments are so long that the chip is not filled)

@@ -8,6 +8,10 @@
 
 #include <cstdlib>
 
+#ifndef GIDDY_RUN_DENSE_KERNEL
+#define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -71,8 +75,12 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	const uint64_t n = uncompressed_length, L = uncompressed_segment_length;
 	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_position_encoding.hpp)
 	const bool sparse = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && n / num_element_runs >= 16;
+	// ... below 16, run arrays 16-byte aligned: the kernel with ONLY that path
+	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && !sparse
+		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse
 		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
+		: dense ? reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
 		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);
 	stream_scratch::lease scratch(stream);
 	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {

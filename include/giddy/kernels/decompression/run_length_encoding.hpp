@@ -52,7 +52,7 @@ namespace detail {
 /// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity
 /// Cache it is 10 points faster at mean runs of 32 (the wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough
 /// runs for a group anyway).
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups>
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups, bool GroupsAlways = false>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*             __restrict__  decompressed,
 	const uint_t<UncompressedSize>*       __restrict__  run_data,
@@ -113,8 +113,9 @@ __device__ __forceinline__ void decompress(
 		}
 
 		// groups of runs through LDS (see above) when the chunk has more runs than one batch and the arrays allow 16-byte loads
-		const bool use_groups = groups::enabled && run_limit - first_run > runs_per_batch
-			&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
+		// (`GroupsAlways`: the wrapper's launch for dense columns, arrays 16-byte aligned: every chunk by groups — the other path is compiled out)
+		const bool use_groups = (GroupsAlways && groups::enabled) || (groups::enabled && run_limit - first_run > runs_per_batch
+			&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16));
 		uint64_t group_base = 0, group_end = 0;            // runs [group_base, group_end) are in LDS (group_base a multiple of 8)
 		uint64_t next_group_base = ~(uint64_t) 0;          // the group that is on its way (none: ~0)
 		typename groups::in_flight coming = { };
@@ -285,6 +286,23 @@ __global__ void decompress(
 	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
 {
 	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true>(decompressed, run_data, run_lengths,
+		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
+}
+
+/// ... with ONLY the groups-of-runs path: the wrapper's launch for columns of mean runs below 16 whose run arrays are 16-byte aligned
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress_dense_runs(
+	uint_t<UncompressedSize>*             __restrict__  decompressed,
+	const uint_t<UncompressedSize>*       __restrict__  run_data,
+	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*           __restrict__  segment_position_anchors,
+	const uint_t<RunLengthSize>*          __restrict__  segment_position_anchor_intra_run_offsets,
+	size_type_by_index_size<UncompressedIndexSize>      segment_length,
+	size_type_by_index_size<UncompressedIndexSize>      num_segments,
+	size_type_by_index_size<RunIndexSize>               num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true, true>(decompressed, run_data, run_lengths,
 		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
 }
 

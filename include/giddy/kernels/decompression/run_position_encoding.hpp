@@ -52,7 +52,7 @@ namespace detail {
 /// before the run; the anchoring period, except when the wrapper has put finer anchors into long segments (run_anchors.hpp: the
 /// anchors then come every `anchoring_period`, a divisor of it and at least a tile long, while the positions still count from
 /// the starts of the segments the column was compressed in).
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups = true>
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups = true, bool GroupsAlways = false>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*          __restrict__  decompressed,
 	const uint_t<UncompressedSize>*    __restrict__  run_data,
@@ -109,8 +109,9 @@ __device__ __forceinline__ void decompress(
 
 		// groups of runs through LDS when the chunk has more runs than one batch and the arrays allow 16-byte loads
 		const uint64_t run_limit = last_candidate + 1;   // (exclusive: the runs this chunk may look at)
-		const bool use_groups = groups::enabled && last_candidate - first_run > runs_per_batch
-			&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
+		// (`GroupsAlways`: the wrapper's launch for dense columns, arrays 16-byte aligned: every chunk by groups — the other path is compiled out)
+		const bool use_groups = (GroupsAlways && groups::enabled) || (groups::enabled && last_candidate - first_run > runs_per_batch
+			&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16));
 		uint64_t group_base = 0, group_end = 0, next_group_base = ~(uint64_t) 0;   // runs [group_base, group_end) are in LDS; the group on its way
 		typename groups::in_flight coming = { };
 		auto request_group = [&](uint64_t base) { next_group_base = base; groups::request(coming, run_start_positions, run_data, base, num_runs, lane); };
@@ -293,6 +294,22 @@ __global__ void decompress(
 	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
 {
 	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>(
+		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
+}
+
+/// The same decoder with ONLY the groups-of-runs path: the wrapper's launch for columns of mean runs below 16 whose run arrays are 16-byte aligned
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void decompress_dense_runs(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
+	size_type_by_index_size<PositionOffsetSize>      anchoring_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, true, true>(
 		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
 }
 
