@@ -56,7 +56,7 @@ launch_configuration_t GIDDY_RLE_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_RLE_TEMPLATE
-void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& resolved_launch_config, arguments_type arguments) const
 {
 	auto decompressed             = argument<uncompressed_type*>(arguments, "decompressed");
 	auto run_data                 = argument<const uncompressed_type*>(arguments, "run_data");
@@ -80,6 +80,10 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
 		: dense ? reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
 		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>);
+	// (the dense kernel wants all the workgroups a CU holds: the launch parameters' cap of 6 — LDS reserved for nothing, measured on mean runs of 32 —
+	// costs it 2-3 points at mean runs of 2-4)
+	launch_configuration_t launch_config = resolved_launch_config;
+	if (dense) { launch_config.dynamic_shared_memory_size = 0; }
 	stream_scratch::lease scratch(stream);
 	// (the pass over the lengths costs 2 x their bytes: at mean runs below 8 it only pays where segments are so long that the chip is not filled)
 	const bool worth_it = runs != 0 && (n / runs >= 8 || L >= 16 * (uint64_t) fine::sub);
