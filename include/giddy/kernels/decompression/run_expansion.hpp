@@ -60,7 +60,7 @@ namespace run_expansion {
 #define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
 #endif
 #ifndef GIDDY_RUN_NARROW_CHUNK_BYTES
-#define GIDDY_RUN_NARROW_CHUNK_BYTES 4096   // output a wavefront of a 1-byte column takes per trip when segments are at least a tile long (4096: one segment of 4096)
+#define GIDDY_RUN_NARROW_CHUNK_BYTES 8192   // output a wavefront of a 1-byte column takes per trip when segments are at least a tile long (two segments of 4096: +2-5 points for RLE, 16384: mixed; not for relative run positions: -15)
 #endif
 #ifndef GIDDY_RUN_ROW_PADDING
 #define GIDDY_RUN_ROW_PADDING 1   // rows of a tile begin on 512-byte boundaries of the output (expand)
