@@ -10,6 +10,7 @@
 // Outputs are named as the decompressors' inputs are (libgiddy_amd/formats.py).  Sizes the caller cannot know in advance
 // (bytes, runs, patches) are left in a device scalar it names ("total_bytes" / "num_element_runs" / "num_patches": uint64_t*).
 #pragma once
+#include <cstdlib>
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/compression/discard_zero_bytes_variable.hpp"
 #include "giddy/kernels/compression/compressed_indices.hpp"
@@ -31,6 +32,15 @@ inline size_t scratch_entries(size_t length) { return 2 * (util::div_rounding_up
 inline size_t discard_zero_bytes_variable_scratch_entries(size_t length, size_t fields_per_container)
 {
 	return std::max(scratch_entries(length), util::div_rounding_up(length, (size_t) threads_per_block * std::max<size_t>(fields_per_container, 1)) + 3);
+}
+
+/// The chained kernels' grid: EXACTLY a workgroup per tile.  A smaller grid walking the tiles at grid stride deadlocks as soon as it is larger
+/// than what the device holds at once: a resident workgroup's second tile waits for the first tile of a workgroup that cannot start
+/// before a resident one ends (seen with 2048 workgroups for 16 384 tiles; 1024 — all resident — ran, no faster than one per tile).
+inline launch_configuration_t chained_launch(uint64_t num_tiles)
+{
+	if (num_tiles > 0x7FFFFFFFull) { throw std::invalid_argument("the column has more tiles than a grid has workgroups"); }
+	return launch_configuration_t((grid_dimension_t) (num_tiles < 1 ? 1 : num_tiles), threads_per_block);
 }
 
 inline launch_configuration_t elementwise_launch(uint64_t length)
@@ -354,7 +364,7 @@ void kernel_t<I, U, RL, RI>::enqueue_launch(stream::id_t stream, const launch_co
 	// who sized by an estimate can tell and come back with bigger buffers
 	const uint64_t capacity = optional_argument<size_t>(arguments, "capacity").value_or((size_t) length);
 	enqueue_zero(stream, totals, 2 * num_tiles * sizeof(uint64_t));
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>), stream, tile_launch(num_tiles),
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>), stream, chained_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"), num_runs,
 		input, totals, totals + num_tiles, segment, length, max_run_length, capacity);
@@ -396,7 +406,7 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch(stream::id_t stream, const launch_
 	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once
 	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
 	enqueue_zero(stream, totals, num_tiles * sizeof(uint64_t));
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, tile_launch(num_tiles),
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, chained_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint64_t*>(arguments, "num_element_runs"), input, totals, segment, length,
 		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));

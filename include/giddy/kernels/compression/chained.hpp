@@ -7,8 +7,8 @@
 // validates itself, no fence is needed, and nothing else is communicated between workgroups.  The states must be ZERO when the
 // kernel starts (the wrappers enqueue a memset of the caller's `tile_totals` scratch).
 //
-// Progress: tile t waits only for tiles before it, and the hardware dispatches a launch's workgroups in index order on every XCD (a
-// kernel's grid strides keep that order) — the smallest unfinished tile's workgroup is therefore always resident and never waits
+// Progress: tile t waits only for tiles before it, and the hardware dispatches a launch's workgroups in index order on every XCD (the
+// launch must have a workgroup per tile: a grid stride over more workgroups than are resident at once deadlocks — compressors.hpp) — the smallest unfinished tile's workgroup is therefore always resident and never waits
 // for anything that has not been dispatched.  (The decoders' chained tiles for long Delta segments rest on the same fact.)
 // Handing tiles out by an atomic ticket instead — so that a tile's predecessors really started before it, whichever XCD lags —
 // was measured and is slower (run-position encoding, 2^28 elements: 0.67 ms against 0.50): the ticket is one more round trip on
