@@ -118,7 +118,10 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 				const auto scratch = stream_scratch::take_zeroed(stream, tiles * sizeof(state_type));
 				if (!scratch) { return false; }
 				auto* states = static_cast<state_type*>(scratch.memory);
-				launch_configuration_t tiles_config((grid_dimension_t) std::min<uint64_t>(tiles, 1u << 20), Waves * warp_size);
+				// (a workgroup per tile, exactly: a grid stride over more workgroups than are resident would leave resident ones waiting for tiles of
+				// workgroups that cannot start — the kernel's bounded spin then falls back to summing the deltas itself: correct, and hopeless)
+				if (tiles > 0x7FFFFFFFull) { return false; }
+				launch_configuration_t tiles_config((grid_dimension_t) tiles, Waves * warp_size);
 				cuda::enqueue_launch(reinterpret_cast<const void*>(chained::decompress<IndexSize, UncompressedSize, CompressedSize, Waves>), stream, tiles_config,
 					decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length, states);
 				stream_scratch::release(stream, scratch);
