@@ -78,7 +78,6 @@ __global__ void __launch_bounds__(threads) sum_run_lengths(
 	const uint64_t num_blocks = (num_runs + runs_per_block - 1) / runs_per_block;
 	for (uint64_t b = blockIdx.x; b < num_blocks; b += gridDim.x) {
 		uint64_t mine = 0;
-		#pragma unroll 4
 		for (unsigned i = wave; i < loads_per_block; i += waves) {
 			const uint64_t first = b * runs_per_block + (uint64_t) i * runs_per_load + lane * per_lane;
 			sum_type sum = 0;
