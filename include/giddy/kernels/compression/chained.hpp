@@ -83,10 +83,17 @@ __device__ __forceinline__ uint64_t sum_before(const uint64_t* states, uint64_t 
 	return sum;
 }
 
+/// The tile's total said EARLY — as soon as it is known, before anything else the workgroup still has to do ahead of its look-back (the tiles
+/// after this one wait for this word).  Any thread may call it; one does the work.  Then exclusive_base(..., already_announced = true).
+__device__ __forceinline__ void announce(uint64_t* states, uint64_t tile, uint64_t tile_total)
+{
+	if (threadIdx.x == 0) { publish(states, tile, tile_total, tile == 0 ? inclusive : aggregate); }
+}
+
 /// What every chained tile does between counting and writing.  EVERY thread of the workgroup calls it (barriers inside) with the
 /// tile's total; returns the sum of the totals of the tiles before `tile`.  `slot`: a uint64_t of LDS.  The last tile stores the
 /// grand total to `grand_total` (if not null).
-__device__ __forceinline__ uint64_t exclusive_base(uint64_t* states, uint64_t tile, uint64_t num_tiles, uint64_t tile_total, uint64_t* slot, uint64_t* grand_total)
+__device__ __forceinline__ uint64_t exclusive_base(uint64_t* states, uint64_t tile, uint64_t num_tiles, uint64_t tile_total, uint64_t* slot, uint64_t* grand_total, bool already_announced = false)
 {
 #ifdef GIDDY_CHAINED_TIMING_WITHOUT_THE_CHAIN   // (measurements only: what the kernels cost without waiting for each other — wrong output)
 	return 0;
@@ -95,7 +102,7 @@ __device__ __forceinline__ uint64_t exclusive_base(uint64_t* states, uint64_t ti
 		const bool first_lane = wave64::lane_id() == 0;
 		uint64_t base = 0;
 		if (tile != 0) {
-			if (first_lane) { publish(states, tile, tile_total, aggregate); }
+			if (first_lane && !already_announced) { publish(states, tile, tile_total, aggregate); }
 			base = sum_before(states, tile);
 		}
 		if (first_lane) {

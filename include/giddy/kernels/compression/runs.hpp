@@ -34,6 +34,7 @@ namespace one_pass {
 #endif
 enum : unsigned { per_lane = GIDDY_ONE_PASS_BITS_PER_LANE, wave_elements = 64 * per_lane, tile = waves_per_block * wave_elements };
 using mask_t = std::conditional<(per_lane > 32), uint64_t, uint32_t>::type;   // a lane's bits, one per element it saw
+enum : unsigned { staged_runs = 2048 };   // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
 __device__ __forceinline__ unsigned count_bits(mask_t m) { return (unsigned) __builtin_popcountll((unsigned long long) m); }
 __device__ __forceinline__ unsigned lowest_bit(mask_t m) { return (unsigned) __builtin_ctzll((unsigned long long) m); }
 __device__ __forceinline__ unsigned highest_bit(mask_t m) { return 63u - (unsigned) __builtin_clzll((unsigned long long) m); }
@@ -170,6 +171,8 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	using S = shape<UncompressedSize>;
 	__shared__ uint32_t wave_totals[waves_per_block];
 	__shared__ uint64_t slot;
+	__shared__ T staged_values[staged_runs];
+	__shared__ uint_t<PositionSize> staged_positions[staged_runs];
 	const uint64_t n = length, L = segment_length, num_tiles = (n + tile - 1) / tile;
 	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
 	for (uint64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
@@ -188,41 +191,58 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		uint32_t wave_before = 0, tile_total = 0;
 		#pragma unroll
 		for (unsigned w = 0; w < waves_per_block; w++) { const uint32_t of_wave = wave_totals[w]; wave_before += w < wave ? of_wave : 0; tile_total += of_wave; }
+		// A tile of at most `staged_runs` runs: their values (read again, out of the L2 they just passed through) and positions go to LDS at their
+		// rank IN THE TILE now — while the tiles before this one are still being waited for — and leave as coalesced copies once the tile knows its
+		// base.  (With the re-reads after the chain a tile spent 10 of its 27 microseconds there.)
+		const bool staged = tile_total <= staged_runs;   // (block-uniform)
+		const uint64_t wave_into_segment = wave_base < n ? wave_base % L : 0, wave_segment = wave_base / L;
+		auto for_each_run_of_the_lane = [&](auto&& emit) {   // emit(rank in the tile, offset in the wavefront, value)
+			constexpr unsigned together = 4;   // (values read that many at a time: one round trip)
+			for (mask_t rest = starts; rest != 0; ) {
+				uint32_t offset[together]; T value[together]; bool have[together];
+				mask_t walk = rest;
+				#pragma unroll
+				for (unsigned i = 0; i < together; i++) {
+					have[i] = walk != 0;
+					const unsigned bit = have[i] ? lowest_bit(walk) : 0;
+					offset[i] = (bit / S::E) * S::row_elements + lane * S::E + bit % S::E;
+					value[i] = have[i] ? input[wave_base + offset[i]] : (T) 0;
+					walk &= walk - 1;
+				}
+				#pragma unroll
+				for (unsigned i = 0; i < together; i++) {
+					if (have[i]) {
+						const unsigned bit = lowest_bit(rest), r = bit / S::E;
+						emit(wave_before + offset_of_row(offsets, r) + count_bits(starts & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E))), offset[i], value[i]);
+						rest &= rest - 1;
+					}
+				}
+			}
+		};
+		auto position_of = [&](uint32_t offset) { return (uint_t<PositionSize>) (PositionsAreRelative ? into_segment(wave_into_segment, offset, L) : wave_base + offset); };
+		chained::announce(states, t, tile_total);   // (the tiles after this one wait for it: before the staging, not after)
+		if (staged) {
+			for_each_run_of_the_lane([&](uint32_t rank, uint32_t offset, T value) { staged_values[rank] = value; staged_positions[rank] = position_of(offset); });
+		}
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-		const uint64_t base = chained::exclusive_base(states, t, num_tiles, tile_total, &slot, num_element_runs) + wave_before;   // runs that start before this wavefront's elements
+		const uint64_t tile_base = chained::exclusive_base(states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // runs that start before the tile (barriers inside: the staging is complete)
+		const uint64_t base = tile_base + wave_before;   // ... before this wavefront's elements
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+		if (staged) {
+			for (uint32_t i = threadIdx.x; i < tile_total; i += threads_per_block) {
+				if (tile_base + i < capacity) { run_data[tile_base + i] = staged_values[i]; run_start_positions[tile_base + i] = staged_positions[i]; }
+			}
+		}
 		if (wave_base >= n) { continue; }
-		const uint64_t wave_into_segment = wave_base % L, wave_segment = wave_base / L;
-
-		// (the values are read again — out of the L2 / the Infinity Cache — `together` at a time: one round trip for that many runs of a lane)
-		constexpr unsigned together = 4;
-		for (mask_t rest = starts; rest != 0; ) {
-			uint32_t offset[together]; T value[together]; bool have[together];
-			mask_t walk = rest;
-			#pragma unroll
-			for (unsigned i = 0; i < together; i++) {
-				have[i] = walk != 0;
-				const unsigned bit = have[i] ? lowest_bit(walk) : 0;
-				offset[i] = (bit / S::E) * S::row_elements + lane * S::E + bit % S::E;
-				value[i] = have[i] ? input[wave_base + offset[i]] : (T) 0;
-				walk &= walk - 1;
-			}
-			#pragma unroll
-			for (unsigned i = 0; i < together; i++) {
-				if (have[i]) {
-					const unsigned bit = lowest_bit(rest), r = bit / S::E;
-					const uint64_t k = base + offset_of_row(offsets, r) + count_bits(starts & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E)));
-					if (k < capacity) {
-						run_data[k] = value[i];
-						run_start_positions[k] = (uint_t<PositionSize>) (PositionsAreRelative ? into_segment(wave_into_segment, offset[i], L) : wave_base + offset[i]);
-					}
-					rest &= rest - 1;
-				}
-			}
+		if (!staged) {
+			for_each_run_of_the_lane([&](uint32_t rank, uint32_t offset, T value) {
+				const uint64_t k = tile_base + rank;
+				if (k < capacity) { run_data[k] = value; run_start_positions[k] = position_of(offset); }
+			});
 		}
 		// the anchors of the segments that begin among this lane's elements: the run covering a segment's first element = the last that starts at or before it
 		#pragma nounroll
@@ -376,39 +396,44 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		uint32_t wave_before = 0, tile_total = 0;
 		#pragma unroll
 		for (unsigned w = 0; w < waves_per_block; w++) { const uint32_t of_wave = wave_totals[w]; wave_before += w < wave ? of_wave : 0; tile_total += of_wave; }
-		const uint64_t base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs) + wave_before;   // pieces that end before this wavefront's elements
-		if (wave_base >= n) { continue; }
-		const uint64_t wave_into_segment = wave_base % L, wave_segment = wave_base / L;
-
 		// a piece begins where a run starts or right after a piece ended; within a lane's row piece, an element's offset into its piece is its distance
 		// from the nearest such place at or before it — or, if there is none in the row piece, the row's own offset + its distance from the row's first
-		// (the values are read again — out of the L2 / the Infinity Cache — `together` at a time: one round trip for that many pieces of a lane)
-		constexpr unsigned together = 4;
-		for (mask_t rest = ends; rest != 0; ) {
-			T value[together]; bool have[together];
-			mask_t walk = rest;
-			#pragma unroll
-			for (unsigned i = 0; i < together; i++) {
-				have[i] = walk != 0;
-				const unsigned bit = have[i] ? lowest_bit(walk) : 0;
-				value[i] = have[i] ? input[wave_base + (bit / S::E) * S::row_elements + lane * S::E + bit % S::E] : (T) 0;
-				walk &= walk - 1;
-			}
-			#pragma unroll
-			for (unsigned i = 0; i < together; i++) {
-				if (have[i]) {
-					const unsigned bit = lowest_bit(rest), r = bit / S::E, e = bit % S::E;
-					const uint64_t k = base + offset_of_row(offsets, r) + count_bits(ends & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E)));
-					const uint32_t begins = (uint32_t) ((((starts >> (r * S::E)) & S::row_mask) | (((ends >> (r * S::E)) & S::row_mask) << 1)) & ((2u << e) - 1) & S::row_mask);   // piece beginnings among the row's elements 0 .. e
-					const offset_type piece_length = begins != 0 ? (offset_type) (e - (31 - __builtin_clz(begins)) + 1) : (offset_type) (offset_at_row(r) + e + 1);
-					if (k < capacity) {
-						run_data[k] = value[i];
-						run_lengths[k] = (uint_t<RunLengthSize>) piece_length;
+		auto for_each_piece_of_the_lane = [&](auto&& emit) {   // emit(rank in the tile, value, length)
+			constexpr unsigned together = 4;   // (values read that many at a time: one round trip)
+			for (mask_t rest = ends; rest != 0; ) {
+				T value[together]; bool have[together];
+				mask_t walk = rest;
+				#pragma unroll
+				for (unsigned i = 0; i < together; i++) {
+					have[i] = walk != 0;
+					const unsigned bit = have[i] ? lowest_bit(walk) : 0;
+					value[i] = have[i] ? input[wave_base + (bit / S::E) * S::row_elements + lane * S::E + bit % S::E] : (T) 0;
+					walk &= walk - 1;
+				}
+				#pragma unroll
+				for (unsigned i = 0; i < together; i++) {
+					if (have[i]) {
+						const unsigned bit = lowest_bit(rest), r = bit / S::E, e = bit % S::E;
+						const uint32_t rank = wave_before + offset_of_row(offsets, r) + count_bits(ends & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E)));
+						const uint32_t begins = (uint32_t) ((((starts >> (r * S::E)) & S::row_mask) | (((ends >> (r * S::E)) & S::row_mask) << 1)) & ((2u << e) - 1) & S::row_mask);   // piece beginnings among the row's elements 0 .. e
+						const offset_type piece_length = begins != 0 ? (offset_type) (e - (31 - __builtin_clz(begins)) + 1) : (offset_type) (offset_at_row(r) + e + 1);
+						emit(rank, value[i], (uint_t<RunLengthSize>) piece_length);
+						rest &= rest - 1;
 					}
-					rest &= rest - 1;
 				}
 			}
-		}
+		};
+		chained::announce(count_states, t, tile_total);   // (the tiles after this one wait for it: before the staging, not after)
+		// (staging the pieces in LDS ahead of the chain, as encode_run_positions does, was measured here too: no gain — 710 against 650-700 us — this
+		// kernel's second chain begins late, behind the first, and has little left to hide)
+		const uint64_t tile_base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // pieces that end before the tile
+		const uint64_t base = tile_base + wave_before;   // ... before this wavefront's elements
+		if (wave_base >= n) { continue; }
+		const uint64_t wave_into_segment = wave_base % L, wave_segment = wave_base / L;
+		for_each_piece_of_the_lane([&](uint32_t rank, T value, uint_t<RunLengthSize> piece_length) {
+			const uint64_t k = tile_base + rank;
+			if (k < capacity) { run_data[k] = value; run_lengths[k] = piece_length; }
+		});
 		#pragma nounroll
 		for (unsigned r = 0; r < S::rows; r++) {
 			const uint32_t offset_in_wave = r * S::row_elements + lane * S::E;
