@@ -198,6 +198,41 @@ def test_launches_are_graph_capturable():
     assert (g.host(out, np.uint64, n) == expect).all()
 
 
+def test_launches_with_scratch_are_graph_capturable():
+    """The wrappers that take scratch of their own — chained Delta tiles, finer anchors for long run-encoded and discard-zero-bytes segments — inside a
+    HIP graph: allocation and release become nodes of the graph (stream_scratch.hpp), two replays give the same bits."""
+    schemes, r, g = _imports()
+    from libgiddy_amd import formats
+    n = 1 << 20
+    f, truth = cases.delta_case(n, 1 << 18, np.uint64, np.uint16, seed=321)
+    col = cases.runs_column(n, 40, np.uint32, seed=322)
+    rle = formats.run_length_encoding(col, 1 << 16, np.uint16)
+    rpe = formats.run_position_encoding(col, 1 << 16, np.uint16, True)
+    d = {k: g.dev(v) for k, v in (("din", f["compressed_input"]), ("danchor", f["anchor_values"]), ("rd", rle["run_data"]), ("rl", rle["run_lengths"]),
+                                  ("ra", rle["position_anchors"]), ("ri", rle["intra_run_anchor_offsets"]), ("pd", rpe["run_data"]), ("pp", rpe["run_start_positions"]),
+                                  ("pa", rpe["position_anchors"]))}
+    out_delta, out_rle, out_rpe = g.dev_empty(n, np.uint64), g.dev_empty(n, np.uint32), g.dev_empty(n, np.uint32)
+    side = torch.cuda.Stream()
+
+    def launches(stream, configs=None):
+        c = configs or [None] * 3
+        return [schemes.delta(out_delta, d["din"], d["danchor"], n, 1 << 18, stream=stream, launch_config=c[0]),
+                schemes.run_length_encoding(out_rle, d["rd"], d["rl"], d["ra"], d["ri"], 1 << 16, rle["num_segments"], rle["num_element_runs"], n, stream=stream, launch_config=c[1]),
+                schemes.run_position_encoding(out_rpe, d["pd"], d["pp"], d["pa"], 1 << 16, rpe["num_anchors"], rpe["num_element_runs"], n, stream=stream, launch_config=c[2])]
+    with torch.cuda.stream(side):
+        configs = launches(side.cuda_stream)   # (resolve outside the capture)
+    side.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=side):
+        launches(torch.cuda.current_stream().cuda_stream, configs)
+    for _ in range(2):
+        for out in (out_delta, out_rle, out_rpe): out.fill_(0xCD)
+        graph.replay()
+        assert (g.host(out_delta, np.uint64, n) == truth).all()
+        assert (g.host(out_rle, np.uint32, n) == col).all()
+        assert (g.host(out_rpe, np.uint32, n) == col).all()
+
+
 def test_dictionary_128_kib_staged_in_lds():
     """a full 16-bit-key dictionary of 16-bit values (128 KiB) is staged in LDS by one 1024-thread workgroup per CU"""
     schemes, r, g = _imports()
