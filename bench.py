@@ -283,6 +283,8 @@ def placement_and_cache(name, work, n, device, steps):
     w.SEED_OFFSET = keep
     out["frac_one_column_repeated"] = frac(timed([work] * steps))
     out["frac_three_columns_in_turn"] = frac(timed([x for _ in range(steps) for x in [work] + others][: 3 * steps]))
+    out["note"] = ("one column repeated: its 200 MB of runs come out of the Infinity Cache; three in turn: from HBM.  Since round 3 the wrappers launch, for columns of "
+                   "mean runs >= 16, a build of the kernel that is set for the second case (DESIGN.md section 4, 'Cold inputs': round 2's kernel 0.85 / 0.62-0.74, this one 0.80-0.82 / 0.74-0.79)")
     del others
     torch.cuda.empty_cache()
     return out
