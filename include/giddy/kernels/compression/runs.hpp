@@ -245,8 +245,13 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			});
 		}
 		// the anchors of the segments that begin among this lane's elements: the run covering a segment's first element = the last that starts at or before it
+		uint64_t row_into_segment = wave_into_segment;   // (wave-uniform) of the row's first element: a row without a segment's first element is skipped whole
 		#pragma nounroll
 		for (unsigned r = 0; r < S::rows; r++) {
+			const bool row_has_a_boundary = row_into_segment == 0 || row_into_segment + S::row_elements > L;
+			row_into_segment += S::row_elements;
+			if (row_into_segment >= L) { row_into_segment = L >= S::row_elements ? row_into_segment - L : row_into_segment % L; }
+			if (!row_has_a_boundary) { continue; }
 			const uint32_t offset = r * S::row_elements + lane * S::E;
 			const uint64_t here = into_segment(wave_into_segment, offset, L);
 			for (uint64_t e = here == 0 ? 0 : L - here; e < S::E && wave_base + offset + e < n; e += L) {
@@ -288,10 +293,16 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	__shared__ uint32_t wave_totals[waves_per_block];
 	__shared__ uint32_t last_starts[waves_per_block];
 	__shared__ uint64_t slot, inherited;
+	__shared__ T staged_values[staged_runs];
+	__shared__ uint_t<RunLengthSize> staged_lengths[staged_runs];
 	const uint64_t n = length, L = segment_length, M = max_run_length, num_tiles = (n + tile - 1) / tile;
 	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
 	for (uint64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
 		const uint64_t tile_begin = t * tile, wave_base = tile_begin + (uint64_t) wave * wave_elements;
+#ifdef GIDDY_CHAINED_STAMPS   // (measurements: started / scanned for starts / knows what reaches in / counted / knows its base / done — behind the states)
+		uint64_t* const stamps = count_states + num_tiles + 6 * t;
+		if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 		T last_value = 0;
 		const mask_t starts = wave_base < n ? run_starts_of_wavefront<T>(input, wave_base, n, lane, last_value) : 0;
 		// does a run start right after the wavefront's last element?
@@ -311,6 +322,9 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			const uint32_t of_row = wave64::read_last_lane(through_me);
 			carry = of_row > carry ? of_row : carry;
 		}
+#ifdef GIDDY_CHAINED_STAMPS
+		if (threadIdx.x == 0) { stamps[1] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 		__syncthreads();   // (the tables may still be read for the tile before)
 		if (lane == 0) { last_starts[wave] = carry; }
 		__syncthreads();
@@ -346,6 +360,9 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		}
 		__syncthreads();
 		const uint64_t start_before_tile = inherited;
+#ifdef GIDDY_CHAINED_STAMPS
+		if (threadIdx.x == 0) { stamps[2] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 
 		// `ends`: bit r * E + e: a piece ends with that element.  offset_at_row(r): the distance of the lane's first element of row r from its
 		// piece's first (where no run starts there), modulo M — from where the run that covers it started
@@ -398,44 +415,69 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		for (unsigned w = 0; w < waves_per_block; w++) { const uint32_t of_wave = wave_totals[w]; wave_before += w < wave ? of_wave : 0; tile_total += of_wave; }
 		// a piece begins where a run starts or right after a piece ended; within a lane's row piece, an element's offset into its piece is its distance
 		// from the nearest such place at or before it — or, if there is none in the row piece, the row's own offset + its distance from the row's first
-		auto for_each_piece_of_the_lane = [&](auto&& emit) {   // emit(rank in the tile, value, length)
+		// The pieces go out through LDS in WINDOWS of `staged_runs` ranks: the lane's pieces whose rank in the tile falls into the window are put there —
+		// value (read again, out of the L2 it just passed through) and length — and the window leaves as coalesced copies.  The FIRST window is
+		// filled before the look-back (while the tiles before this one are waited for: the write phase was 11 of a tile's 36 microseconds), the others —
+		// tiles of more than `staged_runs` pieces: mean runs below 8 — after it.  One copy of the loop in the code: the window is its only variable.
+		auto stage_window = [&](uint32_t window_first) {
 			constexpr unsigned together = 4;   // (values read that many at a time: one round trip)
-			for (mask_t rest = ends; rest != 0; ) {
-				T value[together]; bool have[together];
+			for (mask_t rest = wave_base < n ? ends : 0; rest != 0; ) {
+				T value[together]; uint32_t rank[together]; bool have[together];
 				mask_t walk = rest;
 				#pragma unroll
 				for (unsigned i = 0; i < together; i++) {
-					have[i] = walk != 0;
-					const unsigned bit = have[i] ? lowest_bit(walk) : 0;
-					value[i] = have[i] ? input[wave_base + (bit / S::E) * S::row_elements + lane * S::E + bit % S::E] : (T) 0;
+					const unsigned bit = walk != 0 ? lowest_bit(walk) : 0, r = bit / S::E;
+					rank[i] = wave_before + offset_of_row(offsets, r) + count_bits(ends & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E))) - window_first;   // (wraps below the window)
+					have[i] = walk != 0 && rank[i] < staged_runs;
+					value[i] = have[i] ? input[wave_base + r * S::row_elements + lane * S::E + bit % S::E] : (T) 0;
 					walk &= walk - 1;
 				}
 				#pragma unroll
 				for (unsigned i = 0; i < together; i++) {
-					if (have[i]) {
+					if (rest != 0) {
 						const unsigned bit = lowest_bit(rest), r = bit / S::E, e = bit % S::E;
-						const uint32_t rank = wave_before + offset_of_row(offsets, r) + count_bits(ends & (((mask_t) 1 << bit) - 1) & (S::row_mask << (r * S::E)));
-						const uint32_t begins = (uint32_t) ((((starts >> (r * S::E)) & S::row_mask) | (((ends >> (r * S::E)) & S::row_mask) << 1)) & ((2u << e) - 1) & S::row_mask);   // piece beginnings among the row's elements 0 .. e
-						const offset_type piece_length = begins != 0 ? (offset_type) (e - (31 - __builtin_clz(begins)) + 1) : (offset_type) (offset_at_row(r) + e + 1);
-						emit(rank, value[i], (uint_t<RunLengthSize>) piece_length);
+						if (have[i]) {
+							const uint32_t begins = (uint32_t) ((((starts >> (r * S::E)) & S::row_mask) | (((ends >> (r * S::E)) & S::row_mask) << 1)) & ((2u << e) - 1) & S::row_mask);   // piece beginnings among the row's elements 0 .. e
+							const offset_type piece_length = begins != 0 ? (offset_type) (e - (31 - __builtin_clz(begins)) + 1) : (offset_type) (offset_at_row(r) + e + 1);
+							staged_values[rank[i]] = value[i];
+							staged_lengths[rank[i]] = (uint_t<RunLengthSize>) piece_length;
+						}
 						rest &= rest - 1;
 					}
 				}
 			}
 		};
-		chained::announce(count_states, t, tile_total);   // (the tiles after this one wait for it: before the staging, not after)
-		// (staging the pieces in LDS ahead of the chain, as encode_run_positions does, was measured here too: no gain — 710 against 650-700 us — this
-		// kernel's second chain begins late, behind the first, and has little left to hide)
-		const uint64_t tile_base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // pieces that end before the tile
+#ifdef GIDDY_CHAINED_STAMPS
+		if (threadIdx.x == 0) { stamps[3] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+		chained::announce(count_states, t, tile_total);   // (the tiles after this one wait for it: said as soon as it is known)
+		uint64_t tile_base = 0;   // pieces that end before the tile: known after the first window has been staged
+		for (uint32_t window_first = 0; window_first == 0 || window_first < tile_total; window_first += staged_runs) {
+			if (window_first != 0) { __syncthreads(); }   // (the window before has been copied out)
+			stage_window(window_first);
+			if (window_first == 0) {
+				tile_base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // (barriers inside: the window is complete)
+#ifdef GIDDY_CHAINED_STAMPS
+				if (threadIdx.x == 0) { stamps[4] = __builtin_amdgcn_s_memrealtime(); }
+#endif
+			}
+			else { __syncthreads(); }
+			const uint32_t in_window = tile_total - window_first < staged_runs ? tile_total - window_first : staged_runs;
+			for (uint32_t i = threadIdx.x; i < in_window; i += threads_per_block) {
+				const uint64_t k = tile_base + window_first + i;
+				if (k < capacity) { run_data[k] = staged_values[i]; run_lengths[k] = staged_lengths[i]; }
+			}
+		}
 		const uint64_t base = tile_base + wave_before;   // ... before this wavefront's elements
 		if (wave_base >= n) { continue; }
 		const uint64_t wave_into_segment = wave_base % L, wave_segment = wave_base / L;
-		for_each_piece_of_the_lane([&](uint32_t rank, T value, uint_t<RunLengthSize> piece_length) {
-			const uint64_t k = tile_base + rank;
-			if (k < capacity) { run_data[k] = value; run_lengths[k] = piece_length; }
-		});
+		uint64_t row_into_segment = wave_into_segment;   // (wave-uniform) of the row's first element: a row without a segment's first element is skipped whole
 		#pragma nounroll
 		for (unsigned r = 0; r < S::rows; r++) {
+			const bool row_has_a_boundary = row_into_segment == 0 || row_into_segment + S::row_elements > L;
+			row_into_segment += S::row_elements;
+			if (row_into_segment >= L) { row_into_segment = L >= S::row_elements ? row_into_segment - L : row_into_segment % L; }
+			if (!row_has_a_boundary) { continue; }
 			const uint32_t offset_in_wave = r * S::row_elements + lane * S::E;
 			const uint64_t here = into_segment(wave_into_segment, offset_in_wave, L);
 			const offset_type at_row = offset_at_row(r);
@@ -449,6 +491,9 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 				intra_run_anchor_offsets[segment] = (uint_t<RunLengthSize>) into_piece;
 			}
 		}
+#ifdef GIDDY_CHAINED_STAMPS
+		if (threadIdx.x == 0) { stamps[5] = __builtin_amdgcn_s_memrealtime(); }
+#endif
 	}
 }
 
