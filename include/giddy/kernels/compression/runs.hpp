@@ -29,6 +29,9 @@ namespace one_pass {
 #ifndef GIDDY_ONE_PASS_WAVES_PER_SIMD
 #define GIDDY_ONE_PASS_WAVES_PER_SIMD 4   // (6 and 8 — the compiler then spills — measured slower: profiles/r03_compress_bench.txt)
 #endif
+#ifndef GIDDY_ONE_PASS_TOGETHER
+#define GIDDY_ONE_PASS_TOGETHER 4   // run values a lane reads again at a time
+#endif
 #ifndef GIDDY_ONE_PASS_BITS_PER_LANE
 #define GIDDY_ONE_PASS_BITS_PER_LANE 64
 #endif
@@ -197,7 +200,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		const bool staged = tile_total <= staged_runs;   // (block-uniform)
 		const uint64_t wave_into_segment = wave_base < n ? wave_base % L : 0, wave_segment = wave_base / L;
 		auto for_each_run_of_the_lane = [&](auto&& emit) {   // emit(rank in the tile, offset in the wavefront, value)
-			constexpr unsigned together = 4;   // (values read that many at a time: one round trip)
+			constexpr unsigned together = GIDDY_ONE_PASS_TOGETHER;   // (values read that many at a time: one round trip)
 			for (mask_t rest = starts; rest != 0; ) {
 				uint32_t offset[together]; T value[together]; bool have[together];
 				mask_t walk = rest;
@@ -420,7 +423,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		// filled before the look-back (while the tiles before this one are waited for: the write phase was 11 of a tile's 36 microseconds), the others —
 		// tiles of more than `staged_runs` pieces: mean runs below 8 — after it.  One copy of the loop in the code: the window is its only variable.
 		auto stage_window = [&](uint32_t window_first) {
-			constexpr unsigned together = 4;   // (values read that many at a time: one round trip)
+			constexpr unsigned together = GIDDY_ONE_PASS_TOGETHER;   // (values read that many at a time: one round trip)
 			for (mask_t rest = wave_base < n ? ends : 0; rest != 0; ) {
 				T value[together]; uint32_t rank[together]; bool have[together];
 				mask_t walk = rest;
