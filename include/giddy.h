@@ -29,7 +29,9 @@
  * Conventions: every function returns GIDDY_SUCCESS (0) or a negative giddy_status_t and never
  * throws; giddy_last_error() returns the failed call's message (thread-local).  Pointers passed in
  * arguments are DEVICE pointers owned by the caller; launches are asynchronous on the given HIP
- * stream of the current device and the library never synchronises.
+ * stream of the current device and the library never synchronises: no entry point that enqueues work waits for the
+ * device (the first long column on a stream may ALLOCATE scratch — hipMalloc, which does not wait either; giddy_reserve_scratch
+ * moves that out of the launch path).  giddy_trim() is the one call that waits, and says so.
  */
 #ifndef GIDDY_H_
 #define GIDDY_H_
@@ -122,6 +124,35 @@ int          giddy_enqueue_launch(
                  const giddy_argument_t* arguments, size_t num_arguments);
 
 const void*  giddy_device_function(const giddy_kernel_t* kernel);
+
+/* The kernels the wrapper may launch WITH THE CALLER'S CONFIGURATION: index 0 is giddy_device_function() — the kernel of the reference's
+ * signature —, the others the builds its typed launch picks among (run decoders: columns of short / long runs).  The attributes
+ * giddy_resolve_launch_configuration resolves against are limits that hold for all of them (cuda::device_function_t::attributes()). */
+int          giddy_device_function_count(const giddy_kernel_t* kernel);
+const void*  giddy_device_function_alternate(const giddy_kernel_t* kernel, int index);
+
+/* ---- prepared launches ---------------------------------------------------------------------
+ * A loop that launches the same wrapper many times (a column's chunks): the argument map is built ONCE, entries are rewritten in place,
+ * and a launch copies nothing.  Semantics of each launch are giddy_enqueue_launch's with the handle's current arguments
+ * (cuda::kernel_t::enqueue_launch_with, include/giddy/kernel_wrapper.hpp — this library's addition to the reference's interface). */
+typedef struct giddy_prepared giddy_prepared_t;
+int          giddy_prepare(const giddy_kernel_t* kernel, const giddy_argument_t* arguments, size_t num_arguments, giddy_prepared_t** prepared);
+int          giddy_prepared_update(giddy_prepared_t* prepared, const giddy_argument_t* arguments, size_t num_arguments); /* replaces (or adds) the entries named */
+int          giddy_enqueue_prepared(const giddy_prepared_t* prepared, void* hip_stream, const giddy_launch_configuration_t* launch_configuration);
+void         giddy_release_prepared(giddy_prepared_t* prepared);
+
+/* ---- scratch memory --------------------------------------------------------------------------
+ * Wrappers whose fast paths need memory of their own between their launches (chained tiles of long Delta segments, finer anchors of long
+ * run-encoded / discard-zero-bytes segments, the pipeline's slices) lease it from a process-wide pool (include/giddy/stream_scratch.hpp):
+ * a block goes back to the stream (and host thread) that used it last, which may have it again at once, in stream order.  Without
+ * scratch the wrappers take their scratch-free paths — slower for such columns, never wrong. */
+int          giddy_reserve_scratch(void* hip_stream, uint64_t bytes);   /* a block of >= bytes is there for this stream afterwards: launches on it do not allocate */
+int          giddy_release_scratch(void* hip_stream);                   /* call before destroying a stream: its blocks return to the pool behind an event */
+uint64_t     giddy_trim(void);                                          /* frees every block not in use; WAITS for the work that used them; bytes freed */
+uint64_t     giddy_scratch_held_bytes(void);
+/* What a stream that is being captured into a HIP graph gets: 0 (default) nothing — scratch-free paths inside graphs;
+ * 1 hipMallocAsync / hipFreeAsync, which become nodes of the graph. */
+int          giddy_set_capture_scratch_policy(int policy);
 
 /* ---- a column cut into shards (GPUs of a node) or chunks (a host-to-device pipeline) ---------------------
  * The reference has no multi-GPU or transfer layer (README.md:15-24 states the purpose — move compressed, expand on the

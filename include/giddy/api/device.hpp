@@ -58,6 +58,27 @@ struct scoped_override_t {
 } // namespace current
 } // namespace device
 
+/// Enqueue `kernel_function` with `count` parameter values behind `parameters`.
+/// The runtime reads one pointer per KERNEL parameter.  A caller may pass fewer values than the kernel has
+/// parameters — the reference's own mode-B example gives frame_of_reference::decompress five of its six
+/// (examples/src/modes_of_use/instantiation_of_wrapper.cu:31-38) — so spare slots follow the given ones, each
+/// pointing at zeroes: the missing trailing parameters read as 0 / nullptr instead of whatever lies past the array.
+inline void enqueue_launch_of_packed(const void* kernel_function, stream::id_t stream_id,
+	const launch_configuration_t& launch_config, void* const* parameters, size_t count)
+{
+	if (launch_config.grid_dimensions.volume() == 0) { return; } // empty input: nothing to do
+	enum : size_t { most = 24, spare_slots = 8 };
+	if (count > most) { throw std::invalid_argument("more launch parameters than any kernel of this library takes"); }
+	alignas(16) static const unsigned char zeroes[64] = { };
+	void* argument_pointers[most + spare_slots];
+	for (size_t i = 0; i < count; i++) { argument_pointers[i] = parameters[i]; }
+	for (size_t i = count; i < count + spare_slots; i++) { argument_pointers[i] = const_cast<void*>(static_cast<const void*>(zeroes)); }
+	throw_if_error(
+		hipLaunchKernel(kernel_function, launch_config.grid_dimensions, launch_config.block_dimensions,
+			argument_pointers, launch_config.dynamic_shared_memory_size, stream_id),
+		"hipLaunchKernel");
+}
+
 /// Enqueue `kernel_function` on `stream_id` with the resolved configuration; arguments are passed
 /// by value exactly as given (callers cast to the kernel's parameter types first).
 template <typename KernelFunction, typename... KernelParameters>
@@ -65,20 +86,8 @@ inline void enqueue_launch(
 	KernelFunction kernel_function, stream::id_t stream_id,
 	const launch_configuration_t& launch_config, KernelParameters... parameters)
 {
-	if (launch_config.grid_dimensions.volume() == 0) { return; } // empty input: nothing to do
-	// The runtime reads one pointer per KERNEL parameter.  A caller may pass fewer values than the kernel has
-	// parameters — the reference's own mode-B example gives frame_of_reference::decompress five of its six
-	// (examples/src/modes_of_use/instantiation_of_wrapper.cu:31-38) — so spare slots follow the given ones, each
-	// pointing at zeroes: the missing trailing parameters read as 0 / nullptr instead of whatever lies past the array.
-	alignas(16) static const unsigned char zeroes[64] = { };
-	void* const spare = const_cast<void*>(static_cast<const void*>(zeroes));
-	void* argument_pointers[] = { const_cast<void*>(reinterpret_cast<const void*>(&parameters))...,
-		spare, spare, spare, spare, spare, spare, spare, spare };
-	throw_if_error(
-		hipLaunchKernel(reinterpret_cast<const void*>(kernel_function),
-			launch_config.grid_dimensions, launch_config.block_dimensions,
-			argument_pointers, launch_config.dynamic_shared_memory_size, stream_id),
-		"hipLaunchKernel");
+	void* pointers[] = { nullptr, const_cast<void*>(reinterpret_cast<const void*>(&parameters))... };
+	enqueue_launch_of_packed(reinterpret_cast<const void*>(kernel_function), stream_id, launch_config, pointers + 1, sizeof...(KernelParameters));
 }
 
 template <typename KernelFunction, typename... KernelParameters>

@@ -14,6 +14,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <initializer_list>
 #include <stdexcept>
 #include <string>
 
@@ -141,21 +142,49 @@ inline shared_memory_size_t maximum_dynamic_shared_memory_per_block(
 
 } // namespace device_function
 
+/// A kernel as the wrappers name it: the entry point of the reference's signature, plus — for a wrapper that launches one of several
+/// builds of its decoder with the configuration the caller resolved (the run decoders: columns of short or of long runs) — those builds
+/// as ALTERNATES.  attributes() then states the limits that hold for every one of them (the fewest threads per block any of them
+/// accepts, the most static LDS and registers any of them uses), so that "attributes -> resolve_launch_configuration -> enqueue_launch"
+/// (examples/src/modes_of_use/factory_provided_type_erased_wrapper.cu:20-31) resolves a configuration that whichever build runs can take.
 class device_function_t {
 public:
+	enum : unsigned { max_alternates = 6 };
 	device_function_t(const void* ptr) : ptr_(ptr) { }
+	device_function_t(const void* ptr, std::initializer_list<const void*> alternates) : ptr_(ptr)
+	{
+		for (const void* a : alternates) { if (num_alternates_ < max_alternates && a != nullptr && a != ptr) { alternates_[num_alternates_++] = a; } }
+	}
 	template <typename... Params>
 	device_function_t(void (*kernel)(Params...)) : ptr_(reinterpret_cast<const void*>(kernel)) { }
 	const void* ptr() const { return ptr_; }
 	operator const void*() const { return ptr_; }
-	device_function::attributes_t attributes() const
+	unsigned num_alternates() const { return num_alternates_; }
+	const void* alternate(unsigned i) const { return i < num_alternates_ ? alternates_[i] : nullptr; }
+	static device_function::attributes_t attributes_of(const void* kernel)
 	{
 		hipFuncAttributes a;
-		throw_if_error(hipFuncGetAttributes(&a, ptr_), "hipFuncGetAttributes");
+		throw_if_error(hipFuncGetAttributes(&a, kernel), "hipFuncGetAttributes");
 		return a;
+	}
+	device_function::attributes_t attributes() const
+	{
+		device_function::attributes_t all = attributes_of(ptr_);
+		for (unsigned i = 0; i < num_alternates_; i++) {
+			const device_function::attributes_t a = attributes_of(alternates_[i]);
+			all.maxThreadsPerBlock = a.maxThreadsPerBlock < all.maxThreadsPerBlock ? a.maxThreadsPerBlock : all.maxThreadsPerBlock;
+			all.maxDynamicSharedSizeBytes = a.maxDynamicSharedSizeBytes < all.maxDynamicSharedSizeBytes ? a.maxDynamicSharedSizeBytes : all.maxDynamicSharedSizeBytes;
+			all.sharedSizeBytes = a.sharedSizeBytes > all.sharedSizeBytes ? a.sharedSizeBytes : all.sharedSizeBytes;
+			all.numRegs = a.numRegs > all.numRegs ? a.numRegs : all.numRegs;
+			all.localSizeBytes = a.localSizeBytes > all.localSizeBytes ? a.localSizeBytes : all.localSizeBytes;
+			all.constSizeBytes = a.constSizeBytes > all.constSizeBytes ? a.constSizeBytes : all.constSizeBytes;
+		}
+		return all;
 	}
 private:
 	const void* ptr_;
+	const void* alternates_[max_alternates] = { };
+	unsigned num_alternates_ = 0;
 };
 
 } // namespace cuda

@@ -3,8 +3,13 @@
 // Interface follows the reference's src/cuda/kernel_wrapper.cuh:20-33 (limits), :53-128 (kernel_t),
 // :135-208 (free functions), :214-240 (macro).
 #pragma once
+#include <cstring>
+#include <stdexcept>
 #include <string>
+#include <tuple>
+#include <type_traits>
 #include <unordered_map>
+#include <utility>
 
 #include "giddy/api/device.hpp"
 #include "giddy/api/types.hpp"
@@ -28,6 +33,13 @@ struct kernel_t {
 	virtual void enqueue_launch(
 		stream::id_t stream_id, const launch_configuration_t& launch_config, arguments_type args) const = 0;
 
+	/// enqueue_launch() for a caller that keeps its map (a loop over a column's chunks updating a few entries in place): nothing is copied
+	virtual void enqueue_launch_with(
+		stream::id_t stream_id, const launch_configuration_t& launch_config, const arguments_type& args) const
+	{
+		enqueue_launch(stream_id, launch_config, args);
+	}
+
 	virtual launch_configuration_t resolve_launch_configuration(
 		device::properties_t device_properties, arguments_type extra_arguments,
 		launch_configuration_limits_t limits = { nullopt, nullopt, nullopt }) const
@@ -39,18 +51,96 @@ struct kernel_t {
 		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
 		arguments_type extra_arguments, launch_configuration_limits_t limits = { nullopt, nullopt, nullopt }) const = 0;
 
+	/// The kernel of the reference's signature — what a direct launch gets — carrying, for wrappers that pick among several builds of
+	/// their decoder, those builds as alternates: attributes() states limits that hold for every kernel the resolved configuration may
+	/// be launched with (api/types.hpp).
 	virtual const device_function_t get_device_function() const = 0;
+
+	/// cuda::kernel::enqueue_launch(kernel, [stream,] config, parameters...) for a caller that holds only this base type: parameters[i]
+	/// points at the i-th value as passed, sizes[i] is its size.  A wrapper with a typed launch() of its own (below) re-types them and
+	/// goes through it — so that this call, the typed free function and the argument map all reach the same kernels; this default is the
+	/// reference's behaviour (src/cuda/kernel_wrapper.cuh:141-152): get_device_function() launched with the values as given, missing
+	/// trailing parameters reading as zero.
+	virtual void enqueue_launch_of_packed_parameters(stream::id_t stream_id, const launch_configuration_t& launch_config,
+		void* const* parameters, const size_t* sizes, size_t count) const
+	{
+		(void) sizes;
+		cuda::enqueue_launch_of_packed(get_device_function().ptr(), stream_id, launch_config, parameters, count);
+	}
 
 	virtual ~kernel_t() { }
 };
 
 namespace kernel {
 
+namespace detail {
+
+/// Kernel::launch(stream, config, parameters...) is callable: the wrapper has ONE typed entry point that picks among its kernels
+template <typename Kernel, typename = void, typename... Parameters>
+struct has_typed_launch_impl : std::false_type { };
+template <typename Kernel, typename... Parameters>
+struct has_typed_launch_impl<Kernel,
+	decltype(Kernel::launch(std::declval<stream::id_t>(), std::declval<const launch_configuration_t&>(), std::declval<Parameters>()...), void()),
+	Parameters...> : std::true_type { };
+template <typename Kernel, typename... Parameters>
+using has_typed_launch = has_typed_launch_impl<Kernel, void, Parameters...>;
+
+template <typename... Typed, size_t... Is>
+inline void launch_packed_impl(void (*launch)(stream::id_t, const launch_configuration_t&, Typed...), stream::id_t stream_id,
+	const launch_configuration_t& launch_config, void* const* parameters, const size_t* sizes, size_t count, std::index_sequence<Is...>)
+{
+	if (count > sizeof...(Typed)) { throw std::invalid_argument("more launch parameters than the kernel takes"); }
+	std::tuple<std::decay_t<Typed>...> values { };   // (missing trailing parameters: zero / nullptr, as a direct launch's spare slots)
+	const bool sizes_agree = (... && (Is >= count || sizes[Is] == sizeof(std::decay_t<Typed>)));
+	if (!sizes_agree) { throw std::invalid_argument("a launch parameter does not have the size of the kernel's parameter in its place"); }
+	(..., (Is < count ? (void) std::memcpy(&std::get<Is>(values), parameters[Is], sizeof(std::decay_t<Typed>)) : (void) 0));
+	launch(stream_id, launch_config, std::get<Is>(values)...);
+}
+
+/// the values behind `parameters`, re-typed as launch()'s own parameter types
+template <typename... Typed>
+inline void launch_packed(void (*launch)(stream::id_t, const launch_configuration_t&, Typed...), stream::id_t stream_id,
+	const launch_configuration_t& launch_config, void* const* parameters, const size_t* sizes, size_t count)
+{
+	launch_packed_impl(launch, stream_id, launch_config, parameters, sizes, count, std::index_sequence_for<Typed...>());
+}
+
+} // namespace detail
+
+// A caller that holds the base type (src/cuda/kernel_wrapper.cuh:135-152) ...
 template <typename... KernelParameters>
 inline void enqueue_launch(const kernel_t& kernel, stream::id_t stream_id,
 	const launch_configuration_t& launch_config, KernelParameters... parameters)
 {
-	cuda::enqueue_launch(kernel.get_device_function().ptr(), stream_id, launch_config, parameters...);
+	void* pointers[] = { nullptr, const_cast<void*>(reinterpret_cast<const void*>(&parameters))... };
+	const size_t sizes[] = { 0, sizeof(KernelParameters)... };
+	kernel.enqueue_launch_of_packed_parameters(stream_id, launch_config, pointers + 1, sizes + 1, sizeof...(KernelParameters));
+}
+
+// ... and one that instantiated the wrapper (the reference's "mode of use B", examples/src/modes_of_use/instantiation_of_wrapper.cu:22-38)
+// — the better match for it: the wrapper's typed launch(), the very function its type-erased enqueue_launch() calls.
+template <typename Kernel, typename... KernelParameters,
+	typename = std::enable_if_t<std::is_base_of<kernel_t, Kernel>::value && detail::has_typed_launch<Kernel, KernelParameters...>::value>>
+inline void enqueue_launch(const Kernel&, stream::id_t stream_id,
+	const launch_configuration_t& launch_config, KernelParameters... parameters)
+{
+	Kernel::launch(stream_id, launch_config, parameters...);
+}
+
+template <typename Kernel, typename... KernelParameters,
+	typename = std::enable_if_t<std::is_base_of<kernel_t, Kernel>::value && detail::has_typed_launch<Kernel, KernelParameters...>::value>>
+inline void enqueue_launch(const Kernel&, const launch_configuration_t& launch_config, KernelParameters... parameters)
+{
+	Kernel::launch(stream::default_stream_id, launch_config, parameters...);
+}
+
+template <typename Kernel, typename... KernelParameters,
+	typename = std::enable_if_t<std::is_base_of<kernel_t, Kernel>::value && detail::has_typed_launch<Kernel, KernelParameters...>::value>>
+inline void enqueue_launch(const Kernel&, device::id_t device_id, stream::id_t stream_id,
+	const launch_configuration_t& launch_config, KernelParameters... parameters)
+{
+	device::current::scoped_override_t<> using_device(device_id);
+	Kernel::launch(stream_id, launch_config, parameters...);
 }
 
 template <typename... KernelParameters>

@@ -65,7 +65,7 @@ launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::p
 }
 
 template <unsigned I, unsigned U, unsigned C>
-void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U, C>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
@@ -97,7 +97,7 @@ launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::p
 }
 
 template <unsigned I, unsigned U, unsigned C>
-void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U, C>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		argument<uint_t<C>*>(arguments, "compressed_input"), argument<const uint_t<U>*>(arguments, "input"),
@@ -130,7 +130,7 @@ launch_configuration_t kernel_t<I, U, CS>::resolve_launch_configuration(device::
 }
 
 template <unsigned I, unsigned U, unsigned CS>
-void kernel_t<I, U, CS>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+void kernel_t<I, U, CS>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t&, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	auto input      = argument<const uint_t<U>*>(arguments, "input");
@@ -176,7 +176,7 @@ launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::p
 }
 
 template <unsigned I, typename U, typename C>
-void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U, C>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
@@ -207,7 +207,7 @@ launch_configuration_t kernel_t<I, U, C>::resolve_launch_configuration(device::p
 }
 
 template <unsigned I, typename U, typename C>
-void kernel_t<I, U, C>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U, C>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
@@ -240,7 +240,7 @@ launch_configuration_t kernel_t<I, U, D>::resolve_launch_configuration(device::p
 }
 
 template <unsigned I, unsigned U, unsigned D>
-void kernel_t<I, U, D>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U, D>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		argument<uint_t<D>*>(arguments, "compressed_input"), argument<const uint_t<U>*>(arguments, "input"),
@@ -274,7 +274,7 @@ launch_configuration_t kernel_t<I, U>::resolve_launch_configuration(device::prop
 }
 
 template <unsigned I, unsigned U>
-void kernel_t<I, U>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, U>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	auto states   = argument<unsigned*>(arguments, "slot_states");
 	auto values   = argument<uint64_t*>(arguments, "slot_values");
@@ -313,7 +313,7 @@ launch_configuration_t kernel_t<I, A>::resolve_launch_configuration(device::prop
 }
 
 template <unsigned I, unsigned A>
-void kernel_t<I, A>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<I, A>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	auto num_bitmaps = argument<native_word_t>(arguments, "num_bitmaps");
 	if (num_bitmaps > 256) { throw std::invalid_argument("At most 256 incidence bitmaps are supported"); }
@@ -348,7 +348,7 @@ launch_configuration_t kernel_t<I, U, RL, RI>::resolve_launch_configuration(devi
 }
 
 template <unsigned I, unsigned U, unsigned RL, unsigned RI>
-void kernel_t<I, U, RL, RI>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+void kernel_t<I, U, RL, RI>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t&, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	auto input     = argument<const uint_t<U>*>(arguments, "input");
@@ -395,7 +395,7 @@ launch_configuration_t kernel_t<I, U, P, R, RI>::resolve_launch_configuration(de
 }
 
 template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>
-void kernel_t<I, U, P, R, RI>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+void kernel_t<I, U, P, R, RI>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t&, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	auto input   = argument<const uint_t<U>*>(arguments, "input");
@@ -440,7 +440,7 @@ launch_configuration_t kernel_t<O, I, R>::resolve_launch_configuration(device::p
 }
 
 template <unsigned O, unsigned I, unsigned R>
-void kernel_t<O, I, R>::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<O, I, R>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	auto positions = argument<const uint_t<O>*>(arguments, "positions");
@@ -483,7 +483,7 @@ launch_configuration_t kernel_t<I, E>::resolve_launch_configuration(device::prop
 }
 
 template <unsigned I, unsigned E>
-void kernel_t<I, E>::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+void kernel_t<I, E>::enqueue_launch_with(stream::id_t stream, const launch_configuration_t&, const arguments_type& arguments) const
 {
 	using size_type = size_type_by_index_size<I>;
 	auto decoded = argument<const uint_t<E>*>(arguments, "decoded");

@@ -70,7 +70,7 @@ launch_configuration_t GIDDY_CIP_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_CIP_TEMPLATE
-void GIDDY_CIP_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t&, arguments_type arguments) const
+void GIDDY_CIP_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t&, const arguments_type& arguments) const
 {
 	auto positions         = argument<uint_t<OutputIndexSize>*>(arguments, "positions");
 	auto input_data_length = argument<input_size_type>(arguments, "input_data_length");

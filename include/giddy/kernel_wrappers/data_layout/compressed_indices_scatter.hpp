@@ -46,7 +46,7 @@ launch_configuration_t GIDDY_CIS_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_CIS_TEMPLATE
-void GIDDY_CIS_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void GIDDY_CIS_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	if (launch_config.grid_dimensions == 0) { return; }   // no patches, nothing to do
 

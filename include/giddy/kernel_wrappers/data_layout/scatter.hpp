@@ -44,10 +44,10 @@ launch_configuration_t kernel_t<OutputIndexSize, ElementSize, InputIndexSize, Se
 }
 
 template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize, serialization_factor_t SerializationFactor>
-void kernel_t<OutputIndexSize, ElementSize, InputIndexSize, SerializationFactor>::enqueue_launch(
+void kernel_t<OutputIndexSize, ElementSize, InputIndexSize, SerializationFactor>::enqueue_launch_with(
 	stream::id_t                   stream,
 	const launch_configuration_t&  launch_config,
-	arguments_type                 arguments) const
+	const arguments_type&                 arguments) const
 {
 	auto target       = argument<element_type*>(arguments, "target");
 	auto data         = argument<const element_type*>(arguments, "data");

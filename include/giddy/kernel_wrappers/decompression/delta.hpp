@@ -42,12 +42,28 @@ inline const device::properties_t& current_device_properties()
 	return cached;
 }
 
+/// switches read from the environment ONCE per process (not on the launch path)
+struct environment {
+	bool chained_from_given = false;
+	uint64_t chained_from = 0;
+	static const environment& get()
+	{
+		static const environment e = [] {
+			environment read;
+			if (const char* v = std::getenv("GIDDY_DELTA_CHAINED_FROM")) { read.chained_from_given = true; read.chained_from = (uint64_t) std::strtoull(v, nullptr, 10); }
+			return read;
+		}();
+		return e;
+	}
+};
+
 } // namespace detail
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using compressed_type   = uint_t<CompressedSize>;
 	using uncompressed_type = uint_t<UncompressedSize>;
@@ -64,6 +80,20 @@ public:
 			device_properties, kernel_function_attributes, length, segment_length, limits.dynamic_shared_memory);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
+
+	/// THE decode of a Delta column on `stream`: what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, ...) with
+	/// typed parameters and delta::launch<...>() all run.  Picks among the kernels of kernels/decompression/delta.hpp by the column's shape:
+	/// `decompress` (a wavefront or a workgroup per segment, launched with `launch_config`), chained tiles for long segments (a
+	/// configuration of their own; per-tile states in stream_scratch), or — given `part_anchors_scratch` — long segments in parts.
+	static void launch(
+		stream::id_t                   stream,
+		const launch_configuration_t&  launch_config,
+		uncompressed_type*             decompressed,
+		const compressed_type*         compressed_input,
+		const uncompressed_type*       anchor_values,
+		size_type                      length,
+		size_type                      segment_length,
+		uncompressed_type*             part_anchors_scratch = nullptr);
 };
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
@@ -79,16 +109,34 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::re
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
-void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
+void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 	stream::id_t                   stream,
 	const launch_configuration_t&  launch_config,
-	arguments_type                 arguments) const
+	const arguments_type&                 arguments) const
 {
 	auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
 	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
 	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
 	auto length            = argument<uint_t<IndexSize>>(arguments, "length");
 	auto segment_length    = argument<uint_t<IndexSize>>(arguments, "segment_length");
+	// (an extension: ceil(length / 4096) + 1024 entries, for columns of very long segments where no stream scratch is to be had)
+	auto part_anchors      = optional_argument<uncompressed_type*>(arguments, "part_anchors_scratch");
+	launch(stream, launch_config, decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length,
+		part_anchors ? part_anchors.value() : nullptr);
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
+	stream::id_t                   stream,
+	const launch_configuration_t&  launch_config,
+	uncompressed_type*             decompressed,
+	const compressed_type*         compressed_input,
+	const uncompressed_type*       anchor_values,
+	size_type                      length,
+	size_type                      segment_length,
+	uncompressed_type*             part_anchors)
+{
+	const void* const base_kernel = reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize>);
 
 	// Long segments — more rows than a wavefront takes by itself — as tiles of their own, chained by a decoupled look-back through
 	// per-tile states in stream-ordered scratch memory (kernels/decompression/delta.hpp, namespace chained): every tile a workgroup
@@ -97,10 +145,8 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 	{
 		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
 		const uint64_t n = length, L = segment_length;
-		static const uint64_t chained_from = [] {
-			const char* v = std::getenv("GIDDY_DELTA_CHAINED_FROM");
-			return v ? (uint64_t) std::strtoull(v, nullptr, 10) : (uint64_t) detail::chained_from_rows * traits::row;
-		}();
+		const auto& environment = detail::environment::get();
+		const uint64_t chained_from = environment.chained_from_given ? environment.chained_from : (uint64_t) detail::chained_from_rows * traits::row;
 		const bool aligned = memory_access::is_aligned(decompressed, 16) && memory_access::is_aligned(compressed_input, 16);
 		const unsigned waves = chained::waves_per_tile_for<UncompressedSize, CompressedSize>(n, L);
 		// ... where they beat the block path (a workgroup of up to 16 wavefronts per segment): always when there are fewer segments than compute units,
@@ -109,22 +155,21 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 		// segments (<4,4,1>: 88 % against 77-83 %)
 		const uint64_t num_segments = L == 0 ? 0 : util::div_rounding_up(n, L);
 		const bool preferred = num_segments < (uint64_t) detail::current_device_properties().multiProcessorCount || (UncompressedSize == 8 && CompressedSize <= 2);
-		const bool forced = std::getenv("GIDDY_DELTA_CHAINED_FROM") != nullptr;
+		const bool forced = environment.chained_from_given;
 		if (chained_from != 0 && n > 0 && L >= chained_from && (preferred || forced) && L > (uint64_t) detail::rows_per_chunk * traits::row && aligned && waves != 0) {
 			using state_type = chained::tile_state<UncompressedSize>;
 			auto launch_tiles = [&](auto waves_constant) {
 				constexpr unsigned Waves = decltype(waves_constant)::value;
 				const uint64_t tiles = util::div_rounding_up(n, chained::tile_elements<UncompressedSize, CompressedSize, Waves>());
-				const auto scratch = stream_scratch::take_zeroed(stream, tiles * sizeof(state_type));
-				if (!scratch) { return false; }
-				auto* states = static_cast<state_type*>(scratch.memory);
 				// (a workgroup per tile, exactly: a grid stride over more workgroups than are resident would leave resident ones waiting for tiles of
 				// workgroups that cannot start — the kernel's bounded spin then falls back to summing the deltas itself: correct, and hopeless)
 				if (tiles > 0x7FFFFFFFull) { return false; }
+				stream_scratch::lease scratch(stream);
+				if (!scratch.take_zeroed(tiles * sizeof(state_type))) { return false; }
+				auto* states = static_cast<state_type*>(scratch.memory());
 				launch_configuration_t tiles_config((grid_dimension_t) tiles, Waves * warp_size);
 				cuda::enqueue_launch(reinterpret_cast<const void*>(chained::decompress<IndexSize, UncompressedSize, CompressedSize, Waves>), stream, tiles_config,
-					decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length, states);
-				stream_scratch::release(stream, scratch);
+					decompressed, compressed_input, anchor_values, length, segment_length, states);
 				return true;
 			};
 			if (waves == 16 ? launch_tiles(std::integral_constant<unsigned, 16>()) : waves == 8 ? launch_tiles(std::integral_constant<unsigned, 8>())
@@ -137,8 +182,7 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 	// elements are decoded in PARTS: the parts' delta sums (the two-phase scan's first kernel), the value before each part, and
 	// then this decoder with the parts as its segments — when there are fewer such segments than compute units.  The deltas are read twice:
 	// 55 % of the peak instead of 8 % for segments of 2^24 elements, 33 % instead of 0.5 % for one segment of 2^28.
-	auto part_anchors = optional_argument<uncompressed_type*>(arguments, "part_anchors_scratch");
-	if (part_anchors && segment_length >= detail::long_segment_from && length > 0) {
+	if (part_anchors != nullptr && segment_length >= detail::long_segment_from && length > 0) {
 		uint64_t part = detail::longest_part;
 		while (part >= detail::shortest_part && segment_length % part != 0) { part >>= 1; }
 		const auto& properties = detail::current_device_properties();
@@ -153,24 +197,35 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
 			auto reduction_config = cuda::kernels::resolve_launch_configuration(reduction);
 			if (reduction_config.grid_dimensions.x > num_parts) { reduction_config.grid_dimensions.x = (grid_dimension_t) num_parts; }
 			cuda::enqueue_launch(reinterpret_cast<const void*>(scan::reduce_segments::reduce_segments<IndexSize, plus, compressed_type, widen>), stream, reduction_config,
-				part_anchors.value(), compressed_input, (size_type) length, (size_type) part);
+				part_anchors, compressed_input, length, (size_type) part);
 			cuda::enqueue_launch(reinterpret_cast<const void*>(detail::anchors_of_parts<UncompressedSize>), stream,
 				launch_configuration_t((grid_dimension_t) util::div_rounding_up(num_segments, (uint64_t) 64), 64),
-				part_anchors.value(), anchor_values, num_segments, (uint64_t) segment_length / part, num_parts);
-			launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize> by_parts(properties, get_device_function().attributes(), length, part);
-			cuda::kernel::enqueue_launch(*this, stream, cuda::kernels::resolve_launch_configuration(by_parts),
-				decompressed, compressed_input, static_cast<const uncompressed_type*>(part_anchors.value()), (size_type) length, (size_type) part);
+				part_anchors, anchor_values, num_segments, (uint64_t) segment_length / part, num_parts);
+			launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize> by_parts(properties, device_function_t(base_kernel).attributes(), length, part);
+			cuda::enqueue_launch(base_kernel, stream, cuda::kernels::resolve_launch_configuration(by_parts),
+				decompressed, compressed_input, static_cast<const uncompressed_type*>(part_anchors), length, (size_type) part);
 			return;
 		}
 	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
-		decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length);
+	cuda::enqueue_launch(base_kernel, stream, launch_config, decompressed, compressed_input, anchor_values, length, segment_length);
 }
 
+/// The kernel of the reference's signature (what a direct launch — the reference's third mode of use — runs: right for every segment
+/// length, a workgroup per long segment).  Chained tiles are launched with a configuration of their own, so the attributes of this
+/// kernel are the ones the caller's configuration is resolved against.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
 const device_function_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::get_device_function() const
 {
 	return reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize>);
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uint_t<UncompressedSize>* decompressed, const uint_t<CompressedSize>* compressed_input, const uint_t<UncompressedSize>* anchor_values,
+	size_type_by_index_size<IndexSize> length, size_type_by_index_size<IndexSize> segment_length, uint_t<UncompressedSize>* part_anchors_scratch = nullptr)
+{
+	kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(stream, launch_config, decompressed, compressed_input, anchor_values, length, segment_length, part_anchors_scratch);
 }
 
 } // namespace delta

@@ -47,7 +47,7 @@ launch_configuration_t GIDDY_DZBF_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_DZBF_TEMPLATE
-void GIDDY_DZBF_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void GIDDY_DZBF_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
 	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");

@@ -16,13 +16,6 @@ namespace decompression {
 namespace discard_zero_bytes {
 namespace variable_width {
 
-/// scratch for the finer anchors of long segments: taken on a stream, given back (stream-ordered) when the launches using it are enqueued
-struct fine_anchors_scratch {
-	stream::id_t stream; stream_scratch::block block; void* memory = nullptr;
-	explicit fine_anchors_scratch(stream::id_t stream_) : stream(stream_) { }
-	bool take(size_t bytes) { block = stream_scratch::take(stream, bytes); memory = block.memory; return memory != nullptr; }
-	~fine_anchors_scratch() { stream_scratch::release(stream, block); }
-};
 /// GIDDY_DZBV_FINE_ANCHORS=0 in the environment: long segments are decoded as they are (measurements)
 inline int fine_from_environment()
 {
@@ -34,6 +27,7 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesCo
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using element_size_t     = unsigned;
 	using uncompressed_type  = uint_t<UncompressedSize>;
@@ -48,6 +42,15 @@ public:
 			device_properties, kernel_function_attributes, length_in_elements, segment_length);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
+
+	/// THE decode of a variable-width discard-zero-bytes column on `stream`: what the type-erased enqueue_launch(),
+	/// cuda::kernel::enqueue_launch(kernel, ...) with typed parameters and variable_width::launch<...>() all run.  `decompress` is the one
+	/// decoder; this function gives long segments finer anchors first (scratch from stream_scratch — none to be had: the segments as
+	/// they are) and cuts a long column into consecutive launches of about GIDDY_DZBV_LAUNCH_BYTES of output.
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		uncompressed_type* decompressed, const unsigned char* compressed_data, const element_sizes_container_size_type* packed_element_sizes,
+		const uint_t<IndexSize>* position_anchors, size_type segment_length, size_type length,
+		element_size_t min_represented_element_size, unsigned bits_per_element_size);
 };
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
@@ -61,8 +64,8 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, ElementSizesContain
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_launch(
-	stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_launch_with(
+	stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using index_type = uint_t<IndexSize>;
 	auto decompressed                 = argument<uncompressed_type*>(arguments, "decompressed");
@@ -73,7 +76,18 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	auto length                       = argument<index_type>(arguments, "length");
 	auto min_represented_element_size = argument<element_size_t>(arguments, "min_represented_element_size");
 	auto bits_per_element_size        = argument<unsigned>(arguments, "bits_per_element_size");
+	launch(stream, launch_config, decompressed, compressed_data, packed_element_sizes, position_anchors,
+		(size_type) segment_length, (size_type) length, min_represented_element_size, bits_per_element_size);
+}
 
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uncompressed_type* decompressed, const unsigned char* compressed_data, const element_sizes_container_size_type* packed_element_sizes,
+	const uint_t<IndexSize>* position_anchors, size_type segment_length, size_type length,
+	element_size_t min_represented_element_size, unsigned bits_per_element_size)
+{
+	using index_type = uint_t<IndexSize>;
+	const void* const base_kernel = reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, ElementSizesContainerSize>);
 	// A long launch loses its compact write front: workgroup b runs on XCD b % 8, the XCDs work through their eighths of the grid at
 	// paces that differ by some 10 %, and once their fronts are tens of MiB apart the memory system serves them at 65-70 % of the HBM peak
 	// instead of 81 % (profiles/r03_dzbv_xcd_drift_2p30.txt).  A launch boundary brings the fronts together again, so a long column
@@ -81,7 +95,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	// segments, whole size containers and 16-byte aligned outputs per piece; the anchors are absolute, so compressed_data stays put.
 	// Long segments: anchors for every 1024 elements from the size fields (kernels/..., namespace fine), in stream-ordered scratch memory,
 	// then the decoder on segments of 1024 — where the wide path applies (1-, 2-, 4-bit fields; 4- and 8-byte elements).
-	fine_anchors_scratch fine_anchors(stream);
+	stream_scratch::lease fine_anchors(stream);
 	{
 		constexpr unsigned E = 16 / UncompressedSize;
 		const uint64_t n = length, L = segment_length;
@@ -90,7 +104,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 			&& (reinterpret_cast<uintptr_t>(decompressed) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_element_sizes) & 15) == 0 && fine_from_environment() != 0) {
 			const uint64_t subs = util::div_rounding_up(n, (uint64_t) fine::sub);
 			if (fine_anchors.take((subs + 1) * (sizeof(uint64_t) + sizeof(index_type)))) {
-				auto* totals = static_cast<uint64_t*>(fine_anchors.memory);
+				auto* totals = static_cast<uint64_t*>(fine_anchors.memory());
 				auto* anchors = reinterpret_cast<index_type*>(totals + subs + 1);
 				const auto* size_words = reinterpret_cast<const uint32_t*>(packed_element_sizes);
 				const unsigned min_size = min_represented_element_size;
@@ -128,7 +142,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 	for (size_t first = 0; first < std::max<size_t>(segments, 1); first += std::max<size_t>(segments_per_piece, 1)) {
 		const size_t begin = first * L, end = std::min(n, (first + segments_per_piece) * L);
 		auto piece_config = launch_config;
-		const bool with_fine_anchors = fine_anchors.memory != nullptr;   // (then the caller's grid was resolved for other segments than the launch's)
+		const bool with_fine_anchors = fine_anchors.memory() != nullptr;   // (then the caller's grid was resolved for other segments than the launch's)
 		if (begin != 0 || end != n || with_fine_anchors) {
 			// a piece's own covering grid, within the grid the caller resolved for the column (which may be capped, or limited by the caller)
 			const size_t chunks = util::div_rounding_up(util::div_rounding_up(end - begin, L), (size_t) detail::segments_per_wave_chunk(L, 64 * (16 / UncompressedSize)));
@@ -136,7 +150,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_l
 			const size_t covering = util::div_rounding_up(chunks, std::min<size_t>(wavefronts_per_block, detail::max_waves_per_block));
 			piece_config.grid_dimensions.x = (grid_dimension_t) std::max<size_t>(1, std::min<size_t>(covering, with_fine_anchors ? (size_t) 1 << 18 : (size_t) launch_config.grid_dimensions.x));
 		}
-		cuda::kernel::enqueue_launch(*this, stream, piece_config,
+		cuda::enqueue_launch(base_kernel, stream, piece_config,
 			decompressed + begin, compressed_data, packed_element_sizes + begin / per, position_anchors + first,
 			(size_type) segment_length, (size_type) (end - begin), min_represented_element_size, bits_per_element_size);
 		if (segments_per_piece == 0) { break; }
@@ -147,6 +161,17 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesCo
 const device_function_t kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::get_device_function() const
 {
 	return reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, ElementSizesContainerSize>);
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize = sizeof(native_word_t)>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uint_t<UncompressedSize>* decompressed, const unsigned char* compressed_data, const uint_t<ElementSizesContainerSize>* packed_element_sizes,
+	const uint_t<IndexSize>* position_anchors, size_type_by_index_size<IndexSize> segment_length, size_type_by_index_size<IndexSize> length,
+	unsigned min_represented_element_size, unsigned bits_per_element_size)
+{
+	kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(stream, launch_config, decompressed, compressed_data, packed_element_sizes,
+		position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
 }
 
 } // namespace variable_width

@@ -43,7 +43,7 @@ launch_configuration_t GIDDY_IB_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_IB_TEMPLATE
-void GIDDY_IB_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void GIDDY_IB_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	auto decompressed       = argument<uncompressed_type*>(arguments, "decompressed");
 	auto incidence_bitmaps  = argument<const bit_container_t*>(arguments, "incidence_bitmaps");

@@ -51,10 +51,10 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::re
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
-void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch(
+void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 	stream::id_t                   stream,
 	const launch_configuration_t&  launch_config,
-	arguments_type                 arguments) const
+	const arguments_type&                 arguments) const
 {
 	auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
 	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");

@@ -59,10 +59,10 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
-void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch(
+void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_with(
 	stream::id_t                   stream,
 	const launch_configuration_t&  launch_config,
-	arguments_type                 arguments) const
+	const arguments_type&                 arguments) const
 {
 	auto maybe_cache = optional_argument<bool>(arguments, "cache_dictionary_in_shared_mem");
 

@@ -51,10 +51,10 @@ launch_configuration_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelF
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
-void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_launch(
+void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_launch_with(
 	stream::id_t                   stream,
 	const launch_configuration_t&  launch_config,
-	arguments_type                 arguments) const
+	const arguments_type&                 arguments) const
 {
 	auto decompressed               = argument<Uncompressed*>(arguments, "decompressed");
 	auto compressed_input           = argument<const Compressed*>(arguments, "compressed_input");

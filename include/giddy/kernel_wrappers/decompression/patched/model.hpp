@@ -46,8 +46,8 @@ launch_configuration_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::re
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
-void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch(
-	stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch_with(
+	stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
 	auto length             = argument<index_type>(arguments, "length");

@@ -19,6 +19,7 @@ template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned Ru
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using run_index_type                = uint_t<RunIndexSize>;
 	using uncompressed_index_type       = uint_t<UncompressedIndexSize>;
@@ -40,6 +41,20 @@ public:
 			device_properties, kernel_function_attributes, uncompressed_length, segment_length);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
+
+	/// THE decode of a run-length encoded column on `stream`: what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, ...)
+	/// with typed parameters and run_length_encoding::launch<...>() all run.  Picks the build of the decoder by the column's mean run
+	/// (`decompress_sparse_runs` / `decompress_dense_runs` / `decompress`: kernels/decompression/run_length_encoding.hpp) and, for long
+	/// segments, finds finer anchors first (run_anchors.hpp; scratch from stream_scratch — none to be had: the segments as they are).
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		uncompressed_type* decompressed, const uncompressed_type* run_data, const run_length_type* run_lengths,
+		const run_index_type* position_anchors, const run_length_type* intra_run_anchor_offsets,
+		size_type segment_length, size_type num_segments, run_index_size_type num_element_runs, size_type uncompressed_length);
+
+	/// the three builds of the decoder, any of which launch() may run with the caller's configuration
+	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
+	static const void* sparse_kernel() { return reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
+	static const void* dense_kernel()  { return reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
 };
 
 #define GIDDY_RLE_TEMPLATE template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize>
@@ -56,7 +71,7 @@ launch_configuration_t GIDDY_RLE_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_RLE_TEMPLATE
-void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& resolved_launch_config, arguments_type arguments) const
+void GIDDY_RLE_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& resolved_launch_config, const arguments_type& arguments) const
 {
 	auto decompressed             = argument<uncompressed_type*>(arguments, "decompressed");
 	auto run_data                 = argument<const uncompressed_type*>(arguments, "run_data");
@@ -67,7 +82,16 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	auto num_segments             = argument<size_type>(arguments, "num_segments");
 	auto num_element_runs         = argument<run_index_size_type>(arguments, "num_element_runs");
 	auto uncompressed_length      = argument<size_type>(arguments, "length");
+	launch(stream, resolved_launch_config, decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
+		segment_length, num_segments, num_element_runs, uncompressed_length);
+}
 
+GIDDY_RLE_TEMPLATE
+void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t& resolved_launch_config,
+	uncompressed_type* decompressed, const uncompressed_type* run_data, const run_length_type* run_lengths,
+	const run_index_type* position_anchors, const run_length_type* intra_run_anchor_offsets,
+	size_type segment_length, size_type num_segments, run_index_size_type num_element_runs, size_type uncompressed_length)
+{
 	// Long segments: entry points for every `fine::sub`-th output first — sums of every 64 run lengths, scanned, searched per finer
 	// anchor —, then the decoder on segments of fine::sub (kernels/decompression/run_anchors.hpp).
 	namespace fine = run_expansion::fine;
@@ -76,10 +100,7 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	const bool sparse = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16;
 	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && !sparse
 		&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
-	const void* const decoder = sparse
-		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
-		: dense ? reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>)
-		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>);
+	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	// (the dense kernel wants all the workgroups a CU holds: the launch parameters' cap of 6 — LDS reserved for nothing, measured on mean runs of 32 —
 	// costs it 2-3 points at mean runs of 2-4)
 	launch_configuration_t launch_config = resolved_launch_config;
@@ -117,10 +138,24 @@ void GIDDY_RLE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 		segment_length, num_segments, num_element_runs, uncompressed_length);
 }
 
+/// The kernel of the reference's signature (both paths, decided per chunk: what a direct launch runs), with the two specialised builds
+/// as alternates: its attributes() are limits all three accept, so a configuration resolved against them fits whichever launch() picks.
 GIDDY_RLE_TEMPLATE
 const device_function_t GIDDY_RLE_KERNEL::get_device_function() const
 {
-	return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>);
+	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel() });
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uint_t<UncompressedSize>* decompressed, const uint_t<UncompressedSize>* run_data, const uint_t<RunLengthSize>* run_lengths,
+	const uint_t<RunIndexSize>* position_anchors, const uint_t<RunLengthSize>* intra_run_anchor_offsets,
+	size_type_by_index_size<UncompressedIndexSize> segment_length, size_type_by_index_size<UncompressedIndexSize> num_segments,
+	size_type_by_index_size<RunIndexSize> num_element_runs, size_type_by_index_size<UncompressedIndexSize> uncompressed_length)
+{
+	kernel_t<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>::launch(stream, launch_config, decompressed, run_data, run_lengths,
+		position_anchors, intra_run_anchor_offsets, segment_length, num_segments, num_element_runs, uncompressed_length);
 }
 
 #undef GIDDY_RLE_TEMPLATE

@@ -21,6 +21,7 @@ template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned Po
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using run_index_type                = uint_t<RunIndexSize>;
 	using uncompressed_index_type       = uint_t<UncompressedIndexSize>;
@@ -41,6 +42,24 @@ public:
 			device_properties, kernel_function_attributes, uncompressed_length, uncompressed_segment_length);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
+
+	/// THE decode of a run-position encoded column on `stream`: what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, ...)
+	/// with typed parameters and run_position_encoding::launch<...>() all run.  Picks the build of the decoder by the column's mean run and,
+	/// for long segments, finds finer anchors first (run_anchors.hpp; scratch from stream_scratch — none to be had: the segments as they are).
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		uncompressed_type* decompressed, const uncompressed_type* run_data, const position_offset_type* run_start_positions,
+		const run_index_type* position_anchors, position_offset_size_type uncompressed_segment_length,
+		uncompressed_index_size_type num_anchors, run_index_size_type num_element_runs, uncompressed_index_size_type uncompressed_length);
+
+	/// the builds of the decoder that launch() may run with the caller's configuration
+	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
+	static const void* sparse_kernel() { return reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
+	static const void* dense_kernel()  { return reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
+	static const void* relative_with_finer_anchors_kernel()
+	{
+		if constexpr (PositionsAreRelative) { return reinterpret_cast<const void*>(decompress_relative_with_finer_anchors<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, RunIndexSize>); }
+		else { return nullptr; }
+	}
 };
 
 #define GIDDY_RPE_TEMPLATE template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize>
@@ -58,7 +77,7 @@ launch_configuration_t GIDDY_RPE_KERNEL::resolve_launch_configuration(
 }
 
 GIDDY_RPE_TEMPLATE
-void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, arguments_type arguments) const
+void GIDDY_RPE_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
 	auto decompressed                = argument<uncompressed_type*>(arguments, "decompressed");
 	auto run_data                    = argument<const uncompressed_type*>(arguments, "run_data");
@@ -68,7 +87,16 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	auto num_anchors                 = argument<uncompressed_index_size_type>(arguments, "num_anchors");
 	auto num_element_runs            = argument<run_index_size_type>(arguments, "num_element_runs");
 	auto uncompressed_length         = argument<uncompressed_index_size_type>(arguments, "length");
+	launch(stream, launch_config, decompressed, run_data, run_start_positions, position_anchors,
+		uncompressed_segment_length, num_anchors, num_element_runs, uncompressed_length);
+}
 
+GIDDY_RPE_TEMPLATE
+void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uncompressed_type* decompressed, const uncompressed_type* run_data, const position_offset_type* run_start_positions,
+	const run_index_type* position_anchors, position_offset_size_type uncompressed_segment_length,
+	uncompressed_index_size_type num_anchors, run_index_size_type num_element_runs, uncompressed_index_size_type uncompressed_length)
+{
 	// Long segments: the run covering every `fine::sub`-th output first (a binary search per finer anchor), then the decoder on
 	// segments of fine::sub (kernels/decompression/run_anchors.hpp) — L = 65 536: 65 -> 8x %, L = 2^20: 26 -> 8x % of the HBM peak.
 	namespace fine = run_expansion::fine;
@@ -78,10 +106,7 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 	// ... below 16, run arrays 16-byte aligned: the kernel with ONLY that path
 	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && !sparse
 		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
-	const void* const decoder = sparse
-		? reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
-		: dense ? reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>)
-		: reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);
+	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	stream_scratch::lease scratch(stream);
 	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
@@ -94,8 +119,7 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 			const size_t wavefronts_per_block = std::max<size_t>(1, std::min<size_t>(launch_config.block_dimensions.x / warp_size, run_expansion::max_waves_per_block));
 			config.grid_dimensions.x = (grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) wavefronts_per_block), 1u << 20);
 			if (PositionsAreRelative) {
-				cuda::enqueue_launch(reinterpret_cast<const void*>(
-					decompress_relative_with_finer_anchors<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, RunIndexSize>), stream, config,
+				cuda::enqueue_launch(relative_with_finer_anchors_kernel(), stream, config,
 					decompressed, run_data, run_start_positions, static_cast<const run_index_type*>(finer_anchors),
 					(uint64_t) fine::sub, L, (run_index_size_type) num_fine, num_element_runs, uncompressed_length);
 			}
@@ -112,11 +136,24 @@ void GIDDY_RPE_KERNEL::enqueue_launch(stream::id_t stream, const launch_configur
 		uncompressed_segment_length, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);
 }
 
+/// The kernel of the reference's signature (both paths, decided per chunk: what a direct launch runs), with the specialised builds as
+/// alternates: its attributes() are limits all of them accept, so a configuration resolved against them fits whichever launch() picks.
 GIDDY_RPE_TEMPLATE
 const device_function_t GIDDY_RPE_KERNEL::get_device_function() const
 {
-	return reinterpret_cast<const void*>(
-		decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>);
+	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel(), relative_with_finer_anchors_kernel() });
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uint_t<UncompressedSize>* decompressed, const uint_t<UncompressedSize>* run_data, const uint_t<PositionOffsetSize>* run_start_positions,
+	const uint_t<RunIndexSize>* position_anchors, size_type_by_index_size<PositionOffsetSize> segment_length,
+	size_type_by_index_size<UncompressedIndexSize> num_anchors, size_type_by_index_size<RunIndexSize> num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize> uncompressed_length)
+{
+	kernel_t<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>::launch(stream, launch_config,
+		decompressed, run_data, run_start_positions, position_anchors, segment_length, num_anchors, num_element_runs, uncompressed_length);
 }
 
 #undef GIDDY_RPE_TEMPLATE

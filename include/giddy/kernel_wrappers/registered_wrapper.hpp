@@ -51,5 +51,19 @@ public: \
 		launch_configuration_limits_t limits = { nullopt, nullopt, nullopt }) const override final; \
 	/* the stream is assumed to belong to the current device */ \
 	void enqueue_launch(stream::id_t stream, const launch_configuration_t& launch_config, \
-		arguments_type arguments) const override final; \
+		arguments_type arguments) const override final { enqueue_launch_with(stream, launch_config, arguments); } \
+	/* ... the same, reading the caller's map where it is (what each wrapper defines) */ \
+	void enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, \
+		const arguments_type& arguments) const override final; \
 	const device_function_t get_device_function() const override final
+
+// For a wrapper with ONE typed entry point `static void launch(stream, launch_config, typed parameters...)` — the function its type-erased
+// enqueue_launch() calls after unpacking the map, and the one cuda::kernel::enqueue_launch(kernel, ...) finds for a caller who
+// instantiated the wrapper (kernel_wrapper.hpp): a caller who holds only the base type reaches it too, through this override.
+#define REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(subclass_name) \
+public: \
+	void enqueue_launch_of_packed_parameters(stream::id_t stream_id, const launch_configuration_t& launch_config, \
+		void* const* parameters, const size_t* sizes, size_t count) const override final \
+	{ \
+		cuda::kernel::detail::launch_packed(&subclass_name::launch, stream_id, launch_config, parameters, sizes, count); \
+	}

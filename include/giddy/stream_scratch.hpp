@@ -1,20 +1,31 @@
 // Scratch memory for a wrapper's own use between the launches it enqueues.  The kernels of the reference's signatures have no
-// scratch parameter; the wrappers that need per-tile state (chained tiles for long Delta segments, finer anchors for long
-// discard-zero-bytes segments) get it here and fall back to their scratch-free paths when there is none to be had.
+// scratch parameter (the wrappers are stateless, src/cuda/kernel_wrapper.cuh:35); the wrappers that need per-tile state (chained
+// tiles for long Delta segments, finer anchors for long run / discard-zero-bytes segments, the host-to-device pipeline's slices)
+// get it here and fall back to their scratch-free paths when there is none to be had.
 //
-// Launches on one stream run in order, so ONE block per (device, stream) serves them all: it is kept between launches and costs
-// nothing on the launch path after a stream's first long column; taking stream-ordered memory from the runtime's pool for every
-// launch instead (hipMallocAsync / hipFreeAsync) measured ~50 us per launch.  A block is LEASED from take() to release(): whoever asks
-// for the stream's block while it is out — a wrapper's own scratch inside a pipeline chunk that already staged its slices in it — gets
-// a transient block from the pool instead.  Growing waits for the stream (its earlier launches may still use the old block) — once in
-// a stream's life for a given column size.  A stream that is being CAPTURED into a graph always gets transient blocks: allocation and
-// release become nodes of the graph, and nothing of this cache is baked into it.
+// A process-wide POOL of plain hipMalloc blocks.  A block that is handed back remembers the (device, stream, host thread) that used it
+// last: work enqueued on one stream by one thread runs in order, so that same stream and thread may have it again at once — nothing
+// is waited for and nothing is recorded on the launch path (a mutex and a scan of a handful of entries).  Anybody else gets a block
+// only once an event recorded behind its last use has completed (forget() records one), or a fresh one.  The host thread is part of
+// the key because hipStreamPerThread — and the null stream under -fgpu-default-stream=per-thread — is ONE handle naming a different
+// stream in every thread.  Nothing here synchronises: growing allocates a bigger block and keeps the smaller one for smaller requests
+// (hipFree waits for the device, so blocks are only freed by trim(), which the caller calls when it can afford that).
+//
+//   reserve(stream, bytes)   a block of at least `bytes` is there for `stream` afterwards: the launches that follow do not allocate
+//   forget(stream)           call before destroying a stream: its blocks go back to the pool behind an event, and a later stream that
+//                            happens to get the same handle inherits nothing
+//   trim()                   frees every block that is not out on lease (waits for the work that used them); returns the bytes freed
+//
+// A stream that is being CAPTURED into a graph never gets pool blocks (a replay would use them while somebody else holds them): take()
+// returns an empty block and the wrapper takes its scratch-free path inside graphs — see capture_policy below.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstddef>
 #include <mutex>
-#include <unordered_map>
+#include <thread>
+#include <vector>
 
 #include "giddy/api/types.hpp"
 
@@ -24,70 +35,113 @@ namespace stream_scratch {
 /// what take() hands out; give it back with release() once the launches that use it are enqueued
 struct block {
 	void* memory = nullptr;
-	bool transient = false;   // allocated for this use alone: release() frees it
-	bool from_pool = false;   // ... from the runtime's stream-ordered pool (a capturing stream), freed in stream order
-	unsigned slot = 0;
+	size_t bytes = 0;
+	bool from_runtime_pool = false;   // hipMallocAsync inside a capture (capture_policy::graph_allocation): released by hipFreeAsync
 	explicit operator bool() const { return memory != nullptr; }
 };
 
+/// What a capturing stream gets.  `none`: nothing — the wrappers' scratch-free paths run inside graphs (the default: the graph holds no
+/// pointer into this pool and no allocation nodes).  `graph_allocation`: hipMallocAsync / hipFreeAsync, which become nodes of the graph.
+enum class capture_policy { none, graph_allocation };
+
 namespace detail {
 
-struct cache {
+struct pool {
+	struct entry {
+		void* memory = nullptr;
+		size_t bytes = 0;
+		int device = 0;
+		hipStream_t last_stream = nullptr;
+		std::thread::id last_thread;
+		hipEvent_t passed = nullptr;     // recorded behind the last use when the block lost its stream (forget)
+		bool leased = false;
+		bool bound = false;              // last_stream / last_thread may have it again without waiting
+		bool recorded = false;           // `passed` says when anybody may
+	};
 	std::mutex mutex;
-	struct key { int device; hipStream_t stream; unsigned slot; bool operator==(const key& o) const { return device == o.device && stream == o.stream && slot == o.slot; } };
-	struct hash { size_t operator()(const key& k) const { return (std::hash<const void*>()(k.stream) * 31u + (size_t) k.device) * 7u + k.slot; } };
-	struct entry { void* memory; size_t bytes; bool leased; };
-	std::unordered_map<key, entry, hash> entries;
-	static cache& instance() { static cache c; return c; }
+	std::vector<entry> entries;
+	capture_policy in_capture = capture_policy::none;
+	static pool& instance() { static pool p; return p; }
 };
+
+inline bool idle(pool::entry& e)
+{
+	if (!e.recorded) { return false; }
+	const hipError_t status = hipEventQuery(e.passed);
+	if (status == hipSuccess) { return true; }
+	if (status != hipErrorNotReady) { (void) hipGetLastError(); }
+	return false;
+}
 
 } // namespace detail
 
+inline void set_capture_policy(capture_policy p)
+{
+	auto& pool = detail::pool::instance();
+	std::lock_guard<std::mutex> lock(pool.mutex);
+	pool.in_capture = p;
+}
+
 /// `bytes` of device memory usable by work enqueued on `stream` after this call (contents undefined); empty if there is none to be had
-/// `slot`: a stream has one kept block per slot (0: a launch's own scratch; 1: a pipeline call's per-column arrays, which live across the
-/// launches of the call's chunks)
-inline block take(stream::id_t stream, size_t bytes, unsigned slot = 0)
+inline block take(stream::id_t stream, size_t bytes)
 {
 	block result;
-	result.slot = slot;
+	auto& pool = detail::pool::instance();
 	hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
 	if (hipStreamIsCapturing(stream, &capturing) != hipSuccess) { (void) hipGetLastError(); return result; }
 	if (capturing != hipStreamCaptureStatusNone) {
-		if (hipMallocAsync(&result.memory, bytes, stream) != hipSuccess) { (void) hipGetLastError(); result.memory = nullptr; }
-		result.transient = result.from_pool = result.memory != nullptr;
+		capture_policy policy;
+		{ std::lock_guard<std::mutex> lock(pool.mutex); policy = pool.in_capture; }
+		if (policy == capture_policy::graph_allocation && hipMallocAsync(&result.memory, bytes, stream) == hipSuccess) { result.bytes = bytes; result.from_runtime_pool = true; }
+		else { (void) hipGetLastError(); result.memory = nullptr; }
 		return result;
 	}
 	int device = 0;
 	if (hipGetDevice(&device) != hipSuccess) { (void) hipGetLastError(); return result; }
-	auto& c = detail::cache::instance();
-	std::lock_guard<std::mutex> lock(c.mutex);
-	auto& e = c.entries[{ device, stream, slot }];
-	if (e.leased) {
-		// the stream's block is out: a block of this use's own.  (Not from the runtime's stream-ordered pool: with ROCm 7.2 memory from
-		// hipMallocAsync held stale contents for the kernels that followed an asynchronous copy into it, late in a long process —
-		// tests/test_gpu_sharding.py found it; plain allocations, freed once the stream has run past their use, are slower and safe.)
-		if (hipMalloc(&result.memory, bytes) != hipSuccess) { (void) hipGetLastError(); result.memory = nullptr; }
-		result.transient = result.memory != nullptr;
-		return result;
+	const auto thread = std::this_thread::get_id();
+	std::lock_guard<std::mutex> lock(pool.mutex);
+	detail::pool::entry* best = nullptr;
+	for (auto& e : pool.entries) {
+		if (e.leased || e.device != device || e.bytes < bytes) { continue; }
+		const bool mine = e.bound && e.last_stream == stream && e.last_thread == thread;
+		if (!mine && !detail::idle(e)) { continue; }
+		if (best == nullptr || e.bytes < best->bytes) { best = &e; }
 	}
-	if (e.bytes < bytes) {
-		const size_t wanted = std::max<size_t>(bytes + bytes / 2, (size_t) 1 << 20);
-		void* fresh = nullptr;
-		if (hipMalloc(&fresh, wanted) != hipSuccess) { (void) hipGetLastError(); return result; }
-		if (e.memory != nullptr) {
-			(void) hipStreamSynchronize(stream);   // (the stream's earlier launches may still use the old block)
-			(void) hipFree(e.memory);
-		}
-		e.memory = fresh; e.bytes = wanted;
+	if (best == nullptr) {
+		detail::pool::entry fresh;
+		fresh.bytes = std::max<size_t>(bytes + bytes / 2, (size_t) 1 << 20);
+		fresh.device = device;
+		if (hipMalloc(&fresh.memory, fresh.bytes) != hipSuccess) { (void) hipGetLastError(); return result; }
+		if (hipEventCreateWithFlags(&fresh.passed, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); fresh.passed = nullptr; }
+		pool.entries.push_back(fresh);
+		best = &pool.entries.back();
 	}
-	e.leased = true;
-	result.memory = e.memory;
+	best->leased = true;
+	best->bound = false;
+	best->recorded = false;
+	result.memory = best->memory;
+	result.bytes = best->bytes;
 	return result;
 }
 
-/// ... zeroed (by a memset enqueued on `stream`)
-inline void release(stream::id_t stream, const block& b);
+/// back to the pool: `stream` (as used by this host thread) may have it again at once
+inline void release(stream::id_t stream, const block& b)
+{
+	if (b.memory == nullptr) { return; }
+	if (b.from_runtime_pool) { (void) hipFreeAsync(b.memory, stream); return; }
+	auto& pool = detail::pool::instance();
+	std::lock_guard<std::mutex> lock(pool.mutex);
+	for (auto& e : pool.entries) {
+		if (e.memory != b.memory) { continue; }
+		e.leased = false;
+		e.bound = true;
+		e.last_stream = stream;
+		e.last_thread = std::this_thread::get_id();
+		return;
+	}
+}
 
+/// ... zeroed (by a memset enqueued on `stream`)
 inline block take_zeroed(stream::id_t stream, size_t bytes)
 {
 	block b = take(stream, bytes);
@@ -99,27 +153,69 @@ inline block take_zeroed(stream::id_t stream, size_t bytes)
 	return b;
 }
 
-inline void release(stream::id_t stream, const block& b)
+/// a block of at least `bytes` is there for `stream` (as used by this thread) afterwards; false if the device has none
+inline bool reserve(stream::id_t stream, size_t bytes)
 {
-	if (b.memory == nullptr) { return; }
-	if (b.from_pool) { (void) hipFreeAsync(b.memory, stream); return; }
-	if (b.transient) { (void) hipStreamSynchronize(stream); (void) hipFree(b.memory); return; }   // (a nested use of a stream's scratch: rare)
-	int device = 0;
-	if (hipGetDevice(&device) != hipSuccess) { (void) hipGetLastError(); return; }
-	auto& c = detail::cache::instance();
-	std::lock_guard<std::mutex> lock(c.mutex);
-	auto found = c.entries.find({ device, stream, b.slot });
-	if (found != c.entries.end() && found->second.memory == b.memory) { found->second.leased = false; }
+	const block b = take(stream, bytes);
+	release(stream, b);
+	return (bool) b;
 }
 
-/// take() ... release() as a scope: what a wrapper's enqueue_launch holds while it enqueues the launches that use the block
+/// `stream` is about to be destroyed (or handed to another thread): its blocks go back to the pool behind an event
+inline void forget(stream::id_t stream)
+{
+	auto& pool = detail::pool::instance();
+	const auto thread = std::this_thread::get_id();
+	int device = 0;
+	if (hipGetDevice(&device) != hipSuccess) { (void) hipGetLastError(); return; }
+	std::lock_guard<std::mutex> lock(pool.mutex);
+	for (auto& e : pool.entries) {
+		if (!e.bound || e.leased || e.device != device || e.last_stream != stream || e.last_thread != thread) { continue; }
+		e.bound = false;
+		e.recorded = e.passed != nullptr && hipEventRecord(e.passed, stream) == hipSuccess;
+		if (!e.recorded) { (void) hipGetLastError(); }
+	}
+}
+
+/// frees every block that is not out on lease — waiting for the work that used it —; returns the bytes given back to the device
+inline size_t trim()
+{
+	auto& pool = detail::pool::instance();
+	std::vector<detail::pool::entry> going;
+	{
+		std::lock_guard<std::mutex> lock(pool.mutex);
+		auto kept = std::partition(pool.entries.begin(), pool.entries.end(), [](const detail::pool::entry& e) { return e.leased; });
+		going.assign(kept, pool.entries.end());
+		pool.entries.erase(kept, pool.entries.end());
+	}
+	size_t freed = 0;
+	for (auto& e : going) {
+		if (e.recorded) { (void) hipEventSynchronize(e.passed); }
+		if (hipFree(e.memory) == hipSuccess) { freed += e.bytes; } else { (void) hipGetLastError(); }   // (hipFree waits for the device's pending work)
+		if (e.passed != nullptr) { (void) hipEventDestroy(e.passed); }
+	}
+	return freed;
+}
+
+/// bytes the pool holds at the moment (leased or not)
+inline size_t held_bytes()
+{
+	auto& pool = detail::pool::instance();
+	std::lock_guard<std::mutex> lock(pool.mutex);
+	size_t total = 0;
+	for (const auto& e : pool.entries) { total += e.bytes; }
+	return total;
+}
+
+/// take() ... release() as a scope: what a wrapper's launch holds while it enqueues the launches that use the block
 struct lease {
 	stream::id_t stream;
 	block taken;
 	explicit lease(stream::id_t stream_) : stream(stream_) { }
 	lease(const lease&) = delete;
 	lease& operator=(const lease&) = delete;
-	bool take(size_t bytes) { taken = stream_scratch::take(stream, bytes); return taken.memory != nullptr; }
+	bool take(size_t bytes) { release(stream, taken); taken = stream_scratch::take(stream, bytes); return taken.memory != nullptr; }
+	bool take_zeroed(size_t bytes) { release(stream, taken); taken = stream_scratch::take_zeroed(stream, bytes); return taken.memory != nullptr; }
 	void* memory() const { return taken.memory; }
 	~lease() { release(stream, taken); }
 };

@@ -36,6 +36,9 @@ class giddy_launch_configuration_limits(ctypes.Structure):
 EXPORTED_SYMBOLS = (
     "giddy_kernel_count", "giddy_kernel_key", "giddy_can_produce", "giddy_produce", "giddy_release",
     "giddy_resolve_launch_configuration", "giddy_enqueue_launch", "giddy_device_function",
+    "giddy_device_function_count", "giddy_device_function_alternate",
+    "giddy_prepare", "giddy_prepared_update", "giddy_enqueue_prepared", "giddy_release_prepared",
+    "giddy_reserve_scratch", "giddy_release_scratch", "giddy_trim", "giddy_scratch_held_bytes", "giddy_set_capture_scratch_policy",
     "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host", "giddy_enqueue_gather_on_node",
     "giddy_last_error", "giddy_version",
 )
@@ -79,6 +82,19 @@ def _load():
         ctypes.POINTER(giddy_argument), ctypes.c_size_t]
     lib.giddy_device_function.restype = ctypes.c_void_p
     lib.giddy_device_function.argtypes = [ctypes.c_void_p]
+    lib.giddy_device_function_count.argtypes = [ctypes.c_void_p]
+    lib.giddy_device_function_alternate.restype = ctypes.c_void_p
+    lib.giddy_device_function_alternate.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    lib.giddy_prepare.argtypes = [ctypes.c_void_p, ctypes.POINTER(giddy_argument), ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    lib.giddy_prepared_update.argtypes = [ctypes.c_void_p, ctypes.POINTER(giddy_argument), ctypes.c_size_t]
+    lib.giddy_enqueue_prepared.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(giddy_launch_configuration)]
+    lib.giddy_release_prepared.argtypes = [ctypes.c_void_p]
+    lib.giddy_release_prepared.restype = None
+    lib.giddy_reserve_scratch.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+    lib.giddy_release_scratch.argtypes = [ctypes.c_void_p]
+    lib.giddy_trim.restype = ctypes.c_uint64
+    lib.giddy_scratch_held_bytes.restype = ctypes.c_uint64
+    lib.giddy_set_capture_scratch_policy.argtypes = [ctypes.c_int]
     lib.giddy_enqueue_gather_on_node.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
     lib.giddy_enqueue_gather_on_node.restype = ctypes.c_int

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "c_abi_internal.hpp"
+#include "giddy/stream_scratch.hpp"
 
 namespace giddy_internal {
 
@@ -192,8 +193,79 @@ const void* giddy_device_function(const giddy_kernel_t* kernel)
 	return (kernel != nullptr && kernel->wrapper) ? kernel->wrapper->get_device_function().ptr() : nullptr;
 }
 
+int giddy_device_function_count(const giddy_kernel_t* kernel)
+{
+	return (kernel != nullptr && kernel->wrapper) ? 1 + (int) kernel->wrapper->get_device_function().num_alternates() : 0;
+}
+
+const void* giddy_device_function_alternate(const giddy_kernel_t* kernel, int index)
+{
+	if (kernel == nullptr || !kernel->wrapper || index < 0) { return nullptr; }
+	const auto function = kernel->wrapper->get_device_function();
+	return index == 0 ? function.ptr() : function.alternate((unsigned) index - 1);
+}
+
+int giddy_prepare(const giddy_kernel_t* kernel, const giddy_argument_t* arguments, size_t num_arguments, giddy_prepared_t** prepared)
+{
+	return guarded([&] {
+		const auto& k = checked(kernel);
+		if (prepared == nullptr) { throw std::invalid_argument("null output handle"); }
+		*prepared = new giddy_prepared { k.wrapper.get(), to_map(arguments, num_arguments) };
+	});
+}
+
+int giddy_prepared_update(giddy_prepared_t* prepared, const giddy_argument_t* arguments, size_t num_arguments)
+{
+	return guarded([&] {
+		if (prepared == nullptr || prepared->wrapper == nullptr) { throw std::invalid_argument("null prepared launch"); }
+		for (size_t i = 0; i < num_arguments; i++) {
+			if (arguments[i].name == nullptr) { throw std::invalid_argument("argument without a name"); }
+			prepared->arguments[arguments[i].name] = giddy_internal::to_any(arguments[i]);
+		}
+	});
+}
+
+int giddy_enqueue_prepared(const giddy_prepared_t* prepared, void* hip_stream, const giddy_launch_configuration_t* launch_configuration)
+{
+	return guarded([&] {
+		if (prepared == nullptr || prepared->wrapper == nullptr) { throw std::invalid_argument("null prepared launch"); }
+		if (launch_configuration == nullptr) { throw std::invalid_argument("null launch configuration"); }
+		const cuda::launch_configuration_t config(
+			cuda::dimensions_t(launch_configuration->grid_dimensions[0], launch_configuration->grid_dimensions[1], launch_configuration->grid_dimensions[2]),
+			cuda::dimensions_t(launch_configuration->block_dimensions[0], launch_configuration->block_dimensions[1], launch_configuration->block_dimensions[2]),
+			launch_configuration->dynamic_shared_memory_size);
+		prepared->wrapper->enqueue_launch_with(static_cast<hipStream_t>(hip_stream), config, prepared->arguments);
+	});
+}
+
+void giddy_release_prepared(giddy_prepared_t* prepared) { delete prepared; }
+
+int giddy_reserve_scratch(void* hip_stream, uint64_t bytes)
+{
+	return guarded([&] {
+		if (!cuda::stream_scratch::reserve(static_cast<hipStream_t>(hip_stream), (size_t) bytes)) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for the scratch asked for"); }
+	});
+}
+
+int giddy_release_scratch(void* hip_stream)
+{
+	return guarded([&] { cuda::stream_scratch::forget(static_cast<hipStream_t>(hip_stream)); });
+}
+
+uint64_t giddy_trim(void) { return (uint64_t) cuda::stream_scratch::trim(); }
+
+uint64_t giddy_scratch_held_bytes(void) { return (uint64_t) cuda::stream_scratch::held_bytes(); }
+
+int giddy_set_capture_scratch_policy(int policy)
+{
+	return guarded([&] {
+		if (policy != 0 && policy != 1) { throw std::invalid_argument("capture scratch policy: 0 (none) or 1 (graph allocation)"); }
+		cuda::stream_scratch::set_capture_policy(policy == 1 ? cuda::stream_scratch::capture_policy::graph_allocation : cuda::stream_scratch::capture_policy::none);
+	});
+}
+
 const char* giddy_last_error(void) { return giddy_internal::last_error().c_str(); }
 
-const char* giddy_version(void) { return "libgiddy_amd 0.1 (gfx950)"; }
+const char* giddy_version(void) { return "libgiddy_amd 0.4 (gfx950)"; }
 
 } // extern "C"

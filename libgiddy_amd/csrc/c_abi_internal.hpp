@@ -14,6 +14,12 @@ struct giddy_kernel {
 	std::unique_ptr<cuda::registered::kernel_t> wrapper;
 };
 
+/// a wrapper (owned by its giddy_kernel) with an argument map that is kept between launches
+struct giddy_prepared {
+	const cuda::registered::kernel_t* wrapper;
+	cuda::kernel_t::arguments_type arguments;
+};
+
 namespace giddy_internal {
 
 std::string& last_error();   // this thread's

@@ -17,6 +17,17 @@ namespace {
 
 using giddy_internal::guarded;
 
+/// an event for ordering only, destroyed with its scope (the runtime releases it once a pending record has completed)
+struct ordering_event {
+	hipEvent_t event = nullptr;
+	ordering_event() { cuda::throw_if_error(hipEventCreateWithFlags(&event, hipEventDisableTiming), "hipEventCreateWithFlags"); }
+	ordering_event(const ordering_event&) = delete;
+	ordering_event& operator=(const ordering_event&) = delete;
+	~ordering_event() { if (event != nullptr) { (void) hipEventDestroy(event); } }
+	void record(hipStream_t stream) { cuda::throw_if_error(hipEventRecord(event, stream), "hipEventRecord"); }
+	void make_wait(hipStream_t stream) { cuda::throw_if_error(hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent"); }
+};
+
 uint64_t anchor_value(const giddy_column_shape_t& shape, uint64_t index)
 {
 	if (shape.position_anchors == nullptr) { throw std::invalid_argument("this scheme's cuts read the column's position_anchors: none given"); }
@@ -146,23 +157,25 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 	}
 	const size_t table_offset = whole_bytes;
 	whole_bytes += num_chunks * sizeof(cuda::kernels::data_layout::rebase::chunk_of_entries) + 256;
-	// (the first stream's second kept block: it lives until every stream's last launch of this call — the next call on this stream is ordered
-	// behind those, see the end of this function)
-	const auto whole_block = cuda::stream_scratch::take(first_stream, whole_bytes, 1);
-	if (!whole_block) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a column's per-segment arrays"); }
-	void* whole = whole_block.memory;
+	// (leased until every stream's last launch of this call is enqueued and the first stream is ordered behind them — see the end of this
+	// function; an exception on the way gives it back too)
+	cuda::stream_scratch::lease whole_block(first_stream);
+	if (!whole_block.take(whole_bytes)) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a column's per-segment arrays"); }
+	void* whole = whole_block.memory();
 	char* whole_base = static_cast<char*>(whole);
 	// (the chunk table travels from PINNED memory that outlives this call — an asynchronous copy out of pageable memory may still be reading
-	// it when this function has returned: one buffer per host thread, reused once the previous call's copy out of it is known to be done)
+	// it when this function has returned: one buffer per host thread AND device — a thread that drives several devices records each
+	// device's event on that device's stream —, portable, reused once the previous call's copy out of it is known to be done)
 	using chunk_entry = cuda::kernels::data_layout::rebase::chunk_of_entries;
 	struct pinned_table { chunk_entry* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; };
-	static thread_local pinned_table pinned;
+	static thread_local std::map<int, pinned_table> pinned_tables;
+	pinned_table& pinned = pinned_tables[cuda::device::current::get().id()];
 	if (pinned.copied != nullptr) { cuda::throw_if_error(hipEventSynchronize(pinned.copied), "hipEventSynchronize"); }
 	else { cuda::throw_if_error(hipEventCreateWithFlags(&pinned.copied, hipEventDisableTiming), "hipEventCreate"); }
 	if (pinned.capacity < num_chunks) {
 		if (pinned.memory != nullptr) { (void) hipHostFree(pinned.memory); pinned.memory = nullptr; pinned.capacity = 0; }
 		const size_t capacity = std::max<size_t>(2 * num_chunks, 1024);
-		cuda::throw_if_error(hipHostMalloc(reinterpret_cast<void**>(&pinned.memory), capacity * sizeof(chunk_entry), hipHostMallocDefault), "hipHostMalloc (chunk table)");
+		cuda::throw_if_error(hipHostMalloc(reinterpret_cast<void**>(&pinned.memory), capacity * sizeof(chunk_entry), hipHostMallocPortable), "hipHostMalloc (chunk table)");
 		pinned.capacity = capacity;
 	}
 	chunk_entry* table = pinned.memory;
@@ -189,19 +202,34 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		}
 	}
 	cuda::throw_if_error(hipEventRecord(pinned.copied, first_stream), "hipEventRecord");
-	hipEvent_t uploaded = nullptr;
-	cuda::throw_if_error(hipEventCreateWithFlags(&uploaded, hipEventDisableTiming), "hipEventCreate");
-	cuda::throw_if_error(hipEventRecord(uploaded, first_stream), "hipEventRecord");
-	for (size_t k = 1; k < num_streams; k++) { cuda::throw_if_error(hipStreamWaitEvent(static_cast<hipStream_t>(streams[k]), uploaded, 0), "hipStreamWaitEvent"); }
+	ordering_event uploaded;
+	uploaded.record(first_stream);
+	for (size_t k = 1; k < num_streams; k++) { uploaded.make_wait(static_cast<hipStream_t>(streams[k])); }
 
+	// The wrapper's argument map and the resolver's are built ONCE; a chunk rewrites the entries that differ in place (no allocation per chunk),
+	// and the launch configuration is resolved again only when the chunk's length differs from the previous chunk's.
 	std::vector<giddy_argument_t> chunk_arguments(arguments, arguments + num_arguments);
+	auto map = giddy_internal::to_map(arguments, num_arguments);
+	std::vector<cuda::any*> entry(num_arguments, nullptr);
+	for (size_t i = 0; i < num_arguments; i++) { entry[i] = &map.at(roles[i].name); }
+	// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
+	auto resolution = map;
+	for (size_t i = 0; i < num_arguments; i++) {
+		if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
+			resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
+		}
+	}
+	cuda::any& resolution_length = resolution["length"];
+	cuda::any& resolution_data_length = resolution["data_length"];
+	cuda::launch_configuration_t config;
+	uint64_t config_for_length = ~(uint64_t) 0;
+	std::vector<size_t> offset(num_arguments, 0);
 	for (uint64_t c = 0; c < num_chunks; c++) {
 		const auto& shard = shards[c];
 		if (shard.length() == 0) { continue; }
 		hipStream_t stream = static_cast<hipStream_t>(streams[c % num_streams]);
 		// the chunk's slices of the bulk arrays, each 256-byte aligned within one block of the stream's scratch
 		size_t total = 0;
-		std::vector<size_t> offset(num_arguments, 0);
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
 			if (r.how != sliced_by::elements && r.how != sliced_by::units && r.how != sliced_by::size_containers) { continue; }
@@ -209,50 +237,43 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 			offset[i] = total;
 			total += (slice.size() * r.itemsize + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of a slice's last chunk)
 		}
-		const auto block = cuda::stream_scratch::take(stream, std::max<size_t>(total, 256));
-		if (!block) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
-		char* base = static_cast<char*>(block.memory);
+		// (the stream's block for slices: the chunk this stream decoded last had it, in stream order.  The wrapper's own scratch — chained
+		// Delta tiles, finer anchors of long segments — is another block of the pool: neither waits for the other)
+		cuda::stream_scratch::lease block(stream);
+		if (!block.take(std::max<size_t>(total, 256))) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
+		char* base = static_cast<char*>(block.memory());
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
 			giddy_argument_t& a = chunk_arguments[i];
-			a = arguments[i];
+			bool changed = false;
 			if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
 				const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
 				const size_t bytes = slice.size() * r.itemsize;
 				if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offset[i], static_cast<const char*>(arguments[i].value.pointer) + slice.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a chunk's slice)"); }
-				a.value.pointer = base + offset[i];
+				a.value.pointer = base + offset[i]; changed = true;
 				if (r.positions && shard.position_bias != 0) { enqueue_rebase(stream, base + offset[i], base + offset[i], shard.units.size(), r.itemsize, shard.position_bias); }
 			}
-			else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; }
-			else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; }
-			else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; }
-			else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; } }
+			else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; changed = true; }
+			else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; changed = true; }
+			else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; changed = true; }
+			else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; changed = true; } }
+			if (changed) { *entry[i] = giddy_internal::to_any(a); }
 		}
-		const auto map = giddy_internal::to_map(chunk_arguments.data(), chunk_arguments.size());
-		// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
-		auto resolution = map;
-		resolution["length"] = cuda::any((size_t) shard.length());
-		resolution["data_length"] = cuda::any((size_t) shard.length());
-		for (size_t i = 0; i < num_arguments; i++) {
-			if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
-				resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
-			}
+		if (shard.length() != config_for_length) {
+			resolution_length = cuda::any((size_t) shard.length());
+			resolution_data_length = cuda::any((size_t) shard.length());
+			config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+			config_for_length = shard.length();
 		}
-		const auto config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
-		wrapper->enqueue_launch(stream, config, map);
-		cuda::stream_scratch::release(stream, block);
+		wrapper->enqueue_launch_with(stream, config, map);
 	}
 	// the first stream runs on only when every stream has made its last launch of this call: whatever is enqueued on it next — the next
 	// call's uploads into the same kept block among them — comes after all of this call's readers of the per-segment arrays
 	for (size_t k = 1; k < num_streams; k++) {
-		hipEvent_t done = nullptr;
-		cuda::throw_if_error(hipEventCreateWithFlags(&done, hipEventDisableTiming), "hipEventCreate");
-		cuda::throw_if_error(hipEventRecord(done, static_cast<hipStream_t>(streams[k])), "hipEventRecord");
-		cuda::throw_if_error(hipStreamWaitEvent(first_stream, done, 0), "hipStreamWaitEvent");
-		(void) hipEventDestroy(done);
+		ordering_event done;
+		done.record(static_cast<hipStream_t>(streams[k]));
+		done.make_wait(first_stream);
 	}
-	cuda::stream_scratch::release(first_stream, whole_block);
-	(void) hipEventDestroy(uploaded);
 }
 
 } // namespace

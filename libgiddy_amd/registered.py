@@ -193,6 +193,52 @@ class launch_configuration_limits_t:
         return c
 
 
+class prepared_launch:
+    """giddy_prepared_t: a wrapper with an argument map that is kept between launches; update() rewrites entries in place"""
+
+    def __init__(self, kernel, arguments):
+        self._kernel = kernel   # (keeps the wrapper alive)
+        self._handle = ctypes.c_void_p()
+        array, keep = _marshal(arguments)
+        _check(_native.lib.giddy_prepare(kernel._handle, array, len(arguments), ctypes.byref(self._handle)))
+
+    def update(self, arguments):
+        array, keep = _marshal(arguments)
+        _check(_native.lib.giddy_prepared_update(self._handle, array, len(arguments)))
+
+    def enqueue(self, stream, launch_config):
+        c_config = launch_config._c() if not isinstance(launch_config, giddy_launch_configuration) else launch_config
+        _check(_native.lib.giddy_enqueue_prepared(self._handle, ctypes.c_void_p(int(stream) if stream else None), ctypes.byref(c_config)))
+
+    def __del__(self):
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle and _native is not None and getattr(_native, "lib", None) is not None:
+            _native.lib.giddy_release_prepared(handle)
+
+
+def reserve_scratch(stream, nbytes):
+    """cuda::stream_scratch::reserve: a block of at least `nbytes` is there for `stream` afterwards (launches on it do not allocate)"""
+    _check(_native.lib.giddy_reserve_scratch(ctypes.c_void_p(int(stream) if stream else None), int(nbytes)))
+
+
+def release_scratch(stream):
+    """cuda::stream_scratch::forget: call before destroying a stream"""
+    _check(_native.lib.giddy_release_scratch(ctypes.c_void_p(int(stream) if stream else None)))
+
+
+def trim():
+    """frees every scratch block that is not in use (waits for the work that used them); bytes freed"""
+    return int(_native.lib.giddy_trim())
+
+
+def scratch_held_bytes():
+    return int(_native.lib.giddy_scratch_held_bytes())
+
+
+def set_capture_scratch_policy(graph_allocation):
+    _check(_native.lib.giddy_set_capture_scratch_policy(1 if graph_allocation else 0))
+
+
 class kernel_t:
     """cuda::registered::kernel_t"""
 
@@ -237,6 +283,15 @@ class kernel_t:
 
     def get_device_function(self):
         return _native.lib.giddy_device_function(self._handle)
+
+    def device_functions(self):
+        """the kernels the wrapper may launch with the caller's configuration: [0] is get_device_function(), the kernel of the
+        reference's signature; the others are the builds its typed launch picks among (cuda::device_function_t's alternates)"""
+        return [_native.lib.giddy_device_function_alternate(self._handle, i) for i in range(_native.lib.giddy_device_function_count(self._handle))]
+
+    def prepare(self, arguments):
+        """a launch whose argument map is built once and kept (giddy_prepare): for loops over a column's chunks"""
+        return prepared_launch(self, arguments)
 
     def __del__(self):
         handle, self._handle = getattr(self, "_handle", None), None

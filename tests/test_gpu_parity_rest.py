@@ -95,6 +95,53 @@ def test_incidence_bitmaps(usize, use_dictionary):
         assert (g.host(out, ud, 32 * n_words) == col).all(), (n_words, num_values)
 
 
+@pytest.mark.parametrize("usize,use_dictionary", [(1, True), (2, True), (4, True), (8, True), (1, False)])
+def test_incidence_bitmaps_that_overlap(usize, use_dictionary):
+    """Bitmaps that claim the same elements: the HIGHEST bitmap index wins, as in the reference's loop over the bitmaps in ascending
+    order (src/kernels/decompression/incidence_bitmaps.cuh:47-60: a later bitmap's set bit overwrites an earlier one's).  The format
+    writer only produces disjoint bitmaps, so these are made by hand: the writer's bitmaps, then bits of LOWER-index bitmaps set on
+    top of elements that belong to higher ones (must not change the result), and bits of HIGHER-index bitmaps set on elements of lower
+    ones (must) — two and three bitmaps per element, single bits at container and tile boundaries, and whole containers."""
+    schemes, r, g = _imports()
+    from oracle import oracle
+    ud = np.dtype("u%d" % usize)
+    for n_words, num_values in [(1, 2), (5, 3), (64, 17), (1001, 60), (20000, 33)]:
+        rr = cases.rng(1000 + n_words + usize)
+        if use_dictionary:
+            num_values = min(num_values, int(np.iinfo(ud).max) + 1)
+            pool = rr.choice(min(int(np.iinfo(ud).max) + 1, 1 << 40), size=num_values, replace=False).astype(ud)
+            col = pool[rr.integers(0, num_values, size=32 * n_words)]
+        else:
+            col = rr.integers(0, min(num_values, 200), size=32 * n_words).astype(ud)
+        f = formats.incidence_bitmaps(col, 2, use_dictionary)
+        num_bitmaps, stride = f["num_bitmaps"], len(f["incidence_bitmaps"]) // max(f["num_bitmaps"], 1)
+        if num_bitmaps < 2:
+            continue
+        bitmaps = f["incidence_bitmaps"].copy().reshape(num_bitmaps, stride)
+        n = 32 * n_words
+        # elements to be claimed twice or three times: random ones, plus the first / last bit of containers and of 64-container tiles
+        picks = set(int(e) for e in rr.integers(0, n, size=min(n, 400)))
+        for w in {0, n_words - 1, min(63, n_words - 1), min(64, n_words - 1), n_words // 2}:
+            picks.update({32 * w, 32 * w + 31})
+        for e in sorted(picks):
+            word, bit = e // 32, np.uint32(1 << (e % 32))
+            claimants = rr.choice(num_bitmaps, size=min(num_bitmaps, int(rr.integers(1, 3))), replace=False)
+            for b in claimants:
+                bitmaps[b, word] |= bit
+        # ... and one whole container claimed by every bitmap
+        bitmaps[:, n_words // 3] = np.uint32(0xFFFFFFFF)
+        flat = np.ascontiguousarray(bitmaps.reshape(-1))
+        expect, uncovered = oracle.incidence_bitmaps(flat, f["dictionary_entries"], f["bitmap_length"], num_bitmaps, 2, ud, use_dictionary)
+        assert uncovered == 0
+        assert (expect != col).any(), "the overlaps changed nothing: the case tests nothing"
+        out = g.dev_empty(n, ud)
+        schemes.incidence_bitmaps(out, g.dev(flat), g.dev(f["dictionary_entries"]), f["bitmap_length"], num_bitmaps,
+                                  uncompressed_size=usize, use_dictionary=use_dictionary, stream=g.stream())
+        got = g.host(out, ud, n)
+        bad = np.flatnonzero(got != expect)
+        assert len(bad) == 0, (n_words, num_bitmaps, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+
 def _run_columns():
     yield "geom32", cases.runs_column(300000, 32, np.uint32, seed=6)
     yield "geom2", cases.runs_column(50000, 2, np.uint32, seed=7)
