@@ -90,6 +90,7 @@ def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28, seed_offset=
 
 
 SETTLE_SECONDS = 0.15
+RUN_DECODER_WORKLOADS = ("run_length_encoding", "run_position_encoding_relative", "run_position_encoding_absolute")
 
 
 def timed_steps(work, steps, warmup, barrier, per_step_events=True):
@@ -281,8 +282,10 @@ def placement_and_cache(name, work, n, device, steps):
         other.output = original
         others.append(other)
     w.SEED_OFFSET = keep
-    out["frac_one_column_repeated"] = frac(timed([work] * steps))
-    out["frac_three_columns_in_turn"] = frac(timed([x for _ in range(steps) for x in [work] + others][: 3 * steps]))
+    warm_ms = timed([work] * steps)
+    cold_ms = timed([x for _ in range(steps) for x in [work] + others][: 3 * steps])
+    out["frac_one_column_repeated"], out["ms_one_column_repeated"] = frac(warm_ms), round(warm_ms, 4)
+    out["frac_three_columns_in_turn"], out["ms_three_columns_in_turn"] = frac(cold_ms), round(cold_ms, 4)
     out["note"] = ("one column repeated: its 200 MB of runs come out of the Infinity Cache; three in turn: from HBM.  Since round 3 the wrappers launch, for columns of "
                    "mean runs >= 16, a build of the kernel that is set for the second case (DESIGN.md section 4, 'Cold inputs': round 2's kernel 0.85 / 0.62-0.74, this one 0.80-0.82 / 0.74-0.79)")
     del others
@@ -371,7 +374,13 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
     # TWO timed regions of `steps` steps, the faster one reported (both stated): the checks above leave the GPU idle for seconds, and a first region
     # has been seen 26 % slower than the next on the same box (clocks, or the host thread behind the 16 launches a 2^31 DZB-variable step takes)
     regions = [timed_steps(shard, steps, warmup, barrier, per_step_events=False) for _ in range(2)]
-    elapsed, launch_ms = min(regions, key=lambda r: r[0])
+    # ... the SAME region for every rank: each region's time is its slowest rank's, and the region with the smaller such time is the one reported
+    # (a maximum over ranks of each rank's own faster region could pair rank 0's first region with rank 1's second: optimistic)
+    slowest_per_region = torch.tensor([r[0] for r in regions], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+    if world > 1:
+        dist.all_reduce(slowest_per_region, op=dist.ReduceOp.MAX)
+    chosen = int(torch.argmin(slowest_per_region))
+    elapsed, launch_ms = regions[chosen]
     # every rank's wall time (read before the closing barrier) and every rank's event-timed step, side by side
     times = torch.tensor([[elapsed, launch_ms * 1e-3] if r == rank else [0.0, 0.0] for r in range(world)], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     if world > 1:
@@ -389,12 +398,29 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
              "decompressed_GBps": round(whole.decompressed_bytes * steps / slowest / 1e9, 1), "ms_per_step": round(slowest / steps * 1e3, 4),
              "per_rank_ms_per_step": [round(float(t) / steps * 1e3, 4) for t in times], "per_rank_event_ms_per_step": event_ms,
              "timing": "wall: each rank's clock from after the opening barrier to after its own synchronize(), MAX over ranks; events: one HIP event pair around the rank's %d steps; "
-                       "two such regions are timed and this rank's faster one is reported" % steps,
+                       "two such regions are timed; a region's time is its slowest rank's, and the region with the smaller such time is reported for every rank (region %d here)" % (steps, chosen),
              "this_rank_ms_per_step_of_both_regions": [round(r[0] / steps * 1e3, 4) for r in regions],
              "per_rank_elements": [int(c) for c in counts],
              "world_size_seen_by_the_process_group": dist.get_world_size() if world > 1 else 1,
              "checksum": "%016x" % column_checksum, "shards_checksum_equals_column_checksum": True,
              "this_rank_roofline": roofline(shard, launch_ms, None)}
+    if world == 1:
+        # What ONE rank of 8 would be given, decoded alone on this GPU: shards 0, 3 and 7 of the column cut 8 ways.  shard rate / column rate
+        # is the strong-scaling efficiency to expect at N = 8 from the decode itself (launch tails, the fixed cost of the wrappers' pre-passes on a
+        # column an eighth the size) — a PREDICTION from one GPU; the curve itself needs the 8-GPU node.
+        column_rate = whole.decompressed_bytes * steps / slowest
+        predicted = {}
+        for r8 in (0, 3, 7):
+            eighth = w.Sharded(whole, r8, 8)
+            el8, _ = min((timed_steps(eighth, steps, warmup, barrier, per_step_events=False) for _ in range(2)), key=lambda r: r[0])
+            predicted["rank_%d_of_8" % r8] = {"elements": eighth.n, "ms_per_step": round(el8 / steps * 1e3, 4),
+                                             "decompressed_GBps": round(eighth.decompressed_bytes * steps / el8 / 1e9, 1),
+                                             "shard_rate_over_column_rate": round(eighth.decompressed_bytes * steps / el8 / column_rate, 4)}
+            del eighth
+        entry["shard_of_8_alone_on_this_gpu"] = predicted
+        entry["predicted_strong_efficiency_at_8"] = min(v["shard_rate_over_column_rate"] for v in predicted.values())
+        entry["predicted_strong_efficiency_note"] = ("min over ranks 0, 3, 7 of (that rank's shard-of-8 decoded alone, rate) / (the whole column, rate), both on this one GPU: "
+                                                    "what the decode itself would scale like; NOT a measured scaling curve — no 8-GPU node has been available")
     if gather and world > 1:
         expected = getattr(whole, "values", None) if rank == 0 else None   # (DZB-V keeps the column it compressed)
         if backend == "nccl":
@@ -523,8 +549,18 @@ def main():
                      "decompressed_GBps": round(w.decompressed_bytes * steps / el / 1e9, 1),
                      "ms_per_step": round(el / steps * 1e3, 4),
                      "roofline": roofline(w, launch_ms, committed_traffic(w.kernel, w.algorithmic_bytes, getattr(w, "workload_name", None))), "bit_exact": True}
-            if name in ("run_length_encoding", "run_position_encoding_absolute"):
-                entry["placement_and_cache"] = placement_and_cache(name, w, n, device, steps)
+            if name in RUN_DECODER_WORKLOADS:
+                # THE number of a run decoder's entry is the one with its input COLD (three columns of different seeds decoded in turn):
+                # one column's 200 MB of runs, decoded again and again, come out of the 256 MiB Infinity Cache — a rate only a benchmark sees
+                pc = placement_and_cache(name, w, n, device, steps)
+                warm = entry["roofline"]
+                entry["placement_and_cache"] = pc
+                entry["roofline"] = roofline(w, pc["ms_three_columns_in_turn"], committed_traffic(w.kernel, w.algorithmic_bytes, getattr(w, "workload_name", None)))
+                entry["roofline"].update({"input": "cold: three columns of different seeds decoded in turn into one output, one HIP event pair around the %d launches" % (3 * steps),
+                                          "frac_input_in_infinity_cache": warm["frac"], "mean_launch_ms_input_in_infinity_cache": warm["mean_launch_ms"]})
+                entry["decompressed_GBps_input_in_infinity_cache"], entry["ms_per_step_input_in_infinity_cache"] = entry["decompressed_GBps"], entry["ms_per_step"]
+                entry["decompressed_GBps"] = round(w.decompressed_bytes / (pc["ms_three_columns_in_turn"] * 1e-3) / 1e9, 1)
+                entry["ms_per_step"] = pc["ms_three_columns_in_turn"]
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
             schemes_out[name] = entry

@@ -4,16 +4,16 @@
 // get it here and fall back to their scratch-free paths when there is none to be had.
 //
 // A process-wide POOL of plain hipMalloc blocks.  A block that is handed back remembers the (device, stream, host thread) that used it
-// last: work enqueued on one stream by one thread runs in order, so that same stream and thread may have it again at once — nothing
-// is waited for and nothing is recorded on the launch path (a mutex and a scan of a handful of entries).  Anybody else gets a block
-// only once an event recorded behind its last use has completed (forget() records one), or a fresh one.  The host thread is part of
-// the key because hipStreamPerThread — and the null stream under -fgpu-default-stream=per-thread — is ONE handle naming a different
-// stream in every thread.  Nothing here synchronises: growing allocates a bigger block and keeps the smaller one for smaller requests
-// (hipFree waits for the device, so blocks are only freed by trim(), which the caller calls when it can afford that).
+// last, and an event is recorded behind that use: work enqueued on one stream by one thread runs in order, so that same stream and
+// thread may have the block again at once; anybody else — another stream, the same handle in another thread — gets it once the event
+// has completed (a query, never a wait), or a fresh block.  The host thread is part of the key because hipStreamPerThread — and the
+// null stream under -fgpu-default-stream=per-thread — is ONE handle naming a different stream in every thread.  Nothing here
+// synchronises: growing allocates a bigger block and keeps the smaller one for smaller requests (hipFree waits for the device, so
+// blocks are only freed by trim(), which the caller calls when it can afford that).  Callers that take a new stream from a pool of
+// streams for every column (torch.cuda.Stream() rotates through 32) therefore share a few blocks, not one per stream handle.
 //
 //   reserve(stream, bytes)   a block of at least `bytes` is there for `stream` afterwards: the launches that follow do not allocate
-//   forget(stream)           call before destroying a stream: its blocks go back to the pool behind an event, and a later stream that
-//                            happens to get the same handle inherits nothing
+//   forget(stream)           call before destroying a stream: a later stream that happens to get the same handle inherits nothing
 //   trim()                   frees every block that is not out on lease (waits for the work that used them); returns the bytes freed
 //
 // A stream that is being CAPTURED into a graph never gets pool blocks (a replay would use them while somebody else holds them): take()
@@ -53,7 +53,7 @@ struct pool {
 		int device = 0;
 		hipStream_t last_stream = nullptr;
 		std::thread::id last_thread;
-		hipEvent_t passed = nullptr;     // recorded behind the last use when the block lost its stream (forget)
+		hipEvent_t passed = nullptr;     // recorded behind the last use
 		bool leased = false;
 		bool bound = false;              // last_stream / last_thread may have it again without waiting
 		bool recorded = false;           // `passed` says when anybody may
@@ -137,6 +137,8 @@ inline void release(stream::id_t stream, const block& b)
 		e.bound = true;
 		e.last_stream = stream;
 		e.last_thread = std::this_thread::get_id();
+		e.recorded = e.passed != nullptr && hipEventRecord(e.passed, stream) == hipSuccess;
+		if (!e.recorded) { (void) hipGetLastError(); }
 		return;
 	}
 }
@@ -161,7 +163,8 @@ inline bool reserve(stream::id_t stream, size_t bytes)
 	return (bool) b;
 }
 
-/// `stream` is about to be destroyed (or handed to another thread): its blocks go back to the pool behind an event
+/// `stream` is about to be destroyed (or handed to another thread): its blocks lose their tie to the handle (the event recorded at
+/// their release still says when they are idle)
 inline void forget(stream::id_t stream)
 {
 	auto& pool = detail::pool::instance();
@@ -172,8 +175,6 @@ inline void forget(stream::id_t stream)
 	for (auto& e : pool.entries) {
 		if (!e.bound || e.leased || e.device != device || e.last_stream != stream || e.last_thread != thread) { continue; }
 		e.bound = false;
-		e.recorded = e.passed != nullptr && hipEventRecord(e.passed, stream) == hipSuccess;
-		if (!e.recorded) { (void) hipGetLastError(); }
 	}
 }
 

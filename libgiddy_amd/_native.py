@@ -39,7 +39,7 @@ EXPORTED_SYMBOLS = (
     "giddy_device_function_count", "giddy_device_function_alternate",
     "giddy_prepare", "giddy_prepared_update", "giddy_enqueue_prepared", "giddy_release_prepared",
     "giddy_reserve_scratch", "giddy_release_scratch", "giddy_trim", "giddy_scratch_held_bytes", "giddy_set_capture_scratch_policy",
-    "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host", "giddy_enqueue_gather_on_node",
+    "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host", "giddy_enqueue_gather_on_node", "giddy_enqueue_gather_compressed_on_node",
     "giddy_last_error", "giddy_version",
 )
 
@@ -55,6 +55,12 @@ class giddy_shard(ctypes.Structure):
     _fields_ = [(name, ctypes.c_uint64) for name in (
         "first_segment", "end_segment", "first_element", "end_element", "first_unit", "end_unit",
         "first_size_container", "end_size_container", "anchor_bias", "position_bias")]
+
+
+class giddy_compressed_shard(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("flags", ctypes.c_uint32), ("hip_stream", ctypes.c_void_p),
+                ("arguments", ctypes.POINTER(giddy_argument)), ("bytes", ctypes.POINTER(ctypes.c_uint64)), ("num_arguments", ctypes.c_size_t),
+                ("resolution_arguments", ctypes.POINTER(giddy_argument)), ("num_resolution_arguments", ctypes.c_size_t)]
 
 
 SCHEMES = {"elementwise": 1, "frame_of_reference": 2, "delta": 3, "discard_zero_bytes_variable": 4, "run_length_encoding": 5,
@@ -98,6 +104,8 @@ def _load():
     lib.giddy_enqueue_gather_on_node.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int),
                                                  ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint64), ctypes.c_size_t]
     lib.giddy_enqueue_gather_on_node.restype = ctypes.c_int
+    lib.giddy_enqueue_gather_compressed_on_node.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t,
+                                                            ctypes.POINTER(giddy_compressed_shard), ctypes.c_size_t]
     lib.giddy_shard.argtypes = [ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.c_uint64, ctypes.c_uint64, ctypes.POINTER(giddy_shard)]
     lib.giddy_enqueue_rebase.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint64]
     lib.giddy_decode_from_host.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.POINTER(giddy_column_shape), ctypes.POINTER(giddy_argument), ctypes.c_size_t,

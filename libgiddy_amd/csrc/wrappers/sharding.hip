@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -27,6 +28,20 @@ struct ordering_event {
 	void record(hipStream_t stream) { cuda::throw_if_error(hipEventRecord(event, stream), "hipEventRecord"); }
 	void make_wait(hipStream_t stream) { cuda::throw_if_error(hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent"); }
 };
+
+/// `from`'s copies to and from `to` go device to device (over xGMI) rather than staged through the host: checked, and switched on — once;
+/// a second request is answered hipErrorPeerAccessAlreadyEnabled, which is success here.  Throws where the devices cannot reach each other.
+void enable_peer_access(int from, int to)
+{
+	if (from == to) { return; }
+	int can = 0;
+	cuda::throw_if_error(hipDeviceCanAccessPeer(&can, from, to), "hipDeviceCanAccessPeer");
+	if (!can) { throw cuda::runtime_error(hipErrorPeerAccessUnsupported, "device " + std::to_string(from) + " cannot access device " + std::to_string(to) + " directly: the gather would be staged through the host"); }
+	cuda::device::current::scoped_override_t<> on(from);
+	const hipError_t status = hipDeviceEnablePeerAccess(to, 0);
+	if (status == hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); return; }
+	cuda::throw_if_error(status, "hipDeviceEnablePeerAccess");
+}
 
 uint64_t anchor_value(const giddy_column_shape_t& shape, uint64_t index)
 {
@@ -224,11 +239,10 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 	cuda::launch_configuration_t config;
 	uint64_t config_for_length = ~(uint64_t) 0;
 	std::vector<size_t> offset(num_arguments, 0);
-	for (uint64_t c = 0; c < num_chunks; c++) {
-		const auto& shard = shards[c];
-		if (shard.length() == 0) { continue; }
-		hipStream_t stream = static_cast<hipStream_t>(streams[c % num_streams]);
-		// the chunk's slices of the bulk arrays, each 256-byte aligned within one block of the stream's scratch
+	// the chunk's slices of the bulk arrays, each 256-byte aligned within ONE block per stream, leased for the whole call: the chunks of a
+	// stream follow each other through it in stream order.  (The wrapper's own scratch — chained Delta tiles, finer anchors of long
+	// segments — is another block of the pool: neither waits for the other.)
+	auto slices_of = [&](const cuda::sharding::shard_t& shard) {
 		size_t total = 0;
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
@@ -237,11 +251,21 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 			offset[i] = total;
 			total += (slice.size() * r.itemsize + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of a slice's last chunk)
 		}
-		// (the stream's block for slices: the chunk this stream decoded last had it, in stream order.  The wrapper's own scratch — chained
-		// Delta tiles, finer anchors of long segments — is another block of the pool: neither waits for the other)
-		cuda::stream_scratch::lease block(stream);
-		if (!block.take(std::max<size_t>(total, 256))) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
-		char* base = static_cast<char*>(block.memory());
+		return total;
+	};
+	std::vector<size_t> most(num_streams, 256);
+	for (uint64_t c = 0; c < num_chunks; c++) { if (shards[c].length() != 0) { most[c % num_streams] = std::max(most[c % num_streams], slices_of(shards[c])); } }
+	std::vector<std::unique_ptr<cuda::stream_scratch::lease>> blocks;
+	for (size_t k = 0; k < num_streams && k < num_chunks; k++) {
+		blocks.emplace_back(new cuda::stream_scratch::lease(static_cast<hipStream_t>(streams[k])));
+		if (!blocks.back()->take(most[k])) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
+	}
+	for (uint64_t c = 0; c < num_chunks; c++) {
+		const auto& shard = shards[c];
+		if (shard.length() == 0) { continue; }
+		hipStream_t stream = static_cast<hipStream_t>(streams[c % num_streams]);
+		(void) slices_of(shard);   // (sets `offset`)
+		char* base = static_cast<char*>(blocks[c % num_streams]->memory());
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
 			giddy_argument_t& a = chunk_arguments[i];
@@ -309,6 +333,7 @@ int giddy_enqueue_gather_on_node(void* destination, int root_device, void* root_
 		for (size_t i = 0; i < num_shards; i++) {
 			if (bytes[i] != 0) {
 				if (shards[i] == nullptr) { throw std::invalid_argument("null shard"); }
+				enable_peer_access(devices[i], root_device);
 				cuda::throw_if_error(hipSetDevice(devices[i]), "hipSetDevice (a shard's device)");
 				const auto stream = static_cast<hipStream_t>(hip_streams[i]);
 				cuda::throw_if_error(hipMemcpyPeerAsync(at, root_device, shards[i], devices[i], bytes[i], stream), "hipMemcpyPeerAsync (a decoded shard to the root)");
@@ -323,6 +348,62 @@ int giddy_enqueue_gather_on_node(void* destination, int root_device, void* root_
 			at += bytes[i];
 		}
 		cuda::throw_if_error(hipSetDevice(current), "hipSetDevice (back)");
+	});
+}
+
+int giddy_enqueue_gather_compressed_on_node(const char* key, int root_device, void* const* root_streams, size_t num_root_streams,
+	const giddy_compressed_shard_t* shards, size_t num_shards)
+{
+	return guarded([&] {
+		if (key == nullptr || root_streams == nullptr || num_root_streams == 0 || (num_shards != 0 && shards == nullptr)) { throw std::invalid_argument("null key / streams / shards"); }
+		auto wrapper = cuda::registered::kernel_t::produceSubclass(key);
+		cuda::device::current::scoped_override_t<> on_root(root_device);
+		const auto properties = cuda::device::get(root_device).properties();
+		const auto attributes = wrapper->get_device_function().attributes();
+		for (size_t i = 0; i < num_shards; i++) {
+			const giddy_compressed_shard_t& shard = shards[i];
+			if (shard.num_arguments != 0 && (shard.arguments == nullptr || shard.bytes == nullptr)) { throw std::invalid_argument("a shard without arguments / sizes"); }
+			const auto root_stream = static_cast<hipStream_t>(root_streams[i % num_root_streams]);
+			const bool moves = shard.device != root_device || (shard.flags & GIDDY_SHARD_COPY_EVEN_IF_LOCAL) != 0;
+			// the root's stream waits for what the shard's device has enqueued on the shard's stream so far (its arrays being written, say)
+			{
+				cuda::device::current::scoped_override_t<> on_shard(shard.device);
+				ordering_event ready;
+				ready.record(static_cast<hipStream_t>(shard.hip_stream));
+				ready.make_wait(root_stream);
+			}
+			std::vector<giddy_argument_t> arguments(shard.arguments, shard.arguments + shard.num_arguments);
+			// the compressed arrays cross their link ONCE, into scratch of the root's stream (the next shard on this stream gets the same block,
+			// in stream order), and are decoded from there
+			cuda::stream_scratch::lease block(root_stream);
+			if (moves) {
+				enable_peer_access(root_device, shard.device);
+				size_t total = 0;
+				std::vector<size_t> offset(shard.num_arguments, 0);
+				for (size_t a = 0; a < shard.num_arguments; a++) {
+					if (shard.bytes[a] == 0) { continue; }
+					offset[a] = total;
+					total += (size_t) (shard.bytes[a] + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of an array's last chunk)
+				}
+				if (total != 0 && !block.take(total)) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory on the root for a compressed shard"); }
+				for (size_t a = 0; a < shard.num_arguments; a++) {
+					if (shard.bytes[a] == 0) { continue; }
+					char* at = static_cast<char*>(block.memory()) + offset[a];
+					cuda::throw_if_error(hipMemcpyPeerAsync(at, root_device, arguments[a].value.pointer, shard.device, (size_t) shard.bytes[a], root_stream), "hipMemcpyPeerAsync (a compressed array to the root)");
+					arguments[a].value.pointer = at;
+				}
+			}
+			const auto map = giddy_internal::to_map(arguments.data(), arguments.size());
+			const auto resolution = giddy_internal::to_map(shard.resolution_arguments, shard.num_resolution_arguments);
+			const auto config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+			wrapper->enqueue_launch_with(root_stream, config, map);
+		}
+		// the first root stream runs on only when the others have made their last launch: work enqueued on it afterwards sees the whole column
+		for (size_t k = 1; k < num_root_streams && k < num_shards; k++) {
+			ordering_event done;
+			done.record(static_cast<hipStream_t>(root_streams[k]));
+			done.make_wait(static_cast<hipStream_t>(root_streams[0]));
+		}
 	});
 }
 

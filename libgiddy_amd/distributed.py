@@ -105,3 +105,32 @@ def gather_compressed(shard_fields, shard_function, decode, out, counts, dst=0, 
             if stop > start:
                 decode(fields, out[offsets[r] + start: offsets[r] + stop])
     return received, (total - int(counts[dst])) * out.element_size()
+
+
+def gather_compressed_on_node(key, root_device, root_streams, shards):
+    """giddy_enqueue_gather_compressed_on_node (include/giddy.h): ONE process driving every device of a node — the compressed twin of
+    giddy_enqueue_gather_on_node, and the one-process counterpart of gather_compressed above.  `shards`: a list of dicts
+        device        where the shard's compressed arrays lie
+        stream        a stream of that device (hipStream_t as an integer) behind whose work the arrays are complete
+        arguments     the wrapper's launch arguments for the shard, name -> libgiddy_amd.registered typed value ("decompressed" points INTO the
+                      contiguous buffer on the root)
+        nbytes        name -> bytes of each array that travels (the others stay where they point)
+        resolution    name -> size_t values for launch-configuration resolution
+        copy_even_if_local   copy into the root's scratch even when device == root_device (tests on one GPU)
+    Everything is enqueued; nothing is waited for.  root_streams[0] sees the whole column once it has run."""
+    import ctypes
+    from . import _native
+    from .registered import _marshal, _check
+    c_shards = (_native.giddy_compressed_shard * max(len(shards), 1))()
+    keep = []
+    for slot, shard in zip(c_shards, shards):
+        arguments, kept = _marshal(shard["arguments"])
+        resolution, kept_too = _marshal(shard["resolution"])
+        nbytes = (ctypes.c_uint64 * max(len(shard["arguments"]), 1))(*[int(shard["nbytes"].get(name, 0)) for name in shard["arguments"]])
+        keep += [arguments, kept, resolution, kept_too, nbytes]
+        slot.device, slot.flags = int(shard["device"]), 1 if shard.get("copy_even_if_local") else 0
+        slot.hip_stream = ctypes.c_void_p(int(shard["stream"]) if shard["stream"] else None)
+        slot.arguments, slot.bytes, slot.num_arguments = arguments, nbytes, len(shard["arguments"])
+        slot.resolution_arguments, slot.num_resolution_arguments = resolution, len(shard["resolution"])
+    handles = (ctypes.c_void_p * len(root_streams))(*[int(s) if s else None for s in root_streams])
+    _check(_native.lib.giddy_enqueue_gather_compressed_on_node(key.encode(), int(root_device), handles, len(root_streams), c_shards, len(shards)))

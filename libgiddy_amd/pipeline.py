@@ -226,7 +226,8 @@ def decode_from_host_native(scheme, host_fields, out_dev, *, num_chunks=16, dept
     name = _NATIVE_SCHEMES.get(scheme) or ("run_position_encoding_relative" if instantiation.get("relative", True) else "run_position_encoding_absolute")
     if "position_anchors" in host_fields:
         anchors = host_fields["position_anchors"]
-        shape.position_anchors = anchors.data_ptr() if isinstance(anchors, torch.Tensor) else np.ascontiguousarray(anchors).ctypes.data
+        contiguous_anchors = anchors if isinstance(anchors, torch.Tensor) else np.ascontiguousarray(anchors)   # (alive until the C call has returned)
+        shape.position_anchors = contiguous_anchors.data_ptr() if isinstance(anchors, torch.Tensor) else contiguous_anchors.ctypes.data
         shape.anchor_itemsize = _itemsize(anchors)
         shape.num_anchors = len(anchors)
     streams = [torch.cuda.Stream(device=out_dev.device) for _ in range(depth)]

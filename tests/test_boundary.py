@@ -167,3 +167,37 @@ def test_occupancy_throttle_is_an_lds_reservation_a_caller_can_refuse():
     d = schemes.kernel(schemes.key_dictionary(4, 4, 1))
     config = d.resolve_launch_configuration(r.NOMINAL_MI355X, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(1 << 24)}, None)
     assert config.dynamic_shared_memory_size == 26624   # (1 KiB of dictionary + the occupancy throttle's padding: 6 workgroups per CU)
+
+
+def test_every_build_of_a_run_decoder_accepts_the_configuration_resolved_for_the_base_kernel():
+    """get_device_function() of the run-length / run-position wrappers names `decompress` — the kernel of the reference's signature — while
+    their typed launch may run `decompress_sparse_runs`, `decompress_dense_runs` or `decompress_relative_with_finer_anchors` with the
+    configuration the caller resolved.  Read from the code objects' metadata, without a GPU: every such build accepts at
+    least the workgroup sizes the base kernel accepts, and its static LDS leaves the base kernel's dynamic LDS room — so a configuration
+    that is valid for the base kernel launches whichever build is picked.  (At run time the wrappers go further: attributes() merges all builds'
+    limits — tests/test_gpu_modes.py.)"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import code_object_metadata
+    kernels = code_object_metadata.kernels_of(os.path.join(ROOT, "libgiddy_amd", "libgiddy_amd.so"))
+    assert len(kernels) > 500, len(kernels)
+    families = 0
+    for name, base in kernels.items():
+        m = re.match(r"void cuda::kernels::decompression::(run_length_encoding|run_position_encoding)::decompress<([^>]*)>\(", name)
+        if not m:
+            continue
+        scheme, arguments = m.groups()
+        builds = ["decompress_sparse_runs<%s>" % arguments, "decompress_dense_runs<%s>" % arguments]
+        parts = [a.strip() for a in arguments.split(",")]
+        if scheme == "run_position_encoding" and parts[3] == "true":
+            builds.append("decompress_relative_with_finer_anchors<%s>" % ", ".join(parts[:3] + parts[4:]))
+        for build in builds:
+            prefix = "void cuda::kernels::decompression::%s::%s(" % (scheme, build)
+            found = [record for other, record in kernels.items() if other.startswith(prefix)]
+            assert len(found) == 1, (prefix, len(found))
+            alternate = found[0]
+            assert alternate["max_flat_workgroup_size"] >= base["max_flat_workgroup_size"], (name, build)
+            assert alternate["group_segment_fixed_size"] <= 65536 - 24576, (build, alternate["group_segment_fixed_size"])   # (room for the resolver's largest LDS reservation)
+            assert alternate["private_segment_fixed_size"] == 0, (build, "scratch memory: the build spills vector registers")
+        families += 1
+    assert families == 28, families   # 18 run-length + 10 run-position registrations

@@ -298,3 +298,89 @@ def test_gather_on_node_through_the_c_abi():
     root.synchronize()
     expect = torch.cat(shards)
     assert bool((out == expect).all()) and int(total) == int(expect.sum())
+
+
+@pytest.mark.parametrize("num_chunks,depth", [(3, 2), (8, 3)])
+def test_native_pipeline_with_long_segments(num_chunks, depth):
+    """giddy_decode_from_host over columns whose wrappers take scratch of their OWN inside a chunk (round-3 advisor): chained Delta tiles
+    (segments of 2^18), finer anchors for run decoders (segments of 65 536) and for discard-zero-bytes (segments of 4096) — the chunk's
+    slices and the wrapper's scratch are two blocks of the pool (include/giddy/stream_scratch.hpp), neither waits for the other, and the
+    pool does not grow from one chunk of a stream to the next."""
+    from libgiddy_amd import pipeline, registered
+    n = 1 << 21
+
+    def check(scheme, fields, truth, **extra):
+        out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
+        out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
+        pinned = pipeline.pin(fields)
+        for repetition in range(2):
+            for s in pipeline.decode_from_host_native(scheme, pinned, out, num_chunks=num_chunks, depth=depth, **extra):
+                s.synchronize()
+            if repetition == 0:
+                held = registered.scratch_held_bytes()
+        assert registered.scratch_held_bytes() == held, "the second pass over the same column on the same streams allocated scratch again"
+        del pinned
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
+
+    f, truth = cases.delta_case(n, 1 << 18, np.uint64, np.uint16, seed=13)
+    check("delta", f, truth)
+    col = cases.runs_column(n, 32, np.uint32, seed=15)
+    check("run_length_encoding", formats.run_length_encoding(col, 65536, np.uint16), col)
+    check("run_position_encoding", formats.run_position_encoding(col, 65536, np.uint16, True), col, relative=True)
+    check("run_position_encoding", formats.run_position_encoding(col, 65536, np.uint32, False), col, relative=False)
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 2, seed=14)
+    check("discard_zero_bytes_variable", formats.discard_zero_bytes_variable(col, 4096, 1, 2, np.uint32, 8, element_sizes=sizes), col)
+
+
+def test_gather_compressed_on_node_through_the_c_abi():
+    """giddy_enqueue_gather_compressed_on_node with every "device" being device 0: three COMPRESSED shards of a discard-zero-bytes column and of
+    a run-length column, each complete behind work on its own stream, are copied into the root's scratch (the copy is forced although the
+    shards are local), decoded there into their ranges of one buffer, and the first root stream sees the whole column."""
+    from libgiddy_amd import distributed, registered as r, schemes
+    n, world = 300000 + 77, 3
+    root_streams = [torch.cuda.Stream() for _ in range(2)]
+
+    def on_device(fields, stream):
+        with torch.cuda.stream(stream):
+            return {k: (torch.from_numpy(np.ascontiguousarray(v).reshape(-1).view(np.uint8).copy()).cuda(non_blocking=True) if isinstance(v, np.ndarray) else v) for k, v in fields.items()}
+
+    def gather(key, shard_function, fields, truth, arguments_of, resolution_of):
+        out = torch.full((len(truth) * truth.dtype.itemsize,), 0x5A, dtype=torch.uint8, device="cuda")
+        shards, keep = [], []
+        for rank in range(world):
+            sh = shard_function(fields, rank, world)
+            stream = torch.cuda.Stream()
+            device_fields = on_device(sh.fields, stream)
+            keep.append((stream, device_fields))
+            arguments, nbytes = arguments_of(out[sh.start * truth.dtype.itemsize:], device_fields, sh.fields)
+            shards.append({"device": 0, "stream": stream.cuda_stream, "arguments": arguments, "nbytes": nbytes,
+                           "resolution": resolution_of(sh.fields), "copy_even_if_local": True})
+        distributed.gather_compressed_on_node(key, 0, [s.cuda_stream for s in root_streams], shards)
+        with torch.cuda.stream(root_streams[0]):
+            got = out.clone()
+        root_streams[0].synchronize()
+        got = got.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (key, np.flatnonzero(got != truth)[:5])
+
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 2, seed=24)
+    f = formats.discard_zero_bytes_variable(col, 1024, 1, 2, np.uint32, 8, element_sizes=sizes)
+
+    def dzbv_arguments(out, d, s):
+        arguments = {"decompressed": r.pointer(out, "u64"), "compressed_data": r.const_pointer(d["compressed_data"], "u8"),
+                     "packed_element_sizes": r.const_pointer(d["packed_element_sizes"], "u32"), "position_anchors": r.const_pointer(d["position_anchors"], "u64"),
+                     "segment_length": r.uint64(1024), "length": r.uint64(s["length"]), "min_represented_element_size": r.uint32(1), "bits_per_element_size": r.uint32(2)}
+        return arguments, {k: d[k].numel() for k in ("compressed_data", "packed_element_sizes", "position_anchors")}
+    gather(schemes.key_discard_zero_bytes_variable(8, 8, 4), sharding.discard_zero_bytes_variable, f, col, dzbv_arguments,
+           lambda s: {"length": r.size_t(s["length"]), "segment_length": r.size_t(1024)})
+
+    col = cases.runs_column(n, 32, np.uint32, seed=25)
+    f = formats.run_length_encoding(col, 4096, np.uint16)
+
+    def rle_arguments(out, d, s):
+        arguments = {"decompressed": r.pointer(out, "u32"), "run_data": r.const_pointer(d["run_data"], "u32"), "run_lengths": r.const_pointer(d["run_lengths"], "u16"),
+                     "position_anchors": r.const_pointer(d["position_anchors"], "u32"), "intra_run_anchor_offsets": r.const_pointer(d["intra_run_anchor_offsets"], "u16"),
+                     "segment_length": r.uint32(4096), "num_segments": r.uint32(s["num_segments"]), "num_element_runs": r.uint32(s["num_element_runs"]), "length": r.uint32(s["length"])}
+        return arguments, {k: d[k].numel() for k in ("run_data", "run_lengths", "position_anchors", "intra_run_anchor_offsets")}
+    gather(schemes.key_run_length_encoding(4, 4, 2, 4), sharding.run_length_encoding, f, col, rle_arguments,
+           lambda s: {"length": r.size_t(s["length"]), "segment_length": r.size_t(4096)})

@@ -52,7 +52,12 @@ int main()
 	const double by_handle = microseconds_per_call([&] { (void) giddy_enqueue_prepared(prepared, stream, &config); }, calls);
 	giddy_argument_t moved[2] = { arguments[0], arguments[1] };
 	const double by_handle_updated = microseconds_per_call([&] { (void) giddy_prepared_update(prepared, moved, 2); (void) giddy_enqueue_prepared(prepared, stream, &config); }, calls);
+	hipEvent_t event;
+	(void) hipEventCreateWithFlags(&event, hipEventDisableTiming);
+	const double record = microseconds_per_call([&] { (void) hipEventRecord(event, stream); }, calls);
+	const double query = microseconds_per_call([&] { (void) hipEventQuery(event); }, calls);
 	std::printf("host time per enqueued launch, %d asynchronous launches each (C, one thread):\n", calls);
+	std::printf("  hipEventRecord (what giving a scratch block back to the pool costs) / hipEventQuery  %6.2f / %.2f us\n", record, query);
 	std::printf("  hipLaunchKernel of an empty kernel (the floor)                                  %6.2f us\n", floor);
 	std::printf("  giddy_enqueue_launch  (5 tagged arguments -> map -> wrapper -> hipLaunchKernel)   %6.2f us  (+%.2f over the floor)\n", by_map, by_map - floor);
 	std::printf("  giddy_enqueue_prepared (map kept; nothing copied)                               %6.2f us  (+%.2f)\n", by_handle, by_handle - floor);

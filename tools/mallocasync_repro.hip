@@ -31,7 +31,7 @@ int main(int argc, char** argv)
 	std::vector<unsigned*> patterns(num_streams);
 	unsigned long long* mismatches;
 	OK(hipMalloc(&mismatches, sizeof *mismatches)); OK(hipMemset(mismatches, 0, sizeof *mismatches));
-	for (int s = 0; s < num_streams; s++) { OK(hipStreamCreateWithFlags(&streams[s], hipStreamNonBlocking)); OK(hipHostMalloc(&patterns[s], most_words * 4, hipHostMallocDefault)); }
+	for (int s = 0; s < num_streams; s++) { OK(hipStreamCreateWithFlags(&streams[s], hipStreamNonBlocking)); OK(hipHostMalloc(&patterns[s], (most_words + 4096) * 4, hipHostMallocDefault)); }
 	unsigned long long seed = 12345;
 	for (int it = 0; it < iterations; it++) {
 		const int s = it % num_streams;

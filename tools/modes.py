@@ -55,11 +55,14 @@ def _check(status):
 
 # per scheme: (shim name, arguments of modes_launch_* after (mode, stream, config) from the column's fields, mode-A call)
 def _delta(name):
+    uncompressed_size, compressed_size = int(name.split("_")[2]), int(name.split("_")[3])
+
     def arguments(out, f):
         return [_p(out), _p(f["compressed_input"]), _p(f["anchor_values"]), _u64(f["length"]), _u64(f["segment_length"])]
 
     def mode_a(out, f, stream, config):
-        return schemes.delta(out, f["compressed_input"], f["anchor_values"], f["length"], f["segment_length"], stream=stream, launch_config=config)
+        return schemes.delta(out, f["compressed_input"], f["anchor_values"], f["length"], f["segment_length"],
+                             uncompressed_size=uncompressed_size, compressed_size=compressed_size, stream=stream, launch_config=config)
     return name, arguments, mode_a
 
 
