@@ -330,6 +330,8 @@ const device_function_t kernel_t<I, A>::get_device_function() const { return rei
 // ---- run-length and run-position encoding ------------------------------------------------------------------------------------
 namespace run_length_encoding {
 
+/// ("chain_patience" uint32_t, "chain_fault_tile" uint64_t — optional: how long a tile waits for the tiles before it, and a tile that plays dead for
+/// a test; a chain that breaks leaves 2^64 - 1 in "num_element_runs": kernels/compression/chained.hpp, "Progress")
 /// outputs "run_data", "run_lengths" (room for "capacity" runs — optional size_t, default `length`, the worst case; runs beyond it are
 /// counted but not stored), "position_anchors", "intra_run_anchor_offsets", "num_element_runs" uint64_t* (device scalar, written: the TRUE
 /// number of runs, so a caller who guessed too low can tell); scratch "tile_totals" (scratch_entries(length) entries).  ONE launch:
@@ -367,7 +369,9 @@ void kernel_t<I, U, RL, RI>::enqueue_launch_with(stream::id_t stream, const laun
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>), stream, chained_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"), num_runs,
-		input, totals, totals + num_tiles, segment, length, max_run_length, capacity);
+		input, totals, totals + num_tiles, segment, length, max_run_length, capacity,
+		optional_argument<uint32_t>(arguments, "chain_patience").value_or((uint32_t) chained::default_patience),
+		optional_argument<uint64_t>(arguments, "chain_fault_tile").value_or(chained::no_fault_tile));
 }
 
 template <unsigned I, unsigned U, unsigned RL, unsigned RI>
@@ -409,7 +413,9 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch_with(stream::id_t stream, const la
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, chained_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint64_t*>(arguments, "num_element_runs"), input, totals, segment, length,
-		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));
+		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length),
+		optional_argument<uint32_t>(arguments, "chain_patience").value_or((uint32_t) chained::default_patience),
+		optional_argument<uint64_t>(arguments, "chain_fault_tile").value_or(chained::no_fault_tile));
 }
 
 template <unsigned I, unsigned U, unsigned P, bool R, unsigned RI>

@@ -106,24 +106,41 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	launch_configuration_t launch_config = resolved_launch_config;
 	if (dense) { launch_config.dynamic_shared_memory_size = 0; }
 	stream_scratch::lease scratch(stream);
-	// (the pass over the lengths costs 2 x their bytes: at mean runs below 8 it only pays where segments are so long that the chip is not filled)
-	const bool worth_it = runs != 0 && (n / runs >= 8 || L >= 16 * (uint64_t) fine::sub);
-	if (n > 0 && runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && worth_it && memory_access::is_aligned(run_lengths, 16)) {
+	const auto& environment = run_expansion::fine_environment::get();
+	if (n > 0 && runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && memory_access::is_aligned(run_lengths, 16) && n / runs >= environment.min_mean_run) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
 		const uint64_t tiles = util::div_rounding_up(runs, (uint64_t) fine::runs_per_tile), blocks = util::div_rounding_up(runs, (uint64_t) fine::runs_per_block);
-		const size_t anchors_at = (tiles + blocks) * sizeof(uint64_t), offsets_at = util::round_up(anchors_at + num_fine * sizeof(run_index_type), (size_t) 16);
-		if (num_fine <= std::numeric_limits<size_type>::max() && scratch.take(offsets_at + num_fine * sizeof(run_length_type))) {
-			auto* tile_starts = static_cast<uint64_t*>(scratch.memory());
-			auto* block_totals = tile_starts + tiles;
+		// The pre-pass (kernels/decompression/run_anchors.hpp).  Three launches — sums of every 64 lengths, a scan, a search per finer anchor — read
+		// the lengths twice, in parallel over the whole column: at mean runs below 8 that only pays where segments are so long that the chip is
+		// not filled.  ONE launch — a workgroup per segment scanning the segment's lengths once — is a chain of memory round trips per
+		// workgroup: the faster of the two where all workgroups are resident at once or nearly (at most 8192 segments: what an eighth of a
+		// 2^30-output column, or a whole 2^28 one, has in segments of 32 768 or more) and runs are long (profiles/r04_run_prepass.txt:
+		// 2^28 outputs, mean run 32, segments of 32 768 / 65 536: 68.7 / 70.5-71.5 % against 66.7 / 66.4 %; at 2^30 the three launches win by 1-4 points).
+		const uint64_t segments = util::div_rounding_up(n, L);
+		const bool one_launch = environment.one_launch && (environment.force_one_launch
+			|| (sparse && L >= 4 * (uint64_t) fine::sub && segments <= fine::most_segments_for_one_launch && runs / segments <= fine::most_runs_per_segment_for_one_launch));
+		const bool worth_it = environment.force || one_launch || n / runs >= 8 || L >= 16 * (uint64_t) fine::sub;
+		const size_t sums_bytes = one_launch ? 0 : (tiles + blocks) * sizeof(uint64_t);
+		const size_t anchors_at = sums_bytes, offsets_at = util::round_up(anchors_at + num_fine * sizeof(run_index_type), (size_t) 16);
+		if (worth_it && num_fine <= std::numeric_limits<size_type>::max() && scratch.take(offsets_at + num_fine * sizeof(run_length_type))) {
 			auto* finer_anchors = reinterpret_cast<run_index_type*>(static_cast<char*>(scratch.memory()) + anchors_at);
 			auto* finer_offsets = reinterpret_cast<run_length_type*>(static_cast<char*>(scratch.memory()) + offsets_at);
-			const launch_configuration_t per_block((grid_dimension_t) std::min<uint64_t>(blocks, 1u << 16), fine::threads);
-			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::sum_run_lengths<RunLengthSize>), stream, per_block, tile_starts, block_totals, run_lengths, runs);
-			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::scan_tiles<>), stream, per_block, tile_starts, static_cast<const uint64_t*>(block_totals), runs);
-			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_from_sums<RunLengthSize, RunIndexSize>), stream,
-				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) fine::threads), 1u << 16), fine::threads),
-				finer_anchors, finer_offsets, static_cast<const uint64_t*>(tile_starts), run_lengths, position_anchors, intra_run_anchor_offsets,
-				L, (uint64_t) num_segments, runs, n);
+			if (one_launch) {
+				cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_of_segments<RunLengthSize, RunIndexSize>), stream,
+					launch_configuration_t((grid_dimension_t) std::min<uint64_t>(num_segments, 1u << 20), fine::threads),
+					finer_anchors, finer_offsets, run_lengths, position_anchors, intra_run_anchor_offsets, L, (uint64_t) num_segments, runs, n);
+			}
+			else {
+				auto* tile_starts = static_cast<uint64_t*>(scratch.memory());
+				auto* block_totals = tile_starts + tiles;
+				const launch_configuration_t per_block((grid_dimension_t) std::min<uint64_t>(blocks, 1u << 16), fine::threads);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(fine::sum_run_lengths<RunLengthSize>), stream, per_block, tile_starts, block_totals, run_lengths, runs);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(fine::scan_tiles<>), stream, per_block, tile_starts, static_cast<const uint64_t*>(block_totals), runs);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_from_sums<RunLengthSize, RunIndexSize>), stream,
+					launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) fine::threads), 1u << 16), fine::threads),
+					finer_anchors, finer_offsets, static_cast<const uint64_t*>(tile_starts), run_lengths, position_anchors, intra_run_anchor_offsets,
+					L, (uint64_t) num_segments, runs, n);
+			}
 			auto config = launch_config;
 			const size_t wavefronts_per_block = std::max<size_t>(1, std::min<size_t>(launch_config.block_dimensions.x / warp_size, run_expansion::max_waves_per_block));
 			config.grid_dimensions.x = (grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(num_fine, (uint64_t) wavefronts_per_block), 1u << 20);

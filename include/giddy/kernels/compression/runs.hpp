@@ -168,7 +168,9 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	uint64_t*                        __restrict__  states,
 	size_type_by_index_size<IndexSize>             segment_length,
 	size_type_by_index_size<IndexSize>             length,
-	uint64_t                                       capacity)   // runs the per-run arrays have room for: runs beyond it are counted, not stored
+	uint64_t                                       capacity,   // runs the per-run arrays have room for: runs beyond it are counted, not stored
+	uint32_t                                       patience,   // polls a tile waits for the tiles before it (chained.hpp, "Progress")
+	uint64_t                                       fault_tile) // chained::no_fault_tile; a test's tile that plays dead
 {
 	using T = uint_t<UncompressedSize>;
 	using S = shape<UncompressedSize>;
@@ -179,6 +181,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	const uint64_t n = length, L = segment_length, num_tiles = (n + tile - 1) / tile;
 	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
 	for (uint64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+		if (t == fault_tile) { return; }   // (a test: this tile is never heard of)
 		const uint64_t wave_base = t * tile + (uint64_t) wave * wave_elements;
 #ifdef GIDDY_CHAINED_STAMPS   // (measurements: when a tile started, had counted, knew its base, was done — 100 MHz ticks, behind the states)
 		uint64_t* const stamps = states + num_tiles + 4 * t;
@@ -230,7 +233,8 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-		const uint64_t tile_base = chained::exclusive_base(states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // runs that start before the tile (barriers inside: the staging is complete)
+		const uint64_t tile_base = chained::exclusive_base(states, t, num_tiles, tile_total, &slot, num_element_runs, true, patience);   // runs that start before the tile (barriers inside: the staging is complete)
+		if (tile_base == chained::failed_base) { return; }   // (the chain broke before this tile: every thread sees it; the last tile has said so in *num_element_runs)
 		const uint64_t base = tile_base + wave_before;   // ... before this wavefront's elements
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[2] = __builtin_amdgcn_s_memrealtime(); }
@@ -289,7 +293,9 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	size_type_by_index_size<IndexSize>             segment_length,
 	size_type_by_index_size<IndexSize>             length,
 	uint64_t                                       max_run_length,
-	uint64_t                                       capacity)   // pieces run_data / run_lengths have room for
+	uint64_t                                       capacity,   // pieces run_data / run_lengths have room for
+	uint32_t                                       patience,   // polls a tile waits for the tiles before it (chained.hpp, "Progress")
+	uint64_t                                       fault_tile) // chained::no_fault_tile; a test's tile that plays dead
 {
 	using T = uint_t<UncompressedSize>;
 	using S = shape<UncompressedSize>;
@@ -301,6 +307,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	const uint64_t n = length, L = segment_length, M = max_run_length, num_tiles = (n + tile - 1) / tile;
 	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
 	for (uint64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
+		if (t == fault_tile) { return; }   // (a test: this tile is never heard of)
 		const uint64_t tile_begin = t * tile, wave_base = tile_begin + (uint64_t) wave * wave_elements;
 #ifdef GIDDY_CHAINED_STAMPS   // (measurements: started / scanned for starts / knows what reaches in / counted / knows its base / done — behind the states)
 		uint64_t* const stamps = count_states + num_tiles + 6 * t;
@@ -348,21 +355,29 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 				if (in_tile == 0 && lane == 0) { chained::publish(start_states, t, 0, chained::aggregate); }
 				uint64_t end = t;
 				bool found = false;
-				while ((chained::peek(start_states, t - 1) & chained::flag_mask) == chained::nothing) { __builtin_amdgcn_s_sleep(8); }   // (one word first: chained.hpp)
-				while (!found) {
+				uint32_t polls = 0;
+				bool broken = !chained::wait_for(start_states, t - 1, polls, patience);   // (one word first: chained.hpp)
+				while (!found && !broken) {
 					const uint64_t word = lane < end ? chained::peek(start_states, end - 1 - lane) : (uint64_t) chained::inclusive;   // (before the column: start 0)
-					const uint64_t known = wave64::ballot((word & chained::flag_mask) == chained::inclusive), silent = wave64::ballot((word & chained::flag_mask) == chained::nothing);
+					const uint64_t flag = word & chained::flag_mask;
+					const uint64_t known = wave64::ballot(flag == chained::inclusive), silent = wave64::ballot(flag == chained::nothing || flag == chained::failed);
 					const unsigned first_known = known != 0 ? (unsigned) __builtin_ctzll(known) : 64u, first_silent = silent != 0 ? (unsigned) __builtin_ctzll(silent) : 64u;
 					if (first_known < first_silent) { reaching_in = wave64::read_lane(word, first_known) >> 2; found = true; }
 					else if (first_silent == 64u) { end -= 64; }   // 64 tiles without a start, none of which knows yet: further back
+					else if ((wave64::read_lane(word, first_silent) & chained::flag_mask) == chained::failed || ++polls > patience) { broken = true; }   // a tile before this one gave up, or is not heard of
 					else { __builtin_amdgcn_s_sleep(2); }
 				}
-				if (in_tile == 0 && lane == 0) { chained::publish(start_states, t, reaching_in, chained::inclusive); }
+				if (broken) { reaching_in = chained::failed_base; if (lane == 0) { chained::publish(start_states, t, 0, chained::failed); } }
+				else if (in_tile == 0 && lane == 0) { chained::publish(start_states, t, reaching_in, chained::inclusive); }
 			}
 			if (lane == 0) { inherited = reaching_in; }
 		}
 		__syncthreads();
 		const uint64_t start_before_tile = inherited;
+		if (start_before_tile == chained::failed_base) {   // the chain of run starts broke: this tile gives up in the chain of counts as well (every thread takes this way)
+			if (threadIdx.x == 0) { chained::give_up(count_states, t, num_tiles, num_element_runs); }
+			return;
+		}
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[2] = __builtin_amdgcn_s_memrealtime(); }
 #endif
@@ -459,7 +474,8 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			if (window_first != 0) { __syncthreads(); }   // (the window before has been copied out)
 			stage_window(window_first);
 			if (window_first == 0) {
-				tile_base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs, true);   // (barriers inside: the window is complete)
+				tile_base = chained::exclusive_base(count_states, t, num_tiles, tile_total, &slot, num_element_runs, true, patience);   // (barriers inside: the window is complete)
+				if (tile_base == chained::failed_base) { return; }   // (the chain broke before this tile: every thread sees it)
 #ifdef GIDDY_CHAINED_STAMPS
 				if (threadIdx.x == 0) { stamps[4] = __builtin_amdgcn_s_memrealtime(); }
 #endif

@@ -62,6 +62,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_NARROW_CHUNK_BYTES
 #define GIDDY_RUN_NARROW_CHUNK_BYTES 8192   // output a wavefront of a 1-byte column takes per trip when segments are at least a tile long (two segments of 4096: +2-5 points for RLE, 16384: mixed; not for relative run positions: -15)
 #endif
+#ifndef GIDDY_RUN_WIDE_CHUNK_BYTES
+#define GIDDY_RUN_WIDE_CHUNK_BYTES 0   // output a wavefront of a 4- or 8-byte column takes per trip when segments are at least a tile long (0: one segment)
+#endif
 #ifndef GIDDY_RUN_ROW_PADDING
 #define GIDDY_RUN_ROW_PADDING 1   // rows of a tile begin on 512-byte boundaries of the output (expand)
 #endif

@@ -36,7 +36,8 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 	// (1-byte columns: a tile is 4 KiB of output, and a wavefront that lives for one of them spends its life on its first loads — several
 	// segments in a row, entered once: GIDDY_RUN_NARROW_CHUNK_BYTES of output per trip)
 	if (segment_length >= run_expansion::tile_length) {
-		const uint64_t fit = element_size == 1 ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length : 1;
+		const uint64_t fit = element_size == 1 ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length
+			: element_size >= 4 ? (uint64_t) GIDDY_RUN_WIDE_CHUNK_BYTES / (segment_length * element_size) : 1;
 		return fit > 1 ? fit : 1;
 	}
 	// (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile — 52 -> 66 % at 3000)

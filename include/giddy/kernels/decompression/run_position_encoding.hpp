@@ -36,7 +36,8 @@ namespace detail {
 __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, bool positions_are_relative, unsigned element_size = 4)
 {
 	if (segment_length >= run_expansion::tile_length) {   // (1-byte columns: run_length_encoding.hpp)
-		const uint64_t fit = element_size == 1 && !positions_are_relative ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length : 1;   // (relative positions: a search over the chunk's anchors per candidate costs more than the trip saves)
+		const uint64_t fit = element_size == 1 && !positions_are_relative ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length   // (relative positions: a search over the chunk's anchors per candidate costs more than the trip saves)
+			: element_size >= 4 ? (uint64_t) GIDDY_RUN_WIDE_CHUNK_BYTES / (segment_length * element_size) : 1;
 		return fit > 1 ? fit : 1;
 	}
 	uint64_t fit = run_expansion::tile_length / segment_length;

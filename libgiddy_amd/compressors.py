@@ -193,7 +193,33 @@ class CapacityExceeded(ValueError):
         self.needed = needed
 
 
-def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None):
+class ChainBroken(RuntimeError):
+    """a one-launch compressor's tiles wait for the tiles before them (kernels/compression/chained.hpp); a tile that is not heard of within its
+    patience gives up, every later tile with it, and the count the kernel leaves is 2^64 - 1: nothing was compressed, nothing hangs"""
+
+
+def _chain_arguments(chain):
+    """`chain`: None, or {"patience": polls, "fault_tile": t} (tests: a short patience, a tile that plays dead)"""
+    if not chain:
+        return {}
+    out = {}
+    if "patience" in chain:
+        out["chain_patience"] = r.uint32(chain["patience"])
+    if "fault_tile" in chain:
+        out["chain_fault_tile"] = r.uint64(chain["fault_tile"])
+    return out
+
+
+def _count_of(runs, capacity):
+    count = int(runs[0])
+    if count == -1:   # (2^64 - 1 in the device scalar)
+        raise ChainBroken("the chain of tiles broke: a tile was not heard of within its patience (kernels/compression/chained.hpp)")
+    if count > capacity:
+        raise CapacityExceeded("runs", count, capacity)
+    return count
+
+
+def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None, chain=None):
     """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case).  The kernels are told, store nothing
     beyond it and still report the true number of runs: CapacityExceeded carries it."""
     n, usize, lsize = column.numel(), column.element_size(), _size(run_length_dtype)
@@ -211,16 +237,14 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
                  "intra_run_anchor_offsets": r.pointer(buffers["intra_run_anchor_offsets"], "u%d" % (8 * lsize)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
                  "tile_totals": r.pointer(_scratch(n, device), "u64"),
-                 "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity)})
-    count = int(runs[0])
-    if count > capacity:
-        raise CapacityExceeded("runs", count, capacity)
+                 "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain)})
+    count = _count_of(runs, capacity)
     return {"run_data": buffers["run_data"][:count], "run_lengths": buffers["run_lengths"][:count], "position_anchors": buffers["position_anchors"],
             "intra_run_anchor_offsets": buffers["intra_run_anchor_offsets"], "segment_length": segment_length, "num_segments": nseg,
             "num_element_runs": count, "length": n}
 
 
-def run_position_encoding(column, segment_length, position_dtype=np.uint16, relative=True, index_size=4, capacity=None):
+def run_position_encoding(column, segment_length, position_dtype=np.uint16, relative=True, index_size=4, capacity=None, chain=None):
     n, usize, psize = column.numel(), column.element_size(), _size(position_dtype)
     device = column.device
     capacity = capacity or max(n, 1)
@@ -234,10 +258,8 @@ def run_position_encoding(column, segment_length, position_dtype=np.uint16, rela
                 {"run_data": r.pointer(buffers["run_data"], "u%d" % (8 * usize)), "run_start_positions": r.pointer(buffers["run_start_positions"], "u%d" % (8 * psize)),
                  "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
-                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity)})
-    count = int(runs[0])
-    if count > capacity:
-        raise CapacityExceeded("runs", count, capacity)
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain)})
+    count = _count_of(runs, capacity)
     return {"run_data": buffers["run_data"][:count], "run_start_positions": buffers["run_start_positions"][:count], "position_anchors": buffers["position_anchors"],
             "segment_length": segment_length, "num_anchors": nseg, "num_element_runs": count, "length": n}
 

@@ -1,11 +1,15 @@
 """-m gpu: the device-side compressors (libgiddy_amd.compressors -> C ABI -> HIP kernels under
 include/giddy/kernels/compression/) against the numpy format writers (libgiddy_amd.formats): every output array equal BYTE FOR
 BYTE, every size equal; then the round trip — what the library compressed, the library's decoders turn back into the column."""
+import os
+
 import numpy as np
 import pytest
 
 import cases
 from libgiddy_amd import formats
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
@@ -331,3 +335,35 @@ def test_capacity_is_told_to_the_kernels():
     torch.cuda.synchronize()
     assert int(count[0]) == 5000 and bool((arena[room: 2 * room] == -1).all()) and bool((arena[3 * room:] == -1).all())
     assert (positions.cpu().numpy().view(np.uint32) == where[:room]).all()
+
+
+@pytest.mark.parametrize("scheme", ["run_length_encoding", "run_position_encoding"])
+def test_a_broken_chain_of_tiles_is_reported_not_waited_for(scheme):
+    """The one-launch compressors' tiles wait for the tiles before them (kernels/compression/chained.hpp).  Every wait is bounded: here one tile
+    plays dead ("chain_fault_tile"), the tiles behind it run out of a SHORT patience, give up one after the other, and the count the kernel leaves
+    is 2^64 - 1 — ChainBroken in Python.  Run in a child process under a watchdog: a regression that waits for ever must fail the test, not hang
+    the GPU box (as tests/test_gpu_dictionary_barrier_guard.py does for the dictionary's barrier)."""
+    import subprocess
+    import sys
+    program = r'''
+import sys, os
+sys.path.insert(0, %r)
+import numpy as np, torch
+from libgiddy_amd import compressors
+n = 1 << 22
+column = torch.from_numpy(np.repeat(np.arange(n // 8, dtype=np.uint32), 8).view(np.int32)).cuda()
+compress = getattr(compressors, %r)
+ok = compress(column, 4096)                                     # the chain as it is: fine
+assert ok["num_element_runs"] == n // 8
+for fault_tile in (0, 3, 100):
+    try:
+        compress(column, 4096, chain={"patience": 4000, "fault_tile": fault_tile})
+    except compressors.ChainBroken:
+        continue
+    raise SystemExit("tile %%d played dead and nobody noticed" %% fault_tile)
+again = compress(column, 4096)                                  # and the next launch is none the worse
+assert again["num_element_runs"] == n // 8 and bool((again["run_data"] == ok["run_data"]).all())
+print("chain OK")
+''' % (ROOT, scheme)
+    result = subprocess.run([sys.executable, "-c", program], capture_output=True, text=True, timeout=300)
+    assert result.returncode == 0 and "chain OK" in result.stdout, result.stdout[-2000:] + result.stderr[-2000:]

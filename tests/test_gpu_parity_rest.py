@@ -191,6 +191,22 @@ def test_rle(index_size, usize, lsize, run_index_size):
             assert len(bad) == 0, (name, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
 
 
+@pytest.mark.parametrize("switches", [{"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1"}, {"GIDDY_RUN_FINE_ONE_LAUNCH": "0", "GIDDY_RUN_FINE_FORCE": "1"}],
+                         ids=["one_launch_pre_pass", "three_launch_pre_pass"])
+def test_rle_with_each_pre_pass_forced(switches):
+    """The wrapper picks the pre-pass that finds finer anchors for long segments by the column's shape (one launch: a workgroup per segment;
+    three launches: sums, scan, search).  Here every run-length registration decodes every column of test_rle with EACH of them forced for
+    every shape that admits finer anchors (the switches are read once per process: the cases run in a child interpreter)."""
+    import os
+    import subprocess
+    import sys
+    environment = dict(os.environ, **switches)
+    result = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_rle and not forced", "-p", "no:cacheprovider"],
+                            capture_output=True, text=True, env=environment, timeout=1500)
+    assert result.returncode == 0, result.stdout[-3000:] + result.stderr[-2000:]
+    assert "18 passed" in result.stdout, result.stdout[-500:]
+
+
 RPE_TUPLES = [(4, 1, 2, True), (4, 2, 2, True), (4, 4, 2, True), (4, 8, 2, True), (8, 4, 2, True),
               (4, 1, 4, False), (4, 2, 4, False), (4, 4, 4, False), (4, 8, 4, False), (8, 4, 8, False)]
 

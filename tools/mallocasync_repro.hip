@@ -3,7 +3,7 @@
 // call of include/giddy/stream_scratch.hpp; this is the same traffic WITHOUT the library: several streams, each repeatedly
 //   allocate (sizes vary) -> copy a per-owner pattern in from pinned memory -> verify on the device -> scribble slowly -> free,
 // so that a block freed on one stream (its scribble still running) is what the pool has to offer the next allocation on another.
-//   hipcc --offload-arch=gfx950 -O2 tools/mallocasync_repro.hip -o tools/mallocasync_repro.bin && tools/mallocasync_repro.bin [iterations]
+//   hipcc --offload-arch=gfx950 -O2 tools/mallocasync_repro.hip -o tools/mallocasync_repro.bin && tools/mallocasync_repro.bin [iterations [streams [malloc]]]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -25,7 +25,8 @@ __global__ void scribble_slowly(unsigned* block, size_t words, unsigned garbage,
 
 int main(int argc, char** argv)
 {
-	const int iterations = argc > 1 ? std::atoi(argv[1]) : 2000, num_streams = 4;
+	const int iterations = argc > 1 ? std::atoi(argv[1]) : 2000, num_streams = argc > 2 ? std::atoi(argv[2]) : 4;
+	const bool pool = argc <= 3 || argv[3][0] != 'm';   // third argument "malloc": the CONTROL — the same traffic on hipMalloc / hipFree blocks
 	const size_t most_words = (size_t) 16 << 20;   // 64 MiB
 	std::vector<hipStream_t> streams(num_streams);
 	std::vector<unsigned*> patterns(num_streams);
@@ -41,16 +42,16 @@ int main(int argc, char** argv)
 		OK(hipStreamSynchronize(streams[s]));   // (the pinned pattern buffer of this stream is reused)
 		for (size_t i = 0; i < words; i++) { patterns[s][i] = pattern; }
 		unsigned* block = nullptr;
-		OK(hipMallocAsync(reinterpret_cast<void**>(&block), words * 4, streams[s]));
+		if (pool) { OK(hipMallocAsync(reinterpret_cast<void**>(&block), words * 4, streams[s])); } else { OK(hipMalloc(reinterpret_cast<void**>(&block), words * 4)); }
 		OK(hipMemcpyAsync(block, patterns[s], words * 4, hipMemcpyHostToDevice, streams[s]));
 		verify<<<256, 256, 0, streams[s]>>>(block, words, pattern, mismatches);
 		scribble_slowly<<<64, 256, 0, streams[s]>>>(block, words, 0xDEAD0000u + it, 8);
-		OK(hipFreeAsync(block, streams[s]));
+		if (pool) { OK(hipFreeAsync(block, streams[s])); } else { OK(hipStreamSynchronize(streams[s])); OK(hipFree(block)); }
 	}
 	OK(hipDeviceSynchronize());
 	unsigned long long bad = 0;
 	OK(hipMemcpy(&bad, mismatches, sizeof bad, hipMemcpyDeviceToHost));
-	std::printf("hipMallocAsync repro: %d allocations over %d streams, %llu words read back different from what their owner had just copied in%s\n",
-		iterations, num_streams, bad, bad ? " — STALE CONTENTS REPRODUCED" : " — not reproduced");
+	std::printf("%s: %d allocations over %d streams, %llu words read back different from what their owner had just copied in%s\n",
+		pool ? "hipMallocAsync / hipFreeAsync" : "control (hipMalloc / hipFree)", iterations, num_streams, bad, bad ? " — STALE CONTENTS REPRODUCED" : " — not reproduced");
 	return bad != 0;
 }
