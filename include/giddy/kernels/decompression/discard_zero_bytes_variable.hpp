@@ -56,6 +56,9 @@ using element_size_t = native_word_t;
 #endif
 
 // the wide path (see detail::decompress_wide): 1 = on where it applies
+#ifndef GIDDY_DZBV_PAIRS
+#define GIDDY_DZBV_PAIRS 1   // two-byte elements are cut out of the staged bytes two at a time, by a table of byte permutations (detail::pair_entry)
+#endif
 #ifndef GIDDY_DZBV_WIDE
 #define GIDDY_DZBV_WIDE 1
 #endif
@@ -113,6 +116,28 @@ __device__ __forceinline__ void fill(size_masks& table)
 {
 	if (threadIdx.x < 9) { table.mask[threadIdx.x] = threadIdx.x == 8 ? ~(uint64_t) 0 : ((((uint64_t) 1) << (8 * threadIdx.x)) - 1); }
 	__syncthreads();
+}
+
+/// TWO-BYTE elements, two at a time (round 4).  A lane's eight elements per row cost the general path eight times (size from the field,
+/// two aligned LDS reads, an alignment, a mask from LDS): 2231 instructions per wavefront against 1622 for four-byte elements that are twice
+/// the output bytes per row — issue-bound, 59-64 % of the HBM peak (profiles/r02_pmc_below_70.txt, r04_pmc_below_70.txt).  A PAIR of
+/// neighbouring elements is at most four bytes of input and exactly four bytes of output, so it is ONE byte permutation (v_perm_b32) of the
+/// four input bytes at the pair's offset; which one — and how far the pair advances the offset — depends only on the pair's two size
+/// fields: a table of 2^(2 bits) entries, {selector, bytes}, built once per workgroup for the launch's `min_size` and `bits` (<= 4).
+struct pair_entry { uint32_t selector, bytes; };
+struct size_masks_and_pairs : size_masks { pair_entry pairs[256]; };
+
+__device__ __forceinline__ void fill_pairs(size_masks_and_pairs& table, unsigned min_size, unsigned bits)
+{
+	if (bits > 4) { return; }
+	const unsigned field_mask = (1u << bits) - 1;
+	for (unsigned code = threadIdx.x; code < (1u << (2 * bits)); code += blockDim.x) {
+		unsigned s0 = min_size + (code & field_mask), s1 = min_size + ((code >> bits) & field_mask);
+		s0 = s0 > 2 ? 2 : s0; s1 = s1 > 2 ? 2 : s1;   // (precondition n_i <= sizeof(element); never read more)
+		// output bytes 0, 1: the first element (input bytes 0, 1); bytes 2, 3: the second (input bytes s0, s0 + 1); 0x0c: a zero byte
+		const uint32_t b0 = s0 >= 1 ? 0x00u : 0x0cu, b1 = s0 == 2 ? 0x01u : 0x0cu, b2 = s1 >= 1 ? s0 : 0x0cu, b3 = s1 == 2 ? s0 + 1 : 0x0cu;
+		table.pairs[code] = pair_entry { b0 | (b1 << 8) | (b2 << 16) | (b3 << 24), s0 + s1 };
+	}
 }
 
 /// low `size` bytes of the 8 bytes starting `shift_bytes` into the three aligned words (w0, w1, w2)
@@ -223,15 +248,21 @@ struct row_group {
 	/// takes its byte position from the anchor.  `cursor` (wave-uniform) is advanced.
 	template <bool SpansSegments, unsigned IndexSize>
 	__device__ __forceinline__ void locate(const uint8_t* __restrict__ compressed_data, uint32_t rows_per_segment,
-		segment_cursor<IndexSize>& cursor, unsigned min_size, unsigned bits)
+		segment_cursor<IndexSize>& cursor, unsigned min_size, unsigned bits, const pair_entry* pairs = nullptr)
 	{
 		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) {
 			if (SpansSegments) { cursor.before_row(rows_per_segment); }
 			unsigned lane_bytes = 0;
-			#pragma unroll
-			for (unsigned j = 0; j < E; j++) { lane_bytes += size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask); }
+			if (UncompressedSize == 2 && pairs != nullptr) {
+				#pragma unroll
+				for (unsigned d = 0; d < E / 2; d++) { lane_bytes += pairs[(unsigned) (fields[k] >> (2 * bits * d)) & ((1u << (2 * bits)) - 1u)].bytes; }
+			}
+			else {
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) { lane_bytes += size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask); }
+			}
 			const unsigned inclusive = wave64::inclusive_sum(lane_bytes);
 			const unsigned row_bytes = wave64::read_last_lane(inclusive);
 			const uintptr_t address = reinterpret_cast<uintptr_t>(compressed_data) + cursor.bytes_start;
@@ -267,7 +298,7 @@ struct row_group {
 		wave64::lds_fence();
 	}
 	__device__ __forceinline__ void extract_and_store(uint_t<UncompressedSize>* __restrict__ decompressed, const uint32_t* stage,
-		unsigned lane, uint64_t rows_start, unsigned min_size, unsigned bits, const size_masks& masks) const
+		unsigned lane, uint64_t rows_start, unsigned min_size, unsigned bits, const size_masks& masks, const pair_entry* pairs = nullptr) const
 	{
 		using U = uint_t<UncompressedSize>;
 		const container_type field_mask = bits >= 8 * ElementSizesContainerSize ? ~(container_type) 0 : (((container_type) 1 << bits) - 1);
@@ -277,6 +308,20 @@ struct row_group {
 			const uint32_t* row_stage = stage + k * staging_words;
 			memory_access::group<U, E> values;
 			unsigned at = offset[k];
+			if constexpr (UncompressedSize == 2) {
+				if (pairs != nullptr) {   // (wave-uniform) two elements per step: the pair's four input bytes, one permutation (pair_entry above)
+					#pragma unroll
+					for (unsigned d = 0; d < E / 2; d++) {
+						const pair_entry entry = pairs[(unsigned) (fields[k] >> (2 * bits * d)) & ((1u << (2 * bits)) - 1u)];
+						const unsigned word = at >> 2;
+						const uint32_t four_bytes = __builtin_amdgcn_alignbyte(row_stage[word + 1], row_stage[word], at & 3);
+						values.words[d] = __builtin_amdgcn_perm(0u, four_bytes, entry.selector);
+						at += entry.bytes;
+					}
+					memory_access::store_group<GIDDY_DZBV_STORE_POLICY>(decompressed + i0, values);
+					continue;
+				}
+			}
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) {
 				const unsigned word = at >> 2, size = size_of<UncompressedSize>(fields[k], j, min_size, bits, field_mask);
@@ -672,6 +717,8 @@ __device__ __forceinline__ void decompress_full_groups(
 
 	group_t current, next;
 	container_type after_next[R];
+	// (two-byte elements, size fields of at most 4 bits: pairs of elements by table — pair_entry)
+	const pair_entry* const pairs = (UncompressedSize == 2 && GIDDY_DZBV_PAIRS && bits <= 4) ? static_cast<const size_masks_and_pairs&>(masks).pairs : nullptr;
 	// wave-uniform position of the next group's first size field
 	uint64_t container_base = divide(rows_start, per);
 	unsigned field_base = (unsigned) (rows_start - container_base * per);
@@ -683,17 +730,17 @@ __device__ __forceinline__ void decompress_full_groups(
 	};
 	fetch_fields(current.fields);
 	if (num_groups > 1) { fetch_fields(next.fields); }
-	current.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits);
+	current.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits, pairs);
 	current.request(lane, packed_element_sizes);
 	current.stage_into(stage, lane);
 	for (uint64_t g = 0; g < num_groups; g++) {
 		const bool has_next = g + 1 < num_groups;
 		if (has_next) {
-			next.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits);
+			next.template locate<SpansSegments, IndexSize>(compressed_data, rows_per_segment, cursor, min_size, bits, pairs);
 			next.request(lane, packed_element_sizes);
 		}
 		if (g + 2 < num_groups) { fetch_fields(after_next); }
-		current.extract_and_store(decompressed, stage, lane, rows_start, min_size, bits, masks);
+		current.extract_and_store(decompressed, stage, lane, rows_start, min_size, bits, masks, pairs);
 		rows_start += group_elements;
 		if (has_next) {
 			next.stage_into(stage, lane);
@@ -712,7 +759,7 @@ template <unsigned UncompressedSize>
 struct block_storage {
 	enum : unsigned { R = rows_in_flight, words_per_wave = GIDDY_DZBV_WIDE && wide_staging_words > R * staging_words ? (unsigned) wide_staging_words : R * staging_words };
 	uint32_t staging[max_waves_per_block][words_per_wave];
-	size_masks masks;
+	typename std::conditional<UncompressedSize == 2, size_masks_and_pairs, size_masks>::type masks;   // (two-byte elements: + the table of pairs)
 };
 
 /// What workgroup `block_index` of a grid of `blocks_in_grid` decodes.
@@ -884,7 +931,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 	static_assert(ElementSizesContainerSize == 4 || ElementSizesContainerSize == 8,
 		"Only container types with 32 or 64 bits are currently supported");
 	__shared__ __attribute__((aligned(16))) detail::block_storage<UncompressedSize> storage;
-	detail::fill(storage.masks);
+	if constexpr (UncompressedSize == 2) { detail::fill_pairs(storage.masks, min_represented_element_size, bits_per_element_size); }
+	detail::fill(storage.masks);   // (ends with the barrier)
 	detail::decompress_as_block<IndexSize, UncompressedSize, ElementSizesContainerSize>(blockIdx.x, gridDim.x, storage.staging, storage.masks,
 		decompressed, compressed_data, packed_element_sizes, position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
 }

@@ -1,10 +1,8 @@
 """Summarises tools/pmc_sub70.sh: per-wavefront means of the SQ counters of each profiled instantiation, side by side (only the decoder's own dispatches)."""
 import csv, glob, os, sys
 out = sys.argv[1]
-cases = [("rle_8_1_8_8", "run_length_encoding::decompress<8u, 1u, 8u, 8u>"), ("rle_4_1_1_4", "run_length_encoding::decompress<4u, 1u, 1u, 4u>"),
-         ("ib_4_1_2", "incidence_bitmaps::decompress<4u, 1u, 2u, true>"), ("ib_4_4_2", "incidence_bitmaps::decompress<4u, 4u, 2u, true>"),
-         ("dzbv_4_2_8", "variable_width::decompress<4u, 2u, 8u>"), ("dzbv_4_4_8", "variable_width::decompress<4u, 4u, 8u>"),
-         ("model_patched_short", "model::patched::decompress<4u, short"), ("model_patched_int", "model::patched::decompress<4u, int")]
+cases = [tuple(line.split("|")[i].strip() for i in (0, 2)) for line in open(sys.argv[2] if len(sys.argv) > 2 else os.path.join(os.path.dirname(os.path.abspath(__file__)), "pmc_sub70_cases.txt"))
+         if line.strip() and not line.startswith("#")]
 table = {}
 for name, kernel in cases:
     for path in glob.glob(os.path.join(out, name, "p*", "**", "*counter_collection.csv"), recursive=True):
