@@ -144,12 +144,39 @@ void kernel_t<I, U, CS>::enqueue_launch_with(stream::id_t stream, const launch_c
 	if (length == 0) { return; }
 	const uint64_t per = (8 * CS) / bits, num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) threads_per_block * per);
 	const auto config = tile_launch(num_tiles);
+	auto compressed_data = argument<uint8_t*>(arguments, "compressed_data");
+	auto packed_sizes = argument<uint_t<CS>*>(arguments, "packed_element_sizes");
+	auto anchors = argument<uint_t<I>*>(arguments, "position_anchors");
+	auto unrepresentable = optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr);
+	auto total_bytes = optional_argument<uint64_t*>(arguments, "total_bytes").value_or(nullptr);
+	const uint32_t patience = optional_argument<uint32_t>(arguments, "chain_patience").value_or((uint32_t) chained::default_patience);
+	// The write pass by ROWS of 64 elements per wavefront where the shape allows — fields per container a power of two, a wavefront's bytes within
+	// its staging area, segments of 64 elements or more (kernels/compression/discard_zero_bytes_variable.hpp) — and then in ONE launch, the tiles
+	// chained by a decoupled look-back (the column read once; 2^28 64-bit elements: 2.66 ms in three launches with a thread per container
+	// -> 1.4 ms by rows -> profiles/r04_compress_bench.txt).  Otherwise: count, offsets, write by a thread per container.
+	const unsigned largest = largest_size_of(min_size, bits, U);
+	const bool by_rows = GIDDY_DZBV_COMPRESS_BY_ROWS && compress_by_rows_applies((unsigned) per, largest, (uint64_t) segment);
+	const shared_memory_size_t staging_bytes = (shared_memory_size_t) (waves_per_block * compress_by_rows_staging_words((unsigned) per, largest) * sizeof(uint32_t));
+	if (by_rows && GIDDY_DZBV_COMPRESS_CHAINED && num_tiles <= 0x7FFFFFFFull) {
+		const uint64_t num_links = util::div_rounding_up(num_tiles, (uint64_t) 4);   // (compress_by_rows: a workgroup — a link of the chain — takes four consecutive tiles)
+		enqueue_zero(stream, totals, num_links * sizeof(uint64_t));
+		auto chained_config = chained_launch(num_links);
+		chained_config.dynamic_shared_memory_size = staging_bytes;
+		cuda::enqueue_launch(reinterpret_cast<const void*>(compress_by_rows<I, U, CS, true>), stream, chained_config,
+			compressed_data, packed_sizes, anchors, input, totals, segment, length, min_size, bits, unrepresentable, total_bytes, patience);
+		return;
+	}
 	cuda::enqueue_launch(reinterpret_cast<const void*>(count_bytes<I, U, CS>), stream, config, totals, input, length, min_size, bits);
-	enqueue_exclusive_offsets(stream, totals, num_tiles, optional_argument<uint64_t*>(arguments, "total_bytes").value_or(nullptr));
+	enqueue_exclusive_offsets(stream, totals, num_tiles, total_bytes);
+	if (by_rows) {
+		auto write_config = config;
+		write_config.dynamic_shared_memory_size = staging_bytes;
+		cuda::enqueue_launch(reinterpret_cast<const void*>(compress_by_rows<I, U, CS, false>), stream, write_config,
+			compressed_data, packed_sizes, anchors, input, totals, segment, length, min_size, bits, unrepresentable, static_cast<uint64_t*>(nullptr), patience);
+		return;
+	}
 	cuda::enqueue_launch(reinterpret_cast<const void*>(compress<I, U, CS>), stream, config,
-		argument<uint8_t*>(arguments, "compressed_data"), argument<uint_t<CS>*>(arguments, "packed_element_sizes"),
-		argument<uint_t<I>*>(arguments, "position_anchors"), input, static_cast<const uint64_t*>(totals), segment, length, min_size, bits,
-		optional_argument<native_word_t*>(arguments, "unrepresentable_count").value_or(nullptr));
+		compressed_data, packed_sizes, anchors, input, static_cast<const uint64_t*>(totals), segment, length, min_size, bits, unrepresentable);
 }
 
 template <unsigned I, unsigned U, unsigned CS>
@@ -270,7 +297,10 @@ public:
 template <unsigned I, unsigned U>
 launch_configuration_t kernel_t<I, U>::resolve_launch_configuration(device::properties_t, device_function::attributes_t, arguments_type extra_arguments, launch_configuration_limits_t) const
 {
-	return elementwise_launch(argument<size_t>(extra_arguments, "length"));
+	// (a grid of at most insert_blocks workgroups at grid stride: each fills its LDS cache of known values once for many elements)
+	auto config = elementwise_launch(argument<size_t>(extra_arguments, "length"));
+	if (config.grid_dimensions.x > insert_blocks) { config.grid_dimensions.x = insert_blocks; }
+	return config;
 }
 
 template <unsigned I, unsigned U>

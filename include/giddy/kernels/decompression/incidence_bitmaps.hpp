@@ -26,6 +26,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/on_device/wave64.hpp"
@@ -41,7 +43,8 @@ using bitmap_size_type = size_type_by_index_size<sizeof(bitmap_index_t)>;
 
 namespace detail {
 
-enum : unsigned { max_bitmaps = 256, bitmaps_in_flight = 16, planes = 8, containers_per_wave = 64, max_waves_per_block = 16 };
+enum : unsigned { max_bitmaps = 256, bitmaps_in_flight = 16, planes = 8, containers_per_wave = 64,
+	max_waves_per_block = 4 };   // (the launch parameters cap the workgroup at 256 threads; 16 wavefronts' planes — 32 KiB — held a CU to four workgroups)
 
 struct alignas(16) plane_set { uint32_t plane[planes]; };   // bit j of plane[k] = bit k of the bitmap index of the container's element j
 
@@ -73,73 +76,88 @@ __global__ void decompress(
 		__syncthreads();
 	}
 
+	// LDS is provisioned for max_waves_per_block wavefronts; in a larger workgroup the extra wavefronts sit idle (no barrier follows)
+	const unsigned working_waves = wave64::per_block() < detail::max_waves_per_block ? wave64::per_block() : detail::max_waves_per_block;
+	if (wave64::index_in_block() >= working_waves) { return; }
 	const unsigned lane = wave64::lane_id();
-	detail::plane_set* mine = plane_sets[wave64::index_in_block() % detail::max_waves_per_block];
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	detail::plane_set* mine = plane_sets[wave64::index_in_block()];
+	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
 	const uint64_t words = bitmap_length;
 	const uint64_t aligned_words = (words + BitmapAlignmentInInts - 1) / BitmapAlignmentInInts * BitmapAlignmentInInts;
 	const uint64_t num_chunks = (words + W - 1) / W;
 	const bool aligned = is_aligned(decompressed, 16);
 
-	for (uint64_t chunk = wave; chunk < num_chunks; chunk += num_waves) {
-		// 1. fold this lane's container of every bitmap into index bit-planes
-		const uint64_t w = chunk * W + lane;
-		const bool have = w < words;
-		detail::plane_set folded;
-		#pragma unroll
-		for (unsigned k = 0; k < detail::planes; k++) { folded.plane[k] = 0; }
-		for (unsigned b0 = 0; b0 < num_bitmaps; b0 += B) {
-			standard_bit_container_t word[B];
+	// The index of the winning bitmap has as many bits as the bitmaps need: a column of 16 distinct values folds and unfolds 4 bit-planes, not 8
+	// (round 4: the 1-byte instantiation spent 752 instructions per 2 KiB of output, most of them on planes that were zero: 68 % of the HBM peak).
+	auto with_planes = [&](auto planes_in_use) {
+		constexpr unsigned P = decltype(planes_in_use)::value;
+		for (uint64_t chunk = wave; chunk < num_chunks; chunk += num_waves) {
+			// 1. fold this lane's container of every bitmap into index bit-planes
+			const uint64_t w = chunk * W + lane;
+			const bool have = w < words;
+			uint32_t folded[P];
 			#pragma unroll
-			for (unsigned i = 0; i < B; i++) { word[i] = (have && b0 + i < num_bitmaps) ? bitmaps[(uint64_t) (b0 + i) * aligned_words + w] : 0u; }
-			#pragma unroll
-			for (unsigned i = 0; i < B; i++) {
-				const unsigned b = b0 + i;   // wave-uniform
+			for (unsigned k = 0; k < P; k++) { folded[k] = 0; }
+			for (unsigned b0 = 0; b0 < num_bitmaps; b0 += B) {
+				standard_bit_container_t word[B];
 				#pragma unroll
-				for (unsigned k = 0; k < detail::planes; k++) {
-					const uint32_t select = ((b >> k) & 1u) ? 0xFFFFFFFFu : 0u;
-					folded.plane[k] = (word[i] & select) | (~word[i] & folded.plane[k]);   // v_bfi_b32
+				for (unsigned i = 0; i < B; i++) { word[i] = (have && b0 + i < num_bitmaps) ? bitmaps[(uint64_t) (b0 + i) * aligned_words + w] : 0u; }
+				#pragma unroll
+				for (unsigned i = 0; i < B; i++) {
+					const unsigned b = b0 + i;   // wave-uniform
+					#pragma unroll
+					for (unsigned k = 0; k < P; k++) {
+						const uint32_t select = ((b >> k) & 1u) ? 0xFFFFFFFFu : 0u;
+						folded[k] = (word[i] & select) | (~word[i] & folded[k]);   // v_bfi_b32
+					}
 				}
 			}
-		}
-		mine[lane] = folded;
-		wave64::lds_fence();
+			#pragma unroll
+			for (unsigned k = 0; k < P; k++) { mine[lane].plane[k] = folded[k]; }
+			wave64::lds_fence();
 
-		// 2. outputs in order: E consecutive elements per lane per step
-		const uint64_t chunk_first_element = chunk * W * 32;
-		const uint64_t chunk_elements = (words - chunk * W < W ? words - chunk * W : W) * 32;
-		#pragma unroll 2
-		for (unsigned step = 0; step < (W * 32) / (64 * E); step++) {
-			const unsigned e0 = step * 64 * E + lane * E;
-			if (e0 < chunk_elements) {
-				const detail::plane_set p = mine[e0 >> 5];
-				const unsigned shift = e0 & 31;
-				group<U, E> values;
-				#pragma unroll
-				for (unsigned c = 0; c < (E + 3) / 4; c++) {
-					uint32_t indices = 0;   // byte j = bitmap index of element 4c + j
+			// 2. outputs in order: E consecutive elements per lane per step
+			const uint64_t chunk_first_element = chunk * W * 32;
+			const uint64_t chunk_elements = (words - chunk * W < W ? words - chunk * W : W) * 32;
+			#pragma unroll 2
+			for (unsigned step = 0; step < (W * 32) / (64 * E); step++) {
+				const unsigned e0 = step * 64 * E + lane * E;
+				if (e0 < chunk_elements) {
+					uint32_t p[P];
 					#pragma unroll
-					for (unsigned k = 0; k < detail::planes; k++) {
-						const uint32_t nibble = (p.plane[k] >> (shift + 4 * c)) & 0xFu;
-						indices |= ((nibble * 0x00204081u) & 0x01010101u) << k;   // bit j of the nibble -> bit k of byte j
+					for (unsigned k = 0; k < P; k++) { p[k] = mine[e0 >> 5].plane[k]; }
+					const unsigned shift = e0 & 31;
+					group<U, E> values;
+					#pragma unroll
+					for (unsigned c = 0; c < (E + 3) / 4; c++) {
+						uint32_t indices = 0;   // byte j = bitmap index of element 4c + j
+						#pragma unroll
+						for (unsigned k = 0; k < P; k++) {
+							const uint32_t nibble = (p[k] >> (shift + 4 * c)) & 0xFu;
+							indices |= ((nibble * 0x00204081u) & 0x01010101u) << k;   // bit j of the nibble -> bit k of byte j
+						}
+						#pragma unroll
+						for (unsigned j = 0; j < 4 && 4 * c + j < E; j++) {
+							const unsigned index = (indices >> (8 * j)) & 0xFFu;
+							values[4 * c + j] = UseDictionary ? dictionary[index] : (U) index;
+						}
 					}
-					#pragma unroll
-					for (unsigned j = 0; j < 4 && 4 * c + j < E; j++) {
-						const unsigned index = (indices >> (8 * j)) & 0xFFu;
-						values[4 * c + j] = UseDictionary ? dictionary[index] : (U) index;
+					U* where = decompressed + chunk_first_element + e0;
+					if (aligned) { store_group<memory_access::wide_output_policy<UncompressedSize>(GIDDY_IB_STORE_POLICY)>(where, values); }   // (write-through: +3 / +7 points for 4- / 8-byte elements)
+					else {
+						#pragma unroll
+						for (unsigned j = 0; j < E; j++) { where[j] = values[j]; }
 					}
-				}
-				U* where = decompressed + chunk_first_element + e0;
-				if (aligned) { store_group<memory_access::wide_output_policy<UncompressedSize>(GIDDY_IB_STORE_POLICY)>(where, values); }   // (write-through: +3 / +7 points for 4- / 8-byte elements)
-				else {
-					#pragma unroll
-					for (unsigned j = 0; j < E; j++) { where[j] = values[j]; }
 				}
 			}
+			wave64::lds_fence();   // the planes are overwritten by the next chunk
 		}
-		wave64::lds_fence();   // the planes are overwritten by the next chunk
-	}
+	};
+	if (num_bitmaps <= 4) { with_planes(std::integral_constant<unsigned, 2>()); }
+	else if (num_bitmaps <= 16) { with_planes(std::integral_constant<unsigned, 4>()); }
+	else if (num_bitmaps <= 64) { with_planes(std::integral_constant<unsigned, 6>()); }
+	else { with_planes(std::integral_constant<unsigned, 8>()); }
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned BitmapAlignmentInInts, bool UseDictionary = true>

@@ -97,7 +97,10 @@ def discard_zero_bytes_variable(column, segment_length, min_represented_element_
                  "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
                  "min_represented_element_size": r.uint_t(4)(min_represented_element_size), "bits_per_element_size": r.uint_t(4)(bits_per_element_size),
                  "tile_totals": r.pointer(scratch, "u64"), "total_bytes": r.pointer(total, "u64"), "unrepresentable_count": r.pointer(counter, "u32")}, counter)
-    out["compressed_data"] = data[: int(total[0])]
+    compressed_bytes = int(total[0])
+    if compressed_bytes == -1:   # (2^64 - 1 in the device scalar: kernels/compression/chained.hpp)
+        raise ChainBroken("the chain of tiles broke: a tile was not heard of within its patience")
+    out["compressed_data"] = data[:compressed_bytes]
     return out
 
 
