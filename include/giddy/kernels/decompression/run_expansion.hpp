@@ -65,6 +65,9 @@ namespace run_expansion {
 #ifndef GIDDY_RUN_WIDE_CHUNK_BYTES
 #define GIDDY_RUN_WIDE_CHUNK_BYTES 0   // output a wavefront of a 4- or 8-byte column takes per trip when segments are at least a tile long (0: one segment)
 #endif
+#ifndef GIDDY_RUN_TOUCH_ANCHORS_AHEAD
+#define GIDDY_RUN_TOUCH_ANCHORS_AHEAD 0   // chunks ahead (a multiple of 32: the same XCD's L2) whose anchor a wavefront touches when it starts — the anchor of a chunk is the first of two dependent round trips
+#endif
 #ifndef GIDDY_RUN_ROW_PADDING
 #define GIDDY_RUN_ROW_PADDING 1   // rows of a tile begin on 512-byte boundaries of the output (expand)
 #endif
@@ -101,6 +104,12 @@ __device__ __forceinline__ uint64_t first_chunk_by_address(const void* output, u
 	const uint64_t shift = ((reinterpret_cast<uintptr_t>(output) & (group_bytes - 1)) >> __builtin_ctzll(chunk_bytes)) & (working_waves - 1);
 	return wave >= shift ? wave - shift : wave + num_waves - shift;
 }
+
+/// One load whose value nobody needs: the line is in this XCD's L2 when the wavefront that does need it comes along.  Returns the value — keep it
+/// alive with keep_alive() after the wavefront's own first loads, or the compiler drops the load.
+template <typename T>
+__device__ __forceinline__ uint32_t touch(const T* p) { return (uint32_t) *reinterpret_cast<const volatile uint8_t*>(p); }
+__device__ __forceinline__ void keep_alive(uint32_t value) { asm volatile("" :: "v"(value)); }
 
 /// a run descriptor (length or position): read once
 template <typename T>

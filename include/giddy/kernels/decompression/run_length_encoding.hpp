@@ -102,6 +102,12 @@ __device__ __forceinline__ void decompress(
 		if (segment_start >= n) { break; }
 		const uint64_t chunk_outputs = segments_per_chunk * L;
 		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
+		// (the anchor of the chunk some thousand wavefronts ahead, into this XCD's L2: GIDDY_RUN_TOUCH_ANCHORS_AHEAD)
+		uint32_t touched = 0;
+		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
+			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
+			touched = touch(segment_position_anchors + (ahead < num_segments ? ahead : s));
+		}
 		uint64_t first_run = segment_position_anchors[s];
 		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
 		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s];
@@ -269,6 +275,7 @@ __device__ __forceinline__ void decompress(
 			}
 			first_run = next_first_run; left_in_first_run = next_left_in_first_run;
 		}
+		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0) { keep_alive(touched); }
 	}
 }
 

@@ -101,6 +101,11 @@ __device__ __forceinline__ void decompress(
 		const uint64_t nominal_end = segment_start + segments_per_chunk * L;   // where the first segment after this chunk starts
 		const uint64_t segment_end = nominal_end < n ? nominal_end : n;
 		const uint64_t positions_origin = position_period == L ? segment_start : segment_start / position_period * position_period;
+		uint32_t touched = 0;   // (GIDDY_RUN_TOUCH_ANCHORS_AHEAD: run_length_encoding.hpp)
+		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
+			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
+			touched = touch(position_anchors + (ahead < (uint64_t) num_anchors ? ahead : s));
+		}
 		uint64_t first_run = position_anchors[s];
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
 		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk] : num_runs - 1;
@@ -278,6 +283,7 @@ __device__ __forceinline__ void decompress(
 			}
 			first_run = next_first_run;
 		}
+		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0) { keep_alive(touched); }
 	}
 }
 

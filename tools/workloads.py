@@ -97,6 +97,15 @@ class Dictionary:
     def run(self, stream):
         schemes.dictionary(self.output, self.keys, self.entries, self.n, 256, stream=stream, launch_config=self.config)
 
+    # the column in the format writers' vocabulary; how a shard of it is cut and launched (tools/size_probe.py, bench.py --scaling strong)
+    def column_fields(self):
+        return {"compressed_input": self.keys, "dictionary_entries": self.entries, "length": self.n}
+
+    shard_function = staticmethod(sharding.elementwise)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.dictionary(out, f["compressed_input"], f["dictionary_entries"], f["length"], 256, stream=stream, launch_config=config)
+
     def verify(self, oracle, sample=1 << 22):
         torch.cuda.synchronize()
         n = self.n
@@ -140,6 +149,14 @@ class FrameOfReference:
 
     def run(self, stream):
         schemes.frame_of_reference(self.output, self.comp, self.coefs, self.n, self.L, stream=stream, launch_config=self.config)
+
+    def column_fields(self):
+        return {"compressed_input": self.comp, "segment_model_coefficients": self.coefs, "length": self.n, "segment_length": self.L}
+
+    shard_function = staticmethod(sharding.frame_of_reference)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.frame_of_reference(out, f["compressed_input"], f["segment_model_coefficients"], f["length"], f["segment_length"], stream=stream, launch_config=config)
 
     def verify(self, oracle, sample=1 << 22):
         torch.cuda.synchronize()
@@ -241,6 +258,15 @@ class DeltaPatched:
         if around_dominant_kernel:
             around_dominant_kernel[1]()
         schemes.scatter(self.output, self.patch_val, self.patch_idx, self.p, stream=stream, launch_config=self.patch_config)
+
+    # (the Delta decode alone: what tools/size_probe.py cuts into pieces)
+    def column_fields(self):
+        return {"compressed_input": self.deltas, "anchor_values": self.anchors, "length": self.n, "segment_length": self.L}
+
+    shard_function = staticmethod(sharding.delta)
+
+    def launch_fields(self, out, f, stream, config):
+        return schemes.delta(out, f["compressed_input"], f["anchor_values"], f["length"], f["segment_length"], stream=stream, launch_config=config)
 
     def verify(self, oracle, sample=1 << 22):
         torch.cuda.synchronize()
