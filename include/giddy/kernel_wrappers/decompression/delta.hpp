@@ -1,6 +1,8 @@
 // Kernel wrapper for Delta decompression.  Argument-map keys and exact types follow the
 // reference's src/kernel_wrappers/decompression/delta.cu:49-83.
 #pragma once
+#include <mutex>
+
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/functors/functors.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
@@ -33,13 +35,16 @@ __global__ void anchors_of_parts(uint_t<UncompressedSize>* __restrict__ part_anc
 	}
 }
 
+/// the current device's properties, asked of the runtime once per device and process (not per host thread: the pipeline's worker threads are new every call)
 inline const device::properties_t& current_device_properties()
 {
-	static thread_local int cached_for = -1;
-	static thread_local device::properties_t cached;
-	auto current = device::current::get();
-	if (cached_for != current.id()) { cached = current.properties(); cached_for = current.id(); }
-	return cached;
+	enum : int { most_devices = 64 };
+	static device::properties_t cached[most_devices];
+	static std::once_flag asked[most_devices];
+	const int id = device::current::get().id();
+	if (id < 0 || id >= most_devices) { static thread_local device::properties_t uncached; uncached = device::get(id).properties(); return uncached; }
+	std::call_once(asked[id], [id] { cached[id] = device::get(id).properties(); });
+	return cached[id];
 }
 
 /// switches read from the environment ONCE per process (not on the launch path)

@@ -5,7 +5,9 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <exception>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../c_abi_internal.hpp"
@@ -90,6 +92,17 @@ void enqueue_rebase(hipStream_t stream, void* out, const void* in, uint64_t coun
 }
 
 // ---- the pipeline ----------------------------------------------------------------------------------------------------------
+
+/// chunks from which the pipeline's per-stream loops run on host threads of their own (GIDDY_PIPELINE_THREADED_FROM in the environment, read once; 0: never)
+uint64_t threaded_from_chunks()
+{
+	static const uint64_t from = [] {
+		const char* v = std::getenv("GIDDY_PIPELINE_THREADED_FROM");
+		const uint64_t given = v ? std::strtoull(v, nullptr, 10) : 48;
+		return given == 0 ? ~(uint64_t) 0 : given;
+	}();
+	return from;
+}
 
 enum class sliced_by { nothing, elements, segments, units, size_containers, whole_table };
 
@@ -221,28 +234,10 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 	uploaded.record(first_stream);
 	for (size_t k = 1; k < num_streams; k++) { uploaded.make_wait(static_cast<hipStream_t>(streams[k])); }
 
-	// The wrapper's argument map and the resolver's are built ONCE; a chunk rewrites the entries that differ in place (no allocation per chunk),
-	// and the launch configuration is resolved again only when the chunk's length differs from the previous chunk's.
-	std::vector<giddy_argument_t> chunk_arguments(arguments, arguments + num_arguments);
-	auto map = giddy_internal::to_map(arguments, num_arguments);
-	std::vector<cuda::any*> entry(num_arguments, nullptr);
-	for (size_t i = 0; i < num_arguments; i++) { entry[i] = &map.at(roles[i].name); }
-	// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
-	auto resolution = map;
-	for (size_t i = 0; i < num_arguments; i++) {
-		if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
-			resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
-		}
-	}
-	cuda::any& resolution_length = resolution["length"];
-	cuda::any& resolution_data_length = resolution["data_length"];
-	cuda::launch_configuration_t config;
-	uint64_t config_for_length = ~(uint64_t) 0;
-	std::vector<size_t> offset(num_arguments, 0);
 	// the chunk's slices of the bulk arrays, each 256-byte aligned within ONE block per stream, leased for the whole call: the chunks of a
 	// stream follow each other through it in stream order.  (The wrapper's own scratch — chained Delta tiles, finer anchors of long
 	// segments — is another block of the pool: neither waits for the other.)
-	auto slices_of = [&](const cuda::sharding::shard_t& shard) {
+	auto slices_of = [&](const cuda::sharding::shard_t& shard, std::vector<size_t>& offset) {
 		size_t total = 0;
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
@@ -254,42 +249,84 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		return total;
 	};
 	std::vector<size_t> most(num_streams, 256);
-	for (uint64_t c = 0; c < num_chunks; c++) { if (shards[c].length() != 0) { most[c % num_streams] = std::max(most[c % num_streams], slices_of(shards[c])); } }
+	{
+		std::vector<size_t> offset(num_arguments, 0);
+		for (uint64_t c = 0; c < num_chunks; c++) { if (shards[c].length() != 0) { most[c % num_streams] = std::max(most[c % num_streams], slices_of(shards[c], offset)); } }
+	}
 	std::vector<std::unique_ptr<cuda::stream_scratch::lease>> blocks;
 	for (size_t k = 0; k < num_streams && k < num_chunks; k++) {
 		blocks.emplace_back(new cuda::stream_scratch::lease(static_cast<hipStream_t>(streams[k])));
 		if (!blocks.back()->take(most[k])) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
 	}
-	for (uint64_t c = 0; c < num_chunks; c++) {
-		const auto& shard = shards[c];
-		if (shard.length() == 0) { continue; }
-		hipStream_t stream = static_cast<hipStream_t>(streams[c % num_streams]);
-		(void) slices_of(shard);   // (sets `offset`)
-		char* base = static_cast<char*>(blocks[c % num_streams]->memory());
+	// The chunks of stream k — k, k + num_streams, ... — by one loop: the wrapper's argument map and the resolver's are built ONCE per loop, a chunk
+	// rewrites the entries that differ in place (no allocation per chunk), and the launch configuration is resolved again only when the
+	// chunk's length differs from the previous chunk's.  A chunk costs two or three enqueued operations (its copies, its launch) at ~2.6-4 us of
+	// host time each: with many chunks the loops run on a host thread per stream (round 4; one thread: 14-17 us per chunk, which
+	// bounded run-length columns — their ratio is 21 — at 256 chunks to a third of their rate at 16).
+	const int device_of_the_call = cuda::device::current::get().id();
+	auto chunks_of_stream = [&](size_t k, bool set_device) {
+		if (set_device) { cuda::device::current::set(device_of_the_call); }
+		hipStream_t stream = static_cast<hipStream_t>(streams[k]);
+		std::vector<giddy_argument_t> chunk_arguments(arguments, arguments + num_arguments);
+		auto map = giddy_internal::to_map(arguments, num_arguments);
+		std::vector<cuda::any*> entry(num_arguments, nullptr);
+		for (size_t i = 0; i < num_arguments; i++) { entry[i] = &map.at(roles[i].name); }
+		// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
+		auto resolution = map;
 		for (size_t i = 0; i < num_arguments; i++) {
-			const role& r = roles[i];
-			giddy_argument_t& a = chunk_arguments[i];
-			bool changed = false;
-			if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
-				const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
-				const size_t bytes = slice.size() * r.itemsize;
-				if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offset[i], static_cast<const char*>(arguments[i].value.pointer) + slice.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a chunk's slice)"); }
-				a.value.pointer = base + offset[i]; changed = true;
-				if (r.positions && shard.position_bias != 0) { enqueue_rebase(stream, base + offset[i], base + offset[i], shard.units.size(), r.itemsize, shard.position_bias); }
+			if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
+				resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
 			}
-			else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; changed = true; }
-			else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; changed = true; }
-			else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; changed = true; }
-			else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; changed = true; } }
-			if (changed) { *entry[i] = giddy_internal::to_any(a); }
 		}
-		if (shard.length() != config_for_length) {
-			resolution_length = cuda::any((size_t) shard.length());
-			resolution_data_length = cuda::any((size_t) shard.length());
-			config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
-			config_for_length = shard.length();
+		cuda::any& resolution_length = resolution["length"];
+		cuda::any& resolution_data_length = resolution["data_length"];
+		cuda::launch_configuration_t config;
+		uint64_t config_for_length = ~(uint64_t) 0;
+		std::vector<size_t> offset(num_arguments, 0);
+		char* const base = static_cast<char*>(blocks[k]->memory());
+		for (uint64_t c = k; c < num_chunks; c += num_streams) {
+			const auto& shard = shards[c];
+			if (shard.length() == 0) { continue; }
+			(void) slices_of(shard, offset);
+			for (size_t i = 0; i < num_arguments; i++) {
+				const role& r = roles[i];
+				giddy_argument_t& a = chunk_arguments[i];
+				bool changed = false;
+				if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
+					const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
+					const size_t bytes = slice.size() * r.itemsize;
+					if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offset[i], static_cast<const char*>(arguments[i].value.pointer) + slice.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a chunk's slice)"); }
+					a.value.pointer = base + offset[i]; changed = true;
+					if (r.positions && shard.position_bias != 0) { enqueue_rebase(stream, base + offset[i], base + offset[i], shard.units.size(), r.itemsize, shard.position_bias); }
+				}
+				else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; changed = true; }
+				else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; changed = true; }
+				else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; changed = true; }
+				else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; changed = true; } }
+				if (changed) { *entry[i] = giddy_internal::to_any(a); }
+			}
+			if (shard.length() != config_for_length) {
+				resolution_length = cuda::any((size_t) shard.length());
+				resolution_data_length = cuda::any((size_t) shard.length());
+				config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+				config_for_length = shard.length();
+			}
+			wrapper->enqueue_launch_with(stream, config, map);
 		}
-		wrapper->enqueue_launch_with(stream, config, map);
+	};
+	const size_t loops = std::min<uint64_t>(num_streams, num_chunks);
+	if (loops > 1 && num_chunks >= threaded_from_chunks()) {
+		std::vector<std::exception_ptr> failures(loops);
+		std::vector<std::thread> workers;
+		for (size_t k = 1; k < loops; k++) {
+			workers.emplace_back([&, k] { try { chunks_of_stream(k, true); } catch (...) { failures[k] = std::current_exception(); } });
+		}
+		try { chunks_of_stream(0, false); } catch (...) { failures[0] = std::current_exception(); }
+		for (auto& worker : workers) { worker.join(); }
+		for (const auto& failure : failures) { if (failure) { std::rethrow_exception(failure); } }
+	}
+	else {
+		for (size_t k = 0; k < loops; k++) { chunks_of_stream(k, false); }
 	}
 	// the first stream runs on only when every stream has made its last launch of this call: whatever is enqueued on it next — the next
 	// call's uploads into the same kept block among them — comes after all of this call's readers of the per-segment arrays

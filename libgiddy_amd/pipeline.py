@@ -182,6 +182,32 @@ _NATIVE_SCHEMES = {"dictionary": "elementwise", "discard_zero_bytes_fixed": "ele
                    "delta": "delta", "discard_zero_bytes_variable": "discard_zero_bytes_variable", "run_length_encoding": "run_length_encoding"}
 
 
+def decode_directly_from_pinned_host(scheme, host_fields, out_dev, *, stream=None, **instantiation):
+    """ONE launch, no copies: the decoder reads the compressed column out of PINNED host memory itself, over the host link, while it writes
+    the decoded column to the device.  Pinned memory (hipHostMalloc — what torch's pin_memory() gives) is mapped into the device's address
+    space at the same address, so the kernels take the host pointers as they are; every byte of the compressed column crosses the link once,
+    as with the chunked pipelines, but there is no chunk loop on the host at all (the chunked pipelines pay 3-5 us of host time per enqueued
+    copy or launch: 256 chunks of a run-length column cost more host time than the link needs for its 50 MB).  Decoders that read their
+    input more than once — the pre-passes for long segments — read it over the link as often: for those shapes prefer the chunked pipeline.
+    EVERY array of `host_fields` must be pinned (pin_all()); returns nothing — the launch is on `stream` (default: torch's current)."""
+    _, launch = _SCHEMES[scheme]
+    for name, value in host_fields.items():
+        if isinstance(value, np.ndarray) or (isinstance(value, torch.Tensor) and not value.is_cuda and not value.is_pinned()):
+            raise ValueError("%s is not in pinned memory: decode_directly_from_pinned_host needs every array pinned (pipeline.pin_all)" % name)
+    arrays = [k for k, v in host_fields.items() if isinstance(v, torch.Tensor)]
+    kw = dict(instantiation, out_size=out_dev.element_size(), sizes={k: _itemsize(host_fields[k]) for k in arrays})
+    if scheme == "dictionary":
+        kw.setdefault("num_dictionary_entries", len(host_fields["dictionary_entries"]))
+    launch(out_dev.view(-1), host_fields, stream if stream is not None else torch.cuda.current_stream(out_dev.device).cuda_stream, kw)
+
+
+def pin_all(fields):
+    """every array of a column -> a pinned torch tensor over the same bits (the small ones too: anchors, side tables)"""
+    return {name: (torch.from_numpy(np.ascontiguousarray(value)).pin_memory() if isinstance(value, np.ndarray) else
+                   (value if (value.is_cuda or value.is_pinned()) else value.pin_memory()) if isinstance(value, torch.Tensor) else value)
+            for name, value in fields.items()}
+
+
 def _captured_launch(launch, out, fields, kw):
     """(factory key, launch arguments) of schemes' launch of `fields` — nothing is enqueued"""
     captured = {}

@@ -384,3 +384,35 @@ def test_gather_compressed_on_node_through_the_c_abi():
         return arguments, {k: d[k].numel() for k in ("run_data", "run_lengths", "position_anchors", "intra_run_anchor_offsets")}
     gather(schemes.key_run_length_encoding(4, 4, 2, 4), sharding.run_length_encoding, f, col, rle_arguments,
            lambda s: {"length": r.size_t(s["length"]), "segment_length": r.size_t(4096)})
+
+
+def test_decode_directly_from_pinned_host_memory():
+    """libgiddy_amd.pipeline.decode_directly_from_pinned_host: ONE launch per column, the kernels reading the compressed arrays out of pinned
+    host memory over the link (no staging copy, no chunk loop) — every scheme of the pipelines, bit for bit."""
+    from libgiddy_amd import pipeline
+    from oracle import oracle
+    n = 300000 + 77
+
+    def check(scheme, fields, truth, **extra):
+        out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
+        out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
+        pinned = pipeline.pin_all(fields)
+        pipeline.decode_directly_from_pinned_host(scheme, pinned, out, **extra)
+        torch.cuda.synchronize()
+        got = out.cpu().numpy().view(truth.dtype)
+        assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
+        with pytest.raises(ValueError):
+            pipeline.decode_directly_from_pinned_host(scheme, fields, out, **extra)   # (numpy arrays: not pinned)
+
+    f, truth = cases.delta_case(n, 4096, np.uint64, np.uint16, seed=3)
+    check("delta", f, truth)
+    col, sizes = cases.dzbv_column(n, np.uint64, 1, 2, seed=4)
+    check("discard_zero_bytes_variable", formats.discard_zero_bytes_variable(col, 1024, 1, 2, np.uint32, 8, element_sizes=sizes), col)
+    col = cases.runs_column(n, 32, np.uint32, seed=5)
+    check("run_length_encoding", formats.run_length_encoding(col, 4096, np.uint16), col)
+    check("run_position_encoding", formats.run_position_encoding(col, 4096, np.uint16, True), col, relative=True)
+    check("run_position_encoding", formats.run_position_encoding(col, 4096, np.uint32, False), col, relative=False)
+    f = cases.dictionary_case(n, 256, np.uint32, np.uint8, seed=2)
+    check("dictionary", dict(f, length=n), f["dictionary_entries"][f["compressed_input"].astype(np.int64)])
+    f = cases.for_case(n, 4096, np.int32, np.int16, "linear", seed=6)
+    check("frame_of_reference", f, oracle.frame_of_reference(f["compressed_input"], f["segment_model_coefficients"], n, 4096, np.int32, "linear"), model="linear")
