@@ -216,6 +216,7 @@ int          giddy_enqueue_gather_on_node(void* destination, int root_device, vo
  * For discard-zero-bytes columns that is 2.9 x fewer bytes over xGMI than gathering decoded shards.  Peer access is checked and enabled
  * (an error where the devices cannot reach each other directly).  Cut a shard finer (giddy_shard) for more overlap. */
 #define GIDDY_SHARD_COPY_EVEN_IF_LOCAL 1u    /* copy the arrays into the root's scratch even when the shard already lies on the root (tests on one GPU) */
+#define GIDDY_SHARD_DECODE_IN_PLACE    2u    /* no copy: the root's decoder reads the shard's arrays where they lie, over the link (peer access) — every byte crosses once, nothing is staged */
 typedef struct giddy_compressed_shard {
 	int32_t                  device;                    /* where the shard's compressed arrays lie */
 	uint32_t                 flags;

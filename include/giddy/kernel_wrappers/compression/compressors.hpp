@@ -439,8 +439,9 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch_with(stream::id_t stream, const la
 	if (length == 0) { return; }
 	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once
 	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
-	enqueue_zero(stream, totals, num_tiles * sizeof(uint64_t));
-	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, chained_launch(num_tiles),
+	const uint64_t num_links = util::div_rounding_up(num_tiles, (uint64_t) runs::one_pass::tiles_per_link);   // (a workgroup — a link of the chain — takes that many consecutive tiles)
+	enqueue_zero(stream, totals, num_links * sizeof(uint64_t));
+	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, chained_launch(num_links),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),
 		argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint64_t*>(arguments, "num_element_runs"), input, totals, segment, length,
 		(uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length),

@@ -37,7 +37,11 @@ namespace one_pass {
 #endif
 enum : unsigned { per_lane = GIDDY_ONE_PASS_BITS_PER_LANE, wave_elements = 64 * per_lane, tile = waves_per_block * wave_elements };
 using mask_t = std::conditional<(per_lane > 32), uint64_t, uint32_t>::type;   // a lane's bits, one per element it saw
-enum : unsigned { staged_runs = 2048 };   // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
+enum : unsigned { staged_runs = 2048 };
+#ifndef GIDDY_ONE_PASS_TILES_PER_LINK
+#define GIDDY_ONE_PASS_TILES_PER_LINK 4
+#endif
+enum : unsigned { tiles_per_link = GIDDY_ONE_PASS_TILES_PER_LINK };   // consecutive tiles a workgroup of encode_run_positions takes as ONE link of the chain   // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
 __device__ __forceinline__ unsigned count_bits(mask_t m) { return (unsigned) __builtin_popcountll((unsigned long long) m); }
 __device__ __forceinline__ unsigned lowest_bit(mask_t m) { return (unsigned) __builtin_ctzll((unsigned long long) m); }
 __device__ __forceinline__ unsigned highest_bit(mask_t m) { return 63u - (unsigned) __builtin_clzll((unsigned long long) m); }
@@ -180,23 +184,44 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 	__shared__ uint_t<PositionSize> staged_positions[staged_runs];
 	const uint64_t n = length, L = segment_length, num_tiles = (n + tile - 1) / tile;
 	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
-	for (uint64_t t = blockIdx.x; t < num_tiles; t += gridDim.x) {
-		if (t == fault_tile) { return; }   // (a test: this tile is never heard of)
+	// A workgroup is ONE link of the chain and takes `tiles_per_link` CONSECUTIVE tiles (round 4): it finds the run starts of all of them first —
+	// a lane keeps one bit per element, eight registers for four tiles —, publishes the link's number of runs, and looks back ONCE while its
+	// first tile's runs are being staged: a quarter of the links, each four times as long (16 384 links of 64 KiB: 433-439 us at 2^28 elements).
+	constexpr unsigned K = tiles_per_link;
+	const uint64_t num_links = (num_tiles + K - 1) / K;
+	__shared__ uint32_t link_wave_totals[K][waves_per_block];
+	for (uint64_t link = blockIdx.x; link < num_links; link += gridDim.x) {
+	if (link == fault_tile) { return; }   // (a test: this link is never heard of)
+	mask_t starts_of_tile[K];
+	#pragma unroll
+	for (unsigned k = 0; k < K; k++) {
+		const uint64_t wave_base = (link * K + k) * tile + (uint64_t) wave * wave_elements;
+		T last_value;
+		starts_of_tile[k] = wave_base < n ? run_starts_of_wavefront<T>(input, wave_base, n, lane, last_value) : 0;
+		const uint32_t of_wave = wave64::read_last_lane(wave64::inclusive_sum((uint32_t) count_bits(starts_of_tile[k])));
+		if (lane == 0) { link_wave_totals[k][wave] = of_wave; }
+	}
+	__syncthreads();
+	uint64_t link_total = 0;
+	#pragma unroll
+	for (unsigned k = 0; k < K; k++) { for (unsigned w = 0; w < waves_per_block; w++) { link_total += link_wave_totals[k][w]; } }
+	chained::announce(states, link, link_total);   // (the links after this one wait for it: said as soon as it is known)
+	uint64_t runs_before_tile = 0;   // known from the first tile's look-back on
+	#pragma unroll
+	for (unsigned k = 0; k < K; k++) {
+		const uint64_t t = link * K + k;
+		if (t >= num_tiles) { break; }
 		const uint64_t wave_base = t * tile + (uint64_t) wave * wave_elements;
 #ifdef GIDDY_CHAINED_STAMPS   // (measurements: when a tile started, had counted, knew its base, was done — 100 MHz ticks, behind the states)
 		uint64_t* const stamps = states + num_tiles + 4 * t;
 		if (threadIdx.x == 0) { stamps[0] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-		T last_value;
-		const mask_t starts = wave_base < n ? run_starts_of_wavefront<T>(input, wave_base, n, lane, last_value) : 0;
+		const mask_t starts = starts_of_tile[k];
 		uint64_t offsets[S::groups];
-		const uint32_t wave_total = rank_rows<UncompressedSize>(starts, offsets);
-		__syncthreads();   // (the table may still be read for the tile before)
-		if (lane == 0) { wave_totals[wave] = wave_total; }
-		__syncthreads();
+		(void) rank_rows<UncompressedSize>(starts, offsets);
 		uint32_t wave_before = 0, tile_total = 0;
 		#pragma unroll
-		for (unsigned w = 0; w < waves_per_block; w++) { const uint32_t of_wave = wave_totals[w]; wave_before += w < wave ? of_wave : 0; tile_total += of_wave; }
+		for (unsigned w = 0; w < waves_per_block; w++) { const uint32_t of_wave = link_wave_totals[k][w]; wave_before += w < wave ? of_wave : 0; tile_total += of_wave; }
 		// A tile of at most `staged_runs` runs: their values (read again, out of the L2 they just passed through) and positions go to LDS at their
 		// rank IN THE TILE now — while the tiles before this one are still being waited for — and leave as coalesced copies once the tile knows its
 		// base.  (With the re-reads after the chain a tile spent 10 of its 27 microseconds there.)
@@ -226,15 +251,20 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 			}
 		};
 		auto position_of = [&](uint32_t offset) { return (uint_t<PositionSize>) (PositionsAreRelative ? into_segment(wave_into_segment, offset, L) : wave_base + offset); };
-		chained::announce(states, t, tile_total);   // (the tiles after this one wait for it: before the staging, not after)
+		if (k != 0) { __syncthreads(); }   // (the staging area has been copied out for the tile before)
 		if (staged) {
 			for_each_run_of_the_lane([&](uint32_t rank, uint32_t offset, T value) { staged_values[rank] = value; staged_positions[rank] = position_of(offset); });
 		}
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[1] = __builtin_amdgcn_s_memrealtime(); }
 #endif
-		const uint64_t tile_base = chained::exclusive_base(states, t, num_tiles, tile_total, &slot, num_element_runs, true, patience);   // runs that start before the tile (barriers inside: the staging is complete)
-		if (tile_base == chained::failed_base) { return; }   // (the chain broke before this tile: every thread sees it; the last tile has said so in *num_element_runs)
+		if (k == 0) {   // the link's first tile: its runs are staged — now, and once per link, the look-back (barriers inside: the staging is complete)
+			runs_before_tile = chained::exclusive_base(states, link, num_links, link_total, &slot, num_element_runs, true, patience);
+			if (runs_before_tile == chained::failed_base) { return; }   // (the chain broke before this link: every thread sees it; the last link has said so in *num_element_runs)
+		}
+		else { __syncthreads(); }   // (the staging is complete)
+		const uint64_t tile_base = runs_before_tile;
+		runs_before_tile += tile_total;
 		const uint64_t base = tile_base + wave_before;   // ... before this wavefront's elements
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[2] = __builtin_amdgcn_s_memrealtime(); }
@@ -270,6 +300,8 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 #ifdef GIDDY_CHAINED_STAMPS
 		if (threadIdx.x == 0) { stamps[3] = __builtin_amdgcn_s_memrealtime(); }
 #endif
+	}
+	__syncthreads();   // (the link's tables are rewritten by the workgroup's next link)
 	}
 }
 

@@ -401,7 +401,11 @@ int giddy_enqueue_gather_compressed_on_node(const char* key, int root_device, vo
 			const giddy_compressed_shard_t& shard = shards[i];
 			if (shard.num_arguments != 0 && (shard.arguments == nullptr || shard.bytes == nullptr)) { throw std::invalid_argument("a shard without arguments / sizes"); }
 			const auto root_stream = static_cast<hipStream_t>(root_streams[i % num_root_streams]);
-			const bool moves = shard.device != root_device || (shard.flags & GIDDY_SHARD_COPY_EVEN_IF_LOCAL) != 0;
+			// (GIDDY_SHARD_DECODE_IN_PLACE: no copy at all — the root's decoder reads the shard's arrays where they lie, over the link, as it reads
+			// pinned host memory in libgiddy_amd.pipeline.decode_directly_from_pinned_host: peer access makes a peer's memory addressable)
+			const bool in_place = (shard.flags & GIDDY_SHARD_DECODE_IN_PLACE) != 0;
+			if (in_place) { enable_peer_access(root_device, shard.device); }
+			const bool moves = !in_place && (shard.device != root_device || (shard.flags & GIDDY_SHARD_COPY_EVEN_IF_LOCAL) != 0);
 			// the root's stream waits for what the shard's device has enqueued on the shard's stream so far (its arrays being written, say)
 			{
 				cuda::device::current::scoped_override_t<> on_shard(shard.device);

@@ -117,6 +117,7 @@ def gather_compressed_on_node(key, root_device, root_streams, shards):
         nbytes        name -> bytes of each array that travels (the others stay where they point)
         resolution    name -> size_t values for launch-configuration resolution
         copy_even_if_local   copy into the root's scratch even when device == root_device (tests on one GPU)
+        decode_in_place      no copy: the root's decoder reads the shard's arrays over the link where they lie (peer access)
     Everything is enqueued; nothing is waited for.  root_streams[0] sees the whole column once it has run."""
     import ctypes
     from . import _native
@@ -128,7 +129,7 @@ def gather_compressed_on_node(key, root_device, root_streams, shards):
         resolution, kept_too = _marshal(shard["resolution"])
         nbytes = (ctypes.c_uint64 * max(len(shard["arguments"]), 1))(*[int(shard["nbytes"].get(name, 0)) for name in shard["arguments"]])
         keep += [arguments, kept, resolution, kept_too, nbytes]
-        slot.device, slot.flags = int(shard["device"]), 1 if shard.get("copy_even_if_local") else 0
+        slot.device, slot.flags = int(shard["device"]), (1 if shard.get("copy_even_if_local") else 0) | (2 if shard.get("decode_in_place") else 0)
         slot.hip_stream = ctypes.c_void_p(int(shard["stream"]) if shard["stream"] else None)
         slot.arguments, slot.bytes, slot.num_arguments = arguments, nbytes, len(shard["arguments"])
         slot.resolution_arguments, slot.num_resolution_arguments = resolution, len(shard["resolution"])

@@ -347,6 +347,7 @@ def test_gather_compressed_on_node_through_the_c_abi():
 
     def gather(key, shard_function, fields, truth, arguments_of, resolution_of):
         out = torch.full((len(truth) * truth.dtype.itemsize,), 0x5A, dtype=torch.uint8, device="cuda")
+        torch.cuda.synchronize()   # (the fill is on torch's current stream, the decodes on streams of their own)
         shards, keep = [], []
         for rank in range(world):
             sh = shard_function(fields, rank, world)
@@ -355,7 +356,7 @@ def test_gather_compressed_on_node_through_the_c_abi():
             keep.append((stream, device_fields))
             arguments, nbytes = arguments_of(out[sh.start * truth.dtype.itemsize:], device_fields, sh.fields)
             shards.append({"device": 0, "stream": stream.cuda_stream, "arguments": arguments, "nbytes": nbytes,
-                           "resolution": resolution_of(sh.fields), "copy_even_if_local": True})
+                           "resolution": resolution_of(sh.fields), "copy_even_if_local": rank != 1, "decode_in_place": rank == 1})   # (one shard read where it lies)
         distributed.gather_compressed_on_node(key, 0, [s.cuda_stream for s in root_streams], shards)
         with torch.cuda.stream(root_streams[0]):
             got = out.clone()
