@@ -337,6 +337,50 @@ def time_gather_compressed(whole, shard, counts, rank, world, device, barrier, r
     return report
 
 
+def modes_of_use(n, device, steps):
+    """A = the factory's type-erased wrapper over the C ABI (what everything above times), B = an instantiated wrapper +
+    cuda::kernel::enqueue_launch(kernel, stream, config, typed parameters...), C = the kernel template launched directly — the reference's three
+    documented modes (README.md:94-126) — on C4 (run lengths; ordinary segments and segments of 65 536) and C3 (Delta): % of the HBM peak each, and
+    whether B's and C's outputs equal A's.  tests/cpp/modes_shim.hip behind ctypes (tools/modes.py); the full table: profiles/r04_modes_bench.txt."""
+    import torch
+    import modes
+    import workloads as w
+    stream = torch.cuda.current_stream()
+    out = {"note": "A and B reach the same typed launch (include/giddy/kernel_wrapper.hpp); C is the bare kernel of the reference's signature"}
+
+    def ms_of(run):
+        for _ in range(2):
+            run(stream.cuda_stream)
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        begin.record(stream)
+        for _ in range(steps):
+            run(stream.cuda_stream)
+        end.record(stream); end.synchronize()
+        return begin.elapsed_time(end) / steps
+
+    columns = [("run_length_encoding<4,4,2>, segments of 4096", "rle<4,4,2>", lambda: w.RunLength(n, device)),
+               ("run_length_encoding<4,4,2>, segments of 65536", "rle<4,4,2>", lambda: w.RunLength(n, device, segment_length=65536)),
+               ("delta<4,8,2>, segments of 4096", "delta<4,8,2>", lambda: w.DeltaPatched(n, device))]
+    for label, scheme, make in columns:
+        work = make()
+        fields = work.column_fields()
+        entry, reference = {}, None
+        for mode in ("A", "B", "C"):
+            run = modes.launcher(scheme, fields, work.output, mode)
+            work.output.fill_(-1)
+            run(stream.cuda_stream); torch.cuda.synchronize()
+            if reference is None:
+                reference = work.output.clone()
+            else:
+                entry["%s_equals_A" % mode] = bool((work.output == reference).all())
+            ms = ms_of(run)
+            entry["frac_" + mode] = round(work.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+        out[label] = entry
+        del work, fields, reference
+        torch.cuda.empty_cache()
+    return out
+
+
 def all_reduce_u64_sum(value, world, device, backend):
     """sum of 64-bit checksums over the ranks, wrapping — carried as 16-bit limbs so that no backend's integer addition can overflow"""
     import torch
@@ -567,6 +611,13 @@ def main():
             del w
             torch.cuda.empty_cache()
         line["schemes"] = schemes_out
+
+    # ---- the reference's three modes of use on two of the columns whose wrappers pick among several kernels (N = 1 only) ----
+    if world == 1 and args.schemes != "none":
+        try:
+            line["modes"] = modes_of_use(n, device, max(5, args.steps // 2))
+        except Exception as problem:   # (the C++ shim is test infrastructure: its absence must not cost the bench line)
+            line["modes"] = {"skipped": repr(problem)}
 
     # ---- BASELINE.json configs[3] / configs[4] as stated: one column cut over the ranks (strong scaling), at every N ----
     if args.sharded != "none":
