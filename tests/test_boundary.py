@@ -201,3 +201,28 @@ def test_every_build_of_a_run_decoder_accepts_the_configuration_resolved_for_the
             assert alternate["private_segment_fixed_size"] == 0, (build, "scratch memory: the build spills vector registers")
         families += 1
     assert families == 28, families   # 18 run-length + 10 run-position registrations
+
+
+def test_round_4_entry_points_fail_politely_without_a_device():
+    """giddy_prepare / giddy_enqueue_prepared / the scratch entry points: null handles and bad policies are status codes with a message, and the
+    pool is empty in a process that never launched anything (no device is touched here)."""
+    lib = _native.lib
+    prepared = ctypes.c_void_p()
+    assert lib.giddy_prepare(None, None, 0, ctypes.byref(prepared)) == -1 and b"null kernel handle" in lib.giddy_last_error()
+    assert lib.giddy_enqueue_prepared(None, None, None) == -1
+    assert lib.giddy_prepared_update(None, None, 0) == -1
+    lib.giddy_release_prepared(None)
+    assert lib.giddy_set_capture_scratch_policy(7) == -1
+    assert lib.giddy_set_capture_scratch_policy(0) == 0
+    assert lib.giddy_scratch_held_bytes() == 0 and lib.giddy_trim() == 0
+    kernel = r.kernel_t.produceSubclass(schemes.key_run_length_encoding(4, 4, 2, 4))
+    assert lib.giddy_device_function_count(kernel._handle) == 3          # the kernel of the reference's signature + the builds for short / long runs
+    assert len(set(kernel.device_functions())) == 3 and kernel.device_functions()[0] == kernel.get_device_function()
+    assert lib.giddy_device_function_count(r.kernel_t.produceSubclass(schemes.key_dictionary(4, 4, 1))._handle) == 1
+    relative = r.kernel_t.produceSubclass("decompression::run_position_encoding::kernel_t<4u, 4u, 2u, true, 4u>")
+    assert lib.giddy_device_function_count(relative._handle) == 4        # ... + the one over finer anchors
+    # a prepared launch on a real wrapper, map and all — nothing is launched
+    arguments = {"length": r.size_t(1 << 20), "segment_length": r.size_t(4096)}
+    handle = kernel.prepare(arguments)
+    handle.update({"length": r.size_t(1 << 21)})
+    del handle

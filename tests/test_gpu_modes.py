@@ -133,3 +133,27 @@ def test_scratch_pool_reserve_forget_trim():
         registered.release_scratch(side.cuda_stream)
     assert registered.trim() == held
     assert registered.scratch_held_bytes() == 0
+
+
+def test_prepared_launches_keep_their_map_and_take_updates():
+    """giddy_prepare / giddy_prepared_update / giddy_enqueue_prepared: the argument map is built once, a loop rewrites the entries that change — here the
+    two halves of a Dictionary column decoded by ONE prepared launch whose pointers and length are moved between the launches."""
+    from libgiddy_amd import registered as r, schemes
+    n = 1 << 20
+    keys = torch.randint(0, 256, (n,), dtype=torch.uint8, device="cuda")
+    entries = (torch.arange(256, dtype=torch.int32, device="cuda") * 2654435 + 17)
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    kernel = schemes.kernel(schemes.key_dictionary(4, 4, 1))
+    half = n // 2
+    config = kernel.resolve_launch_configuration(r.CURRENT_DEVICE, {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(half)})
+    prepared = kernel.prepare({"decompressed": r.pointer(out, "u32"), "compressed_input": r.const_pointer(keys, "u8"), "dictionary_entries": r.const_pointer(entries, "u32"),
+                               "length": r.size_type_by_index_size(4)(half), "num_dictionary_entries": r.size_type_by_index_size(1)(256)})
+    stream = torch.cuda.current_stream().cuda_stream
+    prepared.enqueue(stream, config)
+    prepared.update({"decompressed": r.pointer(out[half:], "u32"), "compressed_input": r.const_pointer(keys[half:], "u8")})
+    prepared.enqueue(stream, config)
+    torch.cuda.synchronize()
+    assert bool((out == entries[keys.to(torch.int64)]).all())
+    with pytest.raises(Exception):
+        prepared.update({"length": r.uint64(half)})   # (accepted into the map ...)
+        prepared.enqueue(stream, config)              # ... and refused by the wrapper: it holds another type than the wrapper casts to
