@@ -58,17 +58,29 @@ namespace delta {
 namespace detail {
 
 // build-time tuning knobs (defaults measured on MI355X)
+#ifndef GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS
+#define GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS 1   // segments that are not whole rows: rows laid out by the output's cache lines, a segment boundary inside a row (wave_per_ragged_segment_in_aligned_rows)
+#endif
 #ifndef GIDDY_DELTA_ROWS_IN_FLIGHT
 #define GIDDY_DELTA_ROWS_IN_FLIGHT 0   // 0: the measured best per instantiation (rows_in_flight_for below); n > 0: n for all
 #endif
 #ifndef GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO
 #define GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO 4   // bytes of input per lane per row up to which a chunk's input goes through LDS (wave path)
 #endif
+#ifndef GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH
+#define GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH 0   // (measurement aid: what the ragged path's bookkeeping costs where nothing is ragged)
+#endif
+#ifndef GIDDY_DELTA_RAGGED_STAGED
+#define GIDDY_DELTA_RAGGED_STAGED(uncompressed_size) ((uncompressed_size) == 8)   // ragged segments: staging pays for 64-bit elements (<4,8,2>: 69 % against 60; <4,4,1>: 76 % against 80)
+#endif
 #ifndef GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO
 #define GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO 2   // ... of the fused kernels, whose patch windows share the LDS
 #endif
 #ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
 #define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
+#endif
+#ifndef GIDDY_DELTA_ROWS_PER_CHUNK
+#define GIDDY_DELTA_ROWS_PER_CHUNK 32
 #endif
 #ifndef GIDDY_DELTA_WAVE_PATH_THREADS
 #define GIDDY_DELTA_WAVE_PATH_THREADS 256
@@ -77,7 +89,7 @@ namespace detail {
 enum : unsigned {
 	rows_per_wave_per_sweep = GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP,                // block path
 	wave_path_threads = GIDDY_DELTA_WAVE_PATH_THREADS,
-	rows_per_chunk = 32,                                                          // wave path: rows a wavefront takes per outer-loop trip;
+	rows_per_chunk = GIDDY_DELTA_ROWS_PER_CHUNK,                                                          // wave path: rows a wavefront takes per outer-loop trip;
 	                                                                              // segments of more rows are swept by a whole workgroup
 	max_waves_per_block = 16,
 };
@@ -102,6 +114,20 @@ struct row_traits {
 	// type the in-row prefix is formed in: 64*E elements of at most 2^(8*CompressedSize)-1 each
 	using scan_type = typename std::conditional<(UncompressedSize <= 4 || CompressedSize <= 2), uint32_t, uint64_t>::type;
 };
+
+/// (measurement aid) the workgroup's place in the order the chunks are handed out: blockIdx.x — or, with GIDDY_DELTA_ROTATE_WORKGROUPS, the
+/// workgroups of every group of 8 (one per XCD, the dispatcher deals them round-robin) rotated by the group's number, so that an XCD does
+/// not keep to the same slice of every 8 x 4 chunks
+#ifndef GIDDY_DELTA_ROTATE_WORKGROUPS
+#define GIDDY_DELTA_ROTATE_WORKGROUPS 0
+#endif
+__device__ __forceinline__ unsigned workgroup_in_order()
+{
+	if (!GIDDY_DELTA_ROTATE_WORKGROUPS) { return blockIdx.x; }
+	const unsigned group = blockIdx.x / 8, within = blockIdx.x % 8;
+	if (group * 8 + 8 > gridDim.x) { return blockIdx.x; }
+	return group * 8 + (within + group) % 8;
+}
 
 /// One row: load, scan, return the exclusive-of-row prefixes; `valid` = elements of the row inside the input
 template <unsigned UncompressedSize, unsigned CompressedSize>
@@ -158,6 +184,45 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_se
 	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / rows_per_segment;
 }
 
+/// Whether the segments of a column go a WAVEFRONT each (kernel and launch parameters agree): those of up to `rows_per_chunk` rows — and,
+/// round 4, longer RAGGED segments of 64-bit elements when there are thousands of them: the workgroup path's rows begin where the segment does
+/// (partial cache lines at both ends of every row) and its input loads are 2-8 bytes per lane — 46-68 % of the HBM peak at segments of 5000
+/// and 10000 elements where the wave paths for ragged segments (rows by the output's cache lines, input through LDS) reach 58-74 %.  For
+/// 2- and 4-byte elements the workgroup path is the faster one (78-89 %), and for 2-byte deltas of 64-bit elements too (68 % against 64-67).
+#ifndef GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS
+#define GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS 8192   // 0: never
+#endif
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	if ((L + traits::row - 1) / traits::row <= rows_per_chunk) { return true; }
+	return GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS != 0 && UncompressedSize == 8 && CompressedSize != 2 && L % traits::row != 0
+		&& n / GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS >= L;
+}
+
+/// A chunk's anchors, one per lane (a chunk is at most rows_per_chunk <= 64 segments): ONE vector load that goes out ahead of the chunk's first
+/// rows, where `base = anchors[segment]` at every segment's first row is a load the wavefront has to wait for with its stores unissued
+/// (segments of 12 rows: 66 % of the HBM peak where segments of 16 — two per chunk instead of... — reach 73 %).
+#ifndef GIDDY_DELTA_ANCHORS_AHEAD
+#define GIDDY_DELTA_ANCHORS_AHEAD 1
+#endif
+template <typename U>
+struct chunk_anchors {
+	U mine;
+	uint64_t first;
+	const U* __restrict__ anchors;
+	__device__ __forceinline__ void load(const U* __restrict__ anchors_, uint64_t first_segment, uint64_t segments_per_chunk, uint64_t start, uint64_t end, uint64_t L, unsigned lane)
+	{
+		anchors = anchors_; first = first_segment;
+		if (GIDDY_DELTA_ANCHORS_AHEAD) { mine = (lane < segments_per_chunk && start + lane * L < end) ? anchors[first_segment + lane] : (U) 0; }
+	}
+	__device__ __forceinline__ U of(uint64_t segment) const
+	{
+		return GIDDY_DELTA_ANCHORS_AHEAD ? wave64::read_lane(mine, (unsigned) (segment - first)) : anchors[segment];
+	}
+};
+
 /// wave path: this wavefront decompresses whole segments on its own (several short ones per chunk)
 template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void wave_per_segment(
@@ -168,15 +233,18 @@ __device__ __forceinline__ void wave_per_segment(
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
-	const uint64_t chunk_length = segments_per_wave_chunk(L / traits::row) * L;
+	const uint64_t segments_per_chunk = segments_per_wave_chunk(L / traits::row);
+	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
 
 	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
 		const uint64_t start = c * chunk_length;
 		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
-		uint64_t segment = start / L, next_segment_start = start;   // the chunk starts on a segment boundary
+		uint64_t segment = c * segments_per_chunk, next_segment_start = start;   // the chunk starts on a segment boundary
+		chunk_anchors<U> chunk_anchor_values;
+		chunk_anchor_values.load(anchors, segment, segments_per_chunk, start, end, L, lane);
 		U base = 0;
 		// Software-pipelined: the NEXT group's loads are issued before this group's stores.  CDNA4 retires
 		// vector-memory operations in order, so a load issued after a store cannot be waited for without
@@ -197,7 +265,7 @@ __device__ __forceinline__ void wave_per_segment(
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
 				const uint64_t this_row = row_start + (uint64_t) k * traits::row;
-				if (this_row == next_segment_start && this_row < end) { base = anchors[segment++]; next_segment_start += L; }   // wave-uniform
+				if (this_row == next_segment_start && this_row < end) { base = chunk_anchor_values.of(segment++); next_segment_start += L; }   // wave-uniform
 				rows[k].store(out, this_row, end, lane, base, patches);
 				base += (U) rows[k].total;
 			}
@@ -221,9 +289,10 @@ __device__ __forceinline__ void wave_per_segment_with_staged_input(
 	using C = typename traits::compressed_type;
 	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
-	const uint64_t chunk_length = segments_per_wave_chunk(L / traits::row) * L;
+	const uint64_t segments_per_chunk = segments_per_wave_chunk(L / traits::row);
+	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
 	const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(in);
 
@@ -231,6 +300,8 @@ __device__ __forceinline__ void wave_per_segment_with_staged_input(
 		const uint64_t start = c * chunk_length;
 		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
 		const unsigned chunk_bytes = (unsigned) (end - start) * CompressedSize;
+		chunk_anchors<U> chunk_anchor_values;
+		chunk_anchor_values.load(anchors, c * segments_per_chunk, segments_per_chunk, start, end, L, lane);
 		patches.begin_seek(start, lane);
 		wave64::lds_fence();   // (the previous chunk's rows have been read)
 		for (unsigned at = lane * 16; at < chunk_bytes; at += 64 * 16) {
@@ -243,7 +314,7 @@ __device__ __forceinline__ void wave_per_segment_with_staged_input(
 		}
 		patches.finish_seek(lane);
 		wave64::lds_fence();
-		uint64_t segment = start / L, next_segment_start = start;   // the chunk starts on a segment boundary
+		uint64_t segment = c * segments_per_chunk, next_segment_start = start;   // the chunk starts on a segment boundary
 		U base = 0;
 		for (uint64_t row_start = start; row_start < end; row_start += traits::row) {
 			row_t<UncompressedSize, CompressedSize> row;
@@ -252,7 +323,7 @@ __device__ __forceinline__ void wave_per_segment_with_staged_input(
 			#pragma unroll
 			for (unsigned j = 0; j < traits::E; j++) { row.deltas[j] = (p + j < end) ? staged[j] : (C) 0; }
 			row.scan();
-			if (row_start == next_segment_start) { base = anchors[segment++]; next_segment_start += L; }   // wave-uniform
+			if (row_start == next_segment_start) { base = chunk_anchor_values.of(segment++); next_segment_start += L; }   // wave-uniform
 			row.store(out, row_start, end, lane, base, patches);
 			base += (U) row.total;
 		}
@@ -271,7 +342,7 @@ __device__ __forceinline__ void wave_per_ragged_segment(
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
@@ -296,6 +367,8 @@ __device__ __forceinline__ void wave_per_ragged_segment(
 			return r;   // past the chunk's end: start == end == chunk_end, an empty row
 		};
 		U base = 0;
+		chunk_anchors<U> chunk_anchor_values;
+		chunk_anchor_values.load(anchors, segment, segments_per_chunk, chunk_start, chunk_end, L, lane);
 		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
 		row_bounds bounds[R], next_bounds[R];
 		patches.begin_seek(chunk_start, lane);
@@ -310,12 +383,340 @@ __device__ __forceinline__ void wave_per_ragged_segment(
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
 				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
-				if (bounds[k].first_of_segment) { base = anchors[segment++]; }
+				if (bounds[k].first_of_segment) { base = chunk_anchor_values.of(segment++); }
 				rows[k].store(out, bounds[k].start, bounds[k].end, lane, base, patches);
 				base += (U) rows[k].total;
 			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; }
+		}
+	}
+}
+
+/// Ragged segments, rows laid out by the OUTPUT (round 4).  wave_per_ragged_segment above starts a row wherever a segment starts: with segments
+/// of 1000 or 3000 64-bit elements no row begins on a cache line, every 1 KiB row store is nine partial lines instead of eight whole ones, and
+/// the decoder runs at 61 % of the HBM peak where whole-row segments reach 72-78 %.  Here the chunk's rows begin on ROW-sized boundaries of the output
+/// (a first partial row, then whole aligned rows, a last partial one) whatever the segments do: a row may have ONE segment boundary inside it
+/// (segments of at least a row) — lanes are whole groups of E elements on either side, since segment lengths are multiples of E — and the lanes
+/// behind it count from the new segment's anchor: value = anchor' + (prefix - the prefix at the boundary).  Same pipeline: the next rows' loads
+/// before these rows' stores.
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void wave_per_ragged_segment_in_aligned_rows(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using scan_type = typename traits::scan_type;
+	constexpr unsigned R = traits::rows_in_flight > 4 ? 4 : traits::rows_in_flight;   // (8 rows of 2-byte elements with their bounds in flight spill registers)
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
+	const uint64_t chunk_length = segments_per_chunk * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+
+	struct row_bounds { uint64_t start, end; };   // wave-uniform
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t chunk_start = c * chunk_length;
+		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
+		// elements from the chunk's start to the next row-sized boundary of the OUTPUT (a multiple of E: the output is 16-byte aligned)
+		const uint64_t misplaced = (reinterpret_cast<uintptr_t>(out + chunk_start) / sizeof(U)) % traits::row;
+		const uint64_t head = misplaced == 0 ? traits::row : traits::row - misplaced;
+		uint64_t walk_start = chunk_start;
+		auto take_row = [&]() {
+			row_bounds r;
+			r.start = walk_start;
+			const uint64_t length = walk_start == chunk_start ? head : traits::row;
+			r.end = walk_start + length < chunk_end ? walk_start + length : chunk_end;
+			walk_start = r.end;
+			return r;   // past the chunk's end: start == end == chunk_end, an empty row
+		};
+		uint64_t segment = c * segments_per_chunk, next_boundary = chunk_start;   // the next segment's first element
+		U base = 0;
+		chunk_anchors<U> chunk_anchor_values;
+		chunk_anchor_values.load(anchors, segment, segments_per_chunk, chunk_start, chunk_end, L, lane);
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		row_bounds bounds[R], next_bounds[R];
+		patches.begin_seek(chunk_start, lane);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].load(in, bounds[k].start, bounds[k].end, lane); }
+		patches.finish_seek(lane);
+		while (bounds[0].start < chunk_end) {
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].load(in, next_bounds[k].start, next_bounds[k].end, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
+				if (bounds[k].start == next_boundary) { base = chunk_anchor_values.of(segment++); next_boundary += L; }
+				if (next_boundary < bounds[k].end) {
+					// a segment begins inside the row, at lane `first_behind` (> 0): the lanes from there on count from its anchor
+					const unsigned first_behind = (unsigned) ((next_boundary - bounds[k].start) / traits::E);
+					const scan_type at_boundary = wave64::read_lane(rows[k].prefix[traits::E - 1], first_behind - 1);
+					const U behind = (U) (chunk_anchor_values.of(segment++) - (U) at_boundary);
+					rows[k].store(out, bounds[k].start, bounds[k].end, lane, lane < first_behind ? base : behind, patches);
+					base = behind;
+					next_boundary += L;
+				}
+				else { rows[k].store(out, bounds[k].start, bounds[k].end, lane, base, patches); }
+				base += (U) rows[k].total;
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; }
+		}
+	}
+}
+
+/// Segments SHORTER than a row (round 4): several of them in every row.  wave_per_ragged_segment gives each its own row — segments of 64 elements
+/// of 4 bytes fill a quarter of the lanes and of every store (20 % of the HBM peak; 16-element segments: 6 %).  Here, as above, rows follow the
+/// output's cache lines whatever the segments do, and every LANE works out where it stands: its group of E elements lies in ONE segment (segment
+/// lengths are multiples of E), segment `s` of the chunk; if that segment begins in this row, at lane b, the lane's values count from the
+/// segment's anchor less the row's prefix before lane b (one ds_bpermute); if it began in an earlier row they go on from where that row ended.
+/// The anchors are gathered per lane with the row's own loads (lanes of one segment read one address).  A chunk is as many whole segments
+/// as fill `rows_per_chunk` rows (short_segments_per_wave_chunk; kernel and launch parameters agree).
+#ifndef GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS
+#define GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS 1
+#endif
+#ifndef GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS
+#define GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS 1   // ... and ragged segments of a row or more go the same way (0: wave_per_ragged_segment_in_aligned_rows)
+#endif
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline bool short_segments_share_rows(uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	return GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS && L % traits::E == 0 && L % traits::row != 0
+		&& (L < traits::row || (GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS && (L + traits::row - 1) / traits::row <= rows_per_chunk));
+}
+/// segments per wavefront chunk, of any length (the wave path)
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline uint64_t segments_per_wave_chunk_of(uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	if (L < traits::row && short_segments_share_rows<UncompressedSize, CompressedSize>(L)) { return (uint64_t) rows_per_chunk * traits::row / L; }
+	return segments_per_wave_chunk((L + traits::row - 1) / traits::row);
+}
+
+/// Chunks of the lane-placed path.  A wavefront's chunk had better be EXACTLY rows_per_chunk rows (measured, tools/run_ragged_delta.sh with
+/// GIDDY_DELTA_ROWS_PER_CHUNK builds: chunks of 16 or 32 rows 73 % of the HBM peak, of 21, 24, 30, 31, 33, 48 rows 62-66 % — whole-row segments
+/// of 10 or 12 rows, three or two to a chunk, sit there too; neither the base addresses' alignment nor the number of workgroups explains it,
+/// and the bytes moved are the same).  So where whole segments do not make such a chunk the chunks are WINDOWS of rows_per_chunk rows of the column
+/// whatever the segments do: a window that begins inside a segment first adds up that segment's deltas before the window (at most one segment's
+/// worth of input read a second time — segments of up to GIDDY_DELTA_WINDOWS_UP_TO_ROWS rows go this way).
+#ifndef GIDDY_DELTA_WINDOWS_UP_TO_ROWS
+#define GIDDY_DELTA_WINDOWS_UP_TO_ROWS 4   // 0: chunks of whole segments always (measured with 16: segments of 8-12 rows lose 3-4 points to the second read, of up to 4 rows gain 5-13)
+#endif
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline bool chunks_are_windows(uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	return short_segments_share_rows<UncompressedSize, CompressedSize>(L) && L <= (uint64_t) GIDDY_DELTA_WINDOWS_UP_TO_ROWS * traits::row
+		&& segments_per_wave_chunk_of<UncompressedSize, CompressedSize>(L) * L != (uint64_t) rows_per_chunk * traits::row;
+}
+/// elements per wavefront chunk on the wave path, for segments of any length
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline uint64_t wave_chunk_length_of(uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	if (chunks_are_windows<UncompressedSize, CompressedSize>(L)) { return (uint64_t) rows_per_chunk * traits::row; }
+	return segments_per_wave_chunk_of<UncompressedSize, CompressedSize>(L) * L;
+}
+
+/// `Staged`: the chunk's input — exactly the staging area's rows_per_chunk rows, beginning 16-byte aligned: the caller checks — goes through wave-private
+/// LDS first, in 16-byte loads (64-bit elements from 1-2-byte deltas, whose rows are 2-4 bytes per lane); the rows' ANCHORS are still gathered
+/// a few rows ahead of their use.
+template <unsigned UncompressedSize, unsigned CompressedSize, bool Staged = false, typename Patches>
+__device__ __forceinline__ void wave_rows_of_short_segments(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging = nullptr)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using C = typename traits::compressed_type;
+	using scan_type = typename traits::scan_type;
+	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
+	constexpr unsigned R = Staged ? 4 : (traits::rows_in_flight > 4 ? 4 : traits::rows_in_flight);   // (8 rows of 2-byte elements with their bounds in flight spill registers)
+	constexpr unsigned log2_E = traits::E == 8 ? 3 : (traits::E == 4 ? 2 : 1);
+	static_assert((1u << log2_E) == traits::E, "E is 2, 4 or 8");
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t segments_per_chunk = segments_per_wave_chunk_of<UncompressedSize, CompressedSize>(L);
+	const bool windows = chunks_are_windows<UncompressedSize, CompressedSize>(L);
+	const uint64_t chunk_length = wave_chunk_length_of<UncompressedSize, CompressedSize>(L);   // at most rows_per_chunk rows: 32-bit positions within a chunk
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+	const unsigned segment_length = (unsigned) L;
+	const float segments_per_element = 1.0f / (float) segment_length;
+	using sum_type = typename std::conditional<(sizeof(U) < 4), uint32_t, U>::type;
+
+	struct row_bounds { uint64_t start, end; };   // wave-uniform
+	struct row_places { unsigned segment; U anchor; };   // per lane: the segment (of the chunk) its elements are in, and that segment's anchor
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t chunk_start = c * chunk_length;
+		const uint64_t chunk_end = (chunk_start + chunk_length < n) ? chunk_start + chunk_length : n;
+		const uint64_t first_segment = windows ? chunk_start / L : c * segments_per_chunk;
+		const uint64_t origin = first_segment * L;   // where the chunk's first segment begins: at the chunk's start, or (windows) before it
+		const uint64_t misplaced = (reinterpret_cast<uintptr_t>(out + chunk_start) / sizeof(U)) % traits::row;
+		const uint64_t head = misplaced == 0 ? traits::row : traits::row - misplaced;
+		uint64_t walk_start = chunk_start;
+		auto take_row = [&]() {
+			row_bounds r;
+			r.start = walk_start;
+			const uint64_t length = walk_start == chunk_start ? head : traits::row;
+			r.end = walk_start + length < chunk_end ? walk_start + length : chunk_end;
+			walk_start = r.end;
+			return r;   // past the chunk's end: start == end == chunk_end, an empty row
+		};
+		auto place = [&](const row_bounds& b) {
+			row_places where;
+			const uint64_t p = b.start + (uint64_t) lane * traits::E;
+			const unsigned past_origin = (unsigned) (p - origin);
+			// (past_origin < 2^16, segment_length >= 2: the quotient is exact in single precision — the +0.5 keeps it 0.5 / L away from the integers)
+			where.segment = (unsigned) (((float) past_origin + 0.5f) * segments_per_element);
+			where.anchor = p < b.end ? anchors[first_segment + where.segment] : (U) 0;
+			return where;
+		};
+		U carry = 0;   // the value before this row's first element (of a segment that began in an earlier row)
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		row_bounds bounds[R], next_bounds[R];
+		row_places places[R], next_places[R];
+		patches.begin_seek(chunk_start, lane);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); if (!Staged) { rows[k].load(in, bounds[k].start, bounds[k].end, lane); } places[k] = place(bounds[k]); }
+		if (Staged) {
+			const unsigned chunk_bytes = (unsigned) (chunk_end - chunk_start) * CompressedSize;
+			const uint8_t* from = reinterpret_cast<const uint8_t*>(in) + chunk_start * CompressedSize;
+			wave64::lds_fence();   // (the previous chunk's rows have been read)
+			for (unsigned at = lane * 16; at < chunk_bytes; at += 64 * 16) {
+				if (at + 16 <= chunk_bytes) { *reinterpret_cast<piece_t*>(staging + at) = *reinterpret_cast<const piece_t*>(from + at); }
+				else { for (unsigned b = at; b < chunk_bytes; b++) { staging[b] = from[b]; } }
+			}
+		}
+		if (origin < chunk_start) {   // (wave-uniform) a window that begins inside a segment: the value before its first element
+			sum_type sum = 0;
+			for (uint64_t at = origin; at < chunk_start; at += 4 * traits::row) {
+				row_t<UncompressedSize, CompressedSize> before[4];
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) { before[k].load(in, at + (uint64_t) k * traits::row, chunk_start, lane); }
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) {
+					#pragma unroll
+					for (unsigned j = 0; j < traits::E; j++) { sum += (sum_type) before[k].deltas[j]; }
+				}
+			}
+			carry = (U) (anchors[first_segment] + (U) wave64::read_last_lane(wave64::inclusive_sum(sum)));
+		}
+		patches.finish_seek(lane);
+		if (Staged) { wave64::lds_fence(); }
+		while (bounds[0].start < chunk_end) {
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); if (!Staged) { next[k].load(in, next_bounds[k].start, next_bounds[k].end, lane); } next_places[k] = place(next_bounds[k]); }
+			if (Staged) {
+				#pragma unroll
+				for (unsigned k = 0; k < R; k++) {
+					const uint64_t p = bounds[k].start + (uint64_t) lane * traits::E;
+					const C* staged = reinterpret_cast<const C*>(staging + (p - chunk_start) * CompressedSize);
+					#pragma unroll
+					for (unsigned j = 0; j < traits::E; j++) { rows[k].deltas[j] = (p + j < bounds[k].end) ? staged[j] : (C) 0; }
+				}
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
+				const unsigned row_within_chunk = (unsigned) (bounds[k].start - origin);   // (both from the first segment's start)
+				const unsigned segment_within_chunk = places[k].segment * segment_length;   // where the lane's segment begins
+				const bool begins_here = segment_within_chunk >= row_within_chunk;
+				const unsigned first_lane = begins_here ? (segment_within_chunk - row_within_chunk) >> log2_E : 0u;
+				const scan_type up_to_here = rows[k].prefix[traits::E - 1];   // the row's prefix up to the lane's last element
+				const scan_type before_segment = wave64::read_lane_of_choice(up_to_here, (first_lane + 63u) & 63u);   // (lane 0: not used)
+				const U base = begins_here ? (U) (places[k].anchor - (first_lane == 0 ? (U) 0 : (U) before_segment)) : carry;
+				rows[k].store(out, bounds[k].start, bounds[k].end, lane, base, patches);
+				const unsigned last_lane = (unsigned) ((bounds[k].end - bounds[k].start) >> log2_E) - 1;
+				carry = wave64::read_lane((U) (base + (U) up_to_here), last_lane);
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { if (!Staged) { rows[k].deltas = next[k].deltas; } bounds[k] = next_bounds[k]; places[k] = next_places[k]; }
+		}
+	}
+}
+
+/// ... and with the chunk's input staged through wave-private LDS first (as wave_per_segment_with_staged_input does for whole-row segments): for the
+/// instantiations whose rows are only 2-4 input bytes per lane — 64-bit values from 1-2-byte deltas — element-sized loads per row are what limits
+/// the ragged paths (59-61 % with rows by segment or by cache line alike).  `in` must be 16-byte aligned and the chunk leave 16 bytes of the staging free.
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void wave_per_ragged_segment_with_staged_input(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using C = typename traits::compressed_type;
+	using scan_type = typename traits::scan_type;
+	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
+	const uint64_t chunk_length = segments_per_chunk * L;
+	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
+	const uint8_t* in_bytes = reinterpret_cast<const uint8_t*>(in);
+	constexpr uint64_t piece_capacity = (rows_per_chunk * traits::row * CompressedSize - 16) / CompressedSize / traits::E * traits::E;   // elements (16 bytes are the lead's)
+
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t start = c * chunk_length;
+		const uint64_t end = (start + chunk_length < n) ? start + chunk_length : n;
+		uint64_t segment = c * segments_per_chunk, next_boundary = start;   // the next segment's first element
+		U base = 0;
+		chunk_anchors<U> chunk_anchor_values;
+		chunk_anchor_values.load(anchors, segment, segments_per_chunk, start, end, L, lane);
+		patches.begin_seek(start, lane);
+		// the staging holds a PIECE of the chunk at a time — all of it when the chunk is of up to rows_per_chunk rows; a longer segment's later
+		// pieces begin on row-sized boundaries of the output
+		uint64_t piece_end = 0;
+		for (uint64_t piece_start = start; piece_start < end; piece_start = piece_end) {
+			piece_end = piece_start + piece_capacity;
+			if (piece_end < end) { piece_end -= (reinterpret_cast<uintptr_t>(out + piece_end) / sizeof(U)) % traits::row; } else { piece_end = end; }
+			// (a piece's bytes need not begin on a 16-byte boundary: the `lead` bytes before them come along — the column's own, `in` is aligned)
+			const unsigned lead = (unsigned) ((piece_start * CompressedSize) % 16);
+			const unsigned piece_bytes = lead + (unsigned) (piece_end - piece_start) * CompressedSize;
+			const uint8_t* from = in_bytes + piece_start * CompressedSize - lead;
+			wave64::lds_fence();   // (the previous piece's rows have been read)
+			for (unsigned at = lane * 16; at < piece_bytes; at += 64 * 16) {
+				if (at + 16 <= piece_bytes) {
+					*reinterpret_cast<piece_t*>(staging + at) = *reinterpret_cast<const piece_t*>(from + at);
+				}
+				else {
+					for (unsigned b = at; b < piece_bytes; b++) { staging[b] = from[b]; }
+				}
+			}
+			if (piece_start == start) { patches.finish_seek(lane); }
+			wave64::lds_fence();
+			const uint64_t misplaced = (reinterpret_cast<uintptr_t>(out + piece_start) / sizeof(U)) % traits::row;
+			uint64_t row_end = 0;
+			for (uint64_t row_start = piece_start; row_start < piece_end; row_start = row_end) {
+				const uint64_t length = row_start == piece_start && misplaced != 0 ? traits::row - misplaced : traits::row;   // rows begin on row-sized boundaries of the output
+				row_end = row_start + length < piece_end ? row_start + length : piece_end;
+				row_t<UncompressedSize, CompressedSize> row;
+				const uint64_t p = row_start + (uint64_t) lane * traits::E;
+				const C* staged = reinterpret_cast<const C*>(staging + lead + (p - piece_start) * CompressedSize);
+				#pragma unroll
+				for (unsigned j = 0; j < traits::E; j++) { row.deltas[j] = (p + j < row_end) ? staged[j] : (C) 0; }
+				row.scan();
+				if (row_start == next_boundary) { base = chunk_anchor_values.of(segment++); next_boundary += L; }   // wave-uniform
+				if (next_boundary < row_end) {
+					const unsigned first_behind = (unsigned) ((next_boundary - row_start) / traits::E);
+					const scan_type at_boundary = wave64::read_lane(row.prefix[traits::E - 1], first_behind - 1);
+					const U behind = (U) (chunk_anchor_values.of(segment++) - (U) at_boundary);
+					row.store(out, row_start, row_end, lane, lane < first_behind ? base : behind, patches);
+					base = behind;
+					next_boundary += L;
+				}
+				else { row.store(out, row_start, row_end, lane, base, patches); }
+				base += (U) row.total;
+			}
 		}
 	}
 }
@@ -382,7 +783,7 @@ __device__ __forceinline__ void segmented(
 	using U = uint_t<UncompressedSize>;
 	enum : unsigned { E = 4, row = 64 * E };
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
 	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
 	// a wavefront owns a run of whole segments spanning at least one row
 	const uint64_t segments_per_chunk = L >= row ? 1 : (row + L - 1) / L;
@@ -465,7 +866,7 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(decompressed, 16)
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
-	if (vector_access && rows_per_segment <= rows_per_chunk) {
+	if (vector_access && takes_wave_path<UncompressedSize, CompressedSize>(n, L)) {
 		if constexpr (stages_row_inputs<UncompressedSize, CompressedSize, Patches::enabled>()) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
 			uint8_t* staging = provided_input_staging;
@@ -479,8 +880,27 @@ __device__ __forceinline__ void decompress(
 					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
 				return;
 			}
+			// (segments sharing rows, in chunks of exactly the staging area's size: staged too)
+			if (GIDDY_DELTA_RAGGED_STAGED(UncompressedSize) && staging != nullptr && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
+				&& short_segments_share_rows<UncompressedSize, CompressedSize>(L)
+				&& wave_chunk_length_of<UncompressedSize, CompressedSize>(L) == (uint64_t) rows_per_chunk * traits::row) {
+				wave_rows_of_short_segments<UncompressedSize, CompressedSize, true>(
+					decompressed, compressed_input, anchor_values, n, L, patches,
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
+				return;
+			}
+			// (ragged segments of at least a row, the chunk's bytes 16-byte aligned: staged as well, rows by the output's cache lines)
+			if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_RAGGED_STAGED(UncompressedSize) && staging != nullptr && L >= traits::row && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
+				&& (rows_per_segment > rows_per_chunk || segments_per_wave_chunk(rows_per_segment) * L * CompressedSize + 16 <= staged_chunk_bytes<UncompressedSize, CompressedSize>())) {
+				wave_per_ragged_segment_with_staged_input<UncompressedSize, CompressedSize>(
+					decompressed, compressed_input, anchor_values, n, L, patches,
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
+				return;
+			}
 		}
-		if (L % traits::row == 0) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
+		if (L % traits::row == 0 && !GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
+		else if (short_segments_share_rows<UncompressedSize, CompressedSize>(L)) { wave_rows_of_short_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
+		else if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && L >= traits::row) { wave_per_ragged_segment_in_aligned_rows<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
 		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
 	}
 	else if (vector_access && wave64::per_block() <= max_waves_per_block) {
@@ -818,7 +1238,7 @@ public:
 		auto num_segments = util::div_rounding_up(data_length, segment_length);
 		bool vector_access = segment_length % traits::E == 0;
 		size_t rows_per_segment = util::div_rounding_up(segment_length, (size_t) traits::row);
-		bool wave_path = vector_access && rows_per_segment <= detail::rows_per_chunk;
+		bool wave_path = vector_access && detail::takes_wave_path<UncompressedSize, CompressedSize>(data_length, segment_length);
 		bool block_path = vector_access && !wave_path;
 		if (block_path) {
 			// one workgroup per segment (segments at grid stride), as many wavefronts as one sweep needs
@@ -833,7 +1253,7 @@ public:
 			// one wavefront per segment (or per batch of short segments), at grid stride
 			grid_construction_resolution = warp;
 			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
-			length = wave_path ? util::div_rounding_up(num_segments, (size_t) detail::segments_per_wave_chunk(rows_per_segment))
+			length = wave_path ? util::div_rounding_up(data_length, (size_t) detail::wave_chunk_length_of<UncompressedSize, CompressedSize>(segment_length))
 			                   : util::div_rounding_up(num_segments, per_chunk);
 			upper_limits.threads_in_block = detail::wave_path_threads;
 			// 1-byte deltas of 8-byte elements: 4 resident workgroups per CU are 7 points faster than what fits (measured per instantiation, tools/occupancy_sweep.py)

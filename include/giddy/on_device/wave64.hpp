@@ -126,6 +126,18 @@ __device__ __forceinline__ T read_lane(T v, unsigned lane)
 	}
 }
 template <typename T> __device__ __forceinline__ T read_last_lane(T v) { return read_lane(v, 63u); }
+/// every lane reads lane `from`'s value (a per-lane index: ds_bpermute_b32, 4 bytes at a time)
+template <typename T>
+__device__ __forceinline__ T read_lane_of_choice(T v, unsigned from)
+{
+	static_assert(std::is_integral<T>::value, "integers only");
+	if constexpr (sizeof(T) <= 4) { return (T) __builtin_amdgcn_ds_bpermute((int) (from << 2), (int) v); }
+	else {
+		uint32_t lo = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (from << 2), (int) (uint32_t) v);
+		uint32_t hi = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (from << 2), (int) (uint32_t) ((uint64_t) v >> 32));
+		return (T) (((uint64_t) hi << 32) | lo);
+	}
+}
 template <typename T>
 __device__ __forceinline__ T read_first_lane(T v)
 {

@@ -1,21 +1,32 @@
 #!/bin/bash
-# Runs ON THE GPU BOX: SQ counters of one workload's decoder for several library variants (development aid).
-#   tools/pmc_compare.sh WORKLOAD LOG2N KERNEL_SUBSTRING variant [variant ...]     ("default" = the in-tree library)
-# Three --pmc passes per variant (8 SQ slots each), summarised per wavefront by tools/pmc_compare.py.
+# Runs ON THE GPU BOX: memory-side and SQ counters of the Delta decoder for a list of segment lengths, side by side — what differs between a fast and a slow one?
+#   TUPLE=4,4,2 LS="48 64" bash tools/pmc_compare.sh        (separate --pmc passes per counter group; output: gpurun_out/pmc_compare.txt)
 set -u
 cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
-W=$1; N=$2; K=$3; shift 3
-OUT=gpurun_out/pmc_compare/$W; rm -rf $OUT; mkdir -p $OUT
-P1="SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_WAVE_CYCLES"
-P2="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_WAIT_INST_LDS"
-P3="SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_BUSY_CYCLES SQ_INSTS_BRANCH SQ_INST_CYCLES_VMEM_WR SQ_INST_CYCLES_VMEM_RD"
-for v in "$@"; do
-  if [ "$v" = default ]; then unset GIDDY_LIBRARY_PATH; else export GIDDY_LIBRARY_PATH=$PWD/variants/$v.so; fi
-  i=0
-  for P in "$P1" "$P2" "$P3"; do
-    i=$((i+1))
-    VERIFY=0 rocprofv3 --pmc $P -d $OUT/$v/p$i -o pmc --output-format csv -- python3 tools/bench_one.py $W $N 3 > $OUT/$v.p$i.log 2>&1
+OUT=gpurun_out/pmc_compare; rm -rf $OUT; mkdir -p $OUT
+TUPLE=${TUPLE:-4,4,2}; LS=${LS:-"48 64"}; LOG2N=${LOG2N:-28}
+i=0
+for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_WRITE_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_EA_WRREQ_STALL_sum TCC_EA_RDREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA_WR_UNCACHED_32B_sum"; do
+  i=$((i+1))
+  for L in $LS; do
+    rocprofv3 --pmc $P --kernel-include-regex "delta" -d $OUT/L$L/p$i -o pmc --output-format csv -- python3 tools/staircase.py $TUPLE $L $LOG2N 1 > $OUT/L$L.p$i.log 2>&1
   done
-  VERIFY=0 python3 tools/bench_one.py $W $N 10 | tail -1
 done
-python3 tools/pmc_compare.py $OUT "$K" "$@" | tee $OUT/summary.txt
+python3 - "$OUT" $LS <<'PY' | tee gpurun_out/pmc_compare.txt
+import csv, glob, os, sys
+out, Ls = sys.argv[1], sys.argv[2:]
+table = {}
+for L in Ls:
+    for path in glob.glob(os.path.join(out, "L" + L, "p*", "**", "*counter_collection.csv"), recursive=True):
+        sums, counts = {}, {}
+        for r in csv.DictReader(open(path)):
+            if "decompress" in r["Kernel_Name"]:
+                c = r["Counter_Name"]; sums[c] = sums.get(c, 0.0) + float(r["Counter_Value"]); counts[c] = counts.get(c, 0) + 1
+        for c in sums: table.setdefault(c, {})[L] = sums[c] / counts[c]
+print("%-32s" % "counter (mean per launch)" + "".join("%18s" % ("L=" + L) for L in Ls))
+for c in sorted(table):
+    print("%-32s" % c + "".join("%18s" % ("-" if table[c].get(L) is None else "%.0f" % table[c][L]) for L in Ls))
+for L in Ls:
+    for line in open(os.path.join(out, "L%s.p1.log" % L)):
+        if line.startswith("delta<"): print(line.strip())
+PY
