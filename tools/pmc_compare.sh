@@ -6,10 +6,11 @@ cd "$GRAFT_REPO_ROOT"; export TMPDIR=/tmp
 OUT=gpurun_out/pmc_compare; rm -rf $OUT; mkdir -p $OUT
 TUPLE=${TUPLE:-4,4,2}; LS=${LS:-"48 64"}; LOG2N=${LOG2N:-28}
 i=0
-for P in "FETCH_SIZE" "WRITE_SIZE" "TCC_EA_WRREQ_sum TCC_EA_WRREQ_64B_sum TCC_EA_RDREQ_sum TCC_EA_RDREQ_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_WRITE_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU" "TCC_EA_WRREQ_STALL_sum TCC_EA_RDREQ_STALL_sum TCC_TAG_STALL_sum TCC_EA_WR_UNCACHED_32B_sum"; do
+# (derived TCC_EA_*_sum counters are not available on gfx950 under rocprofv3 here: a pass that names them never returns — only these)
+for P in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_VALU SQ_INSTS_SALU"; do
   i=$((i+1))
   for L in $LS; do
-    rocprofv3 --pmc $P --kernel-include-regex "delta" -d $OUT/L$L/p$i -o pmc --output-format csv -- python3 tools/staircase.py $TUPLE $L $LOG2N 1 > $OUT/L$L.p$i.log 2>&1
+    timeout 120 rocprofv3 --pmc $P --kernel-include-regex "delta" -d $OUT/L$L/p$i -o pmc --output-format csv -- python3 tools/staircase.py $TUPLE $L $LOG2N 1 > $OUT/L$L.p$i.log 2>&1
   done
 done
 python3 - "$OUT" $LS <<'PY' | tee gpurun_out/pmc_compare.txt
