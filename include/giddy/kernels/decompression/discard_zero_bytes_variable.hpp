@@ -190,10 +190,10 @@ struct segment_cursor {
 	uint32_t rows_left_in_segment;
 
 	__device__ __forceinline__ void start_at(const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t segment, uint64_t segment_length, uint64_t length,
-		unsigned segments_per_chunk, unsigned lane)
+		unsigned segments_per_chunk, unsigned lane, unsigned anchors_per_segment = 1)
 	{
 		const bool have = lane < segments_per_chunk && (segment + lane) * segment_length < length;
-		const uint64_t mine = have ? (uint64_t) position_anchors[segment + lane] : 0;
+		const uint64_t mine = have ? (uint64_t) position_anchors[(segment + lane) * anchors_per_segment] : 0;
 		first_anchor = wave64::read_first_lane(mine);
 		later_anchors = (uint32_t) (mine - first_anchor);   // (a chunk is at most rows_per_chunk rows: kilobytes)
 		next_segment_in_chunk = 0; rows_left_in_segment = 0; bytes_start = 0;
@@ -218,6 +218,29 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 	if (segment_length % row != 0) { return 1; }
 	const uint64_t rows_per_segment = segment_length / row;
 	return rows_per_segment >= rows_per_chunk ? 1 : rows_per_chunk / (unsigned) rows_per_segment;   // (no 64-bit division: a wavefront's prologue is short)
+}
+
+/// Segments SHORTER than a row of 64 lanes x E elements (round 4).  A segment used to be a wavefront's unit: one of 64 four-byte elements filled a quarter
+/// of the lanes, had its own anchor load, scan and staging (8 % of the HBM peak; 128 elements: 14 %).  But "the data is not actually broken up into
+/// segments: one can decompress it without using the anchors at all, with no change of semantics" (the reference's discard_zero_bytes_variable.cuh:366-369):
+/// an anchor is a checkpoint of the ONE running sum of element sizes, so every k-th anchor with segments of k x segment_length is the same column.
+/// k makes the coarser segments whole "super-rows" of the wide path (64 size words) when that takes at most 2^16 elements, else whole rows, else
+/// stays 1.  Kernel and launch parameters agree (coalescing_of); GIDDY_DZBV_COALESCE_SHORT_SEGMENTS=0: never.
+#ifndef GIDDY_DZBV_COALESCE_SHORT_SEGMENTS
+#define GIDDY_DZBV_COALESCE_SHORT_SEGMENTS 1
+#endif
+__host__ __device__ inline unsigned coalescing_of(uint64_t segment_length, unsigned row, unsigned bits)
+{
+	if (!GIDDY_DZBV_COALESCE_SHORT_SEGMENTS || segment_length == 0 || segment_length >= row) { return 1; }
+	const unsigned L = (unsigned) segment_length;
+	unsigned low_zeros = 0;
+	while (((L >> low_zeros) & 1u) == 0) { low_zeros++; }
+	// the least k with k * L a multiple of `unit` (a power of two): unit / gcd(L, unit) — or 0 when k * L would exceed 2^16
+	const unsigned super_row = (bits == 1 || bits == 2 || bits == 4) ? 64 * (32 / bits) : 0;
+	unsigned k = 0;
+	if (super_row != 0) { k = (super_row >> low_zeros) == 0 ? 1 : super_row >> low_zeros; if ((uint64_t) k * L > 65536) { k = 0; } }
+	if (k == 0) { k = (row >> low_zeros) == 0 ? 1 : row >> low_zeros; if ((uint64_t) k * L > 65536) { k = 0; } }
+	return k == 0 ? 1 : k;
 }
 
 /// wave-uniform a / b without the ~100-instruction 64-bit division when both fit 32 bits
@@ -546,7 +569,7 @@ __device__ __forceinline__ void decompress_wide(
 	const uint32_t* __restrict__ size_words, const uint_t<IndexSize>* __restrict__ position_anchors,
 	uint32_t* stage, unsigned lane,
 	uint64_t first_segment, unsigned num_segments, unsigned segment_stride, uint64_t L, uint64_t n,
-	unsigned min_size, const size_masks& masks, uint64_t& pos_out, uint64_t& bytes_out)
+	unsigned min_size, const size_masks& masks, uint64_t& pos_out, uint64_t& bytes_out, unsigned anchors_per_segment = 1)
 {
 	using namespace memory_access;
 	using U = uint_t<UncompressedSize>;
@@ -564,7 +587,7 @@ __device__ __forceinline__ void decompress_wide(
 	plan.start(first_segment, num_segments, segment_stride, L, n, rows_staged < rows_of_64_words ? rows_staged : rows_of_64_words);   // (max_rows >= 4: a row is at most 1 KiB)
 
 	// all of the wavefront's anchors with one load (num_segments <= 64)
-	const uint64_t my_anchor = lane < num_segments ? (uint64_t) position_anchors[first_segment + (uint64_t) lane * segment_stride] : 0;
+	const uint64_t my_anchor = lane < num_segments ? (uint64_t) position_anchors[(first_segment + (uint64_t) lane * segment_stride) * anchors_per_segment] : 0;
 
 	auto load_words = [&](const wide_step& s) {
 		if (FullSteps) { return size_words[s.pos / per + lane]; }
@@ -787,9 +810,12 @@ __device__ __forceinline__ void decompress_as_block(
 
 	const unsigned lane = wave64::lane_id();
 	const uint64_t num_waves = blocks_in_grid * working_waves;
-	const uint64_t L = segment_length, n = length;
-	if (L == 0 || bits_per_element_size == 0) { return; }
+	const uint64_t n = length;
+	if (segment_length == 0 || bits_per_element_size == 0) { return; }
 	const unsigned bits = bits_per_element_size;
+	// (short segments: every k-th anchor, segments k times as long — coalescing_of)
+	const unsigned anchors_per_segment = detail::coalescing_of(segment_length, row, bits);
+	const uint64_t L = (uint64_t) segment_length * anchors_per_segment;
 	const unsigned per = (8 * ElementSizesContainerSize) / bits;
 	const unsigned per_reciprocal = per == 1 ? 0u : 0xffffffffu / per + 1;   // ceil(2^32 / per)
 	const bool packed = per % E == 0;   // then E consecutive fields starting at a multiple of E share a container
@@ -845,17 +871,17 @@ __device__ __forceinline__ void decompress_as_block(
 				if (full_steps && !(last_is_partial && batch == 1)) {
 					if (last_is_partial) { batch--; }
 					if constexpr (unrolls) detail::decompress_wide<Bits, IndexSize, UncompressedSize, true>(decompressed, compressed_data, size_words, position_anchors, stage, lane,
-						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at);
+						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at, anchors_per_segment);
 				}
 				else {
 					detail::decompress_wide<Bits, IndexSize, UncompressedSize, false>(decompressed, compressed_data, size_words, position_anchors, stage, lane,
-						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at);
+						segment, batch, stride, L, n, min_represented_element_size, masks, stopped_at, bytes_at, anchors_per_segment);
 				}
 				done += batch;
 				const uint64_t last = segment + (uint64_t) (batch - 1) * stride, last_start = last * L, last_end = last_start + L < n ? last_start + L : n;
 				uint64_t tail = last_start + (last_end - last_start) / row * row;
 				if (tail < last_end) {
-					if (tail == last_start) { bytes_at = wave64::read_first_lane((uint64_t) position_anchors[last]); }   // (not one full row: nothing of it went through the pipeline)
+					if (tail == last_start) { bytes_at = wave64::read_first_lane((uint64_t) position_anchors[last * anchors_per_segment]); }   // (not one full row: nothing of it went through the pipeline)
 					for (; tail < last_end; tail += group_elements) {
 						bytes_at = detail::decompress_rows<false, false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 							decompressed, compressed_data, packed_element_sizes, stage, lane, tail, last_end, bytes_at,
@@ -881,7 +907,7 @@ __device__ __forceinline__ void decompress_as_block(
 		if (segments_per_chunk == 1) {
 			// one anchored segment: full groups of rows on the fast path, then whatever is left — ragged tails,
 			// unaligned outputs, segment lengths that are not whole rows, size fields straddling containers
-			cursor.bytes_start = wave64::read_first_lane((uint64_t) position_anchors[c]);
+			cursor.bytes_start = wave64::read_first_lane((uint64_t) position_anchors[c * anchors_per_segment]);
 			detail::decompress_full_groups<false, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, 0,
 				min_represented_element_size, bits, per, per_reciprocal, masks);
@@ -894,7 +920,7 @@ __device__ __forceinline__ void decompress_as_block(
 		else {
 			// a batch of short segments, each a whole number of rows: the groups of rows span segments
 			const uint32_t rows_per_segment = (uint32_t) (L / row);
-			cursor.start_at(position_anchors, c * segments_per_chunk, L, n, (unsigned) segments_per_chunk, lane);
+			cursor.start_at(position_anchors, c * segments_per_chunk, L, n, (unsigned) segments_per_chunk, lane, anchors_per_segment);
 			detail::decompress_full_groups<true, IndexSize, UncompressedSize, ElementSizesContainerSize>(
 				decompressed, compressed_data, packed_element_sizes, stage, lane, rows_start, num_groups, cursor, rows_per_segment,
 				min_represented_element_size, bits, per, per_reciprocal, masks);
@@ -1094,6 +1120,9 @@ public:
 	{
 		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
 		grid_construction_resolution  = warp;              // a wavefront per span of anchored segments
+		// (short segments are taken several at a time, as one: detail::coalescing_of — with 2-bit size fields, the reference's documented typical
+		// case; other widths only change which multiple is taken, and the kernel covers the column with any grid)
+		segment_length               *= detail::coalescing_of(segment_length, 64 * (16 / UncompressedSize), 2);
 		const size_t chunks           = util::div_rounding_up(util::div_rounding_up(length_in_elements, segment_length),
 		                                    (size_t) detail::segments_per_wave_chunk(segment_length, 64 * (16 / UncompressedSize)));
 		length                        = util::div_rounding_up(chunks, chunks_per_wavefront(chunks, device_properties_));

@@ -60,6 +60,9 @@ def test_dzb_variable(index_size, usize, container, min_size, bits):
     # (long segments that are whole 1024s: finer anchors from the size fields first — incl. a segment of more than 4096 x 1024 elements,
     # a column that ends inside a 1024, one segment for the whole column)
     shapes = [(1, 32), (1000, 64), (1024, 1024), (333333, 1024), (50, 7), (100000, 4096), (70000, 1000), (300000, 32768), (200000 + 77, 65536), (150000, 1 << 20)]
+    # (segments shorter than a row of 64 lanes' elements are taken several at a time, through every k-th anchor: lengths that do and do not divide
+    # the super-row, odd ones, a column that ends inside a coalesced segment — the reference's cuh:366-369 says the anchors may be ignored)
+    shapes += [(250000, 64), (250000 + 37, 16), (99999, 48), (123456, 100), (65536 + 8, 128), (77777, 3), (200000, 255), (200000, 96)]
     if (usize, bits, min_size) == (8, 2, 1):
         shapes += [((5 << 20) + 3000, 5 << 20), (3 << 20, 1 << 20)]
     for n, seglen in shapes:
