@@ -3,6 +3,7 @@
 // memory system itself, or only for the decoders?     hipcc --offload-arch=gfx950 -O3 tools/chunk_size_probe.hip -o /tmp/chunk_size_probe && /tmp/chunk_size_probe
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <vector>
 #include <algorithm>
@@ -50,9 +51,9 @@ template <unsigned D> void run(v4* out, v4* in, uint64_t rows, const char* what)
 	}
 }
 
-int main()
+int main(int argc, char** argv)
 {
-	const uint64_t rows = 1u << 20;   // 1 GiB of output
+	const uint64_t rows = (uint64_t) 1 << (argc > 1 ? atoi(argv[1]) : 20);   // 2^20 rows: 1 GiB of output (2^22: the headline column's 4 GiB — beyond what the Infinity Cache keeps of the input between repetitions)
 	v4 *out, *in;
 	(void) hipMalloc(&out, rows * 1024); (void) hipMalloc(&in, rows * 1024);
 	(void) hipMemset(in, 1, rows * 1024);
