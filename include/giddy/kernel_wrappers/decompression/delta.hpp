@@ -151,15 +151,17 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
 		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
 		const uint64_t n = length, L = segment_length;
 		const auto& environment = detail::environment::get();
-		const uint64_t chained_from = environment.chained_from_given ? environment.chained_from : (uint64_t) detail::chained_from_rows * traits::row;
+		// (64-bit elements from 4-byte deltas: from one tile — 64 rows — on: the block path is at 50-51 % for them at every length, tiles at 71-75 %)
+		const uint64_t chained_from = environment.chained_from_given ? environment.chained_from
+			: (UncompressedSize == 8 && CompressedSize == 4) ? chained::tile_elements<UncompressedSize, CompressedSize, 4>() : (uint64_t) detail::chained_from_rows * traits::row;
 		const bool aligned = memory_access::is_aligned(decompressed, 16) && memory_access::is_aligned(compressed_input, 16);
 		const unsigned waves = chained::waves_per_tile_for<UncompressedSize, CompressedSize>(n, L);
 		// ... where they beat the block path (a workgroup of up to 16 wavefronts per segment): always when there are fewer segments than compute units,
 		// and for 64-bit values from 1-2-byte deltas from one tile per segment on (<4,8,2>, 2^28 elements, segments of 2^14 ...
-		// 2^20: 76 / 76 / 75 / 77 % against 75 / 70 / 69 / 66 %); 32-bit values and wide deltas keep the block path while it has enough
-		// segments (<4,4,1>: 88 % against 77-83 %)
+		// 2^20: 76 / 76 / 75 / 77 % against 75 / 70 / 69 / 66 %) — and from 4-byte deltas (round 4: <8,8,4>, 2^13 ... 2^18: 71-75 % against 50-51 %);
+		// 32-bit values keep the block path while it has enough segments (<4,4,1>: 88 % against 77-83 %)
 		const uint64_t num_segments = L == 0 ? 0 : util::div_rounding_up(n, L);
-		const bool preferred = num_segments < (uint64_t) detail::current_device_properties().multiProcessorCount || (UncompressedSize == 8 && CompressedSize <= 2);
+		const bool preferred = num_segments < (uint64_t) detail::current_device_properties().multiProcessorCount || UncompressedSize == 8;
 		const bool forced = environment.chained_from_given;
 		if (chained_from != 0 && n > 0 && L >= chained_from && (preferred || forced) && L > (uint64_t) detail::rows_per_chunk * traits::row && aligned && waves != 0) {
 			using state_type = chained::tile_state<UncompressedSize>;

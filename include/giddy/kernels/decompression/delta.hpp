@@ -82,6 +82,9 @@ namespace detail {
 #ifndef GIDDY_DELTA_ROWS_PER_CHUNK
 #define GIDDY_DELTA_ROWS_PER_CHUNK 32
 #endif
+#ifndef GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED
+#define GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED 0   // (measured: consecutive rows are as fast or faster — <4,8,1> at 8192: 79 % against 66, <4,4,1> at 10000: 89 against 74)
+#endif
 #ifndef GIDDY_DELTA_WAVE_PATH_THREADS
 #define GIDDY_DELTA_WAVE_PATH_THREADS 256
 #endif
@@ -731,10 +734,15 @@ __device__ __forceinline__ void block_per_segment(
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = rows_per_wave_per_sweep;
-	__shared__ U wave_totals[2][max_waves_per_block];
+	// Which rows of a sweep a wavefront takes: R consecutive ones (GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED = 0) — or every num_waves-th, so that at every step
+	// the workgroup reads and writes num_waves CONSECUTIVE rows, as the fixed-rate decoders' tiles do (the patched kernels keep consecutive rows:
+	// a wavefront's patches are then one stretch of the list).  Either way one barrier per sweep: the rows' totals meet in LDS.
+	constexpr bool interleaved = GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED && !Patches::enabled;
+	__shared__ U row_totals[2][max_waves_per_block * R];
 	const unsigned lane = wave64::lane_id();
 	const unsigned w = wave64::index_in_block();
 	const unsigned num_waves = wave64::per_block();
+	const unsigned rows_per_sweep = num_waves * R;   // at most 128
 	const uint64_t num_segments = (n + L - 1) / L;
 	unsigned buffer = 0;
 
@@ -742,33 +750,34 @@ __device__ __forceinline__ void block_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
-		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * R * traits::row) {
-			const uint64_t mine = sweep_start + (uint64_t) w * R * traits::row;
+		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) rows_per_sweep * traits::row) {
+			auto row_of = [&](unsigned k) { return interleaved ? k * num_waves + w : w * R + k; };   // (wave-uniform) the sweep's row that is this wavefront's k-th
+			const uint64_t mine = sweep_start + (uint64_t) row_of(0) * traits::row;
 			row_t<UncompressedSize, CompressedSize> rows[R];
 			// a wavefront seeks to ITS rows of the sweep, the probes in flight with the rows' own loads (walking there from the
 			// segment's start costs a serial step per patch of every wavefront below, every sweep)
 			if (mine < end) { patches.begin_seek(mine, lane); }
 			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { rows[k].load(in, mine + (uint64_t) k * traits::row, end, lane); }   // rows past `end` load zeros
+			for (unsigned k = 0; k < R; k++) { rows[k].load(in, sweep_start + (uint64_t) row_of(k) * traits::row, end, lane); }   // rows past `end` load zeros
 			if (mine < end) { patches.finish_seek(lane); }
-			U my_total = 0;
 			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { rows[k].scan(); my_total += (U) rows[k].total; }
-			if (lane == 0) { wave_totals[buffer][w] = my_total; }
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); if (lane == 0) { row_totals[buffer][row_of(k)] = (U) rows[k].total; } }
 			__syncthreads();
-			U before = 0, all = 0;
-			for (unsigned v = 0; v < num_waves; v++) {
-				U t = wave_totals[buffer][v];
-				if (v < w) { before += t; }
-				all += t;
-			}
-			U running = (U) (base + before);
+			// every wavefront scans the sweep's (at most 128) row totals: lane l has rows l and 64 + l
+			using sum_type = typename std::conditional<(sizeof(U) < 4), uint32_t, U>::type;   // (the scans are 32 or 64 bits wide)
+			const sum_type low = lane < rows_per_sweep ? (sum_type) row_totals[buffer][lane] : (sum_type) 0;
+			const sum_type high = 64 + lane < rows_per_sweep ? (sum_type) row_totals[buffer][64 + lane] : (sum_type) 0;
+			const sum_type low_inclusive = wave64::inclusive_sum(low);
+			const sum_type low_all = wave64::read_last_lane(low_inclusive);
+			const sum_type high_inclusive = (sum_type) (wave64::inclusive_sum(high) + low_all);
+			const sum_type all = wave64::read_last_lane(high_inclusive);
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
-				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running, patches);
-				running += (U) rows[k].total;
+				const unsigned i = row_of(k);
+				const sum_type before = i < 64 ? wave64::read_lane((sum_type) (low_inclusive - low), i) : wave64::read_lane((sum_type) (high_inclusive - high), i - 64);
+				rows[k].store(out, sweep_start + (uint64_t) i * traits::row, end, lane, (U) (base + (U) before), patches);
 			}
-			base += all;
+			base += (U) all;
 			buffer ^= 1;   // the next sweep writes the other table; this one is re-written only after another barrier
 		}
 	}
