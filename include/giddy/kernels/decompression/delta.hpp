@@ -82,9 +82,6 @@ namespace detail {
 #ifndef GIDDY_DELTA_ROWS_PER_CHUNK
 #define GIDDY_DELTA_ROWS_PER_CHUNK 32
 #endif
-#ifndef GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED
-#define GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED 0   // (measured: consecutive rows are as fast or faster — <4,8,1> at 8192: 79 % against 66, <4,4,1> at 10000: 89 against 74)
-#endif
 #ifndef GIDDY_DELTA_WAVE_PATH_THREADS
 #define GIDDY_DELTA_WAVE_PATH_THREADS 256
 #endif
@@ -172,6 +169,20 @@ struct row_t {
 		#pragma unroll
 		for (unsigned j = 0; j < E; j++) { values[j] = (U) (base + (U) prefix[j]); }
 		if (row_start < end) { patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values); }   // (rows past the end: nothing to patch, and no walking into the next segment's patches)
+		if (p + E <= end) { memory_access::store_group<memory_access::wide_output_policy<sizeof(U)>(GIDDY_DELTA_STORE_POLICY)>(out + p, values); }
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) { if (p + j < end) { out[p + j] = values[j]; } }
+		}
+	}
+	/// ... with the values worked out by the caller (every element its own base)
+	template <typename Patches>
+	__device__ __forceinline__ void store_values(typename traits::uncompressed_type* __restrict__ out, uint64_t row_start, uint64_t end, unsigned lane,
+		memory_access::group<typename traits::uncompressed_type, E> values, Patches& patches) const
+	{
+		using U = typename traits::uncompressed_type;
+		uint64_t p = row_start + (uint64_t) lane * E;
+		if (row_start < end) { patches.template apply_to_row<E>(row_start, (row_start + 64 * E < end) ? row_start + 64 * E : end, lane, values); }
 		if (p + E <= end) { memory_access::store_group<memory_access::wide_output_policy<sizeof(U)>(GIDDY_DELTA_STORE_POLICY)>(out + p, values); }
 		else {
 			#pragma unroll
@@ -724,8 +735,150 @@ __device__ __forceinline__ void wave_per_ragged_segment_with_staged_input(
 	}
 }
 
+/// Segment lengths that are NOT multiples of a lane's E elements (round 4) — 6, 10, 1001, 4094 ...: a lane's group straddles segment boundaries, the 16-byte
+/// paths above do not apply, and the element-wise `segmented` path below runs at 13-17 % of the HBM peak.  Here, for segments of up to rows_per_chunk
+/// rows: chunks are WINDOWS of rows_per_chunk rows of the column (not of segments), rows follow the output's 1 KiB boundaries, loads and stores are 16
+/// bytes per lane as everywhere — and every ELEMENT finds its segment: an element that begins one (position % L == 0; its lane gathers the anchor with
+/// the row's loads) leaves `anchor - the row's prefix before it` in a wave-private LDS table indexed by the segment's number within the row; every element
+/// then reads its segment's entry — or, if its segment began before the row, goes on from where the previous row ended.  A window that begins inside a
+/// segment first adds up that segment's deltas before it (the input from the segment's start to the window: read twice).
+#ifndef GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS
+#define GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS 1
+#endif
+enum : unsigned { any_length_waves = 4 };   // wavefronts per workgroup the LDS tables exist for
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__host__ __device__ inline bool any_length_by_windows(uint64_t L)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	return GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS && L % traits::E != 0 && L <= (uint64_t) rows_per_chunk * traits::row;
+}
+
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+__device__ __forceinline__ void wave_windows_of_any_segments(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases)   // (LDS: traits::row entries, this wavefront's)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using C = typename traits::compressed_type;
+	using scan_type = typename traits::scan_type;
+	using sum_type = typename std::conditional<(sizeof(U) < 4), uint32_t, U>::type;
+	constexpr unsigned E = traits::E;
+	constexpr unsigned R = 2;
+	constexpr unsigned log2_E = E == 8 ? 3 : (E == 4 ? 2 : 1);
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	constexpr uint64_t window = (uint64_t) rows_per_chunk * traits::row;
+	const uint64_t num_chunks = (n + window - 1) / window;
+	const unsigned segment_length = (unsigned) L;
+	const float segments_per_element = 1.0f / (float) segment_length;
+
+	struct row_bounds { uint64_t start, end; };   // wave-uniform
+	struct row_places { unsigned segment, within; U start_anchor[E]; };   // per lane: its first element's segment (of the chunk) and place in it; the anchors of the segments its elements begin
+	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
+		const uint64_t chunk_start = c * window;
+		const uint64_t chunk_end = chunk_start + window < n ? chunk_start + window : n;
+		const uint64_t first_segment = ((chunk_start | L) >> 32) == 0 ? (uint64_t) ((uint32_t) chunk_start / (uint32_t) L) : chunk_start / L;
+		const uint64_t origin = first_segment * L;   // (at most a segment — rows_per_chunk rows — before the window: positions from it fit 16 bits)
+		const uint64_t misplaced = (reinterpret_cast<uintptr_t>(out + chunk_start) / sizeof(U)) % traits::row;
+		const uint64_t head = misplaced == 0 ? traits::row : traits::row - misplaced;
+		uint64_t walk_start = chunk_start;
+		auto take_row = [&]() {
+			row_bounds r;
+			r.start = walk_start;
+			const uint64_t length = walk_start == chunk_start ? head : traits::row;
+			r.end = walk_start + length < chunk_end ? walk_start + length : chunk_end;
+			walk_start = r.end;
+			return r;
+		};
+		auto place = [&](const row_bounds& b) {
+			row_places where;
+			const uint64_t p = b.start + (uint64_t) lane * E;
+			const unsigned past_origin = (unsigned) (p - origin);
+			where.segment = (unsigned) (((float) past_origin + 0.5f) * segments_per_element);   // (exact: see wave_rows_of_short_segments)
+			where.within = past_origin - where.segment * segment_length;
+			unsigned segment = where.segment, within = where.within;
+			#pragma unroll
+			for (unsigned j = 0; j < E; j++) {
+				where.start_anchor[j] = (p + j < b.end && within == 0) ? anchors[first_segment + segment] : (U) 0;
+				if (++within == segment_length) { within = 0; segment++; }
+			}
+			return where;
+		};
+		U carry = 0;
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		row_bounds bounds[R], next_bounds[R];
+		row_places places[R], next_places[R];
+		patches.begin_seek(chunk_start, lane);
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].load(in, bounds[k].start, bounds[k].end, lane); places[k] = place(bounds[k]); }
+		if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
+			sum_type sum = 0;
+			const uint64_t aligned_origin = origin / E * E;   // (16-byte loads: the elements of the first group that lie before the segment are left out)
+			for (uint64_t at = aligned_origin; at < chunk_start; at += 4 * traits::row) {
+				row_t<UncompressedSize, CompressedSize> before[4];
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) { before[k].load(in, at + (uint64_t) k * traits::row, chunk_start, lane); }
+				#pragma unroll
+				for (unsigned k = 0; k < 4; k++) {
+					const uint64_t q = at + (uint64_t) k * traits::row + (uint64_t) lane * E;
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { sum += (q + j >= origin) ? (sum_type) before[k].deltas[j] : (sum_type) 0; }
+				}
+			}
+			carry = (U) (anchors[first_segment] + (U) wave64::read_last_lane(wave64::inclusive_sum(sum)));
+		}
+		patches.finish_seek(lane);
+		while (bounds[0].start < chunk_end) {
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].load(in, next_bounds[k].start, next_bounds[k].end, lane); next_places[k] = place(next_bounds[k]); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
+				const uint64_t p = bounds[k].start + (uint64_t) lane * E;
+				const unsigned row_past_origin = (unsigned) (bounds[k].start - origin);
+				const unsigned first_segment_of_row = wave64::read_first_lane(places[k].segment);
+				// 1. the elements that begin a segment leave its base — anchor less the row's prefix before it — in the table
+				unsigned segment = places[k].segment, within = places[k].within;
+				unsigned segment_of[E]; bool begins_in_row[E];
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) {
+					const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
+					if (p + j < bounds[k].end && within == 0) { segment_bases[segment - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
+					segment_of[j] = segment;
+					begins_in_row[j] = (unsigned) (p - origin) + j - within >= row_past_origin;   // where the element's segment begins, against where the row does
+					if (++within == segment_length) { within = 0; segment++; }
+				}
+				wave64::lds_fence();
+				// 2. every element: its segment's base, or on from the previous row
+				memory_access::group<U, E> values;
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) {
+					const U base = begins_in_row[j] ? segment_bases[segment_of[j] - first_segment_of_row] : carry;
+					values[j] = (U) (base + (U) rows[k].prefix[j]);
+				}
+				wave64::lds_fence();   // (the table is rewritten for the next row)
+				const unsigned last_lane = (unsigned) ((bounds[k].end - bounds[k].start + E - 1) >> log2_E) - 1;   // (a row is whole groups but at the column's end)
+				const unsigned last_slot = (unsigned) ((bounds[k].end - bounds[k].start - 1) & (E - 1));
+				U last_value = values[0];
+				#pragma unroll
+				for (unsigned j = 1; j < E; j++) { if (last_slot == j) { last_value = values[j]; } }
+				carry = wave64::read_lane(last_value, last_lane);
+				rows[k].store_values(out, bounds[k].start, bounds[k].end, lane, values, patches);
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; places[k] = next_places[k]; }
+		}
+	}
+}
+
 /// block path: the workgroup's wavefronts sweep one segment together — wavefront w takes R consecutive
-/// rows of every sweep, so a segment of up to waves*R rows needs ONE barrier
+/// rows of every sweep, so a segment of up to waves*R rows needs ONE barrier.  (Round 4 measured every wavefront taking every num_waves-th row instead — the workgroup
+/// reading and writing num_waves consecutive rows at every step, as the fixed-rate decoders' tiles do: slower or equal everywhere (profiles/r04_delta_segment_lengths.txt),
+/// and its per-row totals cost every path of the kernel 25 registers; not kept.)
 template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
 __device__ __forceinline__ void block_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
@@ -734,15 +887,10 @@ __device__ __forceinline__ void block_per_segment(
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = rows_per_wave_per_sweep;
-	// Which rows of a sweep a wavefront takes: R consecutive ones (GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED = 0) — or every num_waves-th, so that at every step
-	// the workgroup reads and writes num_waves CONSECUTIVE rows, as the fixed-rate decoders' tiles do (the patched kernels keep consecutive rows:
-	// a wavefront's patches are then one stretch of the list).  Either way one barrier per sweep: the rows' totals meet in LDS.
-	constexpr bool interleaved = GIDDY_DELTA_BLOCK_ROWS_INTERLEAVED && !Patches::enabled;
-	__shared__ U row_totals[2][max_waves_per_block * R];
+	__shared__ U wave_totals[2][max_waves_per_block];
 	const unsigned lane = wave64::lane_id();
 	const unsigned w = wave64::index_in_block();
 	const unsigned num_waves = wave64::per_block();
-	const unsigned rows_per_sweep = num_waves * R;   // at most 128
 	const uint64_t num_segments = (n + L - 1) / L;
 	unsigned buffer = 0;
 
@@ -750,34 +898,33 @@ __device__ __forceinline__ void block_per_segment(
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
-		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) rows_per_sweep * traits::row) {
-			auto row_of = [&](unsigned k) { return interleaved ? k * num_waves + w : w * R + k; };   // (wave-uniform) the sweep's row that is this wavefront's k-th
-			const uint64_t mine = sweep_start + (uint64_t) row_of(0) * traits::row;
+		for (uint64_t sweep_start = start; sweep_start < end; sweep_start += (uint64_t) num_waves * R * traits::row) {
+			const uint64_t mine = sweep_start + (uint64_t) w * R * traits::row;
 			row_t<UncompressedSize, CompressedSize> rows[R];
 			// a wavefront seeks to ITS rows of the sweep, the probes in flight with the rows' own loads (walking there from the
 			// segment's start costs a serial step per patch of every wavefront below, every sweep)
 			if (mine < end) { patches.begin_seek(mine, lane); }
 			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { rows[k].load(in, sweep_start + (uint64_t) row_of(k) * traits::row, end, lane); }   // rows past `end` load zeros
+			for (unsigned k = 0; k < R; k++) { rows[k].load(in, mine + (uint64_t) k * traits::row, end, lane); }   // rows past `end` load zeros
 			if (mine < end) { patches.finish_seek(lane); }
+			U my_total = 0;
 			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { rows[k].scan(); if (lane == 0) { row_totals[buffer][row_of(k)] = (U) rows[k].total; } }
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); my_total += (U) rows[k].total; }
+			if (lane == 0) { wave_totals[buffer][w] = my_total; }
 			__syncthreads();
-			// every wavefront scans the sweep's (at most 128) row totals: lane l has rows l and 64 + l
-			using sum_type = typename std::conditional<(sizeof(U) < 4), uint32_t, U>::type;   // (the scans are 32 or 64 bits wide)
-			const sum_type low = lane < rows_per_sweep ? (sum_type) row_totals[buffer][lane] : (sum_type) 0;
-			const sum_type high = 64 + lane < rows_per_sweep ? (sum_type) row_totals[buffer][64 + lane] : (sum_type) 0;
-			const sum_type low_inclusive = wave64::inclusive_sum(low);
-			const sum_type low_all = wave64::read_last_lane(low_inclusive);
-			const sum_type high_inclusive = (sum_type) (wave64::inclusive_sum(high) + low_all);
-			const sum_type all = wave64::read_last_lane(high_inclusive);
+			U before = 0, all = 0;
+			for (unsigned v = 0; v < num_waves; v++) {
+				U t = wave_totals[buffer][v];
+				if (v < w) { before += t; }
+				all += t;
+			}
+			U running = (U) (base + before);
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) {
-				const unsigned i = row_of(k);
-				const sum_type before = i < 64 ? wave64::read_lane((sum_type) (low_inclusive - low), i) : wave64::read_lane((sum_type) (high_inclusive - high), i - 64);
-				rows[k].store(out, sweep_start + (uint64_t) i * traits::row, end, lane, (U) (base + (U) before), patches);
+				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running, patches);
+				running += (U) rows[k].total;
 			}
-			base += (U) all;
+			base += all;
 			buffer ^= 1;   // the next sweep writes the other table; this one is re-written only after another barrier
 		}
 	}
@@ -875,6 +1022,12 @@ __device__ __forceinline__ void decompress(
 		&& memory_access::is_aligned(decompressed, 16)
 		&& memory_access::is_aligned(compressed_input, traits::E * CompressedSize);
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
+	if (any_length_by_windows<UncompressedSize, CompressedSize>(L) && wave64::per_block() <= any_length_waves
+		&& memory_access::is_aligned(decompressed, 16) && memory_access::is_aligned(compressed_input, traits::E * CompressedSize)) {
+		__shared__ uint_t<UncompressedSize> bases_of_segments[any_length_waves][traits::row];
+		wave_windows_of_any_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, bases_of_segments[wave64::index_in_block()]);
+		return;
+	}
 	if (vector_access && takes_wave_path<UncompressedSize, CompressedSize>(n, L)) {
 		if constexpr (stages_row_inputs<UncompressedSize, CompressedSize, Patches::enabled>()) {
 			// (staging exists for the 4 wavefronts of the wave path's 256-thread workgroups)
@@ -1263,7 +1416,8 @@ public:
 			grid_construction_resolution = warp;
 			size_t per_chunk = segment_length >= 256 ? 1 : util::div_rounding_up((size_t) 256, segment_length);
 			length = wave_path ? util::div_rounding_up(data_length, (size_t) detail::wave_chunk_length_of<UncompressedSize, CompressedSize>(segment_length))
-			                   : util::div_rounding_up(num_segments, per_chunk);
+			       : detail::any_length_by_windows<UncompressedSize, CompressedSize>(segment_length) ? util::div_rounding_up(data_length, (size_t) detail::rows_per_chunk * traits::row)
+			       : util::div_rounding_up(num_segments, per_chunk);
 			upper_limits.threads_in_block = detail::wave_path_threads;
 			// 1-byte deltas of 8-byte elements: 4 resident workgroups per CU are 7 points faster than what fits (measured per instantiation, tools/occupancy_sweep.py)
 			if (wave_path && UncompressedSize == 8 && CompressedSize == 1) { resident_blocks_per_multiprocessor_cap = 4u; }

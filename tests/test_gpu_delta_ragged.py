@@ -92,3 +92,50 @@ def test_many_long_ragged_segments_go_by_wavefront(usize, csize):
             bad = np.flatnonzero(got[lead:lead + n] != truth)
             assert len(bad) == 0, (n, seglen, shift_bytes, bad[:5])
             del out, got
+
+
+# segment lengths that are NOT multiples of a lane's 16 bytes of output: elements of one lane in different segments (wave_windows_of_any_segments) —
+# 1 (every element its own anchor), shorter than a lane's group, around a row, up to 32 rows; beyond that the element-wise path
+ODD_SEGMENTS = [1, 2, 3, 5, 6, 10, 63, 100, 255, 257, 1001, 2002, 4094, 4097, 8190, 8191, 16383]
+
+
+@pytest.mark.parametrize("usize,csize", TUPLES)
+@pytest.mark.parametrize("seglen", ODD_SEGMENTS)
+def test_segment_lengths_that_split_a_lanes_group(usize, csize, seglen):
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    st = g.stream()
+    for n in (max(seglen * 21 + 5, 70001), 333337, 9):
+        f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + seglen)
+        d_in, d_anchor = g.dev(f["compressed_input"]), g.dev(f["anchor_values"])
+        for shift_bytes in (0, 496):
+            lead = shift_bytes // usize
+            out = g.dev_empty(n + lead + 64, ud)
+            schemes.delta(out.data_ptr() + shift_bytes, d_in, d_anchor, n, seglen, uncompressed_size=usize, compressed_size=csize, stream=st)
+            got = g.host(out, ud, n + lead + 64)
+            guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+            assert (got[:lead] == guard).all() and (got[lead + n:] == guard).all(), "wrote outside the output"
+            bad = np.flatnonzero(got[lead:lead + n] != truth)
+            assert len(bad) == 0, (n, seglen, shift_bytes, bad[:5])
+
+
+@pytest.mark.parametrize("usize,csize", [(4, 1), (8, 2), (2, 1)])
+@pytest.mark.parametrize("seglen", [3, 10, 1001, 4094])
+def test_odd_segment_lengths_with_patches(usize, csize, seglen):
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    n = 200003
+    f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + seglen)
+    rnd = cases.rng(seglen + usize)
+    positions = np.unique(np.concatenate([rnd.integers(0, n, 1500), np.arange(0, n, max(seglen, 97))[:2000], [n - 1]])).astype(np.uint32)
+    values = rnd.integers(0, np.iinfo(ud).max, len(positions), dtype=ud)
+    expect = truth.copy()
+    expect[positions.astype(np.int64)] = values
+    out = g.dev_empty(n, ud)
+    schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values), g.dev(positions), n, seglen, len(positions),
+                          uncompressed_size=usize, compressed_size=csize, stream=g.stream())
+    got = g.host(out, ud, n)
+    bad = np.flatnonzero(got != expect)
+    assert len(bad) == 0, (n, seglen, bad[:5])
