@@ -1,6 +1,7 @@
 // Kernel wrapper for variable-width discard-zero-bytes decompression.  Argument-map keys and exact
 // types follow the reference's src/kernel_wrappers/decompression/discard_zero_bytes_variable.cu:52-95.
 #pragma once
+#include <limits>
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernels/decompression/discard_zero_bytes_variable.hpp"
 #include "giddy/stream_scratch.hpp"
@@ -95,6 +96,34 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(st
 	// segments, whole size containers and 16-byte aligned outputs per piece; the anchors are absolute, so compressed_data stays put.
 	// Long segments: anchors for every 1024 elements from the size fields (kernels/..., namespace fine), in stream-ordered scratch memory,
 	// then the decoder on segments of 1024 — where the wide path applies (1-, 2-, 4-bit fields; 4- and 8-byte elements).
+	// Segments of a row or more that are NOT whole 1024s (1000, 1023, 10 000 ...: one at a time, ragged ends the slow way — 35-63 % of the HBM peak): every k-th
+	// anchor first, k * segment_length the least common multiple with 1024 — the anchors are checkpoints of one running sum (the reference's cuh:366-369) — and
+	// then the finer anchors below as for any long segment.  (Shorter than a row: the kernel itself takes every k-th anchor, no launch needed.)
+	stream_scratch::lease coarser_anchors(stream);
+	{
+		constexpr unsigned E = 16 / UncompressedSize, row = 64 * E;
+		const uint64_t n = length, L = segment_length;
+		const unsigned bits = bits_per_element_size;
+		const bool eligible = E <= 4 && L % fine::sub != 0 && detail::wide_path_applies(bits, ElementSizesContainerSize, E)
+			&& (reinterpret_cast<uintptr_t>(decompressed) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_element_sizes) & 15) == 0 && fine_from_environment() != 0;
+		if (eligible && n <= L && n > fine::sub) {
+			segment_length = (size_type) std::min<uint64_t>(util::round_up(n, (uint64_t) fine::sub), std::numeric_limits<size_type>::max() / 1024 * 1024);   // (the column is one segment: of any length that holds it)
+		}
+		else if (eligible && n > L && L >= row) {
+			uint64_t common = fine::sub, rest = L;
+			while (rest != 0) { const uint64_t t = common % rest; common = rest; rest = t; }   // gcd(1024, L)
+			const uint64_t stride = fine::sub / common, coarser_length = L * stride;
+			const uint64_t count = util::div_rounding_up(n, coarser_length);
+			if (coarser_length <= (uint64_t) std::numeric_limits<size_type>::max() / 2 && coarser_anchors.take(count * sizeof(index_type))) {
+				auto* coarser = static_cast<index_type*>(coarser_anchors.memory());
+				cuda::enqueue_launch(reinterpret_cast<const void*>(fine::every_kth_anchor<IndexSize>), stream,
+					launch_configuration_t((grid_dimension_t) std::min<uint64_t>(util::div_rounding_up(count, (uint64_t) fine::threads), 1u << 16), fine::threads),
+					coarser, position_anchors, count, stride);
+				position_anchors = coarser;
+				segment_length = (size_type) coarser_length;
+			}
+		}
+	}
 	stream_scratch::lease fine_anchors(stream);
 	{
 		constexpr unsigned E = 16 / UncompressedSize;

@@ -1023,6 +1023,14 @@ __device__ __forceinline__ uint32_t bytes_of_64_pieces(const uint32_t* __restric
 	return mine;
 }
 
+/// coarser[j] = position_anchors[j * stride]: the anchors of segments `stride` times as long (the anchors are checkpoints of one running sum:
+/// the reference's discard_zero_bytes_variable.cuh:366-369)
+template <unsigned IndexSize>
+__global__ void __launch_bounds__(threads) every_kth_anchor(uint_t<IndexSize>* __restrict__ coarser, const uint_t<IndexSize>* __restrict__ position_anchors, uint64_t count, uint64_t stride)
+{
+	for (uint64_t j = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x; j < count; j += (uint64_t) gridDim.x * blockDim.x) { coarser[j] = position_anchors[j * stride]; }
+}
+
 /// totals[k] = bytes of elements [1024 k, 1024 (k + 1)) — a wavefront per 64 of them
 template <unsigned Bits>
 __global__ void __launch_bounds__(threads) totals(

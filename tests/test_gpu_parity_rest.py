@@ -63,6 +63,8 @@ def test_dzb_variable(index_size, usize, container, min_size, bits):
     # (segments shorter than a row of 64 lanes' elements are taken several at a time, through every k-th anchor: lengths that do and do not divide
     # the super-row, odd ones, a column that ends inside a coalesced segment — the reference's cuh:366-369 says the anchors may be ignored)
     shapes += [(250000, 64), (250000 + 37, 16), (99999, 48), (123456, 100), (65536 + 8, 128), (77777, 3), (200000, 255), (200000, 96)]
+    # (segments of a row or more that are not whole 1024s: every k-th anchor up to the least common multiple with 1024, then finer anchors — and one odd segment for the column)
+    shapes += [(400000, 1000), (400001, 1023), (250000, 2050), (300000, 10000), (123457, 300000), (70000, 520)]
     if (usize, bits, min_size) == (8, 2, 1):
         shapes += [((5 << 20) + 3000, 5 << 20), (3 << 20, 1 << 20)]
     for n, seglen in shapes:
