@@ -10,6 +10,13 @@
 #define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
 #endif
 
+#ifndef GIDDY_RUN_FUSED_FROM_SEGMENTS
+#define GIDDY_RUN_FUSED_FROM_SEGMENTS 2048   // long segments of run lengths: pre-pass and decoder in one kernel from this many segments on
+#endif
+#ifndef GIDDY_RUN_FUSED_UP_TO_FINES
+#define GIDDY_RUN_FUSED_UP_TO_FINES 8   // ... of up to this many finer segments (of 8192 outputs) each
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -55,6 +62,8 @@ public:
 	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
 	static const void* sparse_kernel() { return reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
 	static const void* dense_kernel()  { return reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
+	/// ... and, launched with a grid of its own (a workgroup per anchored segment), pre-pass and decoder of long segments in one
+	static const void* long_segments_kernel() { return reinterpret_cast<const void*>(decompress_long_segments<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
 };
 
 #define GIDDY_RLE_TEMPLATE template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize>
@@ -120,6 +129,21 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		const bool one_launch = environment.one_launch && (environment.force_one_launch
 			|| (sparse && L >= 4 * (uint64_t) fine::sub && segments <= fine::most_segments_for_one_launch && runs / segments <= fine::most_runs_per_segment_for_one_launch));
 		const bool worth_it = environment.force || one_launch || n / runs >= 8 || L >= 16 * (uint64_t) fine::sub;
+		// ... and then pre-pass and decode are ONE kernel: the workgroup that scanned a segment's lengths decodes the segment, its finer anchors never leave LDS
+		// (kernels/decompression/run_length_encoding.hpp, decompress_long_segments; profiles/r04_run_prepass.txt)
+		// — where there are enough segments for a workgroup each to fill the chip (2^28 outputs, mean run 32, segments of 32 768 / 65 536: 75.7 / 74.9 % against 68.9 / 71.8 %;
+		// 2048 segments of 131 072: 64 % against 71 %)
+		// — segments of up to 8 finer ones (a wavefront decodes two of them, one after the other: with 16 — segments of 131 072 — the separate launches win again,
+		// 2^30 outputs: 75.6 % against 79.0 %; with 4 and 8: 84.2 / 82.5 % against 78.2 / 78.8 %) —
+		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES
+			&& segments >= (uint64_t) GIDDY_RUN_FUSED_FROM_SEGMENTS && runs / segments <= fine::most_runs_per_segment_for_one_launch;
+		if (fused || (one_launch && environment.force_one_launch && environment.fused && sparse && L / fine::sub <= most_fines_per_long_segment)) {
+			cuda::enqueue_launch(long_segments_kernel(), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(num_segments, 1u << 20), fine::threads),
+				decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
+				segment_length, num_segments, num_element_runs, uncompressed_length);
+			return;
+		}
 		const size_t sums_bytes = one_launch ? 0 : (tiles + blocks) * sizeof(uint64_t);
 		const size_t anchors_at = sums_bytes, offsets_at = util::round_up(anchors_at + num_fine * sizeof(run_index_type), (size_t) 16);
 		if (worth_it && num_fine <= std::numeric_limits<size_type>::max() && scratch.take(offsets_at + num_fine * sizeof(run_length_type))) {
@@ -160,7 +184,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 GIDDY_RLE_TEMPLATE
 const device_function_t GIDDY_RLE_KERNEL::get_device_function() const
 {
-	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel() });
+	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel(), long_segments_kernel() });
 }
 
 /// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")

@@ -45,6 +45,7 @@ struct fine_environment {
 	bool force = false;              // GIDDY_RUN_FINE_FORCE=1: finer anchors whenever the segments allow them
 	bool force_one_launch = false;   // GIDDY_RUN_FINE_ONE_LAUNCH=2: ... by the one-launch pre-pass
 	uint64_t min_mean_run = 0;
+	bool fused = true;               // GIDDY_RUN_FUSED_PREPASS=0: the one-launch pre-pass stays a launch of its own (run lengths)
 	static const fine_environment& get()
 	{
 		static const fine_environment e = [] {
@@ -52,6 +53,7 @@ struct fine_environment {
 			if (const char* v = std::getenv("GIDDY_RUN_FINE_ONE_LAUNCH")) { read.one_launch = v[0] != '0'; read.force_one_launch = v[0] == '2'; }
 			if (const char* v = std::getenv("GIDDY_RUN_FINE_MIN_MEAN_RUN")) { read.min_mean_run = std::strtoull(v, nullptr, 10); }
 			if (const char* v = std::getenv("GIDDY_RUN_FINE_FORCE")) { read.force = v[0] == '1'; }
+			if (const char* v = std::getenv("GIDDY_RUN_FUSED_PREPASS")) { read.fused = v[0] != '0'; }
 			return read;
 		}();
 		return e;
@@ -244,6 +246,98 @@ __global__ void __launch_bounds__(threads) anchors_from_sums(
 /// begins `intra_run_anchor_offsets[s]` before it), as in anchors_from_sums; nothing is read of other segments' runs but the next
 /// segment's anchor, and no scratch beyond the anchors themselves is written.  The three-launch pass above remains for columns
 /// whose segments hold so many runs each (tens of thousands) that a workgroup per segment would leave the chip idle.
+/// (the work for ONE segment, by the whole workgroup; `anchors_out` / `offsets_out`: the segment's finer anchors — in global memory, or in LDS
+/// when the same workgroup goes on to decode the segment: run_length_encoding.hpp, decompress_long_segments)
+template <unsigned RunLengthSize> struct segment_scan_storage {
+	enum : unsigned { per_lane = 16 / RunLengthSize, runs_per_chunk = threads * per_lane, waves = threads / 64 };
+	// end of each of the chunk's runs, counted from where the CHUNK's first run begins (1-2-byte lengths: a chunk's total fits 32 bits — half the LDS, twice the workgroups per CU)
+	using end_type = typename std::conditional<(RunLengthSize <= 2), uint32_t, uint64_t>::type;
+	end_type ends[runs_per_chunk];
+	uint64_t wave_totals[waves];
+};
+
+template <unsigned RunLengthSize, unsigned RunIndexSize>
+__device__ __forceinline__ void finer_anchors_of_one_segment(
+	uint_t<RunIndexSize>* anchors_out, uint_t<RunLengthSize>* offsets_out, segment_scan_storage<RunLengthSize>& storage,
+	const uint_t<RunLengthSize>*  __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*   __restrict__  position_anchors,
+	const uint_t<RunLengthSize>*  __restrict__  intra_run_anchor_offsets,
+	uint64_t s, uint64_t segment_length, uint64_t num_segments, uint64_t num_runs, uint64_t length)
+{
+	using storage_type = segment_scan_storage<RunLengthSize>;
+	constexpr unsigned per_lane = storage_type::per_lane, runs_per_chunk = storage_type::runs_per_chunk, waves = storage_type::waves;
+	using length_type = uint_t<RunLengthSize>;
+	using end_type = typename storage_type::end_type;
+	end_type* const ends = storage.ends;
+	uint64_t* const wave_totals = storage.wave_totals;
+	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
+
+	auto load = [&](uint64_t first, uint64_t from, uint64_t last) {   // this thread's group of the chunk: lengths of runs outside [from, last] count 0
+		memory_access::group<length_type, per_lane> lengths;
+		if (first >= from && first + per_lane <= last + 1) { lengths = memory_access::load_group<length_type, per_lane>(run_lengths + first); }   // (last < num_runs)
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < per_lane; j++) { lengths[j] = (first + j < num_runs && first + j >= from && first + j <= last) ? run_lengths[first + j] : (length_type) 0; }
+		}
+		return lengths;
+	};
+
+	const uint64_t anchor = position_anchors[s], offset = intra_run_anchor_offsets[s];
+	const uint64_t last_run = s + 1 < num_segments ? (uint64_t) position_anchors[s + 1] : num_runs - 1;   // the last run the segment can touch
+	const uint64_t segment_outputs = (s + 1) * segment_length <= length ? segment_length : length - s * segment_length;
+	const uint64_t fines = (segment_outputs + sub - 1) / sub;   // finer anchors of this segment; number 0 is the segment's own
+	if (threadIdx.x == 0) { anchors_out[0] = (uint_t<RunIndexSize>) anchor; offsets_out[0] = (uint_t<RunLengthSize>) offset; }
+	if (fines <= 1) { return; }
+
+	const uint64_t chunk0 = anchor / per_lane * per_lane;   // 16-byte groups: the first chunk begins at the group holding the anchor run
+	uint64_t base = 0;                // where the chunk's first run begins, counted from where the anchor run begins
+	uint64_t last_start = 0;          // ... where the last run seen begins
+	uint64_t next_fine = 1;           // the first finer anchor not yet written
+	auto ahead = load(chunk0 + (uint64_t) threadIdx.x * per_lane, anchor, last_run);
+	for (uint64_t chunk = chunk0; chunk <= last_run && next_fine < fines; chunk += runs_per_chunk) {
+		const uint64_t first = chunk + (uint64_t) threadIdx.x * per_lane;
+		const auto lengths = ahead;
+		if (chunk + runs_per_chunk <= last_run) { ahead = load(first + runs_per_chunk, anchor, last_run); }
+		uint64_t inclusive[per_lane], sum = 0;
+		#pragma unroll
+		for (unsigned j = 0; j < per_lane; j++) { sum += (uint64_t) lengths[j]; inclusive[j] = sum; }
+		const uint64_t scanned = wave64::inclusive_sum(sum);
+		if (lane == 63) { wave_totals[wave] = scanned; }
+		__syncthreads();
+		uint64_t before = scanned - sum, chunk_total = 0;
+		#pragma unroll
+		for (unsigned w = 0; w < waves; w++) { before += w < wave ? wave_totals[w] : 0; chunk_total += wave_totals[w]; }
+		#pragma unroll
+		for (unsigned j = 0; j < per_lane; j++) { ends[threadIdx.x * per_lane + j] = (end_type) (before + inclusive[j]); }
+		__syncthreads();
+		// the finer anchors whose first output lies among this chunk's runs: output j * sub of the segment is at offset + j * sub from where the anchor run begins
+		const uint64_t chunk_end = base + chunk_total;
+		const uint64_t covered = chunk_end > offset ? (chunk_end - offset + sub - 1) / sub : 0;   // finer anchors j < covered begin before chunk_end
+		const uint64_t until = covered < fines ? covered : fines;
+		for (uint64_t j = next_fine + threadIdx.x; j < until; j += threads) {
+			const uint64_t target = offset + j * sub - base;   // (counted from the chunk's first run, as `ends` are)
+			unsigned low = 0, high = runs_per_chunk - 1;   // the first run of the chunk that ends beyond the target
+			while (low < high) {
+				const unsigned middle = (low + high) / 2;
+				if ((uint64_t) ends[middle] > target) { high = middle; } else { low = middle + 1; }
+			}
+			const uint64_t start = low == 0 ? 0 : (uint64_t) ends[low - 1];
+			anchors_out[j] = (uint_t<RunIndexSize>) (chunk + low);
+			offsets_out[j] = (uint_t<RunLengthSize>) (target - start);
+		}
+		if (until > next_fine) { next_fine = until; }
+		// (where the segment's last run begins: what is left of the segment is pinned there if the lengths fall short of the segment)
+		if (chunk + runs_per_chunk > last_run) { const unsigned at = (unsigned) (last_run - chunk); last_start = base + (at == 0 ? 0 : (uint64_t) ends[at - 1]); }
+		base = chunk_end;
+		__syncthreads();   // (`ends` and `wave_totals` are rewritten by the next chunk)
+	}
+	// lengths that do not reach the segment's end (a malformed column): the rest enters at the last run, as the three-launch pass's walk would
+	for (uint64_t j = next_fine + threadIdx.x; j < fines; j += threads) {
+		anchors_out[j] = (uint_t<RunIndexSize>) last_run;
+		offsets_out[j] = (uint_t<RunLengthSize>) (offset + j * sub - last_start);
+	}
+}
+
 template <unsigned RunLengthSize, unsigned RunIndexSize>
 __global__ void __launch_bounds__(threads) anchors_of_segments(
 	uint_t<RunIndexSize>*         __restrict__  fine_anchors,
@@ -256,84 +350,11 @@ __global__ void __launch_bounds__(threads) anchors_of_segments(
 	uint64_t                                    num_runs,
 	uint64_t                                    length)
 {
-	constexpr unsigned per_lane = 16 / RunLengthSize;
-	constexpr unsigned runs_per_chunk = threads * per_lane;
-	constexpr unsigned waves = threads / 64;
-	using length_type = uint_t<RunLengthSize>;
-	// end of each of the chunk's runs, counted from where the CHUNK's first run begins (1-2-byte lengths: a chunk's total fits 32 bits — half the LDS, twice the workgroups per CU)
-	using end_type = typename std::conditional<(RunLengthSize <= 2), uint32_t, uint64_t>::type;
-	__shared__ end_type ends[runs_per_chunk];
-	__shared__ uint64_t wave_totals[waves];
-	const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
+	__shared__ segment_scan_storage<RunLengthSize> storage;
 	const uint64_t per_segment = segment_length / sub;
-
-	auto load = [&](uint64_t first, uint64_t from, uint64_t last) {   // this thread's group of the chunk: lengths of runs outside [from, last] count 0
-		memory_access::group<length_type, per_lane> lengths;
-		if (first >= from && first + per_lane <= last + 1) { lengths = memory_access::load_group<length_type, per_lane>(run_lengths + first); }   // (last < num_runs)
-		else {
-			#pragma unroll
-			for (unsigned j = 0; j < per_lane; j++) { lengths[j] = (first + j < num_runs && first + j >= from && first + j <= last) ? run_lengths[first + j] : (length_type) 0; }
-		}
-		return lengths;
-	};
-
 	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
-		const uint64_t anchor = position_anchors[s], offset = intra_run_anchor_offsets[s];
-		const uint64_t last_run = s + 1 < num_segments ? (uint64_t) position_anchors[s + 1] : num_runs - 1;   // the last run the segment can touch
-		const uint64_t segment_outputs = (s + 1) * segment_length <= length ? segment_length : length - s * segment_length;
-		const uint64_t fines = (segment_outputs + sub - 1) / sub;   // finer anchors of this segment; number 0 is the segment's own
-		uint_t<RunIndexSize>* const anchors_out = fine_anchors + s * per_segment;
-		uint_t<RunLengthSize>* const offsets_out = fine_offsets + s * per_segment;
-		if (threadIdx.x == 0) { anchors_out[0] = (uint_t<RunIndexSize>) anchor; offsets_out[0] = (uint_t<RunLengthSize>) offset; }
-		if (fines <= 1) { continue; }
-
-		const uint64_t chunk0 = anchor / per_lane * per_lane;   // 16-byte groups: the first chunk begins at the group holding the anchor run
-		uint64_t base = 0;                // where the chunk's first run begins, counted from where the anchor run begins
-		uint64_t last_start = 0;          // ... where the last run seen begins
-		uint64_t next_fine = 1;           // the first finer anchor not yet written
-		auto ahead = load(chunk0 + (uint64_t) threadIdx.x * per_lane, anchor, last_run);
-		for (uint64_t chunk = chunk0; chunk <= last_run && next_fine < fines; chunk += runs_per_chunk) {
-			const uint64_t first = chunk + (uint64_t) threadIdx.x * per_lane;
-			const auto lengths = ahead;
-			if (chunk + runs_per_chunk <= last_run) { ahead = load(first + runs_per_chunk, anchor, last_run); }
-			uint64_t inclusive[per_lane], sum = 0;
-			#pragma unroll
-			for (unsigned j = 0; j < per_lane; j++) { sum += (uint64_t) lengths[j]; inclusive[j] = sum; }
-			const uint64_t scanned = wave64::inclusive_sum(sum);
-			if (lane == 63) { wave_totals[wave] = scanned; }
-			__syncthreads();
-			uint64_t before = scanned - sum, chunk_total = 0;
-			#pragma unroll
-			for (unsigned w = 0; w < waves; w++) { before += w < wave ? wave_totals[w] : 0; chunk_total += wave_totals[w]; }
-			#pragma unroll
-			for (unsigned j = 0; j < per_lane; j++) { ends[threadIdx.x * per_lane + j] = (end_type) (before + inclusive[j]); }
-			__syncthreads();
-			// the finer anchors whose first output lies among this chunk's runs: output j * sub of the segment is at offset + j * sub from where the anchor run begins
-			const uint64_t chunk_end = base + chunk_total;
-			const uint64_t covered = chunk_end > offset ? (chunk_end - offset + sub - 1) / sub : 0;   // finer anchors j < covered begin before chunk_end
-			const uint64_t until = covered < fines ? covered : fines;
-			for (uint64_t j = next_fine + threadIdx.x; j < until; j += threads) {
-				const uint64_t target = offset + j * sub - base;   // (counted from the chunk's first run, as `ends` are)
-				unsigned low = 0, high = runs_per_chunk - 1;   // the first run of the chunk that ends beyond the target
-				while (low < high) {
-					const unsigned middle = (low + high) / 2;
-					if ((uint64_t) ends[middle] > target) { high = middle; } else { low = middle + 1; }
-				}
-				const uint64_t start = low == 0 ? 0 : (uint64_t) ends[low - 1];
-				anchors_out[j] = (uint_t<RunIndexSize>) (chunk + low);
-				offsets_out[j] = (uint_t<RunLengthSize>) (target - start);
-			}
-			if (until > next_fine) { next_fine = until; }
-			// (where the segment's last run begins: what is left of the segment is pinned there if the lengths fall short of the segment)
-			if (chunk + runs_per_chunk > last_run) { const unsigned at = (unsigned) (last_run - chunk); last_start = base + (at == 0 ? 0 : (uint64_t) ends[at - 1]); }
-			base = chunk_end;
-			__syncthreads();   // (`ends` and `wave_totals` are rewritten by the next chunk)
-		}
-		// lengths that do not reach the segment's end (a malformed column): the rest enters at the last run, as the three-launch pass's walk would
-		for (uint64_t j = next_fine + threadIdx.x; j < fines; j += threads) {
-			anchors_out[j] = (uint_t<RunIndexSize>) last_run;
-			offsets_out[j] = (uint_t<RunLengthSize>) (offset + j * sub - last_start);
-		}
+		finer_anchors_of_one_segment<RunLengthSize, RunIndexSize>(fine_anchors + s * per_segment, fine_offsets + s * per_segment, storage,
+			run_lengths, position_anchors, intra_run_anchor_offsets, s, segment_length, num_segments, num_runs, length);
 	}
 }
 

@@ -20,6 +20,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/decompression/run_expansion.hpp"
+#include "giddy/kernels/decompression/run_anchors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/util/math.hpp"
 
@@ -49,6 +50,10 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 
 namespace detail {
 
+/// Which chunks a wavefront takes: those of the whole grid at grid stride (`given` false) — or (decompress_long_segments) `first`, `first + stride`, ... below
+/// `limit`, with the anchor arrays beginning at chunk `anchors_from` (they hold one workgroup's segment's finer anchors, in LDS)
+struct chunks_to_take { bool given = false; uint64_t first = 0, stride = 1, limit = 0, anchors_from = 0; };
+
 /// The kernel's body.  `WithGroups`: with the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — without it the kernel
 /// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity
 /// Cache it is 10 points faster at mean runs of 32 (the wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough
@@ -63,7 +68,8 @@ __device__ __forceinline__ void decompress(
 	size_type_by_index_size<UncompressedIndexSize>      segment_length,
 	size_type_by_index_size<UncompressedIndexSize>      num_segments,
 	size_type_by_index_size<RunIndexSize>               num_element_runs,
-	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length,
+	const chunks_to_take                                mine = chunks_to_take())
 {
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
@@ -96,7 +102,7 @@ __device__ __forceinline__ void decompress(
 	const uint64_t num_chunks = (num_segments + segments_per_chunk - 1) / segments_per_chunk;
 	// (4- and 8-byte elements only: narrow columns lose 2-4 points to it even with the output on a page boundary — 41-repetition A/B)
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
-	for (uint64_t c = my_first_chunk; c < num_chunks; c += num_waves) {
+	for (uint64_t c = mine.given ? mine.first : my_first_chunk; c < (mine.given ? mine.limit : num_chunks); c += mine.given ? mine.stride : num_waves) {
 		const uint64_t s = c * segments_per_chunk;
 		const uint64_t segment_start = s * L;
 		if (segment_start >= n) { break; }
@@ -108,14 +114,14 @@ __device__ __forceinline__ void decompress(
 			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
 			touched = touch(segment_position_anchors + (ahead < num_segments ? ahead : s));
 		}
-		uint64_t first_run = segment_position_anchors[s];
+		uint64_t first_run = segment_position_anchors[s - mine.anchors_from];
 		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
-		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s];
+		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s - mine.anchors_from];
 		length_type left_in_first_run = 0;
 		bool entering = true;   // the chunk's first tile: the first run's length is not known yet
 		uint64_t run_limit = num_runs;   // exclusive
 		if (s + segments_per_chunk < num_segments) {
-			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk] + 1;
+			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk - mine.anchors_from] + 1;
 			if (through < run_limit) { run_limit = through; }
 		}
 
@@ -329,6 +335,48 @@ __global__ void decompress_sparse_runs(
 {
 	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
 		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
+}
+
+/// LONG segments of sparse runs in ONE launch (round 4): a workgroup per anchored segment first finds the entry point of every `fine::sub`-th output of
+/// ITS segment — run_anchors.hpp, finer_anchors_of_one_segment: the segment's run lengths streamed once, their ends scanned into LDS, a binary search
+/// per finer anchor — keeps them in LDS, and goes on to decode the segment, a wavefront per finer segment in turn.  The pre-pass as a launch of its own
+/// (fine::anchors_of_segments + decompress_sparse_runs on the finer segments) cost a launch boundary — the decoder's ramp behind the pre-pass's
+/// tail: ~20 us of 200 at 2^28 outputs — and a trip of the anchors through memory.  Segments of up to `most_fines` x fine::sub outputs.
+enum : unsigned { most_fines_per_long_segment = 64 };
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_segments(
+	uint_t<UncompressedSize>*             __restrict__  decompressed,
+	const uint_t<UncompressedSize>*       __restrict__  run_data,
+	const uint_t<RunLengthSize>*          __restrict__  run_lengths,
+	const uint_t<RunIndexSize>*           __restrict__  segment_position_anchors,
+	const uint_t<RunLengthSize>*          __restrict__  segment_position_anchor_intra_run_offsets,
+	size_type_by_index_size<UncompressedIndexSize>      segment_length,
+	size_type_by_index_size<UncompressedIndexSize>      num_segments,
+	size_type_by_index_size<RunIndexSize>               num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+{
+	namespace fine = run_expansion::fine;
+	__shared__ fine::segment_scan_storage<RunLengthSize> storage;
+	__shared__ uint_t<RunIndexSize> finer_anchors[most_fines_per_long_segment + 1];
+	__shared__ uint_t<RunLengthSize> finer_offsets[most_fines_per_long_segment + 1];
+	const uint64_t L = segment_length, n = total_uncompressed_length;
+	const uint64_t per_segment = L / fine::sub;   // (the wrapper: a multiple, at most most_fines_per_long_segment)
+	const uint64_t num_fine = (n + fine::sub - 1) / fine::sub;
+	const unsigned working_waves = wave64::per_block() < run_expansion::max_waves_per_block ? wave64::per_block() : run_expansion::max_waves_per_block;
+	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+		fine::finer_anchors_of_one_segment<RunLengthSize, RunIndexSize>(finer_anchors, finer_offsets, storage,
+			run_lengths, segment_position_anchors, segment_position_anchor_intra_run_offsets, s, L, num_segments, num_element_runs, n);
+		// (the entry after the segment's last: the next segment's own anchor — where the last finer segment's runs end)
+		if (threadIdx.x == 0 && s + 1 < num_segments) { finer_anchors[per_segment] = segment_position_anchors[s + 1]; finer_offsets[per_segment] = segment_position_anchor_intra_run_offsets[s + 1]; }
+		__syncthreads();
+		detail::chunks_to_take mine;
+		mine.given = true; mine.first = s * per_segment + wave64::index_in_block(); mine.stride = working_waves;
+		mine.limit = (s + 1) * per_segment < num_fine ? (s + 1) * per_segment : num_fine; mine.anchors_from = s * per_segment;
+		detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
+			finer_anchors, finer_offsets, (size_type_by_index_size<UncompressedIndexSize>) fine::sub, (size_type_by_index_size<UncompressedIndexSize>) num_fine,
+			num_element_runs, total_uncompressed_length, mine);
+		__syncthreads();   // (the anchors in LDS are the next segment's after this)
+	}
 }
 
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>

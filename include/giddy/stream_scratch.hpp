@@ -100,12 +100,20 @@ inline block take(stream::id_t stream, size_t bytes)
 	if (hipGetDevice(&device) != hipSuccess) { (void) hipGetLastError(); return result; }
 	const auto thread = std::this_thread::get_id();
 	std::lock_guard<std::mutex> lock(pool.mutex);
+	// the smallest block that will do among those this stream (as this thread uses it) released last — ordered behind its earlier use by the stream itself —;
+	// failing that, among the blocks whose last use has completed.  (One's own first: taking another stream's idle block while one's own would do leaves that
+	// stream without its block the next time round, and its request — its own block taken, the taker's not yet idle — allocates: the pool grew by timing.)
 	detail::pool::entry* best = nullptr;
 	for (auto& e : pool.entries) {
 		if (e.leased || e.device != device || e.bytes < bytes) { continue; }
-		const bool mine = e.bound && e.last_stream == stream && e.last_thread == thread;
-		if (!mine && !detail::idle(e)) { continue; }
+		if (!(e.bound && e.last_stream == stream && e.last_thread == thread)) { continue; }
 		if (best == nullptr || e.bytes < best->bytes) { best = &e; }
+	}
+	if (best == nullptr) {
+		for (auto& e : pool.entries) {
+			if (e.leased || e.device != device || e.bytes < bytes || !detail::idle(e)) { continue; }
+			if (best == nullptr || e.bytes < best->bytes) { best = &e; }
+		}
 	}
 	if (best == nullptr) {
 		detail::pool::entry fresh;

@@ -196,8 +196,9 @@ def test_rle(index_size, usize, lsize, run_index_size):
             assert len(bad) == 0, (name, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
 
 
-@pytest.mark.parametrize("switches", [{"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1"}, {"GIDDY_RUN_FINE_ONE_LAUNCH": "0", "GIDDY_RUN_FINE_FORCE": "1"}],
-                         ids=["one_launch_pre_pass", "three_launch_pre_pass"])
+@pytest.mark.parametrize("switches", [{"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1"}, {"GIDDY_RUN_FINE_ONE_LAUNCH": "0", "GIDDY_RUN_FINE_FORCE": "1"},
+                                      {"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1", "GIDDY_RUN_FUSED_PREPASS": "0"}],
+                         ids=["pre_pass_and_decoder_in_one_kernel", "three_launch_pre_pass", "one_launch_pre_pass"])
 def test_rle_with_each_pre_pass_forced(switches):
     """The wrapper picks the pre-pass that finds finer anchors for long segments by the column's shape (one launch: a workgroup per segment;
     three launches: sums, scan, search).  Here every run-length registration decodes every column of test_rle with EACH of them forced for

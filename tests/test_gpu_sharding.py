@@ -313,12 +313,14 @@ def test_native_pipeline_with_long_segments(num_chunks, depth):
         out = torch.full((len(truth),), 0x5A, dtype=torch.uint8, device="cuda").repeat_interleave(truth.dtype.itemsize)
         out = out.view({1: torch.uint8, 2: torch.int16, 4: torch.int32, 8: torch.int64}[truth.dtype.itemsize])
         pinned = pipeline.pin(fields)
-        for repetition in range(2):
+        # (every pass gets streams of its own from torch's pool of them, so a block is "this stream's own" only within a pass: the first two passes may still
+        # add a block — which of the equal-sized idle blocks a request gets depends on the order the pool was filled in — after that nothing may be allocated)
+        for repetition in range(4):
             for s in pipeline.decode_from_host_native(scheme, pinned, out, num_chunks=num_chunks, depth=depth, **extra):
                 s.synchronize()
-            if repetition == 0:
+            if repetition == 1:
                 held = registered.scratch_held_bytes()
-        assert registered.scratch_held_bytes() == held, "the second pass over the same column on the same streams allocated scratch again"
+        assert registered.scratch_held_bytes() == held, "later passes over the same column allocated scratch again"
         del pinned
         got = out.cpu().numpy().view(truth.dtype)
         assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
