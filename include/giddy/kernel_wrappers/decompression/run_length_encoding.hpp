@@ -14,7 +14,7 @@
 #define GIDDY_RUN_FUSED_FROM_SEGMENTS 2048   // long segments of run lengths: pre-pass and decoder in one kernel from this many segments on
 #endif
 #ifndef GIDDY_RUN_FUSED_UP_TO_FINES
-#define GIDDY_RUN_FUSED_UP_TO_FINES 8   // ... of up to this many finer segments (of 8192 outputs) each
+#define GIDDY_RUN_FUSED_UP_TO_FINES 16   // ... of up to this many finer segments (of 8192 outputs) each (64 — what the kernel's LDS holds the anchors of — measured: eight workgroups each scanning a 524 288-segment's 16 384 run lengths lose 5-7 points to the separate launches)
 #endif
 
 namespace cuda {
@@ -135,11 +135,12 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// 2048 segments of 131 072: 64 % against 71 %)
 		// — segments of up to 8 finer ones (a wavefront decodes two of them, one after the other: with 16 — segments of 131 072 — the separate launches win again,
 		// 2^30 outputs: 75.6 % against 79.0 %; with 4 and 8: 84.2 / 82.5 % against 78.2 / 78.8 %) —
+		const uint64_t workgroups_of_one_kernel = segments * util::div_rounding_up(L / fine::sub, (uint64_t) finer_segments_per_workgroup);
 		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES
-			&& segments >= (uint64_t) GIDDY_RUN_FUSED_FROM_SEGMENTS && runs / segments <= fine::most_runs_per_segment_for_one_launch;
+			&& workgroups_of_one_kernel >= (uint64_t) GIDDY_RUN_FUSED_FROM_SEGMENTS && runs / segments <= fine::most_runs_per_segment_for_one_launch;
 		if (fused || (one_launch && environment.force_one_launch && environment.fused && sparse && L / fine::sub <= most_fines_per_long_segment)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
-				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(num_segments, 1u << 20), fine::threads),
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
 				decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
 				segment_length, num_segments, num_element_runs, uncompressed_length);
 			return;

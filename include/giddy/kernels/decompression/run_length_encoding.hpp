@@ -342,7 +342,7 @@ __global__ void decompress_sparse_runs(
 /// per finer anchor — keeps them in LDS, and goes on to decode the segment, a wavefront per finer segment in turn.  The pre-pass as a launch of its own
 /// (fine::anchors_of_segments + decompress_sparse_runs on the finer segments) cost a launch boundary — the decoder's ramp behind the pre-pass's
 /// tail: ~20 us of 200 at 2^28 outputs — and a trip of the anchors through memory.  Segments of up to `most_fines` x fine::sub outputs.
-enum : unsigned { most_fines_per_long_segment = 64 };
+enum : unsigned { most_fines_per_long_segment = 64, finer_segments_per_workgroup = 8 };
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize = UncompressedIndexSize>
 __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_segments(
 	uint_t<UncompressedSize>*             __restrict__  decompressed,
@@ -363,15 +363,21 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 	const uint64_t per_segment = L / fine::sub;   // (the wrapper: a multiple, at most most_fines_per_long_segment)
 	const uint64_t num_fine = (n + fine::sub - 1) / fine::sub;
 	const unsigned working_waves = wave64::per_block() < run_expansion::max_waves_per_block ? wave64::per_block() : run_expansion::max_waves_per_block;
-	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+	// A workgroup decodes at most `finer_segments_per_workgroup` finer segments (two per wavefront: with four — segments of 131 072 — the separate launches were the
+	// faster ones): a longer segment is shared by several workgroups, each of which scans the segment's run lengths for itself (2 bytes per run: kilobytes)
+	const uint64_t parts = (per_segment + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
+	for (uint64_t work = blockIdx.x; work < (uint64_t) num_segments * parts; work += gridDim.x) {
+		const uint64_t s = work / parts, part = work - s * parts;
 		fine::finer_anchors_of_one_segment<RunLengthSize, RunIndexSize>(finer_anchors, finer_offsets, storage,
 			run_lengths, segment_position_anchors, segment_position_anchor_intra_run_offsets, s, L, num_segments, num_element_runs, n);
 		// (the entry after the segment's last: the next segment's own anchor — where the last finer segment's runs end)
 		if (threadIdx.x == 0 && s + 1 < num_segments) { finer_anchors[per_segment] = segment_position_anchors[s + 1]; finer_offsets[per_segment] = segment_position_anchor_intra_run_offsets[s + 1]; }
 		__syncthreads();
 		detail::chunks_to_take mine;
-		mine.given = true; mine.first = s * per_segment + wave64::index_in_block(); mine.stride = working_waves;
-		mine.limit = (s + 1) * per_segment < num_fine ? (s + 1) * per_segment : num_fine; mine.anchors_from = s * per_segment;
+		const uint64_t part_first = s * per_segment + part * finer_segments_per_workgroup;
+		const uint64_t part_limit = part_first + finer_segments_per_workgroup < (s + 1) * per_segment ? part_first + finer_segments_per_workgroup : (s + 1) * per_segment;
+		mine.given = true; mine.first = part_first + wave64::index_in_block(); mine.stride = working_waves;
+		mine.limit = part_limit < num_fine ? part_limit : num_fine; mine.anchors_from = s * per_segment;
 		detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
 			finer_anchors, finer_offsets, (size_type_by_index_size<UncompressedIndexSize>) fine::sub, (size_type_by_index_size<UncompressedIndexSize>) num_fine,
 			num_element_runs, total_uncompressed_length, mine);
