@@ -155,6 +155,15 @@ public:
 	{
 		for (const void* a : alternates) { if (num_alternates_ < max_alternates && a != nullptr && a != ptr) { alternates_[num_alternates_++] = a; } }
 	}
+	/// ... and builds a wrapper launches with a grid and block of ITS OWN choosing (a pre-pass and a decoder in one kernel, a workgroup per segment): listed
+	/// among the alternates — they may be what runs — but attributes() does not let them narrow the limits of a configuration they are never launched with
+	/// (their static LDS would also shift what the resolution reserves to hold a kernel to so many workgroups per compute unit)
+	device_function_t(const void* ptr, std::initializer_list<const void*> alternates, std::initializer_list<const void*> launched_with_their_own_configuration)
+	: device_function_t(ptr, alternates)
+	{
+		num_with_callers_configuration_ = num_alternates_;
+		for (const void* a : launched_with_their_own_configuration) { if (num_alternates_ < max_alternates && a != nullptr && a != ptr) { alternates_[num_alternates_++] = a; } }
+	}
 	template <typename... Params>
 	device_function_t(void (*kernel)(Params...)) : ptr_(reinterpret_cast<const void*>(kernel)) { }
 	const void* ptr() const { return ptr_; }
@@ -170,7 +179,7 @@ public:
 	device_function::attributes_t attributes() const
 	{
 		device_function::attributes_t all = attributes_of(ptr_);
-		for (unsigned i = 0; i < num_alternates_; i++) {
+		for (unsigned i = 0; i < (num_with_callers_configuration_ == ~0u ? num_alternates_ : num_with_callers_configuration_); i++) {
 			const device_function::attributes_t a = attributes_of(alternates_[i]);
 			all.maxThreadsPerBlock = a.maxThreadsPerBlock < all.maxThreadsPerBlock ? a.maxThreadsPerBlock : all.maxThreadsPerBlock;
 			all.maxDynamicSharedSizeBytes = a.maxDynamicSharedSizeBytes < all.maxDynamicSharedSizeBytes ? a.maxDynamicSharedSizeBytes : all.maxDynamicSharedSizeBytes;
@@ -185,6 +194,7 @@ private:
 	const void* ptr_;
 	const void* alternates_[max_alternates] = { };
 	unsigned num_alternates_ = 0;
+	unsigned num_with_callers_configuration_ = ~0u;   // (~0: all of them)
 };
 
 } // namespace cuda

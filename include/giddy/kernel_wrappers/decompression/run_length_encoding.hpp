@@ -185,7 +185,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 GIDDY_RLE_TEMPLATE
 const device_function_t GIDDY_RLE_KERNEL::get_device_function() const
 {
-	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel(), long_segments_kernel() });
+	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel() }, { long_segments_kernel() });
 }
 
 /// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")

@@ -219,7 +219,7 @@ __host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
 /// rows, where `base = anchors[segment]` at every segment's first row is a load the wavefront has to wait for with its stores unissued
 /// (segments of 12 rows: 66 % of the HBM peak where segments of 16 — two per chunk instead of... — reach 73 %).
 #ifndef GIDDY_DELTA_ANCHORS_AHEAD
-#define GIDDY_DELTA_ANCHORS_AHEAD 1
+#define GIDDY_DELTA_ANCHORS_AHEAD 0   // (measured against the same kernels without it, one box, 2^30 elements in segments of 4096: 2-byte elements -5 points, <8,8,2> -1.5, the rest within noise)
 #endif
 template <typename U>
 struct chunk_anchors {
@@ -550,7 +550,7 @@ __device__ __forceinline__ void wave_rows_of_short_segments(
 	using C = typename traits::compressed_type;
 	using scan_type = typename traits::scan_type;
 	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
-	constexpr unsigned R = Staged ? 4 : (traits::rows_in_flight > 4 ? 4 : traits::rows_in_flight);   // (8 rows of 2-byte elements with their bounds in flight spill registers)
+	constexpr unsigned R = Staged ? (Patches::enabled ? 2 : 4) : (traits::rows_in_flight > 4 ? 4 : traits::rows_in_flight);   // (8 rows of 2-byte elements with their bounds in flight spill registers)
 	constexpr unsigned log2_E = traits::E == 8 ? 3 : (traits::E == 4 ? 2 : 1);
 	static_assert((1u << log2_E) == traits::E, "E is 2, 4 or 8");
 	const unsigned lane = wave64::lane_id();
@@ -764,7 +764,7 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 	using scan_type = typename traits::scan_type;
 	using sum_type = typename std::conditional<(sizeof(U) < 4), uint32_t, U>::type;
 	constexpr unsigned E = traits::E;
-	constexpr unsigned R = 2;
+	constexpr unsigned R = Patches::enabled ? 1 : 2;   // (this path's registers count for every path of the kernel: the fused kernels' cursors leave room for one row in flight)
 	constexpr unsigned log2_E = E == 8 ? 3 : (E == 4 ? 2 : 1);
 	const unsigned lane = wave64::lane_id();
 	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
