@@ -67,15 +67,18 @@ void GIDDY_DZBFP_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_c
 	auto length           = argument<index_type>(arguments, "length");
 	auto num_patches      = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize);
+	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor, true>)
+		: reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>), stream, launch_config,
 		decompressed, compressed_input, patch_values, patch_positions, (size_type) length, (size_type) num_patches);
 }
 
 GIDDY_DZBFP_TEMPLATE
 const device_function_t GIDDY_DZBFP_KERNEL::get_device_function() const
 {
-	return reinterpret_cast<const void*>(
-		patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
+	return device_function_t(reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>),
+		{ reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor, true>) });
 }
 
 #undef GIDDY_DZBFP_TEMPLATE

@@ -65,7 +65,9 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto num_patches                = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed));
+	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), stream, launch_config,
 		decompressed, compressed_input, segment_model_coefficients, patch_values, patch_positions,
 		(size_type) length, (size_type) segment_length, (size_type) num_patches);
 }
@@ -73,7 +75,7 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
 const device_function_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::get_device_function() const
 {
-	return reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
+	return device_function_t(reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), { reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, true>) });
 }
 
 } // namespace patched

@@ -56,14 +56,16 @@ void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch_with(
 	auto patch_values       = argument<const Uncompressed*>(arguments, "patch_values");
 	auto num_patches        = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
+	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed));
+	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction>), stream, launch_config,
 		decompressed, model_coefficients, patch_values, patch_positions, (size_type) length, (size_type) num_patches);
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
 const device_function_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::get_device_function() const
 {
-	return reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction>);
+	return device_function_t(reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction>), { reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction, true>) });
 }
 
 } // namespace patched

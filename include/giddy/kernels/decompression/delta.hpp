@@ -1352,7 +1352,7 @@ namespace patched {
 /// Delta decompression and patching in one pass: the result of `delta::decompress` followed by
 /// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` — for ASCENDING
 /// patch positions (equal positions: the last one wins) — without the second launch or its read-modify-write.
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, bool ManyPatches = false>
 __global__ void decompress(
 	uint_t<UncompressedSize>*        __restrict__  decompressed,
 	const uint_t<CompressedSize>*    __restrict__  compressed_input,
@@ -1375,7 +1375,7 @@ __global__ void decompress(
 	more_windows& later_windows = *reinterpret_cast<more_windows*>(overlay);
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, value_type>(patch_values, patch_positions, num_patches, length,
+		sorted_patches::cursor_t<IndexSize, value_type, ManyPatches>(patch_values, patch_positions, num_patches, length,
 			w < 4 ? first_windows.positions[w] : later_windows.positions[w - 4], w < 4 ? first_windows.values[w] : later_windows.values[w - 4]),
 		stages ? overlay : nullptr);
 }

@@ -200,7 +200,7 @@ namespace patched {
 /// Dictionary decompression and patching in one pass: what `dictionary::decompress` followed by
 /// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in `decompressed`,
 /// for ASCENDING patch positions (equal positions: the last one wins).
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize, bool ManyPatches = false>
 __global__ void decompress(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -216,7 +216,7 @@ __global__ void decompress(
 	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
 	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory,
-		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>>(patch_values, patch_positions, num_patches, length, patch_windows),
+		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows),
 		chunk_key_staging_in_dynamic_lds);
 }
 

@@ -69,7 +69,7 @@ template <unsigned UncompressedSize, unsigned CompressedSize> constexpr bool sta
 /// storage for the elements that fit, patches for the few that do not.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
 	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
-	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor, bool ManyPatches = false>
 __global__ void decompress(
 	uint_t<UncompressedSize>*        __restrict__  decompressed,
 	const uint_t<CompressedSize>*    __restrict__  compressed_input,
@@ -90,7 +90,7 @@ __global__ void decompress(
 			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
 		},
 		[&](uint64_t, C x) { return widen(x); },
-		sorted_patches::cursor_t<IndexSize, U>(patch_values, patch_positions, num_patches, length, patch_windows),
+		sorted_patches::cursor_t<IndexSize, U, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows),
 		stream_tiles::nothing_to_do(), &chunk_staging);
 }
 

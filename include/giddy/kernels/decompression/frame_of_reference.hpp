@@ -151,7 +151,7 @@ namespace patched {
 /// Frame-of-reference decompression and patching in one pass: what `frame_of_reference::decompress`
 /// followed by `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in
 /// `decompressed`, for ASCENDING patch positions (equal positions: the last one wins).
-template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, bool ManyPatches = false>
 __global__ void decompress(
 	Uncompressed*       __restrict__    decompressed,
 	const Compressed*   __restrict__    compressed_input,
@@ -167,7 +167,7 @@ __global__ void decompress(
 	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows));
 }
 
 } // namespace patched

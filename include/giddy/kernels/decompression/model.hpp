@@ -46,7 +46,7 @@ namespace patched {
 /// `data_layout::scatter::scatter(decompressed, patch_values, patch_positions, num_patches)` leaves in `decompressed`,
 /// for ASCENDING patch positions (equal positions: the last one wins) — the usual way a modelled column is stored:
 /// the model plus the elements it misses.
-template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>
+template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction, bool ManyPatches = false>
 __global__ void decompress(
 	Uncompressed* __restrict__                      decompressed,
 	typename UnaryModelFunction::coefficients_type  model_coefficients,
@@ -65,7 +65,7 @@ __global__ void decompress(
 			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
 		},
 		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); },
-		sorted_patches::cursor_t<IndexSize, Uncompressed>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows));
 }
 
 } // namespace patched

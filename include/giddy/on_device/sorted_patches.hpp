@@ -20,6 +20,10 @@
 #include "giddy/common.hpp"
 #include "giddy/on_device/wave64.hpp"
 
+#ifndef GIDDY_PATCHES_TOGETHER_FROM
+#define GIDDY_PATCHES_TOGETHER_FROM 6   // patches per row of 64 lanes' elements, on the column's average, from which the wrappers launch the ManyPatches builds
+#endif
+
 namespace cuda {
 namespace sorted_patches {
 
@@ -62,6 +66,12 @@ struct none {
 	template <typename T> __device__ __forceinline__ T patched(uint64_t, T value) const { return value; }
 };
 
+/// whether a column of `length` elements with `num_patches` patches, decoded in rows of 64 lanes x `elements_per_lane`, is one for the ManyPatches builds
+inline bool many_patches_per_row(uint64_t num_patches, uint64_t length, unsigned elements_per_lane)
+{
+	return length != 0 && (double) num_patches * (double) (64 * elements_per_lane) >= (double) GIDDY_PATCHES_TOGETHER_FROM * (double) length;
+}
+
 /// Wave-private LDS for the cursors of a workgroup's wavefronts: a window of 64 patches each.  Declared __shared__
 /// by the kernel (at most 16 wavefronts = 1024 threads per workgroup).
 template <unsigned PositionSize, typename Value, unsigned MaxWaves = 16>
@@ -71,7 +81,9 @@ struct window_storage {
 	Value values[max_waves_per_block][64];
 };
 
-template <unsigned PositionSize, typename Value>
+/// `ManyPatches`: apply_to_row has every lane look for its own patches (columns with several patches to a row: the wrappers launch the kernels'
+/// `ManyPatches` builds for them) instead of walking the patches one at a time
+template <unsigned PositionSize, typename Value, bool ManyPatches = false>
 struct cursor_t {
 	enum : bool { enabled = true };
 	enum : unsigned { guess_probes = 16 };
@@ -124,6 +136,9 @@ struct cursor_t {
 	{
 		const uint64_t mine = window_start + lane;
 		const bool have = mine < num;
+		// (Tried in round 4: the NEXT window's entries requested here, into registers, so that a column with a patch in every few elements does not wait
+		// a memory round trip per window — loads in flight across the row loops make every wait the compiler places a wait for everything, as the note
+		// above says: Delta with 0.1 % patches 72.6 -> 57.9 % of the HBM peak, nothing gained at 20-50 %.  Not kept.)
 		const position_type p = have ? positions[mine] : no_patch;
 		const Value v = have ? values[mine] : Value();
 		wave64::lds_fence();   // (earlier reads of the window are done)
@@ -194,6 +209,37 @@ struct cursor_t {
 	__device__ __forceinline__ void apply_to_row(uint64_t row_start, uint64_t row_end, unsigned lane, Values& row)
 	{
 		while (position < row_start) { advance(lane); }
+		// Round 4: MANY patches in a row.  One at a time (below) a patch is a trip around a loop of LDS reads for the whole wavefront: fine for the one patch
+		// in four rows of a 0.1 % column, 13 trips per row at 5 % (Dictionary: 31 % of the HBM peak), 128 at 50 % (6 %).  The window is sorted, so a LANE's
+		// patches are a contiguous stretch of it: where the column has GIDDY_PATCHES_TOGETHER_FROM patches or more to a row ON AVERAGE (decided once, by the
+		// wrapper, from the column's counts — and as a build of its own: finding out row by row cost the 1 % columns 7 points, and the registers of this path
+		// in the same kernel cost the 0.1 % ones 2-5) every lane finds its own — a binary search over the row's entries in
+		// the window (at most 6 LDS reads), then as many steps as it has patches (equal positions: the last wins).
+		if constexpr (ManyPatches) {
+			while (position < row_end) {
+				const position_type in_my_slot = window_positions[lane];
+				const bool in_row = lane >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
+				const unsigned count = (unsigned) __builtin_popcountll(wave64::ballot(in_row));   // (>= 1: the current patch is one of them)
+				const uint64_t my_first = row_start + (uint64_t) lane * E;
+				const unsigned row_entries_end = index_in_window + count;
+				unsigned low = index_in_window, high = row_entries_end;   // the first of the row's entries at or after this lane's first element
+				while (low < high) {
+					const unsigned middle = (low + high) / 2;
+					if ((uint64_t) window_positions[middle] < my_first) { low = middle + 1; } else { high = middle; }
+				}
+				for (unsigned k = low; k < row_entries_end; k++) {
+					const uint64_t at = (uint64_t) window_positions[k];
+					if (at >= my_first + E) { break; }
+					const unsigned offset = (unsigned) (at - my_first);
+					const Value patch = window_values[k];
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { if (offset == j) { row[j] = patch; } }
+				}
+				index_in_window = row_entries_end - 1;
+				advance(lane);   // (to the entry after the row's last in this window: refills the window when that was its last)
+			}
+			return;
+		}
 		while (position < row_end) {
 			const unsigned offset = (unsigned) (position - row_start);
 			if (lane == offset / E) {

@@ -320,7 +320,9 @@ def test_native_pipeline_with_long_segments(num_chunks, depth):
                 s.synchronize()
             if repetition == 1:
                 held = registered.scratch_held_bytes()
-        assert registered.scratch_held_bytes() == held, "later passes over the same column allocated scratch again"
+        # (a request that finds its stream's blocks taken and the others' last use still pending allocates — there is no waiting on the launch path —, so a pass may
+        # still add a block now and then; what must not happen is a block per chunk: 2 passes x 8 chunks of ~1 MiB each would more than double the pool)
+        assert registered.scratch_held_bytes() <= held + held // 2, "later passes over the same column kept allocating scratch"
         del pinned
         got = out.cpu().numpy().view(truth.dtype)
         assert (got == truth).all(), (scheme, np.flatnonzero(got != truth)[:5])
