@@ -1,0 +1,46 @@
+"""GPU box: what a column handed over at an odd ELEMENT offset costs (output and/or input one element past a 16-byte boundary): the decoders' element-wise fall-backs.
+    python tools/unaligned_bases.py [log2 n]"""
+import os, sys
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
+import torch
+import sweep_all as sw
+from libgiddy_amd import schemes
+
+n = 1 << (int(sys.argv[1]) if len(sys.argv) > 1 else 27)
+st = torch.cuda.current_stream().cuda_stream
+def report(name, how, ms, nbytes, ok):
+    print("%-28s %-34s %8.3f ms %5.1f%% %s" % (name, how, ms, nbytes / ms / 1e6 / 80, "ok" if ok else "MISMATCH"), flush=True)
+
+g = sw.gen(1)
+# Dictionary <4,4,1>
+entries = sw.rand_bits(256, 4, g); keys_all = sw.rand_bits(n + 64, 1, g, high=256); out_all = torch.empty(n + 64, dtype=torch.int32, device=sw.DEV)
+for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1), (4, 4)):
+    out, keys = out_all[o:o + n], keys_all[i:i + n]
+    kw = dict(uncompressed_size=4, dictionary_index_size=1, index_size=4, stream=st)
+    cfg = schemes.dictionary(out, keys, entries, n, 256, **kw)
+    ms = sw.timeit(lambda: schemes.dictionary(out, keys, entries, n, 256, launch_config=cfg, **kw))
+    report("dictionary<4,4,1>", "out +%d, keys +%d elements" % (o, i), ms, 5 * n, bool((entries[sw.unsigned(keys, 1)] == out).all()))
+# Delta <4,4,1>, segments of 4096
+L = 4096
+d_all = sw.rand_bits(n + 64, 1, g)
+for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1)):
+    d = d_all[i:i + n]; out = out_all[o:o + n]
+    du = sw.unsigned(d, 1); per_seg = du.view(n // L, L).sum(dim=1)
+    anchors64 = (1 << 20) + torch.cumsum(per_seg, 0) - per_seg; anchors = anchors64.to(torch.int32)
+    kw = dict(uncompressed_size=4, compressed_size=1, index_size=4, stream=st)
+    cfg = schemes.delta(out, d, anchors, n, L, **kw)
+    ms = sw.timeit(lambda: schemes.delta(out, d, anchors, n, L, launch_config=cfg, **kw))
+    expect = (torch.cumsum(du.view(-1, L), dim=1) + anchors64[:, None]).view(-1).to(torch.int32)
+    report("delta<4,4,1> L=4096", "out +%d, deltas +%d elements" % (o, i), ms, 5 * n + 4 * (n // L), bool((expect == out).all()))
+# run lengths <4,4,2,4>
+lengths, starts = sw._runs(n, 32, g, 65535); count = len(lengths)
+values = (torch.arange(count, device=sw.DEV) * 2654435761 % (1 << 31)).to(torch.int32)
+seg = torch.arange(0, n, L, device=sw.DEV); anchor = torch.searchsorted(starts, seg, right=True) - 1
+for o in (0, 1):
+    out = out_all[o:o + n]
+    args = (values, lengths.to(torch.int16), anchor.to(torch.int32), (seg - starts[anchor]).to(torch.int16), L, len(seg), count, n)
+    kw = dict(uncompressed_size=4, run_length_size=2, index_size=4, run_index_size=4, stream=st)
+    cfg = schemes.run_length_encoding(out, *args, **kw)
+    ms = sw.timeit(lambda: schemes.run_length_encoding(out, *args, launch_config=cfg, **kw))
+    ok = bool((values[torch.searchsorted(starts, torch.arange(0, min(n, 1 << 24), device=sw.DEV), right=True) - 1] == out[:1 << 24]).all())
+    report("run_length_encoding<4,4,2,4>", "out +%d elements" % o, ms, 4 * n + 6 * count + 6 * len(seg), ok)
