@@ -139,3 +139,33 @@ def test_odd_segment_lengths_with_patches(usize, csize, seglen):
     got = g.host(out, ud, n)
     bad = np.flatnonzero(got != expect)
     assert len(bad) == 0, (n, seglen, bad[:5])
+
+
+@pytest.mark.parametrize("block,grid", [(64, 1), (64, 5), (256, 3), (512, 2), (1024, 1), (1024, 9)])
+def test_new_paths_under_any_launch_configuration(block, grid):
+    """the kernels take any grid and any workgroup size (modes B and C hand them their own): short segments sharing rows, ragged ones, lengths that split a
+    lane's group — whose LDS tables exist for 4 wavefronts: larger workgroups take the element-wise path —, many long ragged segments, with and without patches"""
+    import gpu_util as g
+    from libgiddy_amd import schemes, registered as r
+    st = g.stream()
+    config = r.launch_configuration_t((grid, 1, 1), (block, 1, 1), 0)
+    for usize, csize in ((4, 1), (8, 2), (2, 1)):
+        ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+        for seglen in (16, 48, 100, 1000, 1001, 3000, 4094):
+            n = 150000 + seglen
+            f, truth = cases.delta_case(n, seglen, ud, cd, seed=seglen + usize)
+            out = g.dev_empty(n, ud)
+            schemes.delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), n, seglen, uncompressed_size=usize, compressed_size=csize, stream=st, launch_config=config)
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != truth)
+            assert len(bad) == 0, (usize, csize, seglen, bad[:5])
+            positions = np.unique(cases.rng(seglen).integers(0, n, 3000)).astype(np.uint32)
+            values = cases.rng(seglen + 1).integers(0, np.iinfo(ud).max, len(positions), dtype=ud)
+            expect = truth.copy(); expect[positions.astype(np.int64)] = values
+            out = g.dev_empty(n, ud)
+            patched_config = r.launch_configuration_t((grid, 1, 1), (min(block, 256), 1, 1), 0)
+            schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values), g.dev(positions), n, seglen, len(positions),
+                                  uncompressed_size=usize, compressed_size=csize, stream=st, launch_config=patched_config)
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != expect)
+            assert len(bad) == 0, ("patched", usize, csize, seglen, bad[:5])
