@@ -169,6 +169,8 @@ public:
 	const void* ptr() const { return ptr_; }
 	operator const void*() const { return ptr_; }
 	unsigned num_alternates() const { return num_alternates_; }
+	/// how many of the alternates — the first so many — run with the configuration the CALLER resolved (the rest: with one of the wrapper's own)
+	unsigned num_alternates_with_callers_configuration() const { return num_with_callers_configuration_ == ~0u ? num_alternates_ : num_with_callers_configuration_; }
 	const void* alternate(unsigned i) const { return i < num_alternates_ ? alternates_[i] : nullptr; }
 	static device_function::attributes_t attributes_of(const void* kernel)
 	{

@@ -10,13 +10,6 @@
 #define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
 #endif
 
-#ifndef GIDDY_RUN_FUSED_FROM_SEGMENTS
-#define GIDDY_RUN_FUSED_FROM_SEGMENTS 2048   // long segments of run lengths: pre-pass and decoder in one kernel from this many segments on
-#endif
-#ifndef GIDDY_RUN_FUSED_UP_TO_FINES
-#define GIDDY_RUN_FUSED_UP_TO_FINES 16   // ... of up to this many finer segments (of 8192 outputs) each (64 — what the kernel's LDS holds the anchors of — measured: eight workgroups each scanning a 524 288-segment's 16 384 run lengths lose 5-7 points to the separate launches)
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {

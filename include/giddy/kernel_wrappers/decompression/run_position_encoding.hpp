@@ -55,6 +55,8 @@ public:
 	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
 	static const void* sparse_kernel() { return reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
 	static const void* dense_kernel()  { return reinterpret_cast<const void*>(decompress_dense_runs<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
+	/// ... and, launched with a grid of its own (a workgroup per (part of an) anchored segment), the search for finer anchors and the decoder of long segments in one
+	static const void* long_segments_kernel() { return reinterpret_cast<const void*>(decompress_long_segments<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
 	static const void* relative_with_finer_anchors_kernel()
 	{
 		if constexpr (PositionsAreRelative) { return reinterpret_cast<const void*>(decompress_relative_with_finer_anchors<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, RunIndexSize>); }
@@ -110,6 +112,17 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	stream_scratch::lease scratch(stream);
 	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
+		// ... in ONE kernel where segments are of 4 finer ones and there are enough of them for 2048 workgroups (kernels/decompression/run_position_encoding.hpp,
+		// decompress_long_segments).  The search is a cheap launch of its own, unlike the run lengths' scan: 2^28 outputs in segments of 32 768: 76.9 % against 74-75 %
+		// (2^30: 82-85 against 79-80), but of 65 536 — a wavefront decodes two finer segments one after the other: 70-72 % against 74-75 % (profiles/r04_run_prepass.txt)
+		const uint64_t workgroups_of_one_kernel = (uint64_t) num_anchors * util::div_rounding_up(L / fine::sub, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
+		if (run_expansion::fine_environment::get().fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_POSITIONS_FUSED_UP_TO_FINES
+			&& workgroups_of_one_kernel >= (uint64_t) GIDDY_RUN_FUSED_FROM_SEGMENTS) {
+			cuda::enqueue_launch(long_segments_kernel(), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
+				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);
+			return;
+		}
 		if (num_fine <= std::numeric_limits<run_index_size_type>::max() && scratch.take(num_fine * sizeof(run_index_type))) {
 			auto* finer_anchors = static_cast<run_index_type*>(scratch.memory());
 			cuda::enqueue_launch(reinterpret_cast<const void*>(fine::anchors_by_search<PositionOffsetSize, PositionsAreRelative, RunIndexSize>), stream,
@@ -141,7 +154,7 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 GIDDY_RPE_TEMPLATE
 const device_function_t GIDDY_RPE_KERNEL::get_device_function() const
 {
-	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel(), relative_with_finer_anchors_kernel() });
+	return device_function_t(base_kernel(), { sparse_kernel(), dense_kernel(), relative_with_finer_anchors_kernel() }, { long_segments_kernel() });
 }
 
 /// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")

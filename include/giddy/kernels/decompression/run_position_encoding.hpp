@@ -21,6 +21,8 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/decompression/run_expansion.hpp"
+#include "giddy/kernels/decompression/run_anchors.hpp"
+#include "giddy/kernels/decompression/run_length_encoding.hpp"   // (chunks_to_take, the long-segment kernels' constants)
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/util/math.hpp"
 
@@ -63,7 +65,8 @@ __device__ __forceinline__ void decompress(
 	uint64_t                                         position_period,
 	size_type_by_index_size<RunIndexSize>            num_anchors,
 	size_type_by_index_size<RunIndexSize>            num_element_runs,
-	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length,
+	const run_length_encoding::detail::chunks_to_take mine = run_length_encoding::detail::chunks_to_take())   // (decompress_long_segments: one workgroup's chunks, its anchors in LDS)
 {
 	static_assert(PositionsAreRelative || PositionOffsetSize >= UncompressedIndexSize,
 		"If run positions are in absolute values, their type must be able to cover the entire potential range of data");
@@ -94,7 +97,7 @@ __device__ __forceinline__ void decompress(
 	const uint64_t num_chunks = ((uint64_t) num_anchors + segments_per_chunk - 1) / segments_per_chunk;
 	// (4- and 8-byte elements only: narrow columns lose 2-4 points to it even with the output on a page boundary — 41-repetition A/B)
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
-	for (uint64_t c = my_first_chunk; c < num_chunks; c += num_waves) {
+	for (uint64_t c = mine.given ? mine.first : my_first_chunk; c < (mine.given ? mine.limit : num_chunks); c += mine.given ? mine.stride : num_waves) {
 		const uint64_t s = c * segments_per_chunk;
 		const uint64_t segment_start = s * L;
 		if (segment_start >= n) { break; }
@@ -106,12 +109,12 @@ __device__ __forceinline__ void decompress(
 			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
 			touched = touch(position_anchors + (ahead < (uint64_t) num_anchors ? ahead : s));
 		}
-		uint64_t first_run = position_anchors[s];
+		uint64_t first_run = position_anchors[s - mine.anchors_from];
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
-		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk] : num_runs - 1;
+		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk - mine.anchors_from] : num_runs - 1;
 		// lane j: the anchor of the chunk's j-th segment (past the chunk / the column: no run index reaches it)
 		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
-			? (uint64_t) position_anchors[s + lane] : ~(uint64_t) 0;
+			? (uint64_t) position_anchors[s + lane - mine.anchors_from] : ~(uint64_t) 0;
 
 		// groups of runs through LDS when the chunk has more runs than one batch and the arrays allow 16-byte loads
 		const uint64_t run_limit = last_candidate + 1;   // (exclusive: the runs this chunk may look at)
@@ -354,6 +357,60 @@ __global__ void decompress_relative_with_finer_anchors(
 {
 	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, true, RunIndexSize>(
 		decompressed, run_data, run_start_positions, finer_anchors, anchoring_period, position_period, num_anchors, num_element_runs, uncompressed_length);
+}
+
+/// LONG segments of sparse runs in ONE launch (round 4; run_length_encoding.hpp, decompress_long_segments): the workgroup that decodes (its share of) a segment first finds
+/// the run covering every `fine::sub`-th output of it — a binary search of the segment's run positions per finer anchor, a thread each — keeps those anchors in LDS and decodes
+/// the finer segments, a wavefront per finer segment in turn: no launch of the search by itself, no trip of the anchors through memory.
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
+__global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_segments(
+	uint_t<UncompressedSize>*          __restrict__  decompressed,
+	const uint_t<UncompressedSize>*    __restrict__  run_data,
+	const uint_t<PositionOffsetSize>*  __restrict__  run_start_positions,
+	const uint_t<RunIndexSize>*        __restrict__  position_anchors,
+	uint64_t                                         anchoring_period,
+	size_type_by_index_size<RunIndexSize>            num_anchors,
+	size_type_by_index_size<RunIndexSize>            num_element_runs,
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+{
+	namespace fine = run_expansion::fine;
+	using run_length_encoding::most_fines_per_long_segment;
+	using run_length_encoding::finer_segments_per_workgroup;
+	__shared__ uint_t<RunIndexSize> finer_anchors[most_fines_per_long_segment + 1];
+	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
+	const uint64_t per_segment = L / fine::sub;   // (the wrapper: a multiple, at most most_fines_per_long_segment)
+	const uint64_t num_fine = (n + fine::sub - 1) / fine::sub;
+	const unsigned working_waves = wave64::per_block() < run_expansion::max_waves_per_block ? wave64::per_block() : run_expansion::max_waves_per_block;
+	const uint64_t parts = (per_segment + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
+	for (uint64_t work = blockIdx.x; work < (uint64_t) num_anchors * parts; work += gridDim.x) {
+		const uint64_t s = work / parts, part = work - s * parts;
+		const uint64_t segment_outputs = (s + 1) * L <= n ? L : n - s * L;
+		const uint64_t fines = (segment_outputs + fine::sub - 1) / fine::sub;
+		for (uint64_t j = threadIdx.x; j < fines; j += blockDim.x) {   // (fine::anchors_by_search, for this segment)
+			uint64_t low = position_anchors[s];
+			if (j != 0) {
+				uint64_t high = s + 1 < (uint64_t) num_anchors ? (uint64_t) position_anchors[s + 1] : num_runs - 1;
+				if (PositionsAreRelative && high > low && run_start_positions[high] == 0) { high--; }
+				const uint64_t target = (PositionsAreRelative ? 0 : s * L) + j * fine::sub;
+				while (low < high) {
+					const uint64_t middle = low + (high - low + 1) / 2;
+					if ((uint64_t) run_start_positions[middle] <= target) { low = middle; } else { high = middle - 1; }
+				}
+			}
+			finer_anchors[j] = (uint_t<RunIndexSize>) low;
+		}
+		if (threadIdx.x == 0 && s + 1 < (uint64_t) num_anchors) { finer_anchors[per_segment] = position_anchors[s + 1]; }   // (where the last finer segment's candidates end)
+		__syncthreads();
+		run_length_encoding::detail::chunks_to_take mine;
+		const uint64_t part_first = s * per_segment + part * finer_segments_per_workgroup;
+		const uint64_t part_limit = part_first + finer_segments_per_workgroup < (s + 1) * per_segment ? part_first + finer_segments_per_workgroup : (s + 1) * per_segment;
+		mine.given = true; mine.first = part_first + wave64::index_in_block(); mine.stride = working_waves;
+		mine.limit = part_limit < num_fine ? part_limit : num_fine; mine.anchors_from = s * per_segment;
+		detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false>(
+			decompressed, run_data, run_start_positions, finer_anchors, (uint64_t) fine::sub, PositionsAreRelative ? L : (uint64_t) fine::sub,
+			(size_type_by_index_size<RunIndexSize>) num_fine, num_element_runs, uncompressed_length, mine);
+		__syncthreads();   // (the anchors in LDS are the next segment's after this)
+	}
 }
 
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize = UncompressedIndexSize>
