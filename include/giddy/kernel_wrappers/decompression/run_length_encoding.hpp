@@ -109,6 +109,45 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	if (dense) { launch_config.dynamic_shared_memory_size = 0; }
 	stream_scratch::lease scratch(stream);
 	const auto& environment = run_expansion::fine_environment::get();
+	// Segments that are not whole tiles of 4096 outputs (1000, 3000, 10 000, 50 000 ...): a wavefront's chunk of whole segments is then 15.6 or 31.2 KiB, not 16 or 32 —
+	// the chunk-size effect of DESIGN.md section 4 — and a tile is cut at every segment's end: 64-70 % of the HBM peak where whole tiles give 77-79.  Anchors are only entry
+	// points, so GROUPS of such segments — about 32 768 outputs each, whatever that is in segments — go through the long segments' one kernel: the workgroup finds the entry
+	// point of every 8192nd output of its group and decodes from there (kernels/decompression/run_length_encoding.hpp, decompress_long_segments).
+	// (instantiations without the groups-of-runs path — other than 4-byte elements — have one build only: whatever their mean run)
+	// — 8-byte elements: +2-3 points; 2-byte: 46 -> 58 % for segments of 3000 and 10 000, but 75 -> 58 for segments of 1000 (taken from 2048 outputs on); 1-byte: never (61 -> 31)
+	const bool one_kernel_build_applies = sparse || (!run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16
+		&& (UncompressedSize >= 4 || (UncompressedSize == 2 && L >= 2048)));
+	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && L > 0 && (L % run_expansion::tile_length != 0 || environment.group_all) && memory_access::is_aligned(run_lengths, 16)) {
+		// how many segments to a group: its finer segments (8192 outputs each, the last one what is left) are dealt to the workgroup's 4 wavefronts in turn, so a group
+		// of 4 full ones and 232 outputs more (33 segments of 1000) makes one wavefront work twice as long as the others — 59 % where 32 segments give 70: the number
+		// of segments, up to 16 finer segments' worth, that wastes the least of the wavefronts' turns
+		// ... and a whole number of 64-byte blocks of output: groups of 32 400 or 30 000 four-byte outputs run at 72 %, of 32 700 or 31 500 at 62 % (2^28 outputs, every
+		// segment length from 100 to 7000 tried fell on one side or the other by exactly this)
+		uint64_t unit = 64, rest = (L * UncompressedSize) % 64;
+		while (rest != 0) { const uint64_t t = unit % rest; unit = rest; rest = t; }   // gcd(64, bytes per segment)
+		const uint64_t multiple = 64 / unit;   // groups are multiples of this many segments
+		uint64_t per_group = multiple;
+		if (L * multiple <= fine::sub) { per_group = 4 * (uint64_t) fine::sub / (L * multiple) * multiple; }   // (as many as stay within 4 finer segments: the fourth is the one that is short)
+		else {
+			double best = 1e30;
+			for (uint64_t k = multiple; k * L <= 8 * (uint64_t) fine::sub || k == multiple; k += multiple) {   // (up to 8 finer segments: two turns)
+				const uint64_t pieces = util::div_rounding_up(k * L, (uint64_t) fine::sub);
+				const double turns = (double) (util::div_rounding_up(pieces, (uint64_t) 4) * 4), work = (double) (k * L) / (double) fine::sub;
+				if (turns / work < best - 1e-9) { best = turns / work; per_group = k; }
+			}
+		}
+		const uint64_t group_outputs = per_group * L, finer_per_group = util::div_rounding_up(group_outputs, (uint64_t) fine::sub);
+		const uint64_t groups = util::div_rounding_up((uint64_t) num_segments, per_group);
+		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) finer_segments_per_workgroup);
+		if (finer_per_group <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES && workgroups >= environment.fused_from && per_group <= 0xFFFFFFFFull
+			&& runs / groups <= fine::most_runs_per_segment_for_one_launch) {
+			cuda::enqueue_launch(long_segments_kernel(), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups, 1u << 20), fine::threads),
+				decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
+				segment_length, num_segments, num_element_runs, uncompressed_length, (uint32_t) per_group);
+			return;
+		}
+	}
 	if (n > 0 && runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && memory_access::is_aligned(run_lengths, 16) && n / runs >= environment.min_mean_run) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
 		const uint64_t tiles = util::div_rounding_up(runs, (uint64_t) fine::runs_per_tile), blocks = util::div_rounding_up(runs, (uint64_t) fine::runs_per_block);
@@ -130,12 +169,12 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// 2^30 outputs: 75.6 % against 79.0 %; with 4 and 8: 84.2 / 82.5 % against 78.2 / 78.8 %) —
 		const uint64_t workgroups_of_one_kernel = segments * util::div_rounding_up(L / fine::sub, (uint64_t) finer_segments_per_workgroup);
 		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES
-			&& workgroups_of_one_kernel >= (uint64_t) GIDDY_RUN_FUSED_FROM_SEGMENTS && runs / segments <= fine::most_runs_per_segment_for_one_launch;
+			&& workgroups_of_one_kernel >= environment.fused_from && runs / segments <= fine::most_runs_per_segment_for_one_launch;
 		if (fused || (one_launch && environment.force_one_launch && environment.fused && sparse && L / fine::sub <= most_fines_per_long_segment)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
 				decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
-				segment_length, num_segments, num_element_runs, uncompressed_length);
+				segment_length, num_segments, num_element_runs, uncompressed_length, (uint32_t) 1);
 			return;
 		}
 		const size_t sums_bytes = one_launch ? 0 : (tiles + blocks) * sizeof(uint64_t);

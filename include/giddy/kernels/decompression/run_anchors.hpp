@@ -56,6 +56,8 @@ struct fine_environment {
 	bool force_one_launch = false;   // GIDDY_RUN_FINE_ONE_LAUNCH=2: ... by the one-launch pre-pass
 	uint64_t min_mean_run = 0;
 	bool fused = true;               // GIDDY_RUN_FUSED_PREPASS=0: the one-launch pre-pass stays a launch of its own (run lengths)
+	uint64_t fused_from = GIDDY_RUN_FUSED_FROM_SEGMENTS;   // GIDDY_RUN_FUSED_FROM=n: the one-kernel builds from n workgroups on (tests: 1)
+	bool group_all = false;          // GIDDY_RUN_GROUP_ALL=1 (measurements): groups of segments through the long segments' kernel for whole-tile segment lengths too
 	static const fine_environment& get()
 	{
 		static const fine_environment e = [] {
@@ -64,6 +66,8 @@ struct fine_environment {
 			if (const char* v = std::getenv("GIDDY_RUN_FINE_MIN_MEAN_RUN")) { read.min_mean_run = std::strtoull(v, nullptr, 10); }
 			if (const char* v = std::getenv("GIDDY_RUN_FINE_FORCE")) { read.force = v[0] == '1'; }
 			if (const char* v = std::getenv("GIDDY_RUN_FUSED_PREPASS")) { read.fused = v[0] != '0'; }
+			if (const char* v = std::getenv("GIDDY_RUN_GROUP_ALL")) { read.group_all = v[0] == '1'; }
+			if (const char* v = std::getenv("GIDDY_RUN_FUSED_FROM")) { read.fused_from = std::strtoull(v, nullptr, 10); }
 			return read;
 		}();
 		return e;
@@ -272,7 +276,8 @@ __device__ __forceinline__ void finer_anchors_of_one_segment(
 	const uint_t<RunLengthSize>*  __restrict__  run_lengths,
 	const uint_t<RunIndexSize>*   __restrict__  position_anchors,
 	const uint_t<RunLengthSize>*  __restrict__  intra_run_anchor_offsets,
-	uint64_t s, uint64_t segment_length, uint64_t num_segments, uint64_t num_runs, uint64_t length)
+	uint64_t s, uint64_t segment_length, uint64_t num_segments, uint64_t num_runs, uint64_t length,
+	uint64_t anchor_stride = 1)   // (decompress_long_segments on GROUPS of segments: "segment" s is the caller's segments s * stride ..., its anchor their first's)
 {
 	using storage_type = segment_scan_storage<RunLengthSize>;
 	constexpr unsigned per_lane = storage_type::per_lane, runs_per_chunk = storage_type::runs_per_chunk, waves = storage_type::waves;
@@ -292,8 +297,8 @@ __device__ __forceinline__ void finer_anchors_of_one_segment(
 		return lengths;
 	};
 
-	const uint64_t anchor = position_anchors[s], offset = intra_run_anchor_offsets[s];
-	const uint64_t last_run = s + 1 < num_segments ? (uint64_t) position_anchors[s + 1] : num_runs - 1;   // the last run the segment can touch
+	const uint64_t anchor = position_anchors[s * anchor_stride], offset = intra_run_anchor_offsets[s * anchor_stride];
+	const uint64_t last_run = s + 1 < num_segments ? (uint64_t) position_anchors[(s + 1) * anchor_stride] : num_runs - 1;   // the last run the segment can touch
 	const uint64_t segment_outputs = (s + 1) * segment_length <= length ? segment_length : length - s * segment_length;
 	const uint64_t fines = (segment_outputs + sub - 1) / sub;   // finer anchors of this segment; number 0 is the segment's own
 	if (threadIdx.x == 0) { anchors_out[0] = (uint_t<RunIndexSize>) anchor; offsets_out[0] = (uint_t<RunLengthSize>) offset; }

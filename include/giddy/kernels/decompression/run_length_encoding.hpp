@@ -52,7 +52,9 @@ namespace detail {
 
 /// Which chunks a wavefront takes: those of the whole grid at grid stride (`given` false) — or (decompress_long_segments) `first`, `first + stride`, ... below
 /// `limit`, with the anchor arrays beginning at chunk `anchors_from` (they hold one workgroup's segment's finer anchors, in LDS)
-struct chunks_to_take { bool given = false; uint64_t first = 0, stride = 1, limit = 0, anchors_from = 0; };
+/// — and, when the chunks are pieces of a GROUP of the column's segments (any number of outputs, beginning anywhere), chunk `anchors_from` begins at output
+/// `outputs_from` and the group ends before `outputs_until`
+struct chunks_to_take { bool given = false; uint64_t first = 0, stride = 1, limit = 0, anchors_from = 0, outputs_from = 0, outputs_until = ~(uint64_t) 0; };
 
 /// The kernel's body.  `WithGroups`: with the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — without it the kernel
 /// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity
@@ -104,10 +106,11 @@ __device__ __forceinline__ void decompress(
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
 	for (uint64_t c = mine.given ? mine.first : my_first_chunk; c < (mine.given ? mine.limit : num_chunks); c += mine.given ? mine.stride : num_waves) {
 		const uint64_t s = c * segments_per_chunk;
-		const uint64_t segment_start = s * L;
+		const uint64_t segment_start = mine.given ? mine.outputs_from + (s - mine.anchors_from) * L : s * L;
 		if (segment_start >= n) { break; }
 		const uint64_t chunk_outputs = segments_per_chunk * L;
-		const uint64_t segment_end = (segment_start + chunk_outputs < n) ? segment_start + chunk_outputs : n;
+		const uint64_t column_or_group_end = n < mine.outputs_until ? n : mine.outputs_until;
+		const uint64_t segment_end = (segment_start + chunk_outputs < column_or_group_end) ? segment_start + chunk_outputs : column_or_group_end;
 		// (the anchor of the chunk some thousand wavefronts ahead, into this XCD's L2: GIDDY_RUN_TOUCH_ANCHORS_AHEAD)
 		uint32_t touched = 0;
 		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
@@ -353,35 +356,46 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 	size_type_by_index_size<UncompressedIndexSize>      segment_length,
 	size_type_by_index_size<UncompressedIndexSize>      num_segments,
 	size_type_by_index_size<RunIndexSize>               num_element_runs,
-	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length)
+	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length,
+	uint32_t                                            segments_per_group)   // >= 1: a workgroup's unit is this many consecutive segments, entered at the first one's anchor
 {
 	namespace fine = run_expansion::fine;
 	__shared__ fine::segment_scan_storage<RunLengthSize> storage;
 	__shared__ uint_t<RunIndexSize> finer_anchors[most_fines_per_long_segment + 1];
 	__shared__ uint_t<RunLengthSize> finer_offsets[most_fines_per_long_segment + 1];
-	const uint64_t L = segment_length, n = total_uncompressed_length;
-	const uint64_t per_segment = L / fine::sub;   // (the wrapper: a multiple, at most most_fines_per_long_segment)
-	const uint64_t num_fine = (n + fine::sub - 1) / fine::sub;
+	const uint64_t n = total_uncompressed_length;
+	// Anchors are only entry points — the runs of consecutive segments are consecutive — so a GROUP of segments decodes like one segment of as many outputs, of any
+	// length and beginning anywhere: its finer anchors are counted from ITS first output (the last finer segment is as long as what is left of the group).
+	const uint64_t group_outputs = (uint64_t) segment_length * segments_per_group;
+	const uint64_t num_groups = ((uint64_t) num_segments + segments_per_group - 1) / segments_per_group;
+	const uint64_t per_group = (group_outputs + fine::sub - 1) / fine::sub;   // (the wrapper: at most most_fines_per_long_segment)
 	const unsigned working_waves = wave64::per_block() < run_expansion::max_waves_per_block ? wave64::per_block() : run_expansion::max_waves_per_block;
 	// A workgroup decodes at most `finer_segments_per_workgroup` finer segments (two per wavefront: with four — segments of 131 072 — the separate launches were the
-	// faster ones): a longer segment is shared by several workgroups, each of which scans the segment's run lengths for itself (2 bytes per run: kilobytes)
-	const uint64_t parts = (per_segment + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
-	for (uint64_t work = blockIdx.x; work < (uint64_t) num_segments * parts; work += gridDim.x) {
-		const uint64_t s = work / parts, part = work - s * parts;
+	// faster ones): a longer group is shared by several workgroups, each of which scans the group's run lengths for itself (2 bytes per run: kilobytes)
+	const uint64_t parts = (per_group + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
+	for (uint64_t work = blockIdx.x; work < num_groups * parts; work += gridDim.x) {
+		const uint64_t g = work / parts, part = work - g * parts;
+		const uint64_t group_begin = g * group_outputs, group_end = group_begin + group_outputs < n ? group_begin + group_outputs : n;
+		const uint64_t fines = (group_end - group_begin + fine::sub - 1) / fine::sub;
 		fine::finer_anchors_of_one_segment<RunLengthSize, RunIndexSize>(finer_anchors, finer_offsets, storage,
-			run_lengths, segment_position_anchors, segment_position_anchor_intra_run_offsets, s, L, num_segments, num_element_runs, n);
-		// (the entry after the segment's last: the next segment's own anchor — where the last finer segment's runs end)
-		if (threadIdx.x == 0 && s + 1 < num_segments) { finer_anchors[per_segment] = segment_position_anchors[s + 1]; finer_offsets[per_segment] = segment_position_anchor_intra_run_offsets[s + 1]; }
+			run_lengths, segment_position_anchors, segment_position_anchor_intra_run_offsets, g, group_outputs, num_groups, num_element_runs, n, segments_per_group);
+		// (the entry after the group's last: the next group's own anchor — where the last finer segment's runs end)
+		const bool has_next = g + 1 < num_groups;
+		if (threadIdx.x == 0 && has_next) {
+			finer_anchors[fines] = segment_position_anchors[(g + 1) * segments_per_group]; finer_offsets[fines] = segment_position_anchor_intra_run_offsets[(g + 1) * segments_per_group];
+		}
 		__syncthreads();
 		detail::chunks_to_take mine;
-		const uint64_t part_first = s * per_segment + part * finer_segments_per_workgroup;
-		const uint64_t part_limit = part_first + finer_segments_per_workgroup < (s + 1) * per_segment ? part_first + finer_segments_per_workgroup : (s + 1) * per_segment;
-		mine.given = true; mine.first = part_first + wave64::index_in_block(); mine.stride = working_waves;
-		mine.limit = part_limit < num_fine ? part_limit : num_fine; mine.anchors_from = s * per_segment;
+		const uint64_t numbering_from = g * per_group;   // (the finer segments' numbers only have to be this workgroup's own)
+		const uint64_t part_first = part * finer_segments_per_workgroup;
+		const uint64_t part_limit = part_first + finer_segments_per_workgroup < fines ? part_first + finer_segments_per_workgroup : fines;
+		mine.given = true; mine.first = numbering_from + part_first + wave64::index_in_block(); mine.stride = working_waves; mine.limit = numbering_from + part_limit;
+		mine.anchors_from = numbering_from; mine.outputs_from = group_begin; mine.outputs_until = group_end;
 		detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
-			finer_anchors, finer_offsets, (size_type_by_index_size<UncompressedIndexSize>) fine::sub, (size_type_by_index_size<UncompressedIndexSize>) num_fine,
+			finer_anchors, finer_offsets, (size_type_by_index_size<UncompressedIndexSize>) fine::sub,
+			(size_type_by_index_size<UncompressedIndexSize>) (numbering_from + fines + (has_next ? 1 : 0)),   // (as far as the anchors in LDS go)
 			num_element_runs, total_uncompressed_length, mine);
-		__syncthreads();   // (the anchors in LDS are the next segment's after this)
+		__syncthreads();   // (the anchors in LDS are the next group's after this)
 	}
 }
 

@@ -182,7 +182,7 @@ def test_rle(index_size, usize, lsize, run_index_size):
         col = col.astype(np.uint64).astype(ud)
         n = len(col)
         # (the short ones: several segments per wavefront trip; 16384 and up: finer anchors first — kernels/decompression/run_anchors.hpp)
-        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20):
+        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20, 1000, 3000, 50000, 7):
             f = formats.run_length_encoding(col, seglen, "u%d" % lsize, run_index_size)
             expect = oracle.run_length_encoding(f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], seglen, n)
             assert (expect == col).all()
@@ -197,8 +197,9 @@ def test_rle(index_size, usize, lsize, run_index_size):
 
 
 @pytest.mark.parametrize("switches", [{"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1"}, {"GIDDY_RUN_FINE_ONE_LAUNCH": "0", "GIDDY_RUN_FINE_FORCE": "1"},
-                                      {"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1", "GIDDY_RUN_FUSED_PREPASS": "0"}],
-                         ids=["pre_pass_and_decoder_in_one_kernel", "three_launch_pre_pass", "one_launch_pre_pass"])
+                                      {"GIDDY_RUN_FINE_ONE_LAUNCH": "2", "GIDDY_RUN_FINE_FORCE": "1", "GIDDY_RUN_FUSED_PREPASS": "0"},
+                                      {"GIDDY_RUN_FUSED_FROM": "1", "GIDDY_RUN_GROUP_ALL": "1"}],
+                         ids=["pre_pass_and_decoder_in_one_kernel", "three_launch_pre_pass", "one_launch_pre_pass", "groups_of_segments_in_one_kernel"])
 def test_rle_with_each_pre_pass_forced(switches):
     """The wrapper picks the pre-pass that finds finer anchors for long segments by the column's shape (one launch: a workgroup per segment;
     three launches: sums, scan, search).  Here every run-length registration decodes every column of test_rle with EACH of them forced for
