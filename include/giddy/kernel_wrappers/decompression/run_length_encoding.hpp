@@ -118,24 +118,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	const bool one_kernel_build_applies = sparse || (!run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16
 		&& (UncompressedSize >= 4 || (UncompressedSize == 2 && L >= 2048)));
 	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && L > 0 && (L % run_expansion::tile_length != 0 || environment.group_all) && memory_access::is_aligned(run_lengths, 16)) {
-		// how many segments to a group: its finer segments (8192 outputs each, the last one what is left) are dealt to the workgroup's 4 wavefronts in turn, so a group
-		// of 4 full ones and 232 outputs more (33 segments of 1000) makes one wavefront work twice as long as the others — 59 % where 32 segments give 70: the number
-		// of segments, up to 16 finer segments' worth, that wastes the least of the wavefronts' turns
-		// ... and a whole number of 64-byte blocks of output: groups of 32 400 or 30 000 four-byte outputs run at 72 %, of 32 700 or 31 500 at 62 % (2^28 outputs, every
-		// segment length from 100 to 7000 tried fell on one side or the other by exactly this)
-		uint64_t unit = 64, rest = (L * UncompressedSize) % 64;
-		while (rest != 0) { const uint64_t t = unit % rest; unit = rest; rest = t; }   // gcd(64, bytes per segment)
-		const uint64_t multiple = 64 / unit;   // groups are multiples of this many segments
-		uint64_t per_group = multiple;
-		if (L * multiple <= fine::sub) { per_group = 4 * (uint64_t) fine::sub / (L * multiple) * multiple; }   // (as many as stay within 4 finer segments: the fourth is the one that is short)
-		else {
-			double best = 1e30;
-			for (uint64_t k = multiple; k * L <= 8 * (uint64_t) fine::sub || k == multiple; k += multiple) {   // (up to 8 finer segments: two turns)
-				const uint64_t pieces = util::div_rounding_up(k * L, (uint64_t) fine::sub);
-				const double turns = (double) (util::div_rounding_up(pieces, (uint64_t) 4) * 4), work = (double) (k * L) / (double) fine::sub;
-				if (turns / work < best - 1e-9) { best = turns / work; per_group = k; }
-			}
-		}
+		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);   // (run_anchors.hpp)
 		const uint64_t group_outputs = per_group * L, finer_per_group = util::div_rounding_up(group_outputs, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_segments, per_group);
 		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) finer_segments_per_workgroup);

@@ -110,6 +110,21 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	stream_scratch::lease scratch(stream);
+	// ABSOLUTE positions at segment lengths that are not whole tiles of 4096 outputs: groups of segments through the long segments' one kernel, as for run lengths
+	// (kernel_wrappers/decompression/run_length_encoding.hpp; relative positions count from their own segment's start: not for them)
+	if (!PositionsAreRelative && run_expansion::fine_environment::get().fused && sparse && UncompressedSize >= 4 && n > 0 && num_element_runs > 0 && L > 0
+		&& (L % run_expansion::tile_length != 0 || run_expansion::fine_environment::get().group_all)) {
+		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);
+		const uint64_t finer_per_group = util::div_rounding_up(per_group * L, (uint64_t) fine::sub);
+		const uint64_t groups = util::div_rounding_up((uint64_t) num_anchors, per_group);
+		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
+		if (finer_per_group <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES && workgroups >= run_expansion::fine_environment::get().fused_from && per_group <= 0xFFFFFFFFull) {
+			cuda::enqueue_launch(long_segments_kernel(), stream,
+				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups, 1u << 20), fine::threads),
+				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length, (uint32_t) per_group);
+			return;
+		}
+	}
 	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
 		// ... in ONE kernel where segments are of 4 finer ones and there are enough of them for 2048 workgroups (kernels/decompression/run_position_encoding.hpp,
@@ -120,7 +135,7 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 			&& workgroups_of_one_kernel >= run_expansion::fine_environment::get().fused_from) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
-				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length);
+				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length, (uint32_t) 1);
 			return;
 		}
 		if (num_fine <= std::numeric_limits<run_index_size_type>::max() && scratch.take(num_fine * sizeof(run_index_type))) {

@@ -84,6 +84,27 @@ inline uint64_t finer_anchors_from()
 	return from;
 }
 
+/// How many segments of `segment_length` outputs (of `element_size` bytes) make a GROUP for the long segments' one-kernel builds (run_length_encoding.hpp,
+/// run_position_encoding.hpp: decompress_long_segments) — about 4 finer segments of `sub` outputs.  Two things decide whether a group size is fast (2^28 outputs,
+/// every segment length from 100 to 30 000 tried): a whole number of 64-byte blocks of output (62 % of the HBM peak otherwise, against 72), and finer segments —
+/// the last one what is left of the group — that the workgroup's four wavefronts share evenly (33 segments of 1000 — four finer segments and 232 outputs: 59 %).
+inline uint64_t segments_per_group_for(uint64_t segment_length, unsigned element_size, uint64_t sub)
+{
+	const uint64_t L = segment_length;
+	uint64_t unit = 64, rest = (L * element_size) % 64;
+	while (rest != 0) { const uint64_t t = unit % rest; unit = rest; rest = t; }   // gcd(64, bytes per segment)
+	const uint64_t multiple = 64 / unit;   // groups are multiples of this many segments
+	if (L * multiple <= sub) { return 4 * sub / (L * multiple) * multiple; }   // (as many as stay within 4 finer segments: the fourth is the one that is short)
+	uint64_t per_group = multiple;
+	double best = 1e30;
+	for (uint64_t k = multiple; k * L <= 8 * sub || k == multiple; k += multiple) {   // (up to 8 finer segments: two turns)
+		const uint64_t pieces = (k * L + sub - 1) / sub;
+		const double turns = (double) ((pieces + 3) / 4 * 4), work = (double) (k * L) / (double) sub;
+		if (turns / work < best - 1e-9) { best = turns / work; per_group = k; }
+	}
+	return per_group;
+}
+
 namespace fine {
 
 enum : unsigned {

@@ -99,9 +99,10 @@ __device__ __forceinline__ void decompress(
 	const uint64_t my_first_chunk = UncompressedSize >= 4 ? first_chunk_by_address(decompressed, segments_per_chunk * L * UncompressedSize, working_waves, wave, num_waves) : wave;
 	for (uint64_t c = mine.given ? mine.first : my_first_chunk; c < (mine.given ? mine.limit : num_chunks); c += mine.given ? mine.stride : num_waves) {
 		const uint64_t s = c * segments_per_chunk;
-		const uint64_t segment_start = s * L;
+		const uint64_t segment_start = mine.given ? mine.outputs_from + (s - mine.anchors_from) * L : s * L;
 		if (segment_start >= n) { break; }
-		const uint64_t nominal_end = segment_start + segments_per_chunk * L;   // where the first segment after this chunk starts
+		// where the first segment after this chunk starts (a GROUP of segments' last finer segment — decompress_long_segments — ends with the group)
+		const uint64_t nominal_end = segment_start + segments_per_chunk * L < mine.outputs_until ? segment_start + segments_per_chunk * L : mine.outputs_until;
 		const uint64_t segment_end = nominal_end < n ? nominal_end : n;
 		const uint64_t positions_origin = position_period == L ? segment_start : segment_start / position_period * position_period;
 		uint32_t touched = 0;   // (GIDDY_RUN_TOUCH_ANCHORS_AHEAD: run_length_encoding.hpp)
@@ -371,27 +372,30 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 	uint64_t                                         anchoring_period,
 	size_type_by_index_size<RunIndexSize>            num_anchors,
 	size_type_by_index_size<RunIndexSize>            num_element_runs,
-	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length)
+	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length,
+	uint32_t                                         segments_per_group)   // >= 1 (absolute positions; relative ones count from their own segment's start: 1)
 {
 	namespace fine = run_expansion::fine;
 	using run_length_encoding::most_fines_per_long_segment;
 	using run_length_encoding::finer_segments_per_workgroup;
 	__shared__ uint_t<RunIndexSize> finer_anchors[most_fines_per_long_segment + 1];
-	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
-	const uint64_t per_segment = L / fine::sub;   // (the wrapper: a multiple, at most most_fines_per_long_segment)
-	const uint64_t num_fine = (n + fine::sub - 1) / fine::sub;
+	const uint64_t n = uncompressed_length, num_runs = num_element_runs;
+	const uint64_t group_outputs = anchoring_period * segments_per_group;   // (a group of segments decodes like one segment of as many outputs: run_length_encoding.hpp)
+	const uint64_t num_groups = ((uint64_t) num_anchors + segments_per_group - 1) / segments_per_group;
+	const uint64_t per_group = (group_outputs + fine::sub - 1) / fine::sub;   // (the wrapper: at most most_fines_per_long_segment)
 	const unsigned working_waves = wave64::per_block() < run_expansion::max_waves_per_block ? wave64::per_block() : run_expansion::max_waves_per_block;
-	const uint64_t parts = (per_segment + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
-	for (uint64_t work = blockIdx.x; work < (uint64_t) num_anchors * parts; work += gridDim.x) {
-		const uint64_t s = work / parts, part = work - s * parts;
-		const uint64_t segment_outputs = (s + 1) * L <= n ? L : n - s * L;
-		const uint64_t fines = (segment_outputs + fine::sub - 1) / fine::sub;
-		for (uint64_t j = threadIdx.x; j < fines; j += blockDim.x) {   // (fine::anchors_by_search, for this segment)
-			uint64_t low = position_anchors[s];
+	const uint64_t parts = (per_group + finer_segments_per_workgroup - 1) / finer_segments_per_workgroup;
+	for (uint64_t work = blockIdx.x; work < num_groups * parts; work += gridDim.x) {
+		const uint64_t g = work / parts, part = work - g * parts;
+		const uint64_t group_begin = g * group_outputs, group_end = group_begin + group_outputs < n ? group_begin + group_outputs : n;
+		const uint64_t fines = (group_end - group_begin + fine::sub - 1) / fine::sub;
+		const bool has_next = g + 1 < num_groups;
+		for (uint64_t j = threadIdx.x; j < fines; j += blockDim.x) {   // (fine::anchors_by_search, for this group)
+			uint64_t low = position_anchors[g * segments_per_group];
 			if (j != 0) {
-				uint64_t high = s + 1 < (uint64_t) num_anchors ? (uint64_t) position_anchors[s + 1] : num_runs - 1;
+				uint64_t high = has_next ? (uint64_t) position_anchors[(g + 1) * segments_per_group] : num_runs - 1;
 				if (PositionsAreRelative && high > low && run_start_positions[high] == 0) { high--; }
-				const uint64_t target = (PositionsAreRelative ? 0 : s * L) + j * fine::sub;
+				const uint64_t target = (PositionsAreRelative ? 0 : group_begin) + j * fine::sub;
 				while (low < high) {
 					const uint64_t middle = low + (high - low + 1) / 2;
 					if ((uint64_t) run_start_positions[middle] <= target) { low = middle; } else { high = middle - 1; }
@@ -399,17 +403,18 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 			}
 			finer_anchors[j] = (uint_t<RunIndexSize>) low;
 		}
-		if (threadIdx.x == 0 && s + 1 < (uint64_t) num_anchors) { finer_anchors[per_segment] = position_anchors[s + 1]; }   // (where the last finer segment's candidates end)
+		if (threadIdx.x == 0 && has_next) { finer_anchors[fines] = position_anchors[(g + 1) * segments_per_group]; }   // (where the last finer segment's candidates end)
 		__syncthreads();
 		run_length_encoding::detail::chunks_to_take mine;
-		const uint64_t part_first = s * per_segment + part * finer_segments_per_workgroup;
-		const uint64_t part_limit = part_first + finer_segments_per_workgroup < (s + 1) * per_segment ? part_first + finer_segments_per_workgroup : (s + 1) * per_segment;
-		mine.given = true; mine.first = part_first + wave64::index_in_block(); mine.stride = working_waves;
-		mine.limit = part_limit < num_fine ? part_limit : num_fine; mine.anchors_from = s * per_segment;
+		const uint64_t numbering_from = g * per_group;
+		const uint64_t part_first = part * finer_segments_per_workgroup;
+		const uint64_t part_limit = part_first + finer_segments_per_workgroup < fines ? part_first + finer_segments_per_workgroup : fines;
+		mine.given = true; mine.first = numbering_from + part_first + wave64::index_in_block(); mine.stride = working_waves; mine.limit = numbering_from + part_limit;
+		mine.anchors_from = numbering_from; mine.outputs_from = group_begin; mine.outputs_until = group_end;
 		detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false>(
-			decompressed, run_data, run_start_positions, finer_anchors, (uint64_t) fine::sub, PositionsAreRelative ? L : (uint64_t) fine::sub,
-			(size_type_by_index_size<RunIndexSize>) num_fine, num_element_runs, uncompressed_length, mine);
-		__syncthreads();   // (the anchors in LDS are the next segment's after this)
+			decompressed, run_data, run_start_positions, finer_anchors, (uint64_t) fine::sub, PositionsAreRelative ? anchoring_period : (uint64_t) fine::sub,
+			(size_type_by_index_size<RunIndexSize>) (numbering_from + fines + (has_next ? 1 : 0)), num_element_runs, uncompressed_length, mine);
+		__syncthreads();   // (the anchors in LDS are the next group's after this)
 	}
 }
 

@@ -226,7 +226,7 @@ def test_rpe(index_size, usize, psize, relative):
         col = col.astype(np.uint64).astype(ud)
         n = len(col)
         # (the short ones: several segments per wavefront trip; 16384 and up: finer anchors first — kernels/decompression/run_anchors.hpp)
-        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20):
+        for seglen in (1024, 4096, 100, 20000, 65536, 64, 128, 512, 16384, 1 << 20, 1000, 3000, 50000, 7):
             if relative and seglen > 1 << (8 * psize): continue   # (relative positions must fit their type)
             f = formats.run_position_encoding(col, seglen, "u%d" % psize, relative, index_size)
             expect = oracle.run_position_encoding(f["run_data"], f["run_start_positions"], f["position_anchors"], seglen, n, relative)
@@ -238,6 +238,19 @@ def test_rpe(index_size, usize, psize, relative):
             got = g.host(out, ud, n)
             bad = np.flatnonzero(got != col)
             assert len(bad) == 0, (name, seglen, bad[:5], got[bad[:5]], col[bad[:5]])
+
+
+def test_rpe_with_the_one_kernel_builds_forced():
+    """every run-position registration decodes every column of test_rpe with the long segments' one-kernel build — and, absolute positions, groups of segments through
+    it — taken wherever the shape admits it, however few workgroups that makes (the switches are read once per process: a child interpreter)"""
+    import os
+    import subprocess
+    import sys
+    environment = dict(os.environ, GIDDY_RUN_FUSED_FROM="1", GIDDY_RUN_GROUP_ALL="1")
+    result = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "test_rpe and not forced", "-p", "no:cacheprovider"],
+                            capture_output=True, text=True, env=environment, timeout=1500)
+    assert result.returncode == 0, result.stdout[-3000:] + result.stderr[-2000:]
+    assert "10 passed" in result.stdout, result.stdout[-500:]
 
 
 @pytest.mark.parametrize("osize", [4, 8])
