@@ -180,6 +180,22 @@ struct value_staging {
 		dense_granule = 128 / ElementSize };   // a tile that is cut short ends on a multiple of this many outputs
 };
 
+/// A wavefront's chunk of `count` whole segments had better be a whole number of 64-byte blocks of output (round 4, run lengths in 4-byte elements at 2^28 outputs:
+/// chunks of 40 segments of 100, 4 of 900 or 2 of 2000 — 14 400 or 16 000 bytes — 70 % of the HBM peak; of 13 segments of 300, 5 of 700 or 3 of 1100 — 15 600,
+/// 14 000, 13 200 bytes — 65-66 %): `count` rounded down to the multiple that makes it so, where there is one (kernel and launch parameters agree; rounding UP to the first multiple, within
+/// two tiles, gained 2 points at 1100 and 1500 and broke the relative positions' search over a chunk's anchors: not kept).
+#ifndef GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS
+#define GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS 1
+#endif
+__host__ __device__ inline uint64_t whole_64_byte_blocks(uint64_t count, uint64_t segment_length, unsigned element_size)
+{
+	if (!GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS || count <= 1) { return count; }
+	uint64_t unit = 64, rest = (segment_length * element_size) % 64;
+	while (rest != 0) { const uint64_t t = unit % rest; unit = rest; rest = t; }   // gcd(64, bytes per segment)
+	const uint64_t multiple = 64 / unit;
+	return count >= multiple ? count / multiple * multiple : count;
+}
+
 /// Groups of runs (run_length_encoding.hpp, run_position_encoding.hpp): for chunks of many runs the descriptors and values of up to
 /// `group_runs` consecutive runs are brought into LDS by three coalesced 16-byte-per-lane loads, and the chunk's tiles are decoded
 /// from there.  4-byte values with 1-2-byte descriptors (the value area of value_staging holds 512 of them; a group begins on a

@@ -43,7 +43,8 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 	}
 	// (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile — 52 -> 66 % at 3000)
 	uint64_t fit = run_expansion::tile_length / segment_length;
-	return fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST ? GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST : fit;
+	fit = fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST ? GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST : fit;
+	return run_expansion::whole_64_byte_blocks(fit, segment_length, element_size);
 }
 
 } // namespace detail

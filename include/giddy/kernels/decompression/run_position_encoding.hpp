@@ -44,7 +44,8 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 	}
 	uint64_t fit = run_expansion::tile_length / segment_length;
 	if (fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST) { fit = GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST; }   // (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile)
-	return (positions_are_relative && fit > 32) ? 32 : fit;
+	fit = (positions_are_relative && fit > 32) ? 32 : fit;
+	return run_expansion::whole_64_byte_blocks(fit, segment_length, element_size);
 }
 
 } // namespace detail
