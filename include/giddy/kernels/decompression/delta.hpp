@@ -203,6 +203,9 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_se
 /// (partial cache lines at both ends of every row) and its input loads are 2-8 bytes per lane — 46-68 % of the HBM peak at segments of 5000
 /// and 10000 elements where the wave paths for ragged segments (rows by the output's cache lines, input through LDS) reach 58-74 %.  For
 /// 2- and 4-byte elements the workgroup path is the faster one (78-89 %), and for 2-byte deltas of 64-bit elements too (68 % against 64-67).
+#ifndef GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS
+#define GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS 1
+#endif
 #ifndef GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS
 #define GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS 8192   // 0: never
 #endif
@@ -210,7 +213,13 @@ template <unsigned UncompressedSize, unsigned CompressedSize>
 __host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
-	if ((L + traits::row - 1) / traits::row <= rows_per_chunk) { return true; }
+	const uint64_t rows = (L + traits::row - 1) / traits::row;
+	// (whole-row segments of 4-byte elements from 1-byte deltas, 28-32 rows — and of 2-byte elements, 16-32 rows —: a workgroup each, its wavefronts 8 rows apiece; measured at
+	// 2^28 elements, segments of 7168 / 8192: <4,4,1> 81 / 83 -> 89 %, with patches 76 / 78 -> 78 / 87 % (25 rows: 73 -> 67 with patches: not from there); <4,2,1> at 8192: 81 -> 86 %;
+	// ragged segments of that many rows, 2-byte deltas and 64-bit elements lose 3-25 points to it)
+	if (GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS && L % traits::row == 0 && CompressedSize == 1 && rows <= rows_per_chunk
+		&& ((UncompressedSize == 4 && rows >= 28) || (UncompressedSize == 2 && rows >= 16))) { return false; }
+	if (rows <= rows_per_chunk) { return true; }
 	return GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS != 0 && UncompressedSize == 8 && CompressedSize != 2 && L % traits::row != 0
 		&& n / GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS >= L;
 }
