@@ -203,8 +203,20 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_se
 /// (partial cache lines at both ends of every row) and its input loads are 2-8 bytes per lane — 46-68 % of the HBM peak at segments of 5000
 /// and 10000 elements where the wave paths for ragged segments (rows by the output's cache lines, input through LDS) reach 58-74 %.  For
 /// 2- and 4-byte elements the workgroup path is the faster one (78-89 %), and for 2-byte deltas of 64-bit elements too (68 % against 64-67).
+#ifndef GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS
+#define GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS 0
+#endif
+#ifndef GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS
+#define GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS 1
+#endif
+#ifndef GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1
+#define GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1 8   // (28 before a workgroup took several short segments: block_per_segment)
+#endif
+#ifndef GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1
+#define GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1 8
+#endif
 #ifndef GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS
-#define GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS 1
+#define GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS 0   // (see takes_wave_path: what it gains at 2^28 elements is the Infinity Cache's; at 2^30 it loses 5-6 points)
 #endif
 #ifndef GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS
 #define GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS 8192   // 0: never
@@ -214,11 +226,13 @@ __host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	const uint64_t rows = (L + traits::row - 1) / traits::row;
-	// (whole-row segments of 4-byte elements from 1-byte deltas, 28-32 rows — and of 2-byte elements, 16-32 rows —: a workgroup each, its wavefronts 8 rows apiece; measured at
-	// 2^28 elements, segments of 7168 / 8192: <4,4,1> 81 / 83 -> 89 %, with patches 76 / 78 -> 78 / 87 % (25 rows: 73 -> 67 with patches: not from there); <4,2,1> at 8192: 81 -> 86 %;
-	// ragged segments of that many rows, 2-byte deltas and 64-bit elements lose 3-25 points to it)
+	// (Round 4, measured and NOT adopted: whole-row segments of 8-32 rows of 4- and 2-byte elements from 1-byte deltas by WORKGROUPS of four wavefronts, 8 rows apiece, all
+	// eight in flight — a segment of 8 or 16 rows sharing its workgroup with three or one more (block_per_segment).  At 2^28 elements: <4,4,1> at segments of 2048 / 4096 /
+	// 8192: 82 / 82 / 83 -> 89 % of the HBM peak, <4,2,1>: 82 -> 86 %.  At 2^30: 73 / 73 / 71 % against 73 / 78 / 77 % — the 2^28 column's 256 MiB of deltas sit in the
+	// Infinity Cache between repetitions, and the workgroup shape profits from that more than it costs; read from HBM it is the slower one.)
+	if (GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS != 0 && L % traits::row == 0 && rows >= GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS && rows <= rows_per_chunk) { return false; }   // (measurements)
 	if (GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS && L % traits::row == 0 && CompressedSize == 1 && rows <= rows_per_chunk
-		&& ((UncompressedSize == 4 && rows >= 28) || (UncompressedSize == 2 && rows >= 16))) { return false; }
+		&& ((UncompressedSize == 4 && rows >= GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1) || (UncompressedSize == 2 && rows >= GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1))) { return false; }
 	if (rows <= rows_per_chunk) { return true; }
 	return GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS != 0 && UncompressedSize == 8 && CompressedSize != 2 && L % traits::row != 0
 		&& n / GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS >= L;
@@ -903,6 +917,41 @@ __device__ __forceinline__ void block_per_segment(
 	const uint64_t num_segments = (n + L - 1) / L;
 	unsigned buffer = 0;
 
+	// Segments of at most half the workgroup's rows (whole-row segments of 8 or 16 rows under a 4-wavefront workgroup): SEVERAL segments per workgroup, each
+	// taken by 1 or 2 of its wavefronts in one sweep — the same barrier, the totals added up within a segment's wavefronts only
+	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
+	const unsigned waves_per_segment = (unsigned) ((rows_per_segment + R - 1) / R);
+	if (GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS && waves_per_segment * 2 <= num_waves) {
+		const unsigned segments_per_block = num_waves / waves_per_segment;
+		const unsigned mine_of_block = w / waves_per_segment, part = w % waves_per_segment;
+		for (uint64_t first = (uint64_t) blockIdx.x * segments_per_block; first < num_segments; first += (uint64_t) gridDim.x * segments_per_block) {
+			const uint64_t s = first + mine_of_block;
+			const bool working = mine_of_block < segments_per_block && s < num_segments;
+			const uint64_t start = s * L, end = working ? ((start + L < n) ? start + L : n) : start;
+			const uint64_t mine = start + (uint64_t) part * R * traits::row;
+			row_t<UncompressedSize, CompressedSize> rows[R];
+			const U base = working ? anchors[s] : (U) 0;
+			if (working && mine < end) { patches.begin_seek(mine, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].load(in, mine + (uint64_t) k * traits::row, end, lane); }   // (idle wavefronts, rows past `end`: zeros)
+			if (working && mine < end) { patches.finish_seek(lane); }
+			U my_total = 0;
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); my_total += (U) rows[k].total; }
+			if (lane == 0) { wave_totals[buffer][w] = my_total; }
+			__syncthreads();
+			U running = base;
+			for (unsigned v = w - part; v < w; v++) { running += wave_totals[buffer][v]; }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				rows[k].store(out, mine + (uint64_t) k * traits::row, end, lane, running, patches);
+				running += (U) rows[k].total;
+			}
+			buffer ^= 1;
+		}
+		return;
+	}
+
 	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
@@ -1417,6 +1466,10 @@ public:
 				util::div_rounding_up(rows_per_segment, (size_t) detail::rows_per_wave_per_sweep));
 			grid_construction_resolution = block;
 			length = num_segments;
+			if (GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS && waves <= 2) {   // (segments of 8 or 16 rows: 4 or 2 of them to a workgroup of 4 wavefronts — block_per_segment)
+				length = util::div_rounding_up(num_segments, (size_t) (4 / waves));
+				waves = 4;
+			}
 			block_resolution_constraints.max_threads_per_block = (grid_block_dimension_t) (waves * warp_size);
 			upper_limits.threads_in_block = (grid_block_dimension_t) (waves * warp_size);
 		}

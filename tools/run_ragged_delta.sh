@@ -5,7 +5,7 @@ for v in "$@"; do
 import sys, os
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tools"))
 import sweep_all as sw
-n = 1 << 28
+n = 1 << int(os.environ.get('LOG2N', '28'))
 for (I, U, C) in [tuple(int(c) for c in t.split(',')) for t in os.environ.get('TUPLES', '4,8,2 4,8,1 4,4,1 4,4,2 8,8,4 4,2,1').split()]:
     for L in [int(x) for x in os.environ.get('LS', '1000 3000 3504 4096 5000 10000').split()]:
         if L % (16 // U) and not os.environ.get("ODD"): continue
