@@ -117,7 +117,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	// — 8-byte elements: +2-3 points; 2-byte: 46 -> 58 % for segments of 3000 and 10 000, but 75 -> 58 for segments of 1000 (taken from 2048 outputs on); 1-byte: never (61 -> 31)
 	const bool one_kernel_build_applies = sparse || (!run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16
 		&& (UncompressedSize >= 4 || (UncompressedSize == 2 && L >= 2048)));
-	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && ((L % run_expansion::tile_length != 0 && L >= run_expansion::tile_length / 2) || (environment.group_all && L > 0)) && memory_access::is_aligned(run_lengths, 16)) {   // (shorter segments: +2-7 points at 2^28 outputs, -2 at 2^30 — left to the ordinary path)
+	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && ((L % run_expansion::tile_length != 0 && run_expansion::tile_length % L != 0 && L >= run_expansion::tile_length / 2) || (environment.group_all && L > 0)) && memory_access::is_aligned(run_lengths, 16)) {   // (shorter segments: +2-7 points at 2^28 outputs, -2 at 2^30 — left to the ordinary path)
 		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);   // (run_anchors.hpp)
 		const uint64_t group_outputs = per_group * L, finer_per_group = util::div_rounding_up(group_outputs, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_segments, per_group);

@@ -110,10 +110,10 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	stream_scratch::lease scratch(stream);
-	// ABSOLUTE positions at segment lengths that are not whole tiles of 4096 outputs: groups of segments through the long segments' one kernel, as for run lengths
-	// (kernel_wrappers/decompression/run_length_encoding.hpp; relative positions count from their own segment's start: not for them)
-	if (!PositionsAreRelative && run_expansion::fine_environment::get().fused && sparse && UncompressedSize >= 4 && n > 0 && num_element_runs > 0 && L > 0
-		&& ((L % run_expansion::tile_length != 0 && L >= run_expansion::tile_length / 2) || (run_expansion::fine_environment::get().group_all && L > 0))) {   // (shorter segments: 70 -> 64 % at 2^30)
+	// Segment lengths that are not whole tiles of 4096 outputs: groups of segments through the long segments' one kernel, as for run lengths
+	// (kernel_wrappers/decompression/run_length_encoding.hpp; relative positions: a piece of a group finds each run's segment among the column's own anchors)
+	if (run_expansion::fine_environment::get().fused && sparse && UncompressedSize >= 4 && n > 0 && num_element_runs > 0 && (PositionsAreRelative ? L >= 256 : L > 0)   // (a piece of 4096 outputs: within 17 segments of relative positions)
+		&& ((L % run_expansion::tile_length != 0 && run_expansion::tile_length % L != 0 && L >= run_expansion::tile_length / 2) || (run_expansion::fine_environment::get().group_all && L > 0))) {   // (shorter segments: 70 -> 64 % at 2^30)
 		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);
 		const uint64_t finer_per_group = util::div_rounding_up(per_group * L, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_anchors, per_group);

@@ -55,7 +55,12 @@ namespace detail {
 /// `limit`, with the anchor arrays beginning at chunk `anchors_from` (they hold one workgroup's segment's finer anchors, in LDS)
 /// — and, when the chunks are pieces of a GROUP of the column's segments (any number of outputs, beginning anywhere), chunk `anchors_from` begins at output
 /// `outputs_from` and the group ends before `outputs_until`
-struct chunks_to_take { bool given = false; uint64_t first = 0, stride = 1, limit = 0, anchors_from = 0, outputs_from = 0, outputs_until = ~(uint64_t) 0; };
+/// (run positions stored RELATIVE: `segment_anchors` / `segment_period` — the column's own anchors and anchoring period, which its positions count from, when the
+/// chunks are pieces of a group of several of its segments)
+struct chunks_to_take {
+	bool given = false; uint64_t first = 0, stride = 1, limit = 0, anchors_from = 0, outputs_from = 0, outputs_until = ~(uint64_t) 0;
+	const void* segment_anchors = nullptr; uint64_t segment_period = 0;
+};
 
 /// The kernel's body.  `WithGroups`: with the path for chunks of many runs (groups of runs through LDS: run_expansion.hpp) — without it the kernel
 /// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity

@@ -105,7 +105,13 @@ __device__ __forceinline__ void decompress(
 		// where the first segment after this chunk starts (a GROUP of segments' last finer segment — decompress_long_segments — ends with the group)
 		const uint64_t nominal_end = segment_start + segments_per_chunk * L < mine.outputs_until ? segment_start + segments_per_chunk * L : mine.outputs_until;
 		const uint64_t segment_end = nominal_end < n ? nominal_end : n;
-		const uint64_t positions_origin = position_period == L ? segment_start : segment_start / position_period * position_period;
+		// (relative positions in a piece of a GROUP of the column's segments — decompress_long_segments —: the piece may lie across several of them; which one a run
+		// is in is found as for a batch of short segments below, over the COLUMN's anchors of the segments the piece touches)
+		const bool regrouped = PositionsAreRelative && mine.given && mine.segment_anchors != nullptr;   // (wave-uniform)
+		const uint64_t relative_to = regrouped ? mine.segment_period : position_period;
+		const uint64_t positions_origin = relative_to == L ? segment_start : segment_start / relative_to * relative_to;
+		const uint64_t segment_stride = regrouped ? relative_to : L;   // from one segment's start to the next one's, for the positions
+		const unsigned segments_here = regrouped ? (unsigned) ((segment_end - 1) / relative_to - segment_start / relative_to + 1) : (unsigned) segments_per_chunk;
 		uint32_t touched = 0;   // (GIDDY_RUN_TOUCH_ANCHORS_AHEAD: run_length_encoding.hpp)
 		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
 			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
@@ -115,8 +121,10 @@ __device__ __forceinline__ void decompress(
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
 		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk - mine.anchors_from] : num_runs - 1;
 		// lane j: the anchor of the chunk's j-th segment (past the chunk / the column: no run index reaches it)
-		const uint64_t chunk_anchor = (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
-			? (uint64_t) position_anchors[s + lane - mine.anchors_from] : ~(uint64_t) 0;
+		const uint64_t chunk_anchor = regrouped
+			? (lane < segments_here ? (uint64_t) static_cast<const uint_t<RunIndexSize>*>(mine.segment_anchors)[segment_start / relative_to + lane] : ~(uint64_t) 0)
+			: (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
+				? (uint64_t) position_anchors[s + lane - mine.anchors_from] : ~(uint64_t) 0;
 
 		// groups of runs through LDS when the chunk has more runs than one batch and the arrays allow 16-byte loads
 		const uint64_t run_limit = last_candidate + 1;   // (exclusive: the runs this chunk may look at)
@@ -201,17 +209,17 @@ __device__ __forceinline__ void decompress(
 						// Relative positions: the run lies in the chunk's segment i = #{j >= 1 : anchor_j < r} — a binary search over
 						// the anchors held one per lane
 						unsigned segment_in_chunk = 0;
-						if (segments_per_chunk > 1) {   // wave-uniform
+						if (segments_here > 1) {   // wave-uniform
 							const uint64_t r = first_run + 1 + k;
 							#pragma unroll
 							for (unsigned step = 16; step >= 1; step >>= 1) {
 								const unsigned probe = segment_in_chunk + step;
 								const uint64_t anchor = __shfl(chunk_anchor, (int) (probe < 64 ? probe : 63), 64);
-								if (probe < segments_per_chunk && anchor < r) { segment_in_chunk = probe; }
+								if (probe < segments_here && anchor < r) { segment_in_chunk = probe; }
 							}
 						}
 						// ... and at relative position 0 it starts the NEXT segment
-						start = positions_origin + (uint64_t) segment_in_chunk * L + (positions[j] != 0 ? (uint64_t) positions[j] : position_period);
+						start = positions_origin + (uint64_t) segment_in_chunk * segment_stride + (positions[j] != 0 ? (uint64_t) positions[j] : relative_to);
 					}
 					const uint64_t from_tile_start = start - tile_start;
 					offsets[j] = (have && from_tile_start < reach) ? (uint32_t) from_tile_start : ~0u;
@@ -374,7 +382,7 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 	size_type_by_index_size<RunIndexSize>            num_anchors,
 	size_type_by_index_size<RunIndexSize>            num_element_runs,
 	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length,
-	uint32_t                                         segments_per_group)   // >= 1 (absolute positions; relative ones count from their own segment's start: 1)
+	uint32_t                                         segments_per_group)   // >= 1
 {
 	namespace fine = run_expansion::fine;
 	using run_length_encoding::most_fines_per_long_segment;
@@ -394,9 +402,13 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 		for (uint64_t j = threadIdx.x; j < fines; j += blockDim.x) {   // (fine::anchors_by_search, for this group)
 			uint64_t low = position_anchors[g * segments_per_group];
 			if (j != 0) {
-				uint64_t high = has_next ? (uint64_t) position_anchors[(g + 1) * segments_per_group] : num_runs - 1;
+				// (relative positions restart in every segment of the column: the search is among the runs of the segment the finer anchor's output lies in)
+				const uint64_t output = group_begin + j * fine::sub, segment = PositionsAreRelative ? output / anchoring_period : g * segments_per_group;
+				if (PositionsAreRelative) { low = position_anchors[segment]; }
+				uint64_t high = PositionsAreRelative ? (segment + 1 < (uint64_t) num_anchors ? (uint64_t) position_anchors[segment + 1] : num_runs - 1)
+					: (has_next ? (uint64_t) position_anchors[(g + 1) * segments_per_group] : num_runs - 1);
 				if (PositionsAreRelative && high > low && run_start_positions[high] == 0) { high--; }
-				const uint64_t target = (PositionsAreRelative ? 0 : group_begin) + j * fine::sub;
+				const uint64_t target = PositionsAreRelative ? output - segment * anchoring_period : output;
 				while (low < high) {
 					const uint64_t middle = low + (high - low + 1) / 2;
 					if ((uint64_t) run_start_positions[middle] <= target) { low = middle; } else { high = middle - 1; }
@@ -412,6 +424,7 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 		const uint64_t part_limit = part_first + finer_segments_per_workgroup < fines ? part_first + finer_segments_per_workgroup : fines;
 		mine.given = true; mine.first = numbering_from + part_first + wave64::index_in_block(); mine.stride = working_waves; mine.limit = numbering_from + part_limit;
 		mine.anchors_from = numbering_from; mine.outputs_from = group_begin; mine.outputs_until = group_end;
+		if (PositionsAreRelative && segments_per_group > 1) { mine.segment_anchors = position_anchors; mine.segment_period = anchoring_period; }
 		detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false>(
 			decompressed, run_data, run_start_positions, finer_anchors, (uint64_t) fine::sub, PositionsAreRelative ? anchoring_period : (uint64_t) fine::sub,
 			(size_type_by_index_size<RunIndexSize>) (numbering_from + fines + (has_next ? 1 : 0)), num_element_runs, uncompressed_length, mine);

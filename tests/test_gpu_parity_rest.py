@@ -241,8 +241,8 @@ def test_rpe(index_size, usize, psize, relative):
 
 
 def test_rpe_with_the_one_kernel_builds_forced():
-    """every run-position registration decodes every column of test_rpe with the long segments' one-kernel build — and, absolute positions, groups of segments through
-    it — taken wherever the shape admits it, however few workgroups that makes (the switches are read once per process: a child interpreter)"""
+    """every run-position registration decodes every column of test_rpe with the long segments' one-kernel build — and groups of segments through it (relative
+    positions: from segments of 256 outputs on) — taken wherever the shape admits it, however few workgroups that makes (the switches are read once per process: a child interpreter)"""
     import os
     import subprocess
     import sys
