@@ -73,6 +73,13 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 	bool caching = maybe_cache.value_or(launch_config.dynamic_shared_memory_size > 0) && fits;
 	auto serialization_factor = maybe_serialization_factor.value_or(get_default_serialization_factor(caching));
 
+	// A column at an address aligned for its elements only: the build whose wide accesses start at the output's first 16-byte boundary (kernels/decompression/dictionary.hpp)
+	// (... and an output that starts at a 16-byte boundary inside a 128-byte line: that build's tiles start at the next line)
+	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {
+		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, DictionaryIndexSize>), stream, launch_config,
+			decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, caching, serialization_factor);
+		return;
+	}
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries,
 		caching, serialization_factor);
@@ -81,7 +88,10 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
 const device_function_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::get_device_function() const
 {
-	return reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>);
+	// (the any-alignment build takes the configuration resolved for `decompress` — same LDS, no launch bounds; kept out of the merged attributes so that
+	// the configuration of the aligned column is what it has been)
+	return device_function_t(reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>), { },
+		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, DictionaryIndexSize>) });
 }
 
 } // namespace dictionary

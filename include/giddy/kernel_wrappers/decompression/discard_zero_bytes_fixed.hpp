@@ -52,14 +52,20 @@ void GIDDY_DZBF_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_co
 	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
 	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
 	auto length           = argument<uint_t<IndexSize>>(arguments, "length");
+	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {   // (kernels/decompression/discard_zero_bytes_fixed.hpp)
+		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>),
+			stream, launch_config, decompressed, compressed_input, (size_type) length);
+		return;
+	}
 	cuda::kernel::enqueue_launch(*this, stream, launch_config, decompressed, compressed_input, (size_type) length);
 }
 
 GIDDY_DZBF_TEMPLATE
 const device_function_t GIDDY_DZBF_KERNEL::get_device_function() const
 {
-	return reinterpret_cast<const void*>(
-		decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
+	return device_function_t(reinterpret_cast<const void*>(
+		decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>), { },
+		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>) });
 }
 
 #undef GIDDY_DZBF_TEMPLATE

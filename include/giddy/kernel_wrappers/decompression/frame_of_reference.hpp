@@ -63,6 +63,11 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto num_blocks = launch_config.grid_dimensions.x;
 	index_type segments_per_block = num_blocks ? util::div_rounding_up(num_segments, num_blocks) : 0;
 
+	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {   // (kernels/decompression/frame_of_reference.hpp)
+		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), stream, launch_config,
+			decompressed, compressed_input, segment_model_coefficients, (size_type) length, (size_type) segment_length, segments_per_block);
+		return;
+	}
 	cuda::kernel::enqueue_launch(*this, stream, launch_config,
 		decompressed, compressed_input, segment_model_coefficients,
 		(size_type) length, (size_type) segment_length, segments_per_block);
@@ -71,7 +76,9 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
 const device_function_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::get_device_function() const
 {
-	return reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
+	// (the any-alignment build runs with the configuration resolved for `decompress`; not merged into its attributes)
+	return device_function_t(reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), { },
+		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, Uncompressed, Compressed, UnaryModelFunction>) });
 }
 
 } // namespace frame_of_reference

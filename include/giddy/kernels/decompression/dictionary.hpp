@@ -71,7 +71,7 @@ template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr boo
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -89,11 +89,11 @@ __device__ __forceinline__ void translate(
 		for (unsigned j = 0; j < G; j++) { out[j] = lookup(keys[j]); }
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
-	if constexpr (by_wave_chunks<Patches::enabled, UncompressedSize, DictionaryIndexSize, RestagedDictionary>()) {
+	if constexpr (!AnyAlignment && by_wave_chunks<Patches::enabled, UncompressedSize, DictionaryIndexSize, RestagedDictionary>()) {   // (any alignment: tiles only)
 		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
 	}
 	else {
-		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY)>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
+		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
 	}
 }
 
@@ -101,7 +101,7 @@ __device__ __forceinline__ void translate(
 #define GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 4-8-byte values and small dictionaries (0: no cap): with write-through stores 6-7 are 1.5-2.4 points faster than 8
 #endif
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches, bool AnyAlignment = false>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -162,18 +162,18 @@ __device__ __forceinline__ void decompress(
 			__syncthreads();
 			staged_yet = true;
 		};
-		translate<UncompressedSize, DictionaryIndexSize, true>(
+		translate<UncompressedSize, DictionaryIndexSize, true, AnyAlignment>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage);
 	}
 	else if (cache_dictionary_in_shared_memory) {
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();
-		translate<UncompressedSize, DictionaryIndexSize>(
+		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging);
 	}
 	else {
-		translate<UncompressedSize, DictionaryIndexSize>(
+		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment>(
 			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches, chunk_staging);
 	}
 }
@@ -192,6 +192,24 @@ __global__ void decompress(
 {
 	(void) serialization_factor;
 	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
+		length, num_dictionary_entries, cache_dictionary_in_shared_memory, sorted_patches::none());
+}
+
+/// The same, for a column handed over at an address that is aligned for its elements only (a slice [a, b) decoded into `decompressed + a`): 16-byte stores from the
+/// output's first 16-byte boundary on, the keys' loads wide at whatever address that leaves them (stream_tiles.hpp, `AnyAlignment`).  The wrapper launches it when
+/// either address is not as `decompress` wants it for its wide accesses — there that kernel goes one element at a time (26 % of the HBM peak against 88).
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+__global__ void decompress_at_any_alignment(
+	uint_t<UncompressedSize>*           __restrict__  decompressed,
+	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*     __restrict__  dictionary_entries,
+	size_type_by_index_size<IndexSize>                length,
+	size_type_by_index_size<DictionaryIndexSize>      num_dictionary_entries,
+	bool                                              cache_dictionary_in_shared_memory,
+	serialization_factor_t                            serialization_factor)
+{
+	(void) serialization_factor;
+	detail::decompress<UncompressedSize, DictionaryIndexSize, sorted_patches::none, true>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory, sorted_patches::none());
 }
 

@@ -53,6 +53,28 @@ __global__ void decompress(
 		[&](uint64_t, C x) { return widen(x); });
 }
 
+/// The same for a column at an address aligned for its elements only, or inside a 128-byte line: the `AnyAlignment` build of stream_tiles::transform, launched
+/// by the wrapper from the addresses
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
+	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
+	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
+__global__ void decompress_at_any_alignment(
+	uint_t<UncompressedSize>*      __restrict__  decompressed,
+	const uint_t<CompressedSize>*  __restrict__  compressed_input,
+	size_type_by_index_size<IndexSize>           length)
+{
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	constexpr unsigned G = stream_tiles::group_size<U>::value;
+	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
+	stream_tiles::transform<C, U, stream_tiles::steps_per_tile, memory_access::non_temporal, true>(decompressed, compressed_input, length,
+		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
+		},
+		[&](uint64_t, C x) { return widen(x); });
+}
+
 namespace patched {
 
 /// rows of an 8-byte column take 2 or 4 input bytes per lane: a chunk's input comes in with 16-byte loads through LDS then

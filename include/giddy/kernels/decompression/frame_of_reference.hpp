@@ -58,7 +58,7 @@ __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotien
 
 namespace detail {
 
-template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, typename Patches>
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, typename Patches, bool AnyAlignment = false>
 __device__ __forceinline__ void decompress(
 	Uncompressed*       __restrict__    decompressed,
 	const Compressed*   __restrict__    compressed_input,
@@ -81,7 +81,8 @@ __device__ __forceinline__ void decompress(
 	// groups (segment_length % G == 0 — always so for 4-byte outputs, whose segment lengths are multiples of 4) a group
 	// never crosses into the next segment and that one record is all it needs.
 	struct group_context { coefficients_type record; uint64_t segment, within; };
-	const bool groups_stay_in_segment = L % G == 0;
+	// (`AnyAlignment` — stream_tiles.hpp —: groups start at the output's first 128-byte boundary, wherever in a segment that is)
+	const bool groups_stay_in_segment = L % G == 0 && (!AnyAlignment || stream_tiles::elements_before_first_line(decompressed, length) % G == 0);
 	auto prepare = [&](uint64_t first_position) {
 		group_context context;
 		divide<IndexSize>(first_position, L, context.segment, context.within);
@@ -125,7 +126,7 @@ __device__ __forceinline__ void decompress(
 	else {
 		// (write-through stores where a segment's record is its one reference value: +1...2 points; with a line per segment -1...-4)
 		constexpr int stores = sizeof(coefficients_type) == sizeof(Uncompressed) ? memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_FOR_STORE_POLICY) : (int) memory_access::non_temporal;
-		stream_tiles::transform<Compressed, Uncompressed, steps_per_tile<Uncompressed, Compressed>(), stores>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
+		stream_tiles::transform<Compressed, Uncompressed, steps_per_tile<Uncompressed, Compressed>(), stores, AnyAlignment>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
 	}
 }
 
@@ -143,6 +144,23 @@ __global__ void decompress(
 {
 	(void) num_segments_to_decompress_per_block;
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
+		decompressed, compressed_input, segment_model_coefficients, length, segment_length, sorted_patches::none());
+}
+
+/// The same for a column at an address aligned for its elements only, or inside a 128-byte line (a slice [a, b) decoded into `decompressed + a`; `length` and the
+/// segments count from `decompressed`): the `AnyAlignment` build of stream_tiles::transform — the wrapper launches it by the addresses (Dictionary: 26 -> 89 % of the HBM peak).
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+__global__ void decompress_at_any_alignment(
+	Uncompressed*       __restrict__    decompressed,
+	const Compressed*   __restrict__    compressed_input,
+	const typename UnaryModelFunction::coefficients_type*
+	                    __restrict__    segment_model_coefficients,
+	size_type_by_index_size<IndexSize>  length,
+	size_type_by_index_size<IndexSize>  segment_length,
+	uint_t<IndexSize>                   num_segments_to_decompress_per_block)
+{
+	(void) num_segments_to_decompress_per_block;
+	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, sorted_patches::none, true>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length, sorted_patches::none());
 }
 

@@ -43,11 +43,33 @@ template <typename ProduceGroup, typename Inputs, typename Outputs>
 __device__ __forceinline__ auto produce_with(ProduceGroup& produce_group, uint64_t position, const Inputs& inputs, Outputs& outputs, const no_context&)
 	-> decltype(produce_group(position, inputs, outputs), void()) { produce_group(position, inputs, outputs); }
 
+/// elements from `out` to the first 128-byte boundary at or after it (at most n): where the groups of an `AnyAlignment` build of transform() start
+template <typename Out>
+__host__ __device__ __forceinline__ uint64_t elements_before_first_line(const Out* out, uint64_t n)
+{
+	const uint64_t to_boundary = ((128 - (reinterpret_cast<uintptr_t>(out) & 127)) & 127) / sizeof(Out);
+	return to_boundary < n ? to_boundary : n;
+}
+
+/// whether a launch should take the `AnyAlignment` build of a transform() decoder: an output that does not start a 128-byte line, or an input not aligned for a group's load
+template <typename In, typename Out>
+__host__ __forceinline__ bool wants_any_alignment_build(const Out* out, const In* in)
+{
+	constexpr unsigned G = 16 / sizeof(Out);
+	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
+	return (reinterpret_cast<uintptr_t>(out) & 127) != 0 || (reinterpret_cast<uintptr_t>(in) & (in_bytes - 1)) != 0;
+}
+
 /// `prepare(first_position)` -> a group's context (say, its segment's record): for a whole tile ALL the contexts are
 /// requested right behind the tile's input loads and before its first store — a load issued between two stores would
 /// have to wait for the earlier store (CDNA4 counts vector memory operations in order).
 /// `Stores`: memory_access::store_policy of the tile's 16-byte stores
-template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
+/// `AnyAlignment`: a build for arrays aligned for their elements only (a slice [a, b) of a column decoded into `out + a`): the groups start at the first 128-byte
+/// boundary of the OUTPUT — the elements before it go one at a time with the column's last ones — and the input's loads are wide at whatever address that leaves
+/// them.  A build of its own, chosen by the wrapper from the addresses: inside the one kernel the extra address arithmetic cost the aligned column 2 points.
+/// (only for a produce_group that does not care where a group starts: positions are passed as they are in the column, but a group may lie across any boundary)
+template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, bool AnyAlignment = false,
+	typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
 	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare())
@@ -56,6 +78,39 @@ __device__ __forceinline__ void transform(
 	constexpr unsigned G = group_size<Out>::value;
 	constexpr unsigned K = Steps;
 	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
+
+	if constexpr (AnyAlignment) {
+		// (the first 128-BYTE boundary: a wavefront's store instruction then writes whole lines — from a 16-byte boundary that is not one of those, the same tiles run at 54 % of the HBM peak against 91)
+		const uint64_t lead = elements_before_first_line(out, n);
+		Out* __restrict__ out_at_boundary = out + lead;
+		const In* __restrict__ in_at_boundary = in + lead;
+		const uint64_t num_groups = (n - lead) / G;
+		const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+		for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+			const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+			group<In, G> inputs[K];
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				if (g < num_groups) { inputs[k] = load_group_at_any_alignment<In, G>(in_at_boundary + g * G); }
+			}
+			after_loads();
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				if (g >= num_groups) { continue; }
+				group<Out, G> outputs;
+				produce_with(produce_group, lead + g * G, inputs[k], outputs, prepare(lead + g * G));
+				store_group<Stores>(out_at_boundary + g * G, outputs);
+			}
+		}
+		after_loads();
+		const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+		const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+		for (uint64_t p = global_thread; p < lead; p += num_threads) { out[p] = produce_one(p, in[p]); }
+		for (uint64_t p = lead + num_groups * G + global_thread; p < n; p += num_threads) { out[p] = produce_one(p, in[p]); }
+		return;
+	}
 
 	const bool vectorizable = is_aligned(out, 16) && is_aligned(in, in_bytes);
 	const uint64_t num_groups = vectorizable ? n / G : 0;

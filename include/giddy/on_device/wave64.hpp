@@ -224,6 +224,23 @@ __device__ __forceinline__ group<T, N> load_group(const T* __restrict__ p)
 	return g;
 }
 
+/// ... from an address aligned for T only (a column handed over at an odd element offset; gfx950 takes wide loads of global memory at any address — at
+/// the price of the second line a piece may lie across)
+template <typename T, unsigned N>
+__device__ __forceinline__ group<T, N> load_group_at_any_alignment(const T* __restrict__ p)
+{
+	constexpr unsigned bytes = N * sizeof(T);
+	constexpr unsigned piece = bytes >= 16 ? 16 : bytes;
+	typedef typename chunk<piece>::type loose_piece_t __attribute__((aligned(sizeof(T))));
+	using piece_t = typename chunk<piece>::type;
+	group<T, N> g;
+	#pragma unroll
+	for (unsigned i = 0; i < bytes / piece; i++) {
+		reinterpret_cast<piece_t*>(&g)[i] = reinterpret_cast<const loose_piece_t*>(p)[i];
+	}
+	return g;
+}
+
 /// How a 16-byte store treats the caches.  `non_temporal` (`nt`): the line stays in the XCD's L2 marked for early eviction — the
 /// acknowledgement comes back soonest, which is what a wavefront wants that issues LOADS after its stores (the counter is in-order: the run
 /// decoders' look-ups through L1/L2).  `streaming` (`sc1 nt`): write-through, the line is dropped — for output that nobody reads again and

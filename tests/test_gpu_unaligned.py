@@ -93,3 +93,78 @@ def test_unaligned_bases():
     out, out_ptr = _odd_out(g, n, np.int32)
     schemes.model(out_ptr, np.array([7, -3], np.int32), n, stream=st)
     assert (_read(g, out, np.int32, n) == (7 - 3 * np.arange(n)).astype(np.int32)).all()
+
+
+@pytest.mark.parametrize("usize,ksize", [(1, 1), (2, 1), (2, 2), (4, 1), (4, 2), (4, 4), (8, 1), (8, 2), (8, 4)])
+def test_dictionary_at_any_alignment(usize, ksize):
+    """Dictionary's build for columns at an odd element offset (kernels/decompression/dictionary.hpp, decompress_at_any_alignment): output and keys at every
+    combination of a few element offsets from a 16-byte boundary, lengths from nothing to several tiles — bit-exact, nothing written before or past the output."""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud, kd = np.dtype("u%d" % usize), np.dtype("u%d" % ksize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    entries_count = 256 if ksize == 1 else 3000
+    for n in (0, 1, 3, 17, 1000, 70001, 300007):
+        f = cases.dictionary_case(max(n, 1), entries_count, ud, kd, seed=n + usize)
+        keys = f["compressed_input"][:n]
+        expect = f["dictionary_entries"][keys.astype(np.int64)]
+        entries = g.dev(f["dictionary_entries"])
+        for out_offset, key_offset in ((1, 1), (1, 0), (0, 1), (3, 5), (16 // usize - 1 if usize < 16 else 0, 2), (5, 3), (16 // usize, 0), (0, 0)):
+            keys_buffer = g.dev(np.concatenate([np.zeros(key_offset, kd), keys]))
+            out_buffer = g.dev_empty(out_offset + n + 8, ud)
+            schemes.dictionary(out_buffer.data_ptr() + out_offset * usize, keys_buffer.data_ptr() + key_offset * ksize, entries, n, entries_count,
+                               uncompressed_size=usize, dictionary_index_size=ksize, stream=st)
+            full = g.host(out_buffer, ud, out_offset + n + 8)
+            assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, out_offset, key_offset, "wrote outside the output")
+            bad = np.flatnonzero(full[out_offset:out_offset + n] != expect)
+            assert len(bad) == 0, (n, out_offset, key_offset, bad[:5])
+
+
+_OFFSETS = ((1, 1), (1, 0), (0, 1), (3, 5), (5, 3), (0, 0))
+
+
+@pytest.mark.parametrize("index_size,usize,csize,model,model_index_size", [
+    (4, 2, 1, "linear", 4), (4, 4, 1, "linear", 4), (4, 4, 2, "linear", 4), (8, 4, 2, "linear", 8), (4, 2, 1, "constant", 4), (4, 4, 1, "constant", 4), (4, 4, 2, "constant", 4)])
+def test_frame_of_reference_at_any_alignment(index_size, usize, csize, model, model_index_size):
+    """Frame of Reference's build for columns at an odd element offset (decompress_at_any_alignment): its 16-byte groups start wherever in a segment the output's
+    first 128-byte boundary falls — segments that are and are not whole groups, shorter than a group, longer than the column"""
+    import gpu_util as g
+    from oracle import oracle
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud, cd = np.dtype("i%d" % usize), np.dtype("i%d" % csize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    for n, seglen in ((0, 4), (1, 4), (19, 4), (4099, 64), (70001, 12), (70001, 20), (300007, 4096), (300007, 1000), (333, 1000)):
+        f = cases.for_case(max(n, 1), seglen, ud, cd, model, seed=n + usize)
+        comp = f["compressed_input"][:n]
+        expect = oracle.frame_of_reference(comp, f["segment_model_coefficients"], n, seglen, ud, model, model_index_size=model_index_size)
+        coefficients = g.dev(f["segment_model_coefficients"])
+        for out_offset, in_offset in _OFFSETS + ((16 // usize, 0),):
+            in_buffer = g.dev(np.concatenate([np.zeros(in_offset, cd), comp]))
+            out_buffer = g.dev_empty(out_offset + n + 8, ud)
+            schemes.frame_of_reference(out_buffer.data_ptr() + out_offset * usize, in_buffer.data_ptr() + in_offset * csize, coefficients, n, seglen,
+                                       uncompressed_size=usize, compressed_size=csize, model=model, index_size=index_size, model_index_size=model_index_size, stream=st)
+            full = g.host(out_buffer, ud, out_offset + n + 8)
+            assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, seglen, out_offset, in_offset, "wrote outside the output")
+            bad = np.flatnonzero(full[out_offset:out_offset + n] != expect)
+            assert len(bad) == 0, (n, seglen, out_offset, in_offset, bad[:5])
+
+
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
+def test_discard_zero_bytes_fixed_at_any_alignment(usize, csize):
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    for n in (0, 1, 17, 1000, 70001, 300007):
+        comp = cases.rng(n + usize).integers(0, np.iinfo(cd).max, size=n, endpoint=True, dtype=np.uint64).astype(cd)
+        for out_offset, in_offset in _OFFSETS + ((16 // usize, 0),):
+            in_buffer = g.dev(np.concatenate([np.zeros(in_offset, cd), comp]))
+            out_buffer = g.dev_empty(out_offset + n + 8, ud)
+            schemes.discard_zero_bytes_fixed(out_buffer.data_ptr() + out_offset * usize, in_buffer.data_ptr() + in_offset * csize, n,
+                                             uncompressed_size=usize, compressed_size=csize, stream=st)
+            full = g.host(out_buffer, ud, out_offset + n + 8)
+            assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, out_offset, in_offset, "wrote outside the output")
+            assert (full[out_offset:out_offset + n] == comp.astype(ud)).all(), (n, out_offset, in_offset)

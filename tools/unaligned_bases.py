@@ -13,13 +13,23 @@ def report(name, how, ms, nbytes, ok):
 
 g = sw.gen(1)
 # Dictionary <4,4,1>
-entries = sw.rand_bits(256, 4, g); keys_all = sw.rand_bits(n + 64, 1, g, high=256); out_all = torch.empty(n + 64, dtype=torch.int32, device=sw.DEV)
-for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1), (4, 4)):
+entries = sw.rand_bits(256, 4, g); keys_all = sw.rand_bits(n + 2048, 1, g, high=256); out_all = torch.empty(n + 2048, dtype=torch.int32, device=sw.DEV)
+for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1), (4, 4), (32, 32), (1024, 1024), (1025, 3)):
     out, keys = out_all[o:o + n], keys_all[i:i + n]
     kw = dict(uncompressed_size=4, dictionary_index_size=1, index_size=4, stream=st)
     cfg = schemes.dictionary(out, keys, entries, n, 256, **kw)
     ms = sw.timeit(lambda: schemes.dictionary(out, keys, entries, n, 256, launch_config=cfg, **kw))
     report("dictionary<4,4,1>", "out +%d, keys +%d elements" % (o, i), ms, 5 * n, bool((entries[sw.unsigned(keys, 1)] == out).all()))
+# Frame of reference <4,4,2,constant>, segments of 1024
+Lf = 1024
+offsets_all = sw.rand_bits(n + 2048, 2, g); refs = sw.rand_bits(n // Lf + 4, 4, g, high=1 << 20)
+for (o, i) in ((0, 0), (1, 0), (1, 1), (4, 4), (1025, 3)):
+    out, offs = out_all[o:o + n], offsets_all[i:i + n]
+    kw = dict(uncompressed_size=4, compressed_size=2, model="constant", index_size=4, stream=st)
+    cfg = schemes.frame_of_reference(out, offs, refs, n, Lf, **kw)
+    ms = sw.timeit(lambda: schemes.frame_of_reference(out, offs, refs, n, Lf, launch_config=cfg, **kw))
+    expect = (refs[:n // Lf].view(-1, 1) + offs.view(-1, Lf).to(torch.int32)).view(-1)
+    report("frame_of_reference<4,4,2,c>", "out +%d, offsets +%d elements" % (o, i), ms, 6 * n + 4 * (n // Lf), bool((expect == out).all()))
 # Delta <4,4,1>, segments of 4096
 L = 4096
 d_all = sw.rand_bits(n + 64, 1, g)
