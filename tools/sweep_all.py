@@ -358,6 +358,8 @@ def main():
     for key in r.kernel_t.registered_keys():
         if key.startswith("compression::"):
             continue   # (the compressors: tools/compress_bench.py)
+        if os.environ.get("ONLY") and os.environ["ONLY"] not in key:
+            continue   # (development: one family)
         torch.cuda.empty_cache()
         try:
             patched = "::patched::" in key   # the fused decompress-and-patch extensions: 0.1 % patches
