@@ -219,6 +219,8 @@ def test_round_4_entry_points_fail_politely_without_a_device():
     assert lib.giddy_device_function_count(kernel._handle) == 4          # the kernel of the reference's signature + the builds for short / long runs + long segments in one kernel
     assert len(set(kernel.device_functions())) == 4 and kernel.device_functions()[0] == kernel.get_device_function()
     assert lib.giddy_device_function_count(r.kernel_t.produceSubclass(schemes.key_dictionary(4, 4, 1))._handle) == 2   # ... + the build for columns at any element offset
+    assert lib.giddy_device_function_count(r.kernel_t.produceSubclass(schemes.key_frame_of_reference(4, 4, 2, "constant", 4, 4))._handle) == 2
+    assert lib.giddy_device_function_count(r.kernel_t.produceSubclass(schemes.key_discard_zero_bytes_fixed(4, 8, 2))._handle) == 2
     relative = r.kernel_t.produceSubclass("decompression::run_position_encoding::kernel_t<4u, 4u, 2u, true, 4u>")
     assert lib.giddy_device_function_count(relative._handle) == 5        # ... + the one over finer anchors + long segments in one kernel
     # a prepared launch on a real wrapper, map and all — nothing is launched
