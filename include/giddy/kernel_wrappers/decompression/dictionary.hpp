@@ -16,11 +16,25 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryInde
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using dictionary_index_type = uint_t<DictionaryIndexSize>;
 	using dictionary_size_type  = size_type_by_index_size<DictionaryIndexSize>;
 	using uncompressed_type     = uint_t<UncompressedSize>;
 	using size_type             = size_type_by_index_size<IndexSize>;
+
+	/// THE decode on `stream` — what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, typed parameters...) and dictionary::launch<...>()
+	/// all run: `decompress`, or its build for columns at any element offset when the addresses ask for it (kernels/decompression/dictionary.hpp)
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		uncompressed_type* decompressed, const dictionary_index_type* compressed_input, const uncompressed_type* dictionary_entries,
+		size_type length, dictionary_size_type num_dictionary_entries, bool cache_dictionary_in_shared_memory, serialization_factor_t serialization_factor)
+	{
+		const void* kernel = stream_tiles::wants_any_alignment_build(decompressed, compressed_input)
+			? reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, DictionaryIndexSize>)
+			: reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>);
+		cuda::enqueue_launch(kernel, stream, launch_config,
+			decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, cache_dictionary_in_shared_memory, serialization_factor);
+	}
 
 	launch_configuration_t resolve_launch_configuration(
 		device::properties_t              device_properties,
@@ -73,16 +87,7 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 	bool caching = maybe_cache.value_or(launch_config.dynamic_shared_memory_size > 0) && fits;
 	auto serialization_factor = maybe_serialization_factor.value_or(get_default_serialization_factor(caching));
 
-	// A column at an address aligned for its elements only: the build whose wide accesses start at the output's first 16-byte boundary (kernels/decompression/dictionary.hpp)
-	// (... and an output that starts at a 16-byte boundary inside a 128-byte line: that build's tiles start at the next line)
-	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {
-		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, DictionaryIndexSize>), stream, launch_config,
-			decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, caching, serialization_factor);
-		return;
-	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
-		decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries,
-		caching, serialization_factor);
+	launch(stream, launch_config, decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, caching, serialization_factor);
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
@@ -92,6 +97,17 @@ const device_function_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSiz
 	// the configuration of the aligned column is what it has been)
 	return device_function_t(reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>), { },
 		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, DictionaryIndexSize>) });
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	uint_t<UncompressedSize>* decompressed, const uint_t<DictionaryIndexSize>* compressed_input, const uint_t<UncompressedSize>* dictionary_entries,
+	size_type_by_index_size<IndexSize> length, size_type_by_index_size<DictionaryIndexSize> num_dictionary_entries,
+	bool cache_dictionary_in_shared_memory, serialization_factor_t serialization_factor)
+{
+	kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::launch(stream, launch_config, decompressed, compressed_input, dictionary_entries,
+		length, num_dictionary_entries, cache_dictionary_in_shared_memory, serialization_factor);
 }
 
 } // namespace dictionary

@@ -19,10 +19,22 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using uncompressed_type = uint_t<UncompressedSize>;
 	using compressed_type   = uint_t<CompressedSize>;
 	using size_type         = size_type_by_index_size<IndexSize>;
+
+	/// THE decode on `stream` — what the type-erased enqueue_launch() and cuda::kernel::enqueue_launch(kernel, typed parameters...) run: `decompress`, or its build
+	/// for columns at any element offset when the addresses ask for it (kernels/decompression/discard_zero_bytes_fixed.hpp)
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		uncompressed_type* decompressed, const compressed_type* compressed_input, size_type length)
+	{
+		const void* kernel = stream_tiles::wants_any_alignment_build(decompressed, compressed_input)
+			? reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>)
+			: reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
+		cuda::enqueue_launch(kernel, stream, launch_config, decompressed, compressed_input, length);
+	}
 
 	launch_configuration_t resolve_launch_configuration(
 		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
@@ -52,12 +64,7 @@ void GIDDY_DZBF_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_co
 	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
 	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
 	auto length           = argument<uint_t<IndexSize>>(arguments, "length");
-	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {   // (kernels/decompression/discard_zero_bytes_fixed.hpp)
-		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>),
-			stream, launch_config, decompressed, compressed_input, (size_type) length);
-		return;
-	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config, decompressed, compressed_input, (size_type) length);
+	launch(stream, launch_config, decompressed, compressed_input, (size_type) length);
 }
 
 GIDDY_DZBF_TEMPLATE

@@ -14,9 +14,23 @@ template <unsigned IndexSize, typename Uncompressed, typename Compressed, typena
 class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
 
 	using size_type               = size_type_by_index_size<IndexSize>;
 	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
+
+	/// THE decode on `stream` — what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, typed parameters...) and frame_of_reference::launch<...>()
+	/// all run: `decompress`, or its build for columns at any element offset when the addresses ask for it (kernels/decompression/frame_of_reference.hpp)
+	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+		Uncompressed* decompressed, const Compressed* compressed_input, const model_coefficients_type* segment_model_coefficients,
+		size_type length, size_type segment_length, uint_t<IndexSize> num_segments_to_decompress_per_block)
+	{
+		const void* kernel = stream_tiles::wants_any_alignment_build(decompressed, compressed_input)
+			? reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, Uncompressed, Compressed, UnaryModelFunction>)
+			: reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
+		cuda::enqueue_launch(kernel, stream, launch_config,
+			decompressed, compressed_input, segment_model_coefficients, length, segment_length, num_segments_to_decompress_per_block);
+	}
 
 	launch_configuration_t resolve_launch_configuration(
 		device::properties_t           device_properties,
@@ -63,14 +77,7 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto num_blocks = launch_config.grid_dimensions.x;
 	index_type segments_per_block = num_blocks ? util::div_rounding_up(num_segments, num_blocks) : 0;
 
-	if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) {   // (kernels/decompression/frame_of_reference.hpp)
-		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), stream, launch_config,
-			decompressed, compressed_input, segment_model_coefficients, (size_type) length, (size_type) segment_length, segments_per_block);
-		return;
-	}
-	cuda::kernel::enqueue_launch(*this, stream, launch_config,
-		decompressed, compressed_input, segment_model_coefficients,
-		(size_type) length, (size_type) segment_length, segments_per_block);
+	launch(stream, launch_config, decompressed, compressed_input, segment_model_coefficients, (size_type) length, (size_type) segment_length, segments_per_block);
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
@@ -79,6 +86,16 @@ const device_function_t kernel_t<IndexSize, Uncompressed, Compressed, UnaryModel
 	// (the any-alignment build runs with the configuration resolved for `decompress`; not merged into its attributes)
 	return device_function_t(reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), { },
 		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, Uncompressed, Compressed, UnaryModelFunction>) });
+}
+
+/// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+inline void launch(stream::id_t stream, const launch_configuration_t& launch_config,
+	Uncompressed* decompressed, const Compressed* compressed_input, const typename UnaryModelFunction::coefficients_type* segment_model_coefficients,
+	size_type_by_index_size<IndexSize> length, size_type_by_index_size<IndexSize> segment_length, uint_t<IndexSize> num_segments_to_decompress_per_block)
+{
+	kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::launch(stream, launch_config, decompressed, compressed_input, segment_model_coefficients,
+		length, segment_length, num_segments_to_decompress_per_block);
 }
 
 } // namespace frame_of_reference
