@@ -143,6 +143,19 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
 {
 	const void* const base_kernel = reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize>);
 
+	// A column at addresses aligned for its elements only (a slice decoded into `decompressed + a`): the build that takes it by windows whose rows follow the output's
+	// boundaries (kernels/decompression/delta.hpp, decompress_at_any_alignment) — segments of up to 32 rows, the wave paths' workgroups
+	{
+		using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+		if ((!memory_access::is_aligned(decompressed, 16) || !memory_access::is_aligned(compressed_input, traits::E * CompressedSize))
+			&& length > 0 && segment_length > 0 && (uint64_t) segment_length <= (uint64_t) detail::rows_per_chunk * traits::row
+			&& launch_config.block_dimensions.x <= detail::any_length_waves * warp_size && launch_config.block_dimensions.y == 1 && launch_config.block_dimensions.z == 1) {
+			cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize>), stream, launch_config,
+				decompressed, compressed_input, anchor_values, length, segment_length);
+			return;
+		}
+	}
+
 	// Long segments — more rows than a wavefront takes by itself — as tiles of their own, chained by a decoupled look-back through
 	// per-tile states in stream-ordered scratch memory (kernels/decompression/delta.hpp, namespace chained): every tile a workgroup
 	// whatever the segment length, the deltas read once.  (GIDDY_DELTA_CHAINED_FROM in the environment: the segment length, in elements,
@@ -223,7 +236,9 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
 const device_function_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::get_device_function() const
 {
-	return reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize>);
+	// (the any-alignment build runs with the configuration resolved for `decompress`; not merged into its attributes)
+	return device_function_t(reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize>), { },
+		{ reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize>) });
 }
 
 /// kernel_t<...>::launch as a free function: the one-line replacement for a direct launch of `decompress` ("mode C")

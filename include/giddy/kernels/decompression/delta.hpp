@@ -139,10 +139,14 @@ struct row_t {
 	scan_type prefix[E];     // inclusive prefix within the row, per owned element
 	scan_type total;         // sum of the whole row (uniform)
 
+	template <bool AnyAlignment = false>   // (the group's address aligned for an element only: decompress_at_any_alignment)
 	__device__ __forceinline__ void load(const typename traits::compressed_type* __restrict__ in, uint64_t row_start, uint64_t end, unsigned lane)
 	{
 		uint64_t p = row_start + (uint64_t) lane * E;
-		if (p + E <= end) { deltas = memory_access::load_group<typename traits::compressed_type, E>(in + p); }
+		if (p + E <= end) {
+			if constexpr (AnyAlignment) { deltas = memory_access::load_group_at_any_alignment<typename traits::compressed_type, E>(in + p); }
+			else { deltas = memory_access::load_group<typename traits::compressed_type, E>(in + p); }
+		}
 		else {
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) { deltas[j] = (p + j < end) ? in[p + j] : (typename traits::compressed_type) 0; }
@@ -776,7 +780,10 @@ __host__ __device__ inline bool any_length_by_windows(uint64_t L)
 	return GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS && L % traits::E != 0 && L <= (uint64_t) rows_per_chunk * traits::row;
 }
 
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+/// `AnyAlignment` (decompress_at_any_alignment): `out` and `in` aligned for their elements only.  Rows follow the output's 1 KiB boundaries as before — every row but the
+/// window's first is then stored 16 bytes per lane at aligned addresses, wherever the column begins; the first one, up to the boundary, goes element by element; the
+/// rows' loads are 16 bytes per lane at whatever address (gfx950 takes them).
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false>
 __device__ __forceinline__ void wave_windows_of_any_segments(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
 	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases)   // (LDS: traits::row entries, this wavefront's)
@@ -835,14 +842,14 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 		row_places places[R], next_places[R];
 		patches.begin_seek(chunk_start, lane);
 		#pragma unroll
-		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].load(in, bounds[k].start, bounds[k].end, lane); places[k] = place(bounds[k]); }
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].template load<AnyAlignment>(in, bounds[k].start, bounds[k].end, lane); places[k] = place(bounds[k]); }
 		if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
 			sum_type sum = 0;
 			const uint64_t aligned_origin = origin / E * E;   // (16-byte loads: the elements of the first group that lie before the segment are left out)
 			for (uint64_t at = aligned_origin; at < chunk_start; at += 4 * traits::row) {
 				row_t<UncompressedSize, CompressedSize> before[4];
 				#pragma unroll
-				for (unsigned k = 0; k < 4; k++) { before[k].load(in, at + (uint64_t) k * traits::row, chunk_start, lane); }
+				for (unsigned k = 0; k < 4; k++) { before[k].template load<AnyAlignment>(in, at + (uint64_t) k * traits::row, chunk_start, lane); }
 				#pragma unroll
 				for (unsigned k = 0; k < 4; k++) {
 					const uint64_t q = at + (uint64_t) k * traits::row + (uint64_t) lane * E;
@@ -855,7 +862,7 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 		patches.finish_seek(lane);
 		while (bounds[0].start < chunk_end) {
 			#pragma unroll
-			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].load(in, next_bounds[k].start, next_bounds[k].end, lane); next_places[k] = place(next_bounds[k]); }
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].template load<AnyAlignment>(in, next_bounds[k].start, next_bounds[k].end, lane); next_places[k] = place(next_bounds[k]); }
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
 			#pragma unroll
@@ -890,7 +897,12 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 				#pragma unroll
 				for (unsigned j = 1; j < E; j++) { if (last_slot == j) { last_value = values[j]; } }
 				carry = wave64::read_lane(last_value, last_lane);
-				rows[k].store_values(out, bounds[k].start, bounds[k].end, lane, values, patches);
+				if (AnyAlignment && bounds[k].start == chunk_start && !memory_access::is_aligned(out + chunk_start, 16)) {   // (wave-uniform: the row up to the output's boundary)
+					patches.template apply_to_row<E>(bounds[k].start, bounds[k].end, lane, values);
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { if (p + j < bounds[k].end) { out[p + j] = values[j]; } }
+				}
+				else { rows[k].store_values(out, bounds[k].start, bounds[k].end, lane, values, patches); }
 			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; places[k] = next_places[k]; }
@@ -1143,6 +1155,30 @@ __global__ void decompress(
 {
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length, sorted_patches::none());
+}
+
+/// The same for a column at addresses aligned for its elements only (a slice [a, b) decoded into `decompressed + a`, the deltas at `compressed_input + a`), where
+/// `decompress` goes element by element (17-21 % of the HBM peak): windows of the column whose rows follow the output's 1 KiB boundaries, every element finding
+/// its segment (detail::wave_windows_of_any_segments, `AnyAlignment`) — for segments of up to detail::rows_per_chunk rows and workgroups of up to 4 wavefronts, which
+/// is what the wrapper launches it for; anything else: the element-wise path.
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void decompress_at_any_alignment(
+	uint_t<UncompressedSize>*        __restrict__  decompressed,
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*  __restrict__  anchor_values,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length)
+{
+	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+	const uint64_t n = length, L = segment_length;
+	if (n == 0 || L == 0) { return; }
+	if (L <= (uint64_t) detail::rows_per_chunk * traits::row && wave64::per_block() <= detail::any_length_waves) {
+		__shared__ uint_t<UncompressedSize> bases_of_segments[detail::any_length_waves][traits::row];
+		detail::wave_windows_of_any_segments<UncompressedSize, CompressedSize, sorted_patches::none, true>(
+			decompressed, compressed_input, anchor_values, n, L, sorted_patches::none(), bases_of_segments[wave64::index_in_block()]);
+		return;
+	}
+	detail::segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, sorted_patches::none());
 }
 
 // ---- long segments: tiles chained by a decoupled look-back ---------------------------------------------------------------

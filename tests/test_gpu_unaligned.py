@@ -168,3 +168,28 @@ def test_discard_zero_bytes_fixed_at_any_alignment(usize, csize):
             full = g.host(out_buffer, ud, out_offset + n + 8)
             assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, out_offset, in_offset, "wrote outside the output")
             assert (full[out_offset:out_offset + n] == comp.astype(ud)).all(), (n, out_offset, in_offset)
+
+
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
+def test_delta_at_any_alignment(usize, csize):
+    """Delta's build for columns at an odd element offset (kernels/decompression/delta.hpp, decompress_at_any_alignment): windows of the column whose rows follow the
+    output's boundaries — segment lengths that are and are not multiples of a lane's elements or of a row, shorter than a row, as long as the 32 rows the build
+    takes, and longer (the element-wise path); outputs and deltas at several element offsets"""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    row = 64 * 16 // usize
+    for n, seglen in ((1, 4), (19, 4), (5000, 7), (70001, 48), (70001, row), (300007, 1000), (300007, 4096), (300007, 32 * row), (150001, 32 * row + 8), (70001, 100000)):
+        f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + usize + csize, base=(1 << (8 * usize - 2)))
+        anchors = g.dev(f["anchor_values"])
+        for out_offset, in_offset in _OFFSETS + ((16 // usize, 1),):
+            in_buffer = g.dev(np.concatenate([np.zeros(in_offset, cd), f["compressed_input"]]))
+            out_buffer = g.dev_empty(out_offset + n + 8, ud)
+            schemes.delta(out_buffer.data_ptr() + out_offset * usize, in_buffer.data_ptr() + in_offset * csize, anchors, n, seglen,
+                          uncompressed_size=usize, compressed_size=csize, stream=st)
+            full = g.host(out_buffer, ud, out_offset + n + 8)
+            assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, seglen, out_offset, in_offset, "wrote outside the output")
+            bad = np.flatnonzero(full[out_offset:out_offset + n] != truth)
+            assert len(bad) == 0, (n, seglen, out_offset, in_offset, bad[:5])
