@@ -157,3 +157,30 @@ def test_prepared_launches_keep_their_map_and_take_updates():
     with pytest.raises(Exception):
         prepared.update({"length": r.uint64(half)})   # (accepted into the map ...)
         prepared.enqueue(stream, config)              # ... and refused by the wrapper: it holds another type than the wrapper casts to
+
+
+def test_every_mode_decodes_a_column_at_an_odd_element_offset():
+    """Delta <4,4,1> with output and deltas one element past a 16-byte boundary: modes A, B, the base-type launch and the free launch<>() reach the wrapper's
+    typed launch(), which takes the any-alignment build (kernels/decompression/delta.hpp, decompress_at_any_alignment); mode C runs the kernel of the reference's
+    signature, element by element there — the same bits from all of them"""
+    import modes
+    from oracle import oracle as o
+    device = torch.device("cuda", 0)
+    n, L = 1 << 22, 4096
+    deltas_all = torch.randint(0, 256, (n + 1,), dtype=torch.int32, device=device).to(torch.uint8)
+    deltas = deltas_all[1:]
+    sums = torch.cumsum(deltas.to(torch.int64), 0)
+    anchors = torch.cat([torch.zeros(1, dtype=torch.int64, device=device), sums[L - 1:-1:L]]).add_(777).to(torch.int32)
+    out_all = torch.empty(n + 1, dtype=torch.int32, device=device)
+    out = out_all[1:]
+    assert out.data_ptr() % 16 == 4 and deltas.data_ptr() % 4 == 1
+    fields = {"compressed_input": deltas, "anchor_values": anchors, "length": n, "segment_length": L}
+    stream = torch.cuda.current_stream().cuda_stream
+    expect = o.delta(deltas.cpu().numpy(), anchors.cpu().numpy().view(np.uint32), L)
+    for mode in ["A"] + MODES:
+        out_all.fill_(-1)
+        modes.launcher("delta<4,4,1>", fields, out, mode)(stream)
+        torch.cuda.synchronize()
+        got = out_all.cpu().numpy().view(np.uint32)
+        assert got[0] == 0xFFFFFFFF, "mode %s wrote before the output" % mode
+        assert (got[1:] == expect).all(), "mode %s" % mode
