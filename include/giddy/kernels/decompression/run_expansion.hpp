@@ -259,6 +259,18 @@ constexpr int staged_store_policy()
 		? (int) memory_access::non_temporal : (int) GIDDY_RUN_STAGED_STORE_POLICY;
 }
 
+/// a lane's group to an address aligned for an element only: one wide store all the same (gfx950 takes it; the lines it lies across are written in part)
+template <typename T, unsigned N>
+__device__ __forceinline__ void store_group_at_any_alignment(T* __restrict__ p, const memory_access::group<T, N>& g)
+{
+	constexpr unsigned bytes = N * sizeof(T);
+	constexpr unsigned piece = bytes >= 16 ? 16 : bytes;
+	typedef typename memory_access::chunk<piece>::type loose_piece_t __attribute__((aligned(sizeof(T))));
+	using piece_t = typename memory_access::chunk<piece>::type;
+	#pragma unroll
+	for (unsigned i = 0; i < bytes / piece; i++) { reinterpret_cast<loose_piece_t*>(p)[i] = reinterpret_cast<const piece_t*>(&g)[i]; }
+}
+
 /// StagedStores: memory_access::store_policy of the 16-byte stores when the tile's values are staged
 template <unsigned ElementSize, bool Staged, bool AlreadyStaged = false, int StagedStores = memory_access::non_temporal>
 __device__ __forceinline__ void expand(
@@ -377,6 +389,7 @@ __device__ __forceinline__ void expand(
 			if (use_staged) { store_group<StagedStores>(out + p, values); }
 			else { store_group(out + p, values); }
 		}
+		else if (p + E <= tile_len) { store_group_at_any_alignment(out + p, values); }   // (an output aligned for its elements only: 34 -> see DESIGN.md section 4, "what is still a cliff")
 		else {
 			#pragma unroll
 			for (unsigned j = 0; j < E; j++) { if (p + j < tile_len) { out[p + j] = values[j]; } }

@@ -54,3 +54,17 @@ for o in (0, 1):
     ms = sw.timeit(lambda: schemes.run_length_encoding(out, *args, launch_config=cfg, **kw))
     ok = bool((values[torch.searchsorted(starts, torch.arange(0, min(n, 1 << 24), device=sw.DEV), right=True) - 1] == out[:1 << 24]).all())
     report("run_length_encoding<4,4,2,4>", "out +%d elements" % o, ms, 4 * n + 6 * count + 6 * len(seg), ok)
+
+# run positions <4,4,4,absolute>
+positions = starts.to(torch.int32)
+for o in (0, 1):
+    out = out_all[o:o + n]
+    args = (values, positions, anchor.to(torch.int32), L, len(seg), count, n)
+    kw = dict(uncompressed_size=4, position_size=4, relative=False, index_size=4, run_index_size=4, stream=st)
+    try:
+        cfg = schemes.run_position_encoding(out, *args, **kw)
+        ms = sw.timeit(lambda: schemes.run_position_encoding(out, *args, launch_config=cfg, **kw))
+        ok = bool((values[torch.searchsorted(starts, torch.arange(0, min(n, 1 << 24), device=sw.DEV), right=True) - 1] == out[:1 << 24]).all())
+        report("run_position_encoding<4,4,4,abs>", "out +%d elements" % o, ms, 4 * n + 8 * count + 4 * len(seg), ok)
+    except Exception as e:
+        print("run_position_encoding: ", str(e)[:200])
