@@ -193,3 +193,36 @@ def test_delta_at_any_alignment(usize, csize):
             assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, seglen, out_offset, in_offset, "wrote outside the output")
             bad = np.flatnonzero(full[out_offset:out_offset + n] != truth)
             assert len(bad) == 0, (n, seglen, out_offset, in_offset, bad[:5])
+
+
+@pytest.mark.parametrize("usize", [1, 2, 4, 8])
+def test_run_decoders_store_their_rows_at_any_output_offset(usize):
+    """run lengths and run positions (absolute, relative) into outputs 1, 3 and 5 elements past a 16-byte boundary: a tile's rows are stored 16 bytes per lane at
+    whatever address (kernels/decompression/run_expansion.hpp, expand) — every element size, segments that are and are not whole tiles, short runs and long"""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud = np.dtype("u%d" % usize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    n = 150001
+    for mean_run in (3, 40):
+        col = cases.runs_column(n, mean_run, ud, seed=usize + mean_run, max_run=255)
+        for seglen in (4096, 1000, 100):
+            rle = formats.run_length_encoding(col, seglen, np.uint8 if usize < 8 else np.uint16)
+            rpe_absolute = formats.run_position_encoding(col, seglen, "u4", False, 4)
+            rpe_relative = formats.run_position_encoding(col, seglen, "u2", True, 4)
+            for out_offset in (1, 3, 5):
+                def check(decode):
+                    out_buffer = g.dev_empty(out_offset + n + 8, ud)
+                    decode(out_buffer.data_ptr() + out_offset * usize)
+                    full = g.host(out_buffer, ud, out_offset + n + 8)
+                    assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (seglen, out_offset, "wrote outside the output")
+                    bad = np.flatnonzero(full[out_offset:out_offset + n] != col)
+                    assert len(bad) == 0, (mean_run, seglen, out_offset, bad[:5])
+                check(lambda out: schemes.run_length_encoding(out, g.dev(rle["run_data"]), g.dev(rle["run_lengths"]), g.dev(rle["position_anchors"]),
+                                                              g.dev(rle["intra_run_anchor_offsets"]), seglen, rle["num_segments"], rle["num_element_runs"], n,
+                                                              uncompressed_size=usize, run_length_size=rle["run_lengths"].dtype.itemsize, stream=st))
+                for f, psize, relative in ((rpe_absolute, 4, False), (rpe_relative, 2, True)):
+                    check(lambda out: schemes.run_position_encoding(out, g.dev(f["run_data"]), g.dev(f["run_start_positions"]), g.dev(f["position_anchors"]), seglen,
+                                                                    f["num_anchors"], f["num_element_runs"], n, uncompressed_size=usize, position_size=psize,
+                                                                    relative=relative, stream=st))
