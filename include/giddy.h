@@ -141,6 +141,60 @@ int          giddy_prepared_update(giddy_prepared_t* prepared, const giddy_argum
 int          giddy_enqueue_prepared(const giddy_prepared_t* prepared, void* hip_stream, const giddy_launch_configuration_t* launch_configuration);
 void         giddy_release_prepared(giddy_prepared_t* prepared);
 
+/* (a giddy_prepared_t shares its wrapper with the giddy_kernel_t it was prepared from: either may be released first) */
+
+/* ---- batches: MANY small columns, ONE launch ------------------------------------------------------
+ * The reference launches once per column (src/cuda/kernel_wrapper.cuh:135-147) and exists to expand chunks of columns where they
+ * arrive (README.md:15-24); a launch per small chunk costs the host microseconds and the device a ramp and a tail
+ * (profiles/r05_size_sweep_round_start.txt: a column of 2^20 elements decodes at 5-20 % of the rate of one of 2^28).  A batch
+ * (include/giddy/batch.hpp) is a table of PIECES — each a column as giddy_enqueue_launch would be given it — decoded by one launch of
+ * the wrapper's batch kernel: pieces are independent, of any lengths (0 and 1 included), each with the workgroups its own launch
+ * configuration would have had.  Wrappers that launch batches: Dictionary, Frame of Reference, Delta, both Discard-Zero-Bytes
+ * forms, Run-Length and Run-Position encoding (giddy_can_launch_batches).
+ *
+ *   giddy_batch_create(kernel, device, &batch);
+ *   for each piece:  giddy_batch_add(batch, launch arguments, n, resolution arguments, m);   <- host only: nothing is enqueued
+ *   giddy_enqueue_batch(batch, stream);     <- one asynchronous copy of the tables (the first time, or after a change) + ONE launch
+ *   ... giddy_enqueue_batch(batch, stream) again decodes the same pieces again; giddy_batch_clear() starts another table.
+ *   giddy_batch_release(batch);             <- once the launches that read its tables have run (it frees device memory: waits)
+ *
+ * Pieces want what single columns want: outputs on 128-byte lines and inputs aligned for wide loads (a piece elsewhere switches the
+ * whole batch to the any-alignment build of Dictionary / Frame of Reference / fixed-width Discard-Zero-Bytes); the run decoders
+ * pick their build by the mean run of the whole batch. */
+typedef struct giddy_batch giddy_batch_t;
+
+/* The tables where the device reads them — the layouts are a contract (cuda::batch::piece_t / block_t): a caller may also WRITE them on
+ * the device (a kernel that cuts a column it has just received) and launch with giddy_enqueue_batch_of_device_tables. */
+typedef struct giddy_batch_piece {
+	uint64_t  slot[12];      /* parameter i of the kernel of the reference's signature, in its order, zero-extended (pointers: the address; bool: 0 / 1) */
+	uint32_t  blocks;        /* workgroups of the launch that decode this piece (0: none) */
+	uint32_t  first_block;   /* the first of them */
+	uint64_t  reserved;
+} giddy_batch_piece_t;       /* 112 bytes, 16-byte aligned */
+typedef struct giddy_batch_block { uint32_t piece, block_in_piece; } giddy_batch_block_t;   /* workgroup w of the launch: entry w */
+typedef struct giddy_batch_tables {
+	const giddy_batch_piece_t*  pieces;                       /* device memory */
+	const giddy_batch_block_t*  blocks;                       /* device memory, 8-byte aligned; num_blocks entries */
+	uint32_t                    num_pieces, num_blocks;
+	uint32_t                    block_size;                   /* threads per workgroup of the launch */
+	uint32_t                    dynamic_shared_memory_size;
+	uint64_t                    hints[4];                     /* run decoders: [0] outputs and [1] runs of all pieces, [2] != 0: some run array is not 16-byte aligned; [3] != 0: a piece needs the any-alignment build */
+} giddy_batch_tables_t;
+
+int          giddy_can_launch_batches(const giddy_kernel_t* kernel);   /* 1 / 0 */
+int          giddy_batch_create(const giddy_kernel_t* kernel, int device_id /* as giddy_resolve_launch_configuration */, giddy_batch_t** batch);
+/* one more piece: the launch arguments of giddy_enqueue_launch and the resolution arguments of giddy_resolve_launch_configuration for THAT column */
+int          giddy_batch_add(giddy_batch_t* batch, const giddy_argument_t* launch_arguments, size_t num_launch_arguments,
+                             const giddy_argument_t* resolution_arguments, size_t num_resolution_arguments);
+int          giddy_batch_clear(giddy_batch_t* batch);
+uint64_t     giddy_batch_num_pieces(const giddy_batch_t* batch);
+uint64_t     giddy_batch_num_blocks(const giddy_batch_t* batch);       /* workgroups of the one launch */
+int          giddy_batch_upload(giddy_batch_t* batch, void* hip_stream);   /* the tables to the device now (asynchronous, pinned staging); giddy_enqueue_batch does it when needed */
+int          giddy_enqueue_batch(giddy_batch_t* batch, void* hip_stream);
+int          giddy_batch_tables(const giddy_batch_t* batch, giddy_batch_tables_t* tables);   /* where an uploaded batch's tables lie */
+int          giddy_enqueue_batch_of_device_tables(const giddy_kernel_t* kernel, void* hip_stream, const giddy_batch_tables_t* tables);
+void         giddy_batch_release(giddy_batch_t* batch);
+
 /* ---- scratch memory --------------------------------------------------------------------------
  * Wrappers whose fast paths need memory of their own between their launches (chained tiles of long Delta segments, finer anchors of long
  * run-encoded / discard-zero-bytes segments, the pipeline's slices) lease it from a process-wide pool (include/giddy/stream_scratch.hpp):

@@ -1,0 +1,193 @@
+// MANY small columns decoded by ONE launch.
+//
+// The reference's unit of work is one launch per column (src/cuda/kernel_wrapper.cuh:135-147); its premise is chunks of
+// compressed columns crossing a link and being expanded where they arrive (README.md:15-24) — and chunks are small.  A
+// launch costs the host 3-10 us and the device a ramp and a tail: on MI355X a column of 2^20 elements decodes at 5-20 %
+// of the rate of a column of 2^28, one of 2^16 at 1 % (profiles/r05_size_sweep_round_start.txt).  A BATCH is a table of
+// PIECES — each the parameter list of the wrapper's kernel for one column, as a direct launch would pass it — and a table
+// of BLOCKS that deals the workgroups of one launch out to the pieces: workgroup w runs as "block blocks[w].block_in_piece
+// of the pieces[blocks[w].piece].blocks blocks of that piece" (on_device/launch_grid.hpp: the decoders' bodies stride by
+// that instead of blockIdx.x / gridDim.x).  Pieces are independent columns: any lengths (0 and 1 included), any segment
+// lengths, each with the number of blocks its own launch configuration would have had.
+//
+//   cuda::batch::table_t table;
+//   kernel.add_to_batch(table, kernel.resolve_launch_configuration(device, piece_resolution_arguments), piece_launch_arguments);   // per piece
+//   cuda::batch::uploaded_t on_device(table, stream);          // one asynchronous copy of both tables (pinned staging)
+//   kernel.enqueue_launch_of_batch(stream, on_device.view());  // ONE launch; as often as wanted while `on_device` lives
+//
+// Both tables may equally be WRITTEN BY THE DEVICE (a kernel that cuts a column it has just received): the layouts below
+// are the contract, `giddy_enqueue_batch_of_device_tables` (giddy.h) the entry point that takes them as they lie.
+#pragma once
+#include <hip/hip_runtime_api.h>
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <type_traits>
+#include <vector>
+
+#include "giddy/api/types.hpp"
+
+namespace cuda {
+namespace batch {
+
+enum : unsigned { slots_per_piece = 12, hints_per_batch = 4 };
+
+/// One piece: parameter i of the kernel of the reference's signature (the wrapper's `launch` parameters, in order) in slot i,
+/// zero-extended to 64 bits (pointers: the address; bool: 0 / 1; little-endian, so a value's bytes are the slot's first)
+struct alignas(16) piece_t {
+	uint64_t  slot[slots_per_piece];
+	uint32_t  blocks;        // workgroups of the batch launch that decode this piece (0: none — an empty piece)
+	uint32_t  first_block;   // ... of which the first is this workgroup of the launch
+	uint64_t  reserved;
+};
+static_assert(sizeof(piece_t) == 112, "piece records are 112 bytes (giddy.h: giddy_batch_piece_t)");
+
+/// workgroup w of the launch: block `block_in_piece` of piece `piece`
+struct block_t { uint32_t piece, block_in_piece; };
+
+template <typename T>
+inline uint64_t as_slot(T value)
+{
+	static_assert(std::is_trivially_copyable<T>::value && sizeof(T) <= 8, "a launch parameter that does not fit a 64-bit slot");
+	uint64_t slot = 0;
+	std::memcpy(&slot, &value, sizeof(T));
+	return slot;
+}
+
+/// what enqueue_launch_of_batch() takes: both tables where the device reads them, and what the launch needs to know of them
+struct on_device_t {
+	const piece_t*          pieces = nullptr;
+	const block_t*          blocks = nullptr;
+	uint32_t                num_pieces = 0, num_blocks = 0;
+	grid_block_dimension_t  block_size = 0;
+	shared_memory_size_t    dynamic_shared_memory_size = 0;
+	uint64_t                hints[hints_per_batch] = { };   // per scheme (run decoders: outputs, runs, whether every run array is 16-byte aligned)
+};
+
+/// The tables as the host builds them.  add(): a piece with the blocks of ITS OWN resolved configuration; the launch takes the largest
+/// block size and the most dynamic LDS any piece asked for (every decoder body is correct under any configuration: SURVEY.md section 8b).
+class table_t {
+public:
+	template <typename... Parameters>
+	void add(const launch_configuration_t& piece_configuration, Parameters... parameters)
+	{
+		static_assert(sizeof...(Parameters) <= slots_per_piece, "more launch parameters than a piece record has slots");
+		piece_t piece { };
+		unsigned i = 0;
+		(..., (piece.slot[i++] = as_slot(parameters)));
+		add_packed(piece_configuration, piece);
+	}
+
+	/// ... with the slots filled in by the caller
+	void add_packed(const launch_configuration_t& piece_configuration, piece_t piece)
+	{
+		const size_t blocks = piece_configuration.grid_dimensions.volume();
+		if (blocks_.size() + blocks > 0x7FFFFFFFull) { throw std::invalid_argument("a batch of more than 2^31 - 1 workgroups"); }
+		piece.blocks = (uint32_t) blocks;
+		piece.first_block = (uint32_t) blocks_.size();
+		const uint32_t index = (uint32_t) pieces_.size();
+		for (uint32_t b = 0; b < piece.blocks; b++) { blocks_.push_back(block_t { index, b }); }
+		pieces_.push_back(piece);
+		const grid_block_dimension_t block_size = (grid_block_dimension_t) piece_configuration.block_dimensions.volume();
+		if (block_size > block_size_) { block_size_ = block_size; }
+		if (piece_configuration.dynamic_shared_memory_size > dynamic_shared_memory_size_) { dynamic_shared_memory_size_ = piece_configuration.dynamic_shared_memory_size; }
+	}
+
+	void clear() { pieces_.clear(); blocks_.clear(); block_size_ = 0; dynamic_shared_memory_size_ = 0; for (auto& h : hints) { h = 0; } }
+
+	const std::vector<piece_t>& pieces() const { return pieces_; }
+	const std::vector<block_t>& blocks() const { return blocks_; }
+	std::vector<piece_t>& pieces() { return pieces_; }
+	grid_block_dimension_t block_size() const { return block_size_; }
+	shared_memory_size_t dynamic_shared_memory_size() const { return dynamic_shared_memory_size_; }
+	size_t bytes() const { return pieces_.size() * sizeof(piece_t) + blocks_.size() * sizeof(block_t); }
+
+	uint64_t hints[hints_per_batch] = { };
+
+private:
+	std::vector<piece_t>    pieces_;
+	std::vector<block_t>    blocks_;
+	grid_block_dimension_t  block_size_ = 0;
+	shared_memory_size_t    dynamic_shared_memory_size_ = 0;
+};
+
+/// A table's copy on the current device.  upload() copies asynchronously on `stream` out of PINNED staging memory; launches enqueued on that stream
+/// afterwards see the tables.  The device block is kept and re-used when a later table fits (a re-upload is ordered behind the earlier launches by
+/// the stream; a caller that re-uploads on ANOTHER stream orders the two itself); the staging is kept per copy in flight — a staging block is written
+/// again only once the copy made from it has completed (an event query, never a wait), so re-building and re-uploading a table in a loop does not
+/// stall the host.  Lives until the launches that read it have run (as a giddy_prepared_t does); the destructor frees device memory, which waits.
+class uploaded_t {
+public:
+	uploaded_t() = default;
+	uploaded_t(const table_t& table, stream::id_t stream) { upload(table, stream); }
+	uploaded_t(const uploaded_t&) = delete;
+	uploaded_t& operator=(const uploaded_t&) = delete;
+	~uploaded_t()
+	{
+		if (device_ != nullptr) { (void) hipFree(device_); }          // (waits for the device's pending work: no copy is in flight after it)
+		for (auto& s : staging_) {
+			if (s.memory != nullptr) { (void) hipHostFree(s.memory); }
+			if (s.copied != nullptr) { (void) hipEventDestroy(s.copied); }
+		}
+	}
+
+	void upload(const table_t& table, stream::id_t stream)
+	{
+		const size_t pieces_bytes = table.pieces().size() * sizeof(piece_t), blocks_bytes = table.blocks().size() * sizeof(block_t);
+		const size_t bytes = pieces_bytes + blocks_bytes;
+		if (bytes > device_capacity_) {
+			if (device_ != nullptr) { (void) hipFree(device_); device_ = nullptr; device_capacity_ = 0; }
+			const size_t wanted = bytes + bytes / 4 + 4096;
+			throw_if_error(hipMalloc(&device_, wanted), "hipMalloc of a batch's tables");
+			device_capacity_ = wanted;
+		}
+		if (bytes != 0) {
+			staging_block& from = idle_staging(bytes);
+			std::memcpy(from.memory, table.pieces().data(), pieces_bytes);
+			std::memcpy(static_cast<char*>(from.memory) + pieces_bytes, table.blocks().data(), blocks_bytes);
+			throw_if_error(hipMemcpyAsync(device_, from.memory, bytes, hipMemcpyHostToDevice, stream), "copy of a batch's tables to the device");
+			from.in_flight = from.copied != nullptr && hipEventRecord(from.copied, stream) == hipSuccess;
+			if (!from.in_flight) { (void) hipGetLastError(); throw_if_error(hipStreamSynchronize(stream), "waiting for the copy of a batch's tables"); }
+		}
+		view_.pieces = static_cast<const piece_t*>(device_);
+		view_.blocks = reinterpret_cast<const block_t*>(static_cast<const char*>(device_) + pieces_bytes);
+		view_.num_pieces = (uint32_t) table.pieces().size();
+		view_.num_blocks = (uint32_t) table.blocks().size();
+		view_.block_size = table.block_size();
+		view_.dynamic_shared_memory_size = table.dynamic_shared_memory_size();
+		for (unsigned i = 0; i < hints_per_batch; i++) { view_.hints[i] = table.hints[i]; }
+	}
+
+	const on_device_t& view() const { return view_; }
+
+private:
+	struct staging_block { void* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; bool in_flight = false; };
+
+	/// a staging block of at least `bytes` that no copy is still reading
+	staging_block& idle_staging(size_t bytes)
+	{
+		for (auto& s : staging_) {
+			if (s.in_flight) {
+				const hipError_t status = hipEventQuery(s.copied);
+				if (status == hipSuccess) { s.in_flight = false; }
+				else if (status != hipErrorNotReady) { (void) hipGetLastError(); }
+			}
+			if (!s.in_flight && s.capacity >= bytes) { return s; }
+		}
+		staging_block fresh;
+		fresh.capacity = bytes + bytes / 4 + 4096;
+		throw_if_error(hipHostMalloc(&fresh.memory, fresh.capacity, hipHostMallocDefault), "hipHostMalloc of a batch's staging");
+		if (hipEventCreateWithFlags(&fresh.copied, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); fresh.copied = nullptr; }
+		staging_.push_back(fresh);
+		return staging_.back();
+	}
+
+	void* device_ = nullptr;
+	size_t device_capacity_ = 0;
+	std::vector<staging_block> staging_;
+	on_device_t view_;
+};
+
+} // namespace batch
+} // namespace cuda

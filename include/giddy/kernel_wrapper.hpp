@@ -13,6 +13,7 @@
 
 #include "giddy/api/device.hpp"
 #include "giddy/api/types.hpp"
+#include "giddy/batch.hpp"
 #include "giddy/optional_and_any.hpp"
 
 namespace cuda {
@@ -66,6 +67,26 @@ struct kernel_t {
 	{
 		(void) sizes;
 		cuda::enqueue_launch_of_packed(get_device_function().ptr(), stream_id, launch_config, parameters, count);
+	}
+
+	// ---- batches: many small columns, ONE launch (giddy/batch.hpp; this library's addition to the reference's interface) ----------------
+
+	/// whether the two functions below do anything but throw
+	virtual bool launches_batches() const { return false; }
+
+	/// One more piece of `table`: the column `piece_arguments` describe — exactly what enqueue_launch() would be given for it — with the workgroups of
+	/// `piece_config`, the configuration resolve_launch_configuration() resolved for THAT column.  Same exceptions as enqueue_launch() for the map.
+	virtual void add_to_batch(batch::table_t& table, const launch_configuration_t& piece_config, const arguments_type& piece_arguments) const
+	{
+		(void) table; (void) piece_config; (void) piece_arguments;
+		throw std::logic_error("this kernel wrapper does not launch batches");
+	}
+
+	/// every piece of the tables decoded by one launch on `stream_id` (tables: batch::uploaded_t::view(), or wherever the caller keeps them on the device)
+	virtual void enqueue_launch_of_batch(stream::id_t stream_id, const batch::on_device_t& tables) const
+	{
+		(void) stream_id; (void) tables;
+		throw std::logic_error("this kernel wrapper does not launch batches");
 	}
 
 	virtual ~kernel_t() { }

@@ -69,6 +69,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using compressed_type   = uint_t<CompressedSize>;
 	using uncompressed_type = uint_t<UncompressedSize>;
@@ -84,6 +85,37 @@ public:
 		launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize> params(
 			device_properties, kernel_function_attributes, length, segment_length, limits.dynamic_shared_memory);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t&, const arguments_type& arguments, Sink&& sink)
+	{
+		auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
+		auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
+		auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
+		auto length            = argument<uint_t<IndexSize>>(arguments, "length");
+		auto segment_length    = argument<uint_t<IndexSize>>(arguments, "segment_length");
+		// (an extension: ceil(length / 4096) + 1024 entries, for columns of very long segments where no stream scratch is to be had)
+		auto part_anchors      = optional_argument<uncompressed_type*>(arguments, "part_anchors_scratch");
+		sink(decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length, part_anchors ? part_anchors.value() : nullptr);
+	}
+
+	/// a column as one piece of a batch (giddy/batch.hpp): decoded by `decompress` — a wavefront or a workgroup per segment, whatever the segments' length; pieces are
+	/// short, and launch()'s chained tiles are for segments that leave the chip empty by themselves (`part_anchors_scratch` is not used)
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const compressed_type* compressed_input, const uncompressed_type* anchor_values,
+		size_type length, size_type segment_length, uncompressed_type* = nullptr)
+	{
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		table.add(piece_config, decompressed, compressed_input, anchor_values, length, segment_length);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		cuda::enqueue_launch(reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, UncompressedSize, CompressedSize>>), stream,
+			launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
 	}
 
 	/// THE decode of a Delta column on `stream`: what the type-erased enqueue_launch(), cuda::kernel::enqueue_launch(kernel, ...) with
@@ -119,15 +151,7 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 	const launch_configuration_t&  launch_config,
 	const arguments_type&                 arguments) const
 {
-	auto decompressed      = argument<uncompressed_type*>(arguments, "decompressed");
-	auto compressed_input  = argument<const compressed_type*>(arguments, "compressed_input");
-	auto anchor_values     = argument<const uncompressed_type*>(arguments, "anchor_values");
-	auto length            = argument<uint_t<IndexSize>>(arguments, "length");
-	auto segment_length    = argument<uint_t<IndexSize>>(arguments, "segment_length");
-	// (an extension: ceil(length / 4096) + 1024 entries, for columns of very long segments where no stream scratch is to be had)
-	auto part_anchors      = optional_argument<uncompressed_type*>(arguments, "part_anchors_scratch");
-	launch(stream, launch_config, decompressed, compressed_input, anchor_values, (size_type) length, (size_type) segment_length,
-		part_anchors ? part_anchors.value() : nullptr);
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>

@@ -17,6 +17,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using dictionary_index_type = uint_t<DictionaryIndexSize>;
 	using dictionary_size_type  = size_type_by_index_size<DictionaryIndexSize>;
@@ -34,6 +35,28 @@ public:
 			: reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, DictionaryIndexSize>);
 		cuda::enqueue_launch(kernel, stream, launch_config,
 			decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, cache_dictionary_in_shared_memory, serialization_factor);
+	}
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t& launch_config, const arguments_type& arguments, Sink&& sink);
+
+	/// a column as one piece of a batch (giddy/batch.hpp); hints[3]: some piece lies where `decompress` would go element by element
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const dictionary_index_type* compressed_input, const uncompressed_type* dictionary_entries,
+		size_type length, dictionary_size_type num_dictionary_entries, bool cache_dictionary_in_shared_memory, serialization_factor_t serialization_factor)
+	{
+		if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) { table.hints[3] = 1; }
+		table.add(piece_config, decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, cache_dictionary_in_shared_memory, serialization_factor);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		const void* kernel = tables.hints[3] != 0
+			? reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, UncompressedSize, DictionaryIndexSize, true>>)
+			: reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, UncompressedSize, DictionaryIndexSize, false>>);
+		cuda::enqueue_launch(kernel, stream, launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
 	}
 
 	launch_configuration_t resolve_launch_configuration(
@@ -73,6 +96,16 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 	const launch_configuration_t&  launch_config,
 	const arguments_type&                 arguments) const
 {
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>
+template <typename Sink>
+void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::with_typed_parameters(
+	const launch_configuration_t&  launch_config,
+	const arguments_type&          arguments,
+	Sink&&                         sink)
+{
 	auto maybe_cache = optional_argument<bool>(arguments, "cache_dictionary_in_shared_mem");
 	auto maybe_serialization_factor = optional_argument<serialization_factor_t>(arguments, "serialization_factor");
 
@@ -87,7 +120,7 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 	bool caching = maybe_cache.value_or(launch_config.dynamic_shared_memory_size > 0) && fits;
 	auto serialization_factor = maybe_serialization_factor.value_or(get_default_serialization_factor(caching));
 
-	launch(stream, launch_config, decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, caching, serialization_factor);
+	sink(decompressed, compressed_input, dictionary_entries, length, num_dictionary_entries, caching, serialization_factor);
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>

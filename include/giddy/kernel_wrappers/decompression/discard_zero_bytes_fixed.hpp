@@ -20,6 +20,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using uncompressed_type = uint_t<UncompressedSize>;
 	using compressed_type   = uint_t<CompressedSize>;
@@ -34,6 +35,33 @@ public:
 			? reinterpret_cast<const void*>(decompress_at_any_alignment<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>)
 			: reinterpret_cast<const void*>(decompress<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>);
 		cuda::enqueue_launch(kernel, stream, launch_config, decompressed, compressed_input, length);
+	}
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t&, const arguments_type& arguments, Sink&& sink)
+	{
+		auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
+		auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
+		auto length           = argument<uint_t<IndexSize>>(arguments, "length");
+		sink(decompressed, compressed_input, (size_type) length);
+	}
+
+	/// a column as one piece of a batch (giddy/batch.hpp); hints[3]: some piece lies where `decompress` would go element by element
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const compressed_type* compressed_input, size_type length)
+	{
+		if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) { table.hints[3] = 1; }
+		table.add(piece_config, decompressed, compressed_input, length);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		const void* kernel = tables.hints[3] != 0
+			? reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), true>>)
+			: reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), false>>);
+		cuda::enqueue_launch(kernel, stream, launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
 	}
 
 	launch_configuration_t resolve_launch_configuration(
@@ -61,10 +89,7 @@ launch_configuration_t GIDDY_DZBF_KERNEL::resolve_launch_configuration(
 GIDDY_DZBF_TEMPLATE
 void GIDDY_DZBF_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
-	auto decompressed     = argument<uncompressed_type*>(arguments, "decompressed");
-	auto compressed_input = argument<const compressed_type*>(arguments, "compressed_input");
-	auto length           = argument<uint_t<IndexSize>>(arguments, "length");
-	launch(stream, launch_config, decompressed, compressed_input, (size_type) length);
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
 }
 
 GIDDY_DZBF_TEMPLATE

@@ -29,6 +29,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using element_size_t     = unsigned;
 	using uncompressed_type  = uint_t<UncompressedSize>;
@@ -42,6 +43,40 @@ public:
 		launch_config_resolution_params_t<IndexSize, UncompressedSize, ElementSizesContainerSize> params(
 			device_properties, kernel_function_attributes, length_in_elements, segment_length);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
+	}
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t&, const arguments_type& arguments, Sink&& sink)
+	{
+		using index_type = uint_t<IndexSize>;
+		auto decompressed                 = argument<uncompressed_type*>(arguments, "decompressed");
+		auto compressed_data              = argument<const unsigned char*>(arguments, "compressed_data");
+		auto packed_element_sizes         = argument<const element_sizes_container_size_type*>(arguments, "packed_element_sizes");
+		auto position_anchors             = argument<const index_type*>(arguments, "position_anchors");
+		auto segment_length               = argument<index_type>(arguments, "segment_length");
+		auto length                       = argument<index_type>(arguments, "length");
+		auto min_represented_element_size = argument<element_size_t>(arguments, "min_represented_element_size");
+		auto bits_per_element_size        = argument<unsigned>(arguments, "bits_per_element_size");
+		sink(decompressed, compressed_data, packed_element_sizes, position_anchors, (size_type) segment_length, (size_type) length, min_represented_element_size, bits_per_element_size);
+	}
+
+	/// a column as one piece of a batch (giddy/batch.hpp): decoded by `decompress` on its segments as they are (pieces are short; launch()'s finer anchors
+	/// for long segments and its cuts of long columns are for columns that fill the chip by themselves)
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const unsigned char* compressed_data, const element_sizes_container_size_type* packed_element_sizes,
+		const uint_t<IndexSize>* position_anchors, size_type segment_length, size_type length,
+		element_size_t min_represented_element_size, unsigned bits_per_element_size)
+	{
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		table.add(piece_config, decompressed, compressed_data, packed_element_sizes, position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_pieces<IndexSize, UncompressedSize, ElementSizesContainerSize>), stream,
+			launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
 	}
 
 	/// THE decode of a variable-width discard-zero-bytes column on `stream`: what the type-erased enqueue_launch(),
@@ -68,17 +103,7 @@ template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesCo
 void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::enqueue_launch_with(
 	stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
-	using index_type = uint_t<IndexSize>;
-	auto decompressed                 = argument<uncompressed_type*>(arguments, "decompressed");
-	auto compressed_data              = argument<const unsigned char*>(arguments, "compressed_data");
-	auto packed_element_sizes         = argument<const element_sizes_container_size_type*>(arguments, "packed_element_sizes");
-	auto position_anchors             = argument<const index_type*>(arguments, "position_anchors");
-	auto segment_length               = argument<index_type>(arguments, "segment_length");
-	auto length                       = argument<index_type>(arguments, "length");
-	auto min_represented_element_size = argument<element_size_t>(arguments, "min_represented_element_size");
-	auto bits_per_element_size        = argument<unsigned>(arguments, "bits_per_element_size");
-	launch(stream, launch_config, decompressed, compressed_data, packed_element_sizes, position_anchors,
-		(size_type) segment_length, (size_type) length, min_represented_element_size, bits_per_element_size);
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
@@ -106,8 +131,8 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(st
 		const unsigned bits = bits_per_element_size;
 		const bool eligible = E <= 4 && L % fine::sub != 0 && detail::wide_path_applies(bits, ElementSizesContainerSize, E)
 			&& (reinterpret_cast<uintptr_t>(decompressed) & 15) == 0 && (reinterpret_cast<uintptr_t>(packed_element_sizes) & 15) == 0 && fine_from_environment() != 0;
-		if (eligible && n <= L && n > fine::sub) {
-			segment_length = (size_type) std::min<uint64_t>(util::round_up(n, (uint64_t) fine::sub), std::numeric_limits<size_type>::max() / 1024 * 1024);   // (the column is one segment: of any length that holds it)
+		if (eligible && n <= L && n > fine::sub && util::round_up(n, (uint64_t) fine::sub) <= (uint64_t) std::numeric_limits<size_type>::max()) {
+			segment_length = (size_type) util::round_up(n, (uint64_t) fine::sub);   // (the column is one segment: of any length that holds it — where such a length can be stated: else the caller's)
 		}
 		else if (eligible && n > L && L >= row) {
 			uint64_t common = fine::sub, rest = L;

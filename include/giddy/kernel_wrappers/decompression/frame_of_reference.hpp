@@ -15,6 +15,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using size_type               = size_type_by_index_size<IndexSize>;
 	using model_coefficients_type = typename UnaryModelFunction::coefficients_type;
@@ -30,6 +31,29 @@ public:
 			: reinterpret_cast<const void*>(decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>);
 		cuda::enqueue_launch(kernel, stream, launch_config,
 			decompressed, compressed_input, segment_model_coefficients, length, segment_length, num_segments_to_decompress_per_block);
+	}
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t& launch_config, const arguments_type& arguments, Sink&& sink);
+
+	/// a column as one piece of a batch (giddy/batch.hpp); hints[3]: some piece lies where `decompress` would go element by element
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		Uncompressed* decompressed, const Compressed* compressed_input, const model_coefficients_type* segment_model_coefficients,
+		size_type length, size_type segment_length, uint_t<IndexSize> num_segments_to_decompress_per_block)
+	{
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		if (stream_tiles::wants_any_alignment_build(decompressed, compressed_input)) { table.hints[3] = 1; }
+		table.add(piece_config, decompressed, compressed_input, segment_model_coefficients, length, segment_length, num_segments_to_decompress_per_block);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		const void* kernel = tables.hints[3] != 0
+			? reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, Uncompressed, Compressed, UnaryModelFunction, true>>)
+			: reinterpret_cast<const void*>(batch::decode_pieces<piece_body<IndexSize, Uncompressed, Compressed, UnaryModelFunction, false>>);
+		cuda::enqueue_launch(kernel, stream, launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
 	}
 
 	launch_configuration_t resolve_launch_configuration(
@@ -63,6 +87,16 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	const launch_configuration_t&  launch_config,
 	const arguments_type&                 arguments) const
 {
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
+}
+
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>
+template <typename Sink>
+void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::with_typed_parameters(
+	const launch_configuration_t&  launch_config,
+	const arguments_type&          arguments,
+	Sink&&                         sink)
+{
 	using index_type = uint_t<IndexSize>;
 
 	auto decompressed               = argument<Uncompressed*>(arguments, "decompressed");
@@ -77,7 +111,7 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto num_blocks = launch_config.grid_dimensions.x;
 	index_type segments_per_block = num_blocks ? util::div_rounding_up(num_segments, num_blocks) : 0;
 
-	launch(stream, launch_config, decompressed, compressed_input, segment_model_coefficients, (size_type) length, (size_type) segment_length, segments_per_block);
+	sink(decompressed, compressed_input, segment_model_coefficients, (size_type) length, (size_type) segment_length, segments_per_block);
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction>

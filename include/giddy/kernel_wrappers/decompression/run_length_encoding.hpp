@@ -20,6 +20,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using run_index_type                = uint_t<RunIndexSize>;
 	using uncompressed_index_type       = uint_t<UncompressedIndexSize>;
@@ -51,6 +52,51 @@ public:
 		const run_index_type* position_anchors, const run_length_type* intra_run_anchor_offsets,
 		size_type segment_length, size_type num_segments, run_index_size_type num_element_runs, size_type uncompressed_length);
 
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t&, const arguments_type& arguments, Sink&& sink)
+	{
+		auto decompressed             = argument<uncompressed_type*>(arguments, "decompressed");
+		auto run_data                 = argument<const uncompressed_type*>(arguments, "run_data");
+		auto run_lengths              = argument<const run_length_type*>(arguments, "run_lengths");
+		auto position_anchors         = argument<const run_index_type*>(arguments, "position_anchors");
+		auto intra_run_anchor_offsets = argument<const run_length_type*>(arguments, "intra_run_anchor_offsets");
+		auto segment_length           = argument<size_type>(arguments, "segment_length");
+		auto num_segments             = argument<size_type>(arguments, "num_segments");
+		auto num_element_runs         = argument<run_index_size_type>(arguments, "num_element_runs");
+		auto uncompressed_length      = argument<size_type>(arguments, "length");
+		sink(decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets, segment_length, num_segments, num_element_runs, uncompressed_length);
+	}
+
+	/// a column as one piece of a batch (giddy/batch.hpp).  hints: [0] outputs and [1] runs of all pieces — the batch's mean run picks the build of the
+	/// decoder, as launch() does for one column —, [2] some piece's run arrays are not 16-byte aligned (no dense build then)
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const uncompressed_type* run_data, const run_length_type* run_lengths,
+		const run_index_type* position_anchors, const run_length_type* intra_run_anchor_offsets,
+		size_type segment_length, size_type num_segments, run_index_size_type num_element_runs, size_type uncompressed_length)
+	{
+		if (segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		table.hints[0] += uncompressed_length; table.hints[1] += num_element_runs;
+		if (!memory_access::is_aligned(run_lengths, 16) || !memory_access::is_aligned(run_data, 16)) { table.hints[2] = 1; }
+		table.add(piece_config, decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets, segment_length, num_segments, num_element_runs, uncompressed_length);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		constexpr bool has_groups = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled;
+		const uint64_t outputs = tables.hints[0], runs = tables.hints[1];
+		const bool sparse = has_groups && runs != 0 && outputs / runs >= 16;
+		const bool dense = GIDDY_RUN_DENSE_KERNEL && has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
+		const void* kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false, false>>);
+		if constexpr (has_groups) {   // (the other instantiations have the one build)
+			if (dense) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true, true>>); }
+			else if (!sparse) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true, false>>); }
+		}
+		// (the dense build wants all the workgroups a CU holds: launch())
+		cuda::enqueue_launch(kernel, stream, launch_configuration_t(tables.num_blocks, tables.block_size, dense ? 0 : tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
+	}
+
 	/// the three builds of the decoder, any of which launch() may run with the caller's configuration
 	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
 	static const void* sparse_kernel() { return reinterpret_cast<const void*>(decompress_sparse_runs<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize>); }
@@ -75,17 +121,7 @@ launch_configuration_t GIDDY_RLE_KERNEL::resolve_launch_configuration(
 GIDDY_RLE_TEMPLATE
 void GIDDY_RLE_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& resolved_launch_config, const arguments_type& arguments) const
 {
-	auto decompressed             = argument<uncompressed_type*>(arguments, "decompressed");
-	auto run_data                 = argument<const uncompressed_type*>(arguments, "run_data");
-	auto run_lengths              = argument<const run_length_type*>(arguments, "run_lengths");
-	auto position_anchors         = argument<const run_index_type*>(arguments, "position_anchors");
-	auto intra_run_anchor_offsets = argument<const run_length_type*>(arguments, "intra_run_anchor_offsets");
-	auto segment_length           = argument<size_type>(arguments, "segment_length");
-	auto num_segments             = argument<size_type>(arguments, "num_segments");
-	auto num_element_runs         = argument<run_index_size_type>(arguments, "num_element_runs");
-	auto uncompressed_length      = argument<size_type>(arguments, "length");
-	launch(stream, resolved_launch_config, decompressed, run_data, run_lengths, position_anchors, intra_run_anchor_offsets,
-		segment_length, num_segments, num_element_runs, uncompressed_length);
+	with_typed_parameters(resolved_launch_config, arguments, [&](auto... parameters) { launch(stream, resolved_launch_config, parameters...); });
 }
 
 GIDDY_RLE_TEMPLATE

@@ -22,6 +22,7 @@ class kernel_t : public cuda::registered::kernel_t {
 public:
 	REGISTERED_KERNEL_WRAPPER_BOILERPLATE_DEFINITIONS(kernel_t);
 	REGISTERED_KERNEL_WRAPPER_TYPED_LAUNCH(kernel_t);
+	REGISTERED_KERNEL_WRAPPER_BATCHES(kernel_t);
 
 	using run_index_type                = uint_t<RunIndexSize>;
 	using uncompressed_index_type       = uint_t<UncompressedIndexSize>;
@@ -50,6 +51,49 @@ public:
 		uncompressed_type* decompressed, const uncompressed_type* run_data, const position_offset_type* run_start_positions,
 		const run_index_type* position_anchors, position_offset_size_type uncompressed_segment_length,
 		uncompressed_index_size_type num_anchors, run_index_size_type num_element_runs, uncompressed_index_size_type uncompressed_length);
+
+	/// the argument map unpacked: sink(launch()'s parameters) — for the one launch and for a piece of a batch alike
+	template <typename Sink>
+	static void with_typed_parameters(const launch_configuration_t&, const arguments_type& arguments, Sink&& sink)
+	{
+		auto decompressed                = argument<uncompressed_type*>(arguments, "decompressed");
+		auto run_data                    = argument<const uncompressed_type*>(arguments, "run_data");
+		auto run_start_positions         = argument<const position_offset_type*>(arguments, "run_start_positions");
+		auto position_anchors            = argument<const run_index_type*>(arguments, "position_anchors");
+		auto uncompressed_segment_length = argument<position_offset_size_type>(arguments, "segment_length");
+		auto num_anchors                 = argument<uncompressed_index_size_type>(arguments, "num_anchors");
+		auto num_element_runs            = argument<run_index_size_type>(arguments, "num_element_runs");
+		auto uncompressed_length         = argument<uncompressed_index_size_type>(arguments, "length");
+		sink(decompressed, run_data, run_start_positions, position_anchors, uncompressed_segment_length, num_anchors, num_element_runs, uncompressed_length);
+	}
+
+	/// a column as one piece of a batch (giddy/batch.hpp).  hints: [0] outputs and [1] runs of all pieces — the batch's mean run picks the build of the
+	/// decoder, as launch() does for one column —, [2] some piece's run arrays are not 16-byte aligned (no dense build then)
+	static void add_piece(batch::table_t& table, const launch_configuration_t& piece_config,
+		uncompressed_type* decompressed, const uncompressed_type* run_data, const position_offset_type* run_start_positions,
+		const run_index_type* position_anchors, position_offset_size_type uncompressed_segment_length,
+		uncompressed_index_size_type num_anchors, run_index_size_type num_element_runs, uncompressed_index_size_type uncompressed_length)
+	{
+		if (uncompressed_segment_length == 0) { throw std::invalid_argument("The segment length must be a positive number"); }
+		table.hints[0] += uncompressed_length; table.hints[1] += num_element_runs;
+		if (!memory_access::is_aligned(run_start_positions, 16) || !memory_access::is_aligned(run_data, 16)) { table.hints[2] = 1; }
+		table.add(piece_config, decompressed, run_data, run_start_positions, position_anchors, uncompressed_segment_length, num_anchors, num_element_runs, uncompressed_length);
+	}
+
+	/// ... and the batch's ONE launch
+	static void launch_batch(stream::id_t stream, const batch::on_device_t& tables)
+	{
+		constexpr bool has_groups = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled;
+		const uint64_t outputs = tables.hints[0], runs = tables.hints[1];
+		const bool sparse = has_groups && runs != 0 && outputs / runs >= 16;
+		const bool dense = GIDDY_RUN_DENSE_KERNEL && has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
+		const void* kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false, false>>);
+		if constexpr (has_groups) {   // (the other instantiations have the one build)
+			if (dense) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, true, true>>); }
+			else if (!sparse) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, true, false>>); }
+		}
+		cuda::enqueue_launch(kernel, stream, launch_configuration_t(tables.num_blocks, tables.block_size, tables.dynamic_shared_memory_size), tables.pieces, tables.blocks);
+	}
 
 	/// the builds of the decoder that launch() may run with the caller's configuration
 	static const void* base_kernel()   { return reinterpret_cast<const void*>(decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize>); }
@@ -81,16 +125,7 @@ launch_configuration_t GIDDY_RPE_KERNEL::resolve_launch_configuration(
 GIDDY_RPE_TEMPLATE
 void GIDDY_RPE_KERNEL::enqueue_launch_with(stream::id_t stream, const launch_configuration_t& launch_config, const arguments_type& arguments) const
 {
-	auto decompressed                = argument<uncompressed_type*>(arguments, "decompressed");
-	auto run_data                    = argument<const uncompressed_type*>(arguments, "run_data");
-	auto run_start_positions         = argument<const position_offset_type*>(arguments, "run_start_positions");
-	auto position_anchors            = argument<const run_index_type*>(arguments, "position_anchors");
-	auto uncompressed_segment_length = argument<position_offset_size_type>(arguments, "segment_length");
-	auto num_anchors                 = argument<uncompressed_index_size_type>(arguments, "num_anchors");
-	auto num_element_runs            = argument<run_index_size_type>(arguments, "num_element_runs");
-	auto uncompressed_length         = argument<uncompressed_index_size_type>(arguments, "length");
-	launch(stream, launch_config, decompressed, run_data, run_start_positions, position_anchors,
-		uncompressed_segment_length, num_anchors, num_element_runs, uncompressed_length);
+	with_typed_parameters(launch_config, arguments, [&](auto... parameters) { launch(stream, launch_config, parameters...); });
 }
 
 GIDDY_RPE_TEMPLATE

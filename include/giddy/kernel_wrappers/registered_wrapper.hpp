@@ -67,3 +67,18 @@ public: \
 	{ \
 		cuda::kernel::detail::launch_packed(&subclass_name::launch, stream_id, launch_config, parameters, sizes, count); \
 	}
+
+// For a wrapper that decodes BATCHES (giddy/batch.hpp).  The wrapper defines
+//   template <typename Sink> static void with_typed_parameters(const launch_configuration_t&, const arguments_type&, Sink&&)   the map unpacked: sink(typed parameters of launch()...)
+//   static void add_piece(batch::table_t&, const launch_configuration_t&, typed parameters...)                              (this macro's default: table.add)
+//   static void launch_batch(stream::id_t, const batch::on_device_t&)                                                        the ONE launch
+// and this macro routes the three virtuals of cuda::kernel_t through them — enqueue_launch_with() included, so that the single launch and
+// the piece of a batch read the caller's map by the same lines.
+#define REGISTERED_KERNEL_WRAPPER_BATCHES(subclass_name) \
+public: \
+	bool launches_batches() const override final { return true; } \
+	void add_to_batch(cuda::batch::table_t& table, const launch_configuration_t& piece_config, const arguments_type& piece_arguments) const override final \
+	{ \
+		with_typed_parameters(piece_config, piece_arguments, [&](auto... parameters) { subclass_name::add_piece(table, piece_config, parameters...); }); \
+	} \
+	void enqueue_launch_of_batch(stream::id_t stream, const cuda::batch::on_device_t& tables) const override final { subclass_name::launch_batch(stream, tables); }

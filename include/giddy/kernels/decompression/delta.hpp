@@ -45,6 +45,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/wave64.hpp"
@@ -114,20 +115,6 @@ struct row_traits {
 	// type the in-row prefix is formed in: 64*E elements of at most 2^(8*CompressedSize)-1 each
 	using scan_type = typename std::conditional<(UncompressedSize <= 4 || CompressedSize <= 2), uint32_t, uint64_t>::type;
 };
-
-/// (measurement aid) the workgroup's place in the order the chunks are handed out: blockIdx.x — or, with GIDDY_DELTA_ROTATE_WORKGROUPS, the
-/// workgroups of every group of 8 (one per XCD, the dispatcher deals them round-robin) rotated by the group's number, so that an XCD does
-/// not keep to the same slice of every 8 x 4 chunks
-#ifndef GIDDY_DELTA_ROTATE_WORKGROUPS
-#define GIDDY_DELTA_ROTATE_WORKGROUPS 0
-#endif
-__device__ __forceinline__ unsigned workgroup_in_order()
-{
-	if (!GIDDY_DELTA_ROTATE_WORKGROUPS) { return blockIdx.x; }
-	const unsigned group = blockIdx.x / 8, within = blockIdx.x % 8;
-	if (group * 8 + 8 > gridDim.x) { return blockIdx.x; }
-	return group * 8 + (within + group) % 8;
-}
 
 /// One row: load, scan, return the exclusive-of-row prefixes; `valid` = elements of the row inside the input
 template <unsigned UncompressedSize, unsigned CompressedSize>
@@ -265,17 +252,18 @@ struct chunk_anchors {
 };
 
 /// wave path: this wavefront decompresses whole segments on its own (several short ones per chunk)
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk(L / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
@@ -320,18 +308,19 @@ __device__ __forceinline__ void wave_per_segment(
 /// (at most 4 KiB) arrives first, as 16-byte-per-lane loads, and is handed out row by row through wave-private LDS.
 /// (Measured with the bare access pattern, tools/stream_probe4.hip: 68 % of peak with 2-byte loads per row, 73 % with
 /// wide loads through LDS; the decoder itself: 63 -> see DESIGN.md.)
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_segment_with_staged_input(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	using C = typename traits::compressed_type;
 	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk(L / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
@@ -374,17 +363,18 @@ __device__ __forceinline__ void wave_per_segment_with_staged_input(
 /// wave path for segments that are not whole rows (segment_length % E == 0 is all it takes for 16-byte access:
 /// 1000, 3000, 10000 ...): rows are laid out from each segment's start, the last row of a segment is cut short,
 /// and the next segment's first row begins right where it ends — same pipeline, rows of two lengths.
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_ragged_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	constexpr unsigned R = traits::rows_in_flight;
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
@@ -441,18 +431,19 @@ __device__ __forceinline__ void wave_per_ragged_segment(
 /// (segments of at least a row) — lanes are whole groups of E elements on either side, since segment lengths are multiples of E — and the lanes
 /// behind it count from the new segment's anchor: value = anchor' + (prefix - the prefix at the boundary).  Same pipeline: the next rows' loads
 /// before these rows' stores.
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_ragged_segment_in_aligned_rows(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
 	using scan_type = typename traits::scan_type;
 	constexpr unsigned R = traits::rows_in_flight > 4 ? 4 : traits::rows_in_flight;   // (8 rows of 2-byte elements with their bounds in flight spill registers)
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
@@ -567,10 +558,11 @@ __host__ __device__ inline uint64_t wave_chunk_length_of(uint64_t L)
 /// `Staged`: the chunk's input — exactly the staging area's rows_per_chunk rows, beginning 16-byte aligned: the caller checks — goes through wave-private
 /// LDS first, in 16-byte loads (64-bit elements from 1-2-byte deltas, whose rows are 2-4 bytes per lane); the rows' ANCHORS are still gathered
 /// a few rows ahead of their use.
-template <unsigned UncompressedSize, unsigned CompressedSize, bool Staged = false, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, bool Staged = false, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_rows_of_short_segments(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging = nullptr)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging = nullptr,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -581,8 +573,8 @@ __device__ __forceinline__ void wave_rows_of_short_segments(
 	constexpr unsigned log2_E = traits::E == 8 ? 3 : (traits::E == 4 ? 2 : 1);
 	static_assert((1u << log2_E) == traits::E, "E is 2, 4 or 8");
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk_of<UncompressedSize, CompressedSize>(L);
 	const bool windows = chunks_are_windows<UncompressedSize, CompressedSize>(L);
 	const uint64_t chunk_length = wave_chunk_length_of<UncompressedSize, CompressedSize>(L);   // at most rows_per_chunk rows: 32-bit positions within a chunk
@@ -687,10 +679,11 @@ __device__ __forceinline__ void wave_rows_of_short_segments(
 /// ... and with the chunk's input staged through wave-private LDS first (as wave_per_segment_with_staged_input does for whole-row segments): for the
 /// instantiations whose rows are only 2-4 input bytes per lane — 64-bit values from 1-2-byte deltas — element-sized loads per row are what limits
 /// the ragged paths (59-61 % with rows by segment or by cache line alike).  `in` must be 16-byte aligned and the chunk leave 16 bytes of the staging free.
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_ragged_segment_with_staged_input(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint8_t* staging,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -698,8 +691,8 @@ __device__ __forceinline__ void wave_per_ragged_segment_with_staged_input(
 	using scan_type = typename traits::scan_type;
 	typedef uint32_t piece_t __attribute__((ext_vector_type(4)));
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	const uint64_t segments_per_chunk = segments_per_wave_chunk((L + traits::row - 1) / traits::row);
 	const uint64_t chunk_length = segments_per_chunk * L;
 	const uint64_t num_chunks = (n + chunk_length - 1) / chunk_length;
@@ -783,10 +776,11 @@ __host__ __device__ inline bool any_length_by_windows(uint64_t L)
 /// `AnyAlignment` (decompress_at_any_alignment): `out` and `in` aligned for their elements only.  Rows follow the output's 1 KiB boundaries as before — every row but the
 /// window's first is then stored 16 bytes per lane at aligned addresses, wherever the column begins; the first one, up to the boundary, goes element by element; the
 /// rows' loads are 16 bytes per lane at whatever address (gfx950 takes them).
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_windows_of_any_segments(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases)   // (LDS: traits::row entries, this wavefront's)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases,   // (LDS: traits::row entries, this wavefront's)
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -797,8 +791,8 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 	constexpr unsigned R = Patches::enabled ? 1 : 2;   // (this path's registers count for every path of the kernel: the fused kernels' cursors leave room for one row in flight)
 	constexpr unsigned log2_E = E == 8 ? 3 : (E == 4 ? 2 : 1);
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	constexpr uint64_t window = (uint64_t) rows_per_chunk * traits::row;
 	const uint64_t num_chunks = (n + window - 1) / window;
 	const unsigned segment_length = (unsigned) L;
@@ -914,10 +908,11 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 /// rows of every sweep, so a segment of up to waves*R rows needs ONE barrier.  (Round 4 measured every wavefront taking every num_waves-th row instead — the workgroup
 /// reading and writing num_waves consecutive rows at every step, as the fixed-rate decoders' tiles do: slower or equal everywhere (profiles/r04_delta_segment_lengths.txt),
 /// and its per-row totals cost every path of the kernel 25 registers; not kept.)
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void block_per_segment(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches,
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -936,7 +931,7 @@ __device__ __forceinline__ void block_per_segment(
 	if (GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS && waves_per_segment * 2 <= num_waves) {
 		const unsigned segments_per_block = num_waves / waves_per_segment;
 		const unsigned mine_of_block = w / waves_per_segment, part = w % waves_per_segment;
-		for (uint64_t first = (uint64_t) blockIdx.x * segments_per_block; first < num_segments; first += (uint64_t) gridDim.x * segments_per_block) {
+		for (uint64_t first = (uint64_t) grid.block() * segments_per_block; first < num_segments; first += (uint64_t) grid.blocks() * segments_per_block) {
 			const uint64_t s = first + mine_of_block;
 			const bool working = mine_of_block < segments_per_block && s < num_segments;
 			const uint64_t start = s * L, end = working ? ((start + L < n) ? start + L : n) : start;
@@ -964,7 +959,7 @@ __device__ __forceinline__ void block_per_segment(
 		return;
 	}
 
-	for (uint64_t s = blockIdx.x; s < num_segments; s += gridDim.x) {
+	for (uint64_t s = grid.block(); s < num_segments; s += grid.blocks()) {
 		const uint64_t start = s * L;
 		const uint64_t end = (start + L < n) ? start + L : n;
 		U base = anchors[s];
@@ -1001,16 +996,17 @@ __device__ __forceinline__ void block_per_segment(
 }
 
 /// general path: any segment length, any alignment — segmented scan with reset at segment heads
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void segmented(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
-	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches)
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches,
+	Grid grid = Grid())
 {
 	using U = uint_t<UncompressedSize>;
 	enum : unsigned { E = 4, row = 64 * E };
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) workgroup_in_order() * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	// a wavefront owns a run of whole segments spanning at least one row
 	const uint64_t segments_per_chunk = L >= row ? 1 : (row + L - 1) / L;
 	const uint64_t chunk_length = segments_per_chunk * L;
@@ -1079,11 +1075,12 @@ template <unsigned UncompressedSize, unsigned CompressedSize> constexpr unsigned
 }
 
 /// picks the path (wave-uniform decision): see the notes at the top of this file
-template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches>
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>* __restrict__ decompressed, const uint_t<CompressedSize>* __restrict__ compressed_input,
 	const uint_t<UncompressedSize>* __restrict__ anchor_values, uint64_t n, uint64_t L, Patches patches,
-	uint8_t* provided_input_staging = nullptr)   // (the fused kernel's: 4 x staged_chunk_bytes, shared with its patch windows)
+	uint8_t* provided_input_staging = nullptr,   // (the fused kernel's: 4 x staged_chunk_bytes, shared with its patch windows)
+	Grid grid = Grid())   // (launch_grid.hpp: the launch's own, or a batch piece's part of it)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	if (n == 0 || L == 0) { return; }
@@ -1095,7 +1092,7 @@ __device__ __forceinline__ void decompress(
 	if (any_length_by_windows<UncompressedSize, CompressedSize>(L) && wave64::per_block() <= any_length_waves
 		&& memory_access::is_aligned(decompressed, 16) && memory_access::is_aligned(compressed_input, traits::E * CompressedSize)) {
 		__shared__ uint_t<UncompressedSize> bases_of_segments[any_length_waves][traits::row];
-		wave_windows_of_any_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, bases_of_segments[wave64::index_in_block()]);
+		wave_windows_of_any_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, bases_of_segments[wave64::index_in_block()], grid);
 		return;
 	}
 	if (vector_access && takes_wave_path<UncompressedSize, CompressedSize>(n, L)) {
@@ -1109,7 +1106,7 @@ __device__ __forceinline__ void decompress(
 			if (staging != nullptr && L % traits::row == 0 && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)) {
 				wave_per_segment_with_staged_input<UncompressedSize, CompressedSize>(
 					decompressed, compressed_input, anchor_values, n, L, patches,
-					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>(), grid);
 				return;
 			}
 			// (segments sharing rows, in chunks of exactly the staging area's size: staged too)
@@ -1118,7 +1115,7 @@ __device__ __forceinline__ void decompress(
 				&& wave_chunk_length_of<UncompressedSize, CompressedSize>(L) == (uint64_t) rows_per_chunk * traits::row) {
 				wave_rows_of_short_segments<UncompressedSize, CompressedSize, true>(
 					decompressed, compressed_input, anchor_values, n, L, patches,
-					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>(), grid);
 				return;
 			}
 			// (ragged segments of at least a row, the chunk's bytes 16-byte aligned: staged as well, rows by the output's cache lines)
@@ -1126,20 +1123,20 @@ __device__ __forceinline__ void decompress(
 				&& (rows_per_segment > rows_per_chunk || segments_per_wave_chunk(rows_per_segment) * L * CompressedSize + 16 <= staged_chunk_bytes<UncompressedSize, CompressedSize>())) {
 				wave_per_ragged_segment_with_staged_input<UncompressedSize, CompressedSize>(
 					decompressed, compressed_input, anchor_values, n, L, patches,
-					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>());
+					staging + wave64::index_in_block() * staged_chunk_bytes<UncompressedSize, CompressedSize>(), grid);
 				return;
 			}
 		}
-		if (L % traits::row == 0 && !GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
-		else if (short_segments_share_rows<UncompressedSize, CompressedSize>(L)) { wave_rows_of_short_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
-		else if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && L >= traits::row) { wave_per_ragged_segment_in_aligned_rows<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
-		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches); }
+		if (L % traits::row == 0 && !GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
+		else if (short_segments_share_rows<UncompressedSize, CompressedSize>(L)) { wave_rows_of_short_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, nullptr, grid); }
+		else if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && L >= traits::row) { wave_per_ragged_segment_in_aligned_rows<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
+		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
 	}
 	else if (vector_access && wave64::per_block() <= max_waves_per_block) {
-		block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
+		block_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid);
 	}
 	else {
-		segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches);
+		segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid);
 	}
 }
 
@@ -1156,6 +1153,19 @@ __global__ void decompress(
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length, sorted_patches::none());
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record, its body
+/// — every path of it — on the piece's part of the grid
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
+			piece.get<uint_t<UncompressedSize>*>(0), piece.get<const uint_t<CompressedSize>*>(1), piece.get<const uint_t<UncompressedSize>*>(2),
+			piece.get<size_type_by_index_size<IndexSize>>(3), piece.get<size_type_by_index_size<IndexSize>>(4), sorted_patches::none(), nullptr, grid);
+	}
+};
 
 /// The same for a column at addresses aligned for its elements only (a slice [a, b) decoded into `decompressed + a`, the deltas at `compressed_input + a`), where
 /// `decompress` goes element by element (17-21 % of the HBM peak): windows of the column whose rows follow the output's 1 KiB boundaries, every element finding

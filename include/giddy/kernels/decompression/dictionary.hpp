@@ -25,6 +25,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
@@ -71,7 +72,7 @@ template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr boo
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -79,7 +80,8 @@ __device__ __forceinline__ void translate(
 	Lookup                                            lookup,
 	Patches                                           patches,
 	chunk_key_storage<UncompressedSize, DictionaryIndexSize>* chunk_staging,
-	AfterLoads                                        after_loads = AfterLoads())
+	AfterLoads                                        after_loads = AfterLoads(),
+	Grid                                              grid = Grid())
 {
 	using key_type = uint_t<DictionaryIndexSize>;
 	using value_type = uint_t<UncompressedSize>;
@@ -90,10 +92,10 @@ __device__ __forceinline__ void translate(
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
 	if constexpr (!AnyAlignment && by_wave_chunks<Patches::enabled, UncompressedSize, DictionaryIndexSize, RestagedDictionary>()) {   // (any alignment: tiles only)
-		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging);
+		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging, grid);
 	}
 	else {
-		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment>(decompressed, compressed_input, n, produce_group, produce_one, after_loads);
+		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);
 	}
 }
 
@@ -101,7 +103,7 @@ __device__ __forceinline__ void translate(
 #define GIDDY_DICT_WIDE_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 4-8-byte values and small dictionaries (0: no cap): with write-through stores 6-7 are 1.5-2.4 points faster than 8
 #endif
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches, bool AnyAlignment = false>
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -110,7 +112,8 @@ __device__ __forceinline__ void decompress(
 	uint64_t                                          num_dictionary_entries,
 	bool                                              cache_dictionary_in_shared_memory,
 	Patches                                           patches,
-	bool                                              chunk_key_staging_in_dynamic_lds = false)   // (behind the dictionary)
+	bool                                              chunk_key_staging_in_dynamic_lds = false,   // (behind the dictionary)
+	Grid                                              grid = Grid())                              // (launch_grid.hpp: the launch's own, or a batch piece's part of it)
 {
 	using value_type = uint_t<UncompressedSize>;
 	using key_type = uint_t<DictionaryIndexSize>;
@@ -163,18 +166,18 @@ __device__ __forceinline__ void decompress(
 			staged_yet = true;
 		};
 		translate<UncompressedSize, DictionaryIndexSize, true, AnyAlignment>(
-			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage);
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage, grid);
 	}
 	else if (cache_dictionary_in_shared_memory) {
 		value_type* staged = reinterpret_cast<value_type*>(dynamic_lds);
 		for (uint64_t i = threadIdx.x; i < num_dictionary_entries; i += blockDim.x) { staged[i] = dictionary_entries[i]; }
 		__syncthreads();
 		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment>(
-			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging);
+			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stream_tiles::nothing_to_do(), grid);
 	}
 	else {
 		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment>(
-			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches, chunk_staging);
+			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches, chunk_staging, stream_tiles::nothing_to_do(), grid);
 	}
 }
 
@@ -212,6 +215,20 @@ __global__ void decompress_at_any_alignment(
 	detail::decompress<UncompressedSize, DictionaryIndexSize, sorted_patches::none, true>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory, sorted_patches::none());
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record,
+/// its body on the piece's part of the grid.  `AnyAlignment`: the build for pieces at any element offset (the wrapper takes it for the whole batch when one piece asks).
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize, bool AnyAlignment = false>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		detail::decompress<UncompressedSize, DictionaryIndexSize, sorted_patches::none, AnyAlignment>(
+			piece.get<uint_t<UncompressedSize>*>(0), piece.get<const uint_t<DictionaryIndexSize>*>(1), piece.get<const uint_t<UncompressedSize>*>(2),
+			piece.get<size_type_by_index_size<IndexSize>>(3), piece.get<size_type_by_index_size<DictionaryIndexSize>>(4), piece.get<bool>(5),
+			sorted_patches::none(), false, grid);
+	}
+};
 
 namespace patched {
 

@@ -11,6 +11,7 @@
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/on_device/stream_tiles.hpp"
 #include "giddy/on_device/wave64.hpp"
@@ -33,6 +34,31 @@ struct pad_high_bytes {
 	__host__ __device__ result_type operator()(const argument_type& x) const { return (result_type) x; }
 };
 
+namespace detail {
+
+/// the kernels' body (`AnyAlignment`: the build of stream_tiles::transform for arrays aligned for their elements only; `grid`: launch_grid.hpp)
+template <unsigned UncompressedSize, unsigned CompressedSize, cuda::endianness_t UncompressedEndianness, bool AnyAlignment = false, typename Grid = launch_grid::whole>
+__device__ __forceinline__ void decompress(
+	uint_t<UncompressedSize>*      __restrict__  decompressed,
+	const uint_t<CompressedSize>*  __restrict__  compressed_input,
+	uint64_t                                     length,
+	Grid                                         grid = Grid())
+{
+	using U = uint_t<UncompressedSize>;
+	using C = uint_t<CompressedSize>;
+	constexpr unsigned G = stream_tiles::group_size<U>::value;
+	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
+	stream_tiles::transform<C, U, stream_tiles::steps_per_tile, memory_access::non_temporal, AnyAlignment>(decompressed, compressed_input, length,
+		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
+		},
+		[&](uint64_t, C x) { return widen(x); },
+		stream_tiles::nothing_to_do(), stream_tiles::nothing_to_prepare(), grid);
+}
+
+} // namespace detail
+
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize,
 	cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness,
 	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
@@ -41,16 +67,7 @@ __global__ void decompress(
 	const uint_t<CompressedSize>*  __restrict__  compressed_input,
 	size_type_by_index_size<IndexSize>           length)
 {
-	using U = uint_t<UncompressedSize>;
-	using C = uint_t<CompressedSize>;
-	constexpr unsigned G = stream_tiles::group_size<U>::value;
-	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
-	stream_tiles::transform<C, U>(decompressed, compressed_input, length,
-		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
-			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
-		},
-		[&](uint64_t, C x) { return widen(x); });
+	detail::decompress<UncompressedSize, CompressedSize, UncompressedEndianness>(decompressed, compressed_input, length);
 }
 
 /// The same for a column at an address aligned for its elements only, or inside a 128-byte line: the `AnyAlignment` build of stream_tiles::transform, launched
@@ -63,17 +80,20 @@ __global__ void decompress_at_any_alignment(
 	const uint_t<CompressedSize>*  __restrict__  compressed_input,
 	size_type_by_index_size<IndexSize>           length)
 {
-	using U = uint_t<UncompressedSize>;
-	using C = uint_t<CompressedSize>;
-	constexpr unsigned G = stream_tiles::group_size<U>::value;
-	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
-	stream_tiles::transform<C, U, stream_tiles::steps_per_tile, memory_access::non_temporal, true>(decompressed, compressed_input, length,
-		[&](uint64_t, const memory_access::group<C, G>& in, memory_access::group<U, G>& out) {
-			#pragma unroll
-			for (unsigned j = 0; j < G; j++) { out[j] = widen(in[j]); }
-		},
-		[&](uint64_t, C x) { return widen(x); });
+	detail::decompress<UncompressedSize, CompressedSize, UncompressedEndianness, true>(decompressed, compressed_input, length);
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record, its body
+/// on the piece's part of the grid
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize, cuda::endianness_t UncompressedEndianness = cuda::compilation_target_endianness, bool AnyAlignment = false>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		detail::decompress<UncompressedSize, CompressedSize, UncompressedEndianness, AnyAlignment>(
+			piece.get<uint_t<UncompressedSize>*>(0), piece.get<const uint_t<CompressedSize>*>(1), piece.get<size_type_by_index_size<IndexSize>>(2), grid);
+	}
+};
 
 namespace patched {
 

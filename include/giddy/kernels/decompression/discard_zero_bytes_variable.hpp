@@ -39,6 +39,7 @@
 
 #include "giddy/common.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -961,6 +962,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 	detail::fill(storage.masks);   // (ends with the barrier)
 	detail::decompress_as_block<IndexSize, UncompressedSize, ElementSizesContainerSize>(blockIdx.x, gridDim.x, storage.staging, storage.masks,
 		decompressed, compressed_data, packed_element_sizes, position_anchors, segment_length, length, min_represented_element_size, bits_per_element_size);
+}
+
+/// The pieces of a batch launch (giddy/batch.hpp): `decompress` with its parameters out of the calling workgroup's piece's record, as that piece's block
+/// (a kernel of its own rather than batch::decode_pieces<>: the register and occupancy attributes above are part of how this decoder was tuned)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress_pieces(
+	const batch::piece_t* __restrict__ pieces, const batch::block_t* __restrict__ blocks)
+{
+	const batch::located_piece mine = batch::piece_of_this_block(pieces, blocks);
+	const element_size_t min_represented_element_size = mine.piece.get<element_size_t>(6);
+	const native_word_t bits_per_element_size = mine.piece.get<native_word_t>(7);
+	__shared__ __attribute__((aligned(16))) detail::block_storage<UncompressedSize> storage;
+	if constexpr (UncompressedSize == 2) { detail::fill_pairs(storage.masks, min_represented_element_size, bits_per_element_size); }
+	detail::fill(storage.masks);   // (ends with the barrier)
+	detail::decompress_as_block<IndexSize, UncompressedSize, ElementSizesContainerSize>(mine.grid.block(), mine.grid.blocks(), storage.staging, storage.masks,
+		mine.piece.get<uint_t<UncompressedSize>*>(0), mine.piece.get<const uint8_t*>(1), mine.piece.get<const uint_t<ElementSizesContainerSize>*>(2),
+		mine.piece.get<const uint_t<IndexSize>*>(3), mine.piece.get<size_type_by_index_size<IndexSize>>(4), mine.piece.get<size_type_by_index_size<IndexSize>>(5),
+		min_represented_element_size, bits_per_element_size);
 }
 
 // ---- long segments: finer anchors from the size fields ----------------------------------------------------------------------

@@ -27,6 +27,7 @@
 #include "giddy/kernels/launch_config_resolution_params.hpp"
 #include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/stream_tiles.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/on_device/wave64.hpp"
 #include "giddy/util/math.hpp"
 
@@ -58,7 +59,7 @@ __device__ __forceinline__ void divide(uint64_t p, uint64_t l, uint64_t& quotien
 
 namespace detail {
 
-template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, typename Patches, bool AnyAlignment = false>
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void decompress(
 	Uncompressed*       __restrict__    decompressed,
 	const Compressed*   __restrict__    compressed_input,
@@ -66,7 +67,8 @@ __device__ __forceinline__ void decompress(
 	                    __restrict__    segment_model_coefficients,
 	uint64_t                            length,
 	uint64_t                            L,
-	Patches                             patches)
+	Patches                             patches,
+	Grid                                grid = Grid())   // (launch_grid.hpp: the launch's own, or a batch piece's part of it)
 {
 	using model_index_type = typename UnaryModelFunction::index_type;
 	using coefficients_type = typename UnaryModelFunction::coefficients_type;
@@ -121,12 +123,12 @@ __device__ __forceinline__ void decompress(
 		constexpr bool stages = stream_tiles::stages_chunk_input<Compressed, Uncompressed, stage_up_to>();
 		__shared__ stream_tiles::chunk_input_storage<Compressed, Uncompressed, stages> chunk_staging;
 		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8, stage_up_to>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches,
-			stream_tiles::nothing_to_do(), &chunk_staging);
+			stream_tiles::nothing_to_do(), &chunk_staging, grid);
 	}
 	else {
 		// (write-through stores where a segment's record is its one reference value: +1...2 points; with a line per segment -1...-4)
 		constexpr int stores = sizeof(coefficients_type) == sizeof(Uncompressed) ? memory_access::wide_output_policy<sizeof(Uncompressed)>(GIDDY_FOR_STORE_POLICY) : (int) memory_access::non_temporal;
-		stream_tiles::transform<Compressed, Uncompressed, steps_per_tile<Uncompressed, Compressed>(), stores, AnyAlignment>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare);
+		stream_tiles::transform<Compressed, Uncompressed, steps_per_tile<Uncompressed, Compressed>(), stores, AnyAlignment>(decompressed, compressed_input, length, produce_group, produce_one, stream_tiles::nothing_to_do(), prepare, grid);
 	}
 }
 
@@ -163,6 +165,19 @@ __global__ void decompress_at_any_alignment(
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, sorted_patches::none, true>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length, sorted_patches::none());
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record,
+/// its body on the piece's part of the grid.  `AnyAlignment`: the build for pieces at any element offset (taken for the whole batch when one piece asks).
+template <unsigned IndexSize, typename Uncompressed, typename Compressed, typename UnaryModelFunction, bool AnyAlignment = false>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, sorted_patches::none, AnyAlignment>(
+			piece.get<Uncompressed*>(0), piece.get<const Compressed*>(1), piece.get<const typename UnaryModelFunction::coefficients_type*>(2),
+			piece.get<size_type_by_index_size<IndexSize>>(3), piece.get<size_type_by_index_size<IndexSize>>(4), sorted_patches::none(), grid);
+	}
+};
 
 namespace patched {
 

@@ -22,6 +22,7 @@
 #include "giddy/kernels/decompression/run_expansion.hpp"
 #include "giddy/kernels/decompression/run_anchors.hpp"
 #include "giddy/kernels/launch_config_resolution_params.hpp"
+#include "giddy/on_device/batch_pieces.hpp"
 #include "giddy/util/math.hpp"
 
 namespace cuda {
@@ -66,7 +67,7 @@ struct chunks_to_take {
 /// is 15 registers lighter and, more to the point, its waits are not the stricter of two paths': with the compressed input NOT in the Infinity
 /// Cache it is 10 points faster at mean runs of 32 (the wrapper launches it for columns whose mean run is 16 or more, where no chunk has enough
 /// runs for a group anyway).
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups, bool GroupsAlways = false>
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups, bool GroupsAlways = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*             __restrict__  decompressed,
 	const uint_t<UncompressedSize>*       __restrict__  run_data,
@@ -77,7 +78,8 @@ __device__ __forceinline__ void decompress(
 	size_type_by_index_size<UncompressedIndexSize>      num_segments,
 	size_type_by_index_size<RunIndexSize>               num_element_runs,
 	size_type_by_index_size<UncompressedIndexSize>      total_uncompressed_length,
-	const chunks_to_take                                mine = chunks_to_take())
+	const chunks_to_take                                mine = chunks_to_take(),
+	Grid                                                grid = Grid())   // (launch_grid.hpp: the launch's own, or a batch piece's part of it)
 {
 	using namespace run_expansion;
 	__shared__ tile_entry tables[max_waves_per_block][tile_words];
@@ -98,8 +100,8 @@ __device__ __forceinline__ void decompress(
 	if (wave64::index_in_block() >= working_waves) { return; }
 	const unsigned lane = wave64::lane_id();
 	tile_entry* table = tables[wave64::index_in_block()];
-	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
+	const uint64_t wave = (uint64_t) grid.block() * working_waves + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * working_waves;
 	const uint64_t L = segment_length, n = total_uncompressed_length, num_runs = num_element_runs;
 	using length_type = typename std::conditional<(RunLengthSize > 4), uint64_t, uint32_t>::type;   // what a run's length is computed with
 
@@ -345,6 +347,22 @@ __global__ void decompress_sparse_runs(
 	detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false>(decompressed, run_data, run_lengths,
 		segment_position_anchors, segment_position_anchor_intra_run_offsets, segment_length, num_segments, num_element_runs, total_uncompressed_length);
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record, the body
+/// — with or without the groups-of-runs path, as the three kernels above; the wrapper picks by the batch's mean run — on the piece's part of the grid
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize, bool WithGroups, bool GroupsAlways>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		using size_type = size_type_by_index_size<UncompressedIndexSize>;
+		detail::decompress<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, WithGroups, GroupsAlways>(
+			piece.get<uint_t<UncompressedSize>*>(0), piece.get<const uint_t<UncompressedSize>*>(1), piece.get<const uint_t<RunLengthSize>*>(2),
+			piece.get<const uint_t<RunIndexSize>*>(3), piece.get<const uint_t<RunLengthSize>*>(4),
+			piece.get<size_type>(5), piece.get<size_type>(6), piece.get<size_type_by_index_size<RunIndexSize>>(7), piece.get<size_type>(8),
+			detail::chunks_to_take(), grid);
+	}
+};
 
 /// LONG segments of sparse runs in ONE launch (round 4): a workgroup per anchored segment first finds the entry point of every `fine::sub`-th output of
 /// ITS segment — run_anchors.hpp, finer_anchors_of_one_segment: the segment's run lengths streamed once, their ends scanned into LDS, a binary search

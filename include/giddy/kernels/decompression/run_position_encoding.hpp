@@ -56,7 +56,7 @@ namespace detail {
 /// before the run; the anchoring period, except when the wrapper has put finer anchors into long segments (run_anchors.hpp: the
 /// anchors then come every `anchoring_period`, a divisor of it and at least a tile long, while the positions still count from
 /// the starts of the segments the column was compressed in).
-template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups = true, bool GroupsAlways = false>
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups = true, bool GroupsAlways = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void decompress(
 	uint_t<UncompressedSize>*          __restrict__  decompressed,
 	const uint_t<UncompressedSize>*    __restrict__  run_data,
@@ -67,7 +67,8 @@ __device__ __forceinline__ void decompress(
 	size_type_by_index_size<RunIndexSize>            num_anchors,
 	size_type_by_index_size<RunIndexSize>            num_element_runs,
 	size_type_by_index_size<UncompressedIndexSize>   uncompressed_length,
-	const run_length_encoding::detail::chunks_to_take mine = run_length_encoding::detail::chunks_to_take())   // (decompress_long_segments: one workgroup's chunks, its anchors in LDS)
+	const run_length_encoding::detail::chunks_to_take mine = run_length_encoding::detail::chunks_to_take(),   // (decompress_long_segments: one workgroup's chunks, its anchors in LDS)
+	Grid                                             grid = Grid())                                            // (launch_grid.hpp: the launch's own, or a batch piece's part of it)
 {
 	static_assert(PositionsAreRelative || PositionOffsetSize >= UncompressedIndexSize,
 		"If run positions are in absolute values, their type must be able to cover the entire potential range of data");
@@ -87,8 +88,8 @@ __device__ __forceinline__ void decompress(
 	if (wave64::index_in_block() >= working_waves) { return; }
 	const unsigned lane = wave64::lane_id();
 	tile_entry* table = tables[wave64::index_in_block()];
-	const uint64_t wave = (uint64_t) blockIdx.x * working_waves + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * working_waves;
+	const uint64_t wave = (uint64_t) grid.block() * working_waves + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * working_waves;
 	const uint64_t L = anchoring_period, n = uncompressed_length, num_runs = num_element_runs;
 
 	// Short segments are taken a tile's worth at a time — the runs of consecutive segments are consecutive, so k segments
@@ -351,6 +352,22 @@ __global__ void decompress_sparse_runs(
 	detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false>(
 		decompressed, run_data, run_start_positions, position_anchors, anchoring_period, anchoring_period, num_anchors, num_element_runs, uncompressed_length);
 }
+
+/// A piece of a batch launch (giddy/batch.hpp; launched as batch::decode_pieces<piece_body<...>>): `decompress`'s parameters out of the piece's record, the body
+/// — with or without the groups-of-runs path, as the three kernels above; the wrapper picks by the batch's mean run — on the piece's part of the grid
+template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, bool PositionsAreRelative, unsigned RunIndexSize, bool WithGroups, bool GroupsAlways>
+struct piece_body {
+	enum : unsigned { max_threads_per_block = 1024 };
+	static __device__ __forceinline__ void run(const batch::piece_view piece, const launch_grid::part grid)
+	{
+		const uint64_t anchoring_period = piece.get<size_type_by_index_size<PositionOffsetSize>>(4);
+		detail::decompress<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, WithGroups, GroupsAlways>(
+			piece.get<uint_t<UncompressedSize>*>(0), piece.get<const uint_t<UncompressedSize>*>(1), piece.get<const uint_t<PositionOffsetSize>*>(2),
+			piece.get<const uint_t<RunIndexSize>*>(3), anchoring_period, anchoring_period,
+			piece.get<size_type_by_index_size<RunIndexSize>>(5), piece.get<size_type_by_index_size<RunIndexSize>>(6), piece.get<size_type_by_index_size<UncompressedIndexSize>>(7),
+			run_length_encoding::detail::chunks_to_take(), grid);
+	}
+};
 
 /// The same decoder over anchors finer than the segments the relative positions count from (the wrapper's launch for long segments)
 template <unsigned UncompressedIndexSize, unsigned UncompressedSize, unsigned PositionOffsetSize, unsigned RunIndexSize = UncompressedIndexSize>

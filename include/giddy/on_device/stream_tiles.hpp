@@ -12,6 +12,7 @@
 #include <cstdint>
 
 #include "giddy/kernels/tuning.hpp"
+#include "giddy/on_device/launch_grid.hpp"
 #include "giddy/on_device/sorted_patches.hpp"
 #include "giddy/on_device/wave64.hpp"
 
@@ -69,10 +70,10 @@ __host__ __forceinline__ bool wants_any_alignment_build(const Out* out, const In
 /// them.  A build of its own, chosen by the wrapper from the addresses: inside the one kernel the extra address arithmetic cost the aligned column 2 points.
 /// (only for a produce_group that does not care where a group starts: positions are passed as they are in the column, but a group may lie across any boundary)
 template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, bool AnyAlignment = false,
-	typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare>
+	typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
-	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare())
+	AfterLoads after_loads = AfterLoads(), Prepare prepare = Prepare(), Grid grid = Grid())   // (`grid`: launch_grid.hpp — the launch's own, or a batch piece's part of it)
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -86,7 +87,7 @@ __device__ __forceinline__ void transform(
 		const In* __restrict__ in_at_boundary = in + lead;
 		const uint64_t num_groups = (n - lead) / G;
 		const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
-		for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+		for (uint64_t tile = grid.block(); tile * groups_per_tile < num_groups; tile += grid.blocks()) {
 			const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 			group<In, G> inputs[K];
 			#pragma unroll
@@ -105,8 +106,8 @@ __device__ __forceinline__ void transform(
 			}
 		}
 		after_loads();
-		const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-		const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+		const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
+		const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 		for (uint64_t p = global_thread; p < lead; p += num_threads) { out[p] = produce_one(p, in[p]); }
 		for (uint64_t p = lead + num_groups * G + global_thread; p < n; p += num_threads) { out[p] = produce_one(p, in[p]); }
 		return;
@@ -116,7 +117,7 @@ __device__ __forceinline__ void transform(
 	const uint64_t num_groups = vectorizable ? n / G : 0;
 	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
 
-	for (uint64_t tile = blockIdx.x; tile * groups_per_tile < num_groups; tile += gridDim.x) {
+	for (uint64_t tile = grid.block(); tile * groups_per_tile < num_groups; tile += grid.blocks()) {
 		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 		group<In, G> inputs[K];
 		if ((tile + 1) * groups_per_tile <= num_groups) {
@@ -163,8 +164,8 @@ __device__ __forceinline__ void transform(
 	}
 
 	after_loads();
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) { out[p] = produce_one(p, in[p]); }
 }
 
@@ -209,11 +210,11 @@ struct alignas(16) chunk_input_storage {
 };
 
 template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, unsigned StageUpToBytesPerLane = 2,
-	typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do>
+	typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void transform_and_patch(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
 	AfterLoads after_loads = AfterLoads(),   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
-	chunk_input_storage<In, Out, stages_chunk_input<In, Out, StageUpToBytesPerLane>()>* staging = nullptr)
+	chunk_input_storage<In, Out, stages_chunk_input<In, Out, StageUpToBytesPerLane>()>* staging = nullptr, Grid grid = Grid())
 {
 	using namespace memory_access;
 	constexpr unsigned G = group_size<Out>::value;
@@ -226,8 +227,8 @@ __device__ __forceinline__ void transform_and_patch(
 	const uint64_t num_rows = vectorizable ? n / row : 0;   // whole rows; the rest goes one element at a time
 	const uint64_t num_chunks = (num_rows + rows_per_chunk - 1) / rows_per_chunk;
 	const unsigned lane = wave64::lane_id();
-	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
-	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t wave = (uint64_t) grid.block() * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 
 	constexpr bool stage_chunk_input = stages_chunk_input<In, Out, StageUpToBytesPerLane>();
 	constexpr unsigned chunk_input_bytes = rows_per_chunk * row * sizeof(In);
@@ -295,8 +296,8 @@ __device__ __forceinline__ void transform_and_patch(
 	}
 
 	after_loads();
-	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
-	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+	const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 	for (uint64_t p = num_rows * row + global_thread; p < n; p += num_threads) { out[p] = patches.patched(p, produce_one(p, in[p])); }
 }
 

@@ -38,10 +38,17 @@ EXPORTED_SYMBOLS = (
     "giddy_resolve_launch_configuration", "giddy_enqueue_launch", "giddy_device_function",
     "giddy_device_function_count", "giddy_device_function_alternate",
     "giddy_prepare", "giddy_prepared_update", "giddy_enqueue_prepared", "giddy_release_prepared",
+    "giddy_can_launch_batches", "giddy_batch_create", "giddy_batch_add", "giddy_batch_clear", "giddy_batch_num_pieces", "giddy_batch_num_blocks",
+    "giddy_batch_upload", "giddy_enqueue_batch", "giddy_batch_tables", "giddy_enqueue_batch_of_device_tables", "giddy_batch_release",
     "giddy_reserve_scratch", "giddy_release_scratch", "giddy_trim", "giddy_scratch_held_bytes", "giddy_set_capture_scratch_policy",
     "giddy_shard", "giddy_enqueue_rebase", "giddy_decode_from_host", "giddy_enqueue_gather_on_node", "giddy_enqueue_gather_compressed_on_node",
     "giddy_last_error", "giddy_version",
 )
+
+
+class giddy_batch_tables(ctypes.Structure):
+    _fields_ = [("pieces", ctypes.c_void_p), ("blocks", ctypes.c_void_p), ("num_pieces", ctypes.c_uint32), ("num_blocks", ctypes.c_uint32),
+                ("block_size", ctypes.c_uint32), ("dynamic_shared_memory_size", ctypes.c_uint32), ("hints", ctypes.c_uint64 * 4)]
 
 
 class giddy_column_shape(ctypes.Structure):
@@ -96,6 +103,20 @@ def _load():
     lib.giddy_enqueue_prepared.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(giddy_launch_configuration)]
     lib.giddy_release_prepared.argtypes = [ctypes.c_void_p]
     lib.giddy_release_prepared.restype = None
+    lib.giddy_can_launch_batches.argtypes = [ctypes.c_void_p]
+    lib.giddy_batch_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+    lib.giddy_batch_add.argtypes = [ctypes.c_void_p, ctypes.POINTER(giddy_argument), ctypes.c_size_t, ctypes.POINTER(giddy_argument), ctypes.c_size_t]
+    lib.giddy_batch_clear.argtypes = [ctypes.c_void_p]
+    lib.giddy_batch_num_pieces.argtypes = [ctypes.c_void_p]
+    lib.giddy_batch_num_pieces.restype = ctypes.c_uint64
+    lib.giddy_batch_num_blocks.argtypes = [ctypes.c_void_p]
+    lib.giddy_batch_num_blocks.restype = ctypes.c_uint64
+    lib.giddy_batch_upload.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.giddy_enqueue_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    lib.giddy_batch_tables.argtypes = [ctypes.c_void_p, ctypes.POINTER(giddy_batch_tables)]
+    lib.giddy_enqueue_batch_of_device_tables.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(giddy_batch_tables)]
+    lib.giddy_batch_release.argtypes = [ctypes.c_void_p]
+    lib.giddy_batch_release.restype = None
     lib.giddy_reserve_scratch.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
     lib.giddy_release_scratch.argtypes = [ctypes.c_void_p]
     lib.giddy_trim.restype = ctypes.c_uint64

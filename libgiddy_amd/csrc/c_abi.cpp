@@ -87,6 +87,7 @@ cuda::any to_any(const giddy_argument_t& a)
 
 cuda::kernel_t::arguments_type to_map(const giddy_argument_t* arguments, size_t n)
 {
+	if (arguments == nullptr && n != 0) { throw std::invalid_argument("null argument array"); }
 	cuda::kernel_t::arguments_type map;
 	for (size_t i = 0; i < n; i++) {
 		if (arguments[i].name == nullptr) { throw std::invalid_argument("argument without a name"); }
@@ -129,7 +130,7 @@ int giddy_produce(const char* key, giddy_kernel_t** kernel)
 	return guarded([&] {
 		if (key == nullptr || kernel == nullptr) { throw std::invalid_argument("null key or output handle"); }
 		auto wrapper = cuda::registered::kernel_t::produceSubclass(key);
-		*kernel = new giddy_kernel { std::move(wrapper) };
+		*kernel = new giddy_kernel { std::shared_ptr<const cuda::registered::kernel_t>(std::move(wrapper)) };
 	});
 }
 
@@ -210,7 +211,7 @@ int giddy_prepare(const giddy_kernel_t* kernel, const giddy_argument_t* argument
 	return guarded([&] {
 		const auto& k = checked(kernel);
 		if (prepared == nullptr) { throw std::invalid_argument("null output handle"); }
-		*prepared = new giddy_prepared { k.wrapper.get(), to_map(arguments, num_arguments) };
+		*prepared = new giddy_prepared { k.wrapper, to_map(arguments, num_arguments) };
 	});
 }
 
@@ -218,6 +219,7 @@ int giddy_prepared_update(giddy_prepared_t* prepared, const giddy_argument_t* ar
 {
 	return guarded([&] {
 		if (prepared == nullptr || prepared->wrapper == nullptr) { throw std::invalid_argument("null prepared launch"); }
+		if (arguments == nullptr && num_arguments != 0) { throw std::invalid_argument("null argument array"); }
 		for (size_t i = 0; i < num_arguments; i++) {
 			if (arguments[i].name == nullptr) { throw std::invalid_argument("argument without a name"); }
 			prepared->arguments[arguments[i].name] = giddy_internal::to_any(arguments[i]);
@@ -239,6 +241,118 @@ int giddy_enqueue_prepared(const giddy_prepared_t* prepared, void* hip_stream, c
 }
 
 void giddy_release_prepared(giddy_prepared_t* prepared) { delete prepared; }
+
+// ---- batches (include/giddy/batch.hpp) --------------------------------------------------------------------------------
+
+int giddy_can_launch_batches(const giddy_kernel_t* kernel)
+{
+	return (kernel != nullptr && kernel->wrapper && kernel->wrapper->launches_batches()) ? 1 : 0;
+}
+
+int giddy_batch_create(const giddy_kernel_t* kernel, int device_id, giddy_batch_t** batch)
+{
+	return guarded([&] {
+		const auto& k = checked(kernel);
+		if (batch == nullptr) { throw std::invalid_argument("null output handle"); }
+		if (!k.wrapper->launches_batches()) { throw std::logic_error("this kernel wrapper does not launch batches"); }
+		std::unique_ptr<giddy_batch> b(new giddy_batch);
+		b->wrapper = k.wrapper;
+		if (device_id == GIDDY_NOMINAL_MI355X_DEVICE) {
+			b->properties = cuda::device::properties_t::nominal_mi355x();
+			b->attributes = cuda::device_function::attributes_t();
+		}
+		else {
+			if (device_id == GIDDY_CURRENT_DEVICE) { device_id = cuda::device::current::get().id(); }
+			b->properties = cuda::device::get(device_id).properties();
+			cuda::device::current::scoped_override_t<> use(device_id);
+			b->attributes = k.wrapper->get_device_function().attributes();
+		}
+		b->device_id = device_id;
+		*batch = b.release();
+	});
+}
+
+int giddy_batch_add(giddy_batch_t* batch, const giddy_argument_t* launch_arguments, size_t num_launch_arguments,
+	const giddy_argument_t* resolution_arguments, size_t num_resolution_arguments)
+{
+	return guarded([&] {
+		if (batch == nullptr || !batch->wrapper) { throw std::invalid_argument("null batch"); }
+		const auto piece_config = batch->wrapper->resolve_launch_configuration(batch->properties, batch->attributes,
+			to_map(resolution_arguments, num_resolution_arguments), cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+		batch->wrapper->add_to_batch(batch->table, piece_config, to_map(launch_arguments, num_launch_arguments));
+		batch->uploaded = false;
+	});
+}
+
+int giddy_batch_clear(giddy_batch_t* batch)
+{
+	return guarded([&] {
+		if (batch == nullptr) { throw std::invalid_argument("null batch"); }
+		batch->table.clear();
+		batch->uploaded = false;
+	});
+}
+
+uint64_t giddy_batch_num_pieces(const giddy_batch_t* batch) { return batch != nullptr ? (uint64_t) batch->table.pieces().size() : 0; }
+uint64_t giddy_batch_num_blocks(const giddy_batch_t* batch) { return batch != nullptr ? (uint64_t) batch->table.blocks().size() : 0; }
+
+int giddy_batch_upload(giddy_batch_t* batch, void* hip_stream)
+{
+	return guarded([&] {
+		if (batch == nullptr || !batch->wrapper) { throw std::invalid_argument("null batch"); }
+		if (batch->device_id == GIDDY_NOMINAL_MI355X_DEVICE) { throw std::logic_error("a batch created for the nominal device has no device to be uploaded to"); }
+		batch->on_device.upload(batch->table, static_cast<hipStream_t>(hip_stream));
+		batch->uploaded = true;
+	});
+}
+
+int giddy_enqueue_batch(giddy_batch_t* batch, void* hip_stream)
+{
+	return guarded([&] {
+		if (batch == nullptr || !batch->wrapper) { throw std::invalid_argument("null batch"); }
+		if (!batch->uploaded) {
+			if (batch->device_id == GIDDY_NOMINAL_MI355X_DEVICE) { throw std::logic_error("a batch created for the nominal device cannot be launched"); }
+			batch->on_device.upload(batch->table, static_cast<hipStream_t>(hip_stream));
+			batch->uploaded = true;
+		}
+		if (batch->on_device.view().num_blocks == 0) { return; }
+		batch->wrapper->enqueue_launch_of_batch(static_cast<hipStream_t>(hip_stream), batch->on_device.view());
+	});
+}
+
+int giddy_batch_tables(const giddy_batch_t* batch, giddy_batch_tables_t* tables)
+{
+	return guarded([&] {
+		if (batch == nullptr || tables == nullptr) { throw std::invalid_argument("null batch or output"); }
+		if (!batch->uploaded) { throw std::logic_error("the batch has not been uploaded since it was last changed"); }
+		const auto& view = batch->on_device.view();
+		tables->pieces = reinterpret_cast<const giddy_batch_piece_t*>(view.pieces);
+		tables->blocks = reinterpret_cast<const giddy_batch_block_t*>(view.blocks);
+		tables->num_pieces = view.num_pieces; tables->num_blocks = view.num_blocks;
+		tables->block_size = view.block_size; tables->dynamic_shared_memory_size = view.dynamic_shared_memory_size;
+		for (unsigned i = 0; i < cuda::batch::hints_per_batch; i++) { tables->hints[i] = view.hints[i]; }
+	});
+}
+
+int giddy_enqueue_batch_of_device_tables(const giddy_kernel_t* kernel, void* hip_stream, const giddy_batch_tables_t* tables)
+{
+	return guarded([&] {
+		const auto& k = checked(kernel);
+		if (tables == nullptr) { throw std::invalid_argument("null tables"); }
+		if (tables->num_blocks == 0) { return; }
+		if (tables->pieces == nullptr || tables->blocks == nullptr) { throw std::invalid_argument("null piece or block table"); }
+		if (tables->block_size == 0 || tables->block_size > 1024) { throw std::invalid_argument("a batch's block size must be 1 ... 1024 threads"); }
+		cuda::batch::on_device_t view;
+		view.pieces = reinterpret_cast<const cuda::batch::piece_t*>(tables->pieces);
+		view.blocks = reinterpret_cast<const cuda::batch::block_t*>(tables->blocks);
+		view.num_pieces = tables->num_pieces; view.num_blocks = tables->num_blocks;
+		view.block_size = tables->block_size; view.dynamic_shared_memory_size = tables->dynamic_shared_memory_size;
+		for (unsigned i = 0; i < cuda::batch::hints_per_batch; i++) { view.hints[i] = tables->hints[i]; }
+		k.wrapper->enqueue_launch_of_batch(static_cast<hipStream_t>(hip_stream), view);
+	});
+}
+
+void giddy_batch_release(giddy_batch_t* batch) { delete batch; }
 
 int giddy_reserve_scratch(void* hip_stream, uint64_t bytes)
 {
@@ -266,6 +380,6 @@ int giddy_set_capture_scratch_policy(int policy)
 
 const char* giddy_last_error(void) { return giddy_internal::last_error().c_str(); }
 
-const char* giddy_version(void) { return "libgiddy_amd 0.4 (gfx950)"; }
+const char* giddy_version(void) { return "libgiddy_amd 0.5 (gfx950)"; }
 
 } // extern "C"

@@ -4,6 +4,7 @@
 #include "giddy.h"
 
 #include <any>
+#include <memory>
 #include <stdexcept>
 #include <string>
 
@@ -11,13 +12,24 @@
 #include "giddy/kernel_wrappers/registered_wrapper.hpp"
 
 struct giddy_kernel {
-	std::unique_ptr<cuda::registered::kernel_t> wrapper;
+	std::shared_ptr<const cuda::registered::kernel_t> wrapper;
 };
 
-/// a wrapper (owned by its giddy_kernel) with an argument map that is kept between launches
+/// a wrapper with an argument map that is kept between launches (the wrapper is shared with the giddy_kernel_t it was prepared from: releasing that one first is fine)
 struct giddy_prepared {
-	const cuda::registered::kernel_t* wrapper;
+	std::shared_ptr<const cuda::registered::kernel_t> wrapper;
 	cuda::kernel_t::arguments_type arguments;
+};
+
+/// a batch (include/giddy/batch.hpp): the tables as the host builds them, their copy on the device, the wrapper that launches them
+struct giddy_batch {
+	std::shared_ptr<const cuda::registered::kernel_t> wrapper;
+	int device_id;                         // a HIP device, or GIDDY_NOMINAL_MI355X_DEVICE (pieces can be added and counted, not uploaded)
+	cuda::device::properties_t properties;
+	cuda::device_function::attributes_t attributes;
+	cuda::batch::table_t table;
+	cuda::batch::uploaded_t on_device;
+	bool uploaded = false;                 // `on_device` holds `table` as it is now
 };
 
 namespace giddy_internal {

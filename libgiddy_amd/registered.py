@@ -216,6 +216,57 @@ class prepared_launch:
             _native.lib.giddy_release_prepared(handle)
 
 
+class batch_t:
+    """giddy_batch_t (include/giddy/batch.hpp): MANY small columns decoded by ONE launch.
+
+        batch = kernel.batch(device)                                  # wrappers for which kernel.launches_batches()
+        for each column: batch.add(launch_arguments, resolution_arguments)   # what enqueue_launch / resolve_launch_configuration take for it; host only
+        batch.enqueue(stream)                                         # the tables to the device (first time / after a change) and ONE launch
+    Keep it alive until the launches that read its tables have run."""
+
+    def __init__(self, kernel, device=CURRENT_DEVICE):
+        self._kernel = kernel
+        self._handle = ctypes.c_void_p()
+        self._keep = []   # the buffers behind the pieces' pointers
+        _check(_native.lib.giddy_batch_create(kernel._handle, int(device), ctypes.byref(self._handle)))
+
+    def add(self, launch_arguments, resolution_arguments):
+        launch, keep_launch = _marshal(launch_arguments)
+        resolve, keep_resolve = _marshal(resolution_arguments)
+        _check(_native.lib.giddy_batch_add(self._handle, launch, len(launch_arguments), resolve, len(resolution_arguments)))
+        self._keep.append([a.keepalive for a in launch_arguments.values() if a.keepalive is not None])
+
+    def clear(self):
+        _check(_native.lib.giddy_batch_clear(self._handle))
+        self._keep = []
+
+    @property
+    def num_pieces(self):
+        return int(_native.lib.giddy_batch_num_pieces(self._handle))
+
+    @property
+    def num_blocks(self):
+        """workgroups of the one launch"""
+        return int(_native.lib.giddy_batch_num_blocks(self._handle))
+
+    def upload(self, stream):
+        _check(_native.lib.giddy_batch_upload(self._handle, ctypes.c_void_p(int(stream) if stream else None)))
+
+    def enqueue(self, stream):
+        _check(_native.lib.giddy_enqueue_batch(self._handle, ctypes.c_void_p(int(stream) if stream else None)))
+
+    def tables(self):
+        """where the uploaded tables lie (giddy_batch_tables_t): for giddy_enqueue_batch_of_device_tables"""
+        out = _native.giddy_batch_tables()
+        _check(_native.lib.giddy_batch_tables(self._handle, ctypes.byref(out)))
+        return out
+
+    def __del__(self):
+        handle, self._handle = getattr(self, "_handle", None), None
+        if handle and _native is not None and getattr(_native, "lib", None) is not None:
+            _native.lib.giddy_batch_release(handle)
+
+
 def reserve_scratch(stream, nbytes):
     """cuda::stream_scratch::reserve: a block of at least `nbytes` is there for `stream` afterwards (launches on it do not allocate)"""
     _check(_native.lib.giddy_reserve_scratch(ctypes.c_void_p(int(stream) if stream else None), int(nbytes)))
@@ -288,6 +339,17 @@ class kernel_t:
         """the kernels the wrapper may launch with the caller's configuration: [0] is get_device_function(), the kernel of the
         reference's signature; the others are the builds its typed launch picks among (cuda::device_function_t's alternates)"""
         return [_native.lib.giddy_device_function_alternate(self._handle, i) for i in range(_native.lib.giddy_device_function_count(self._handle))]
+
+    def launches_batches(self):
+        return bool(_native.lib.giddy_can_launch_batches(self._handle))
+
+    def batch(self, device=CURRENT_DEVICE):
+        """an empty batch of this wrapper's columns (giddy_batch_create)"""
+        return batch_t(self, device)
+
+    def enqueue_launch_of_batch(self, stream, tables):
+        """one launch over tables that lie on the device already (a giddy_batch_tables: batch_t.tables(), or written by the caller's own kernel)"""
+        _check(_native.lib.giddy_enqueue_batch_of_device_tables(self._handle, ctypes.c_void_p(int(stream) if stream else None), ctypes.byref(tables)))
 
     def prepare(self, arguments):
         """a launch whose argument map is built once and kept (giddy_prepare): for loops over a column's chunks"""

@@ -22,7 +22,48 @@ def kernel(key):
     return _kernels[key]
 
 
+class into_batch:
+    """`with schemes.into_batch() as pieces:` — the scheme functions called inside ADD their column to one batch (libgiddy_amd.registered.batch_t,
+    include/giddy/batch.hpp) instead of launching it: same arguments, nothing is enqueued (`stream`, `launch_config` are ignored; every
+    call must name the same kernel instantiation).  Afterwards `pieces.enqueue(stream)` decodes them all with ONE launch — as often as wanted."""
+    _current = None
+
+    def __init__(self, device=r.CURRENT_DEVICE):
+        self.device, self.key, self.batch = device, None, None
+
+    def __enter__(self):
+        assert into_batch._current is None, "batches do not nest"
+        into_batch._current = self
+        return self
+
+    def __exit__(self, *exc):
+        into_batch._current = None
+        return False
+
+    def _add(self, key, resolve_arguments, launch_arguments):
+        if self.batch is None:
+            self.key, self.batch = key, kernel(key).batch(self.device)
+        if key != self.key:
+            raise r.InvalidArgument("one batch, one kernel instantiation: %s after %s" % (key, self.key))
+        self.batch.add(launch_arguments, resolve_arguments)
+
+    @property
+    def num_pieces(self):
+        return self.batch.num_pieces if self.batch is not None else 0
+
+    @property
+    def num_blocks(self):
+        return self.batch.num_blocks if self.batch is not None else 0
+
+    def enqueue(self, stream):
+        if self.batch is not None:
+            self.batch.enqueue(stream)
+
+
 def _run(key, resolve_arguments, launch_arguments, stream, device, limits, launch_config):
+    if into_batch._current is not None:
+        into_batch._current._add(key, resolve_arguments, launch_arguments)
+        return None
     k = kernel(key)
     if launch_config is None:
         launch_config = k.resolve_launch_configuration(device, resolve_arguments, limits)

@@ -3,7 +3,7 @@ input COLD: a size's "columns" are consecutive shards of one big column (whole s
 them as move >= 1.5 GiB, so no launch finds its input or its output's lines in the 256 MiB Infinity Cache; each is decoded into its own range of
 the big output.
 
-    python tools/size_sweep.py [WORKLOAD,... | all] [min_log2=16] [max_log2=30] [--batch]
+    python tools/size_sweep.py [WORKLOAD,... | all] [min_log2=16] [max_log2=30] [--batch] [--quick]
 
 Per workload and size, % of the 8 TB/s HBM peak over the algorithmic bytes:
   stream   the columns launched back to back from the host (what a loop over chunks gets: launch overhead included)
@@ -22,6 +22,7 @@ ALL = ("dictionary", "frame_of_reference", "delta_patched", "run_length_encoding
        "run_position_encoding_absolute", "discard_zero_bytes_variable")
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 with_batch = "--batch" in sys.argv
+quick = "--quick" in sys.argv   # no graph, no launch after idle
 names = ALL if not args or args[0] == "all" else tuple(args[0].split(","))
 min_log2 = int(args[1]) if len(args) > 1 else 16
 max_log2 = int(args[2]) if len(args) > 2 else 30
@@ -50,7 +51,7 @@ def bytes_of(shard, out):
     return out.numel() * out.element_size() + sum(v.numel() * v.element_size() for v in shard.fields.values() if isinstance(v, torch.Tensor))
 
 
-table = {}
+table, batch_table = {}, {}
 for name in names:
     top = min(max_log2, 28) if name.startswith("discard_zero_bytes_variable") else max_log2
     w = bench.make_workload(name, 1 << top, device, cap=1 << top)
@@ -81,6 +82,7 @@ for name in names:
         stream_ms = events_ms(all_columns)
         graph_pct = float("nan")
         try:
+            if quick: raise RuntimeError("skipped (--quick)")
             side = torch.cuda.Stream()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, stream=side):
@@ -92,17 +94,22 @@ for name in names:
             del graph
         except Exception as e:   # (a wrapper that needs scratch refuses a capturing stream)
             torch.cuda.synchronize()
-            print("#   graph capture failed at 2^%d: %s" % (log2n, str(e).splitlines()[0][:120]), flush=True)
+            if not quick: print("#   graph capture failed at 2^%d: %s" % (log2n, str(e).splitlines()[0][:120]), flush=True)
         batch_text = ""
-        if with_batch and hasattr(w, "batch_of"):
-            launch_batch = w.batch_of(outs, [s.fields for s in shards], stream)
-            batch_ms = events_ms(launch_batch)
-            batch_text = "   batch %5.1f %%" % pct(total, batch_ms)
+        if with_batch:
+            from libgiddy_amd import schemes
+            with schemes.into_batch() as batched:   # (the same calls, added to one batch instead of launched)
+                for o, s in zip(outs, shards): w.launch_fields(o, s.fields, stream, None)
+            batched.enqueue(stream); torch.cuda.synchronize()
+            batch_ms = events_ms(lambda: batched.enqueue(stream))
+            batch_text = "   batch %5.1f %% (%d workgroups)" % (pct(total, batch_ms), batched.num_blocks)
+            if hasattr(w, "values"):
+                assert bool((w.output[:shards[-1].stop] == w.values[:shards[-1].stop]).all())
         # one launch after idle: a column in the middle of the rotation (not touched for >= COLD_BYTES)
         k = m // 2
         first_events, first_wall = [], []
         for _ in range(3):
-            time.sleep(IDLE_SECONDS)
+            if not quick: time.sleep(IDLE_SECONDS)
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             t0 = time.perf_counter()
             a.record(); w.launch_fields(outs[k], shards[k].fields, stream, configs[k]); b.record()
@@ -113,6 +120,7 @@ for name in names:
         print("%-34s 2^%d  x%-4d  stream %5.1f %%  (%.1f us each)   graph %5.1f %%%s   first after idle: %.1f us by events = %4.1f %%, %.0f us on the host's clock"
               % (name, log2n, m, pct(total, stream_ms), stream_ms * 1e3 / m, graph_pct, batch_text, fe, pct(one, fe / 1e3), fw), flush=True)
         table.setdefault(name, {})[log2n] = max(pct(total, stream_ms), graph_pct if graph_pct == graph_pct else 0)
+        if with_batch: batch_table.setdefault(name, {})[log2n] = pct(total, batch_ms)
         if hasattr(w, "values") and log2n == min_log2:
             torch.cuda.synchronize()
             hi = shards[-1].stop
@@ -121,8 +129,10 @@ for name in names:
     del w, fields
     torch.cuda.empty_cache()
 
-print("# the smallest size at which a decoder (best of stream / graph) still holds 70 % / 50 % of the HBM peak:")
-for name, by_size in table.items():
+for title, results in (("a launch per column (best of stream / graph)", table), ("ONE launch for all the columns of a size (batch)", batch_table)):
+  if not results: continue
+  print("# the smallest size at which a decoder still holds 70 %% / 50 %% of the HBM peak, %s:" % title)
+  for name, by_size in results.items():
     def smallest(bar):
         held = [k for k in sorted(by_size) if all(by_size[j] >= bar for j in by_size if j >= k)]
         return ("2^%d" % held[0]) if held else "never"
