@@ -22,6 +22,8 @@
 
 #include <cstdint>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <type_traits>
 #include <vector>
@@ -112,80 +114,114 @@ private:
 	shared_memory_size_t    dynamic_shared_memory_size_ = 0;
 };
 
-/// A table's copy on the current device.  upload() copies asynchronously on `stream` out of PINNED staging memory; launches enqueued on that stream
-/// afterwards see the tables.  The device block is kept and re-used when a later table fits (a re-upload is ordered behind the earlier launches by
-/// the stream; a caller that re-uploads on ANOTHER stream orders the two itself); the staging is kept per copy in flight — a staging block is written
-/// again only once the copy made from it has completed (an event query, never a wait), so re-building and re-uploading a table in a loop does not
-/// stall the host.  Lives until the launches that read it have run (as a giddy_prepared_t does); the destructor frees device memory, which waits.
+/// PINNED host memory for the copies of tables to devices: a process-wide pool of blocks, each re-used only once the copy that was made from it has
+/// completed (an event query, never a wait) — so a table may be re-built and uploaded again, or a function that uploaded one may return, while the
+/// copy is still in flight.  Blocks are portable (any device) and live as long as the process.
+class staging_pool {
+public:
+	struct block { void* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; bool in_flight = false, taken = false; };
+
+	static staging_pool& instance() { static staging_pool pool; return pool; }
+
+	/// a block of at least `bytes` that no copy is reading: fill it, enqueue the copy, then copy_enqueued()
+	block* take(size_t bytes)
+	{
+		std::lock_guard<std::mutex> lock(mutex_);
+		for (auto& b : blocks_) {
+			if (b->taken) { continue; }
+			if (b->in_flight) {
+				const hipError_t status = hipEventQuery(b->copied);
+				if (status == hipSuccess) { b->in_flight = false; }
+				else if (status != hipErrorNotReady) { (void) hipGetLastError(); }
+			}
+			if (!b->in_flight && b->capacity >= bytes) { b->taken = true; return b.get(); }
+		}
+		std::unique_ptr<block> fresh(new block);
+		fresh->capacity = bytes + bytes / 4 + 4096;
+		throw_if_error(hipHostMalloc(&fresh->memory, fresh->capacity, hipHostMallocPortable), "hipHostMalloc of staging for a batch's tables");
+		if (hipEventCreateWithFlags(&fresh->copied, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); fresh->copied = nullptr; }
+		fresh->taken = true;
+		blocks_.push_back(std::move(fresh));
+		return blocks_.back().get();
+	}
+
+	/// the copy out of `b` has been enqueued on `stream` (of the current device): `b` is anybody's again once it has run
+	void copy_enqueued(block* b, stream::id_t stream)
+	{
+		const bool recorded = b->copied != nullptr && hipEventRecord(b->copied, stream) == hipSuccess;
+		if (!recorded) { (void) hipGetLastError(); (void) hipStreamSynchronize(stream); }   // (no event to be had: wait for the copy itself)
+		std::lock_guard<std::mutex> lock(mutex_);
+		b->in_flight = recorded;
+		b->taken = false;
+	}
+
+private:
+	std::mutex mutex_;
+	std::vector<std::unique_ptr<block>> blocks_;
+};
+
+/// bytes of device memory a table's copy takes
+inline size_t device_bytes_of(const table_t& table) { return table.bytes(); }
+
+/// `table` written to `host_memory` as it will lie at `device_memory` once copied there (both >= device_bytes_of(table), 16-byte aligned): for callers
+/// that move several tables — or tables and something else — with ONE copy of their own
+inline on_device_t place(void* host_memory, const void* device_memory, const table_t& table)
+{
+	const size_t pieces_bytes = table.pieces().size() * sizeof(piece_t), blocks_bytes = table.blocks().size() * sizeof(block_t);
+	if (pieces_bytes != 0) { std::memcpy(host_memory, table.pieces().data(), pieces_bytes); }
+	if (blocks_bytes != 0) { std::memcpy(static_cast<char*>(host_memory) + pieces_bytes, table.blocks().data(), blocks_bytes); }
+	on_device_t view;
+	view.pieces = static_cast<const piece_t*>(device_memory);
+	view.blocks = reinterpret_cast<const block_t*>(static_cast<const char*>(device_memory) + pieces_bytes);
+	view.num_pieces = (uint32_t) table.pieces().size();
+	view.num_blocks = (uint32_t) table.blocks().size();
+	view.block_size = table.block_size();
+	view.dynamic_shared_memory_size = table.dynamic_shared_memory_size();
+	for (unsigned i = 0; i < hints_per_batch; i++) { view.hints[i] = table.hints[i]; }
+	return view;
+}
+
+/// `table` copied into `device_memory` (>= device_bytes_of(table), 16-byte aligned) asynchronously on `stream`, out of the staging pool
+inline on_device_t upload_into(void* device_memory, const table_t& table, stream::id_t stream)
+{
+	const size_t bytes = device_bytes_of(table);
+	if (bytes == 0) { return place(nullptr, device_memory, table); }
+	staging_pool::block* from = staging_pool::instance().take(bytes);
+	const on_device_t view = place(from->memory, device_memory, table);
+	const hipError_t status = hipMemcpyAsync(device_memory, from->memory, bytes, hipMemcpyHostToDevice, stream);
+	staging_pool::instance().copy_enqueued(from, stream);
+	throw_if_error(status, "copy of a batch's tables to the device");
+	return view;
+}
+
+/// A table's copy on the current device, in memory of its own: kept and re-used when a later table fits (a re-upload is ordered behind the earlier
+/// launches by the stream; a caller that re-uploads on ANOTHER stream orders the two itself).  Lives until the launches that read it have run (as
+/// a giddy_prepared_t does); the destructor frees device memory, which waits for the device.
 class uploaded_t {
 public:
 	uploaded_t() = default;
 	uploaded_t(const table_t& table, stream::id_t stream) { upload(table, stream); }
 	uploaded_t(const uploaded_t&) = delete;
 	uploaded_t& operator=(const uploaded_t&) = delete;
-	~uploaded_t()
-	{
-		if (device_ != nullptr) { (void) hipFree(device_); }          // (waits for the device's pending work: no copy is in flight after it)
-		for (auto& s : staging_) {
-			if (s.memory != nullptr) { (void) hipHostFree(s.memory); }
-			if (s.copied != nullptr) { (void) hipEventDestroy(s.copied); }
-		}
-	}
+	~uploaded_t() { if (device_ != nullptr) { (void) hipFree(device_); } }
 
 	void upload(const table_t& table, stream::id_t stream)
 	{
-		const size_t pieces_bytes = table.pieces().size() * sizeof(piece_t), blocks_bytes = table.blocks().size() * sizeof(block_t);
-		const size_t bytes = pieces_bytes + blocks_bytes;
-		if (bytes > device_capacity_) {
-			if (device_ != nullptr) { (void) hipFree(device_); device_ = nullptr; device_capacity_ = 0; }
+		const size_t bytes = device_bytes_of(table);
+		if (bytes > capacity_) {
+			if (device_ != nullptr) { (void) hipFree(device_); device_ = nullptr; capacity_ = 0; }
 			const size_t wanted = bytes + bytes / 4 + 4096;
 			throw_if_error(hipMalloc(&device_, wanted), "hipMalloc of a batch's tables");
-			device_capacity_ = wanted;
+			capacity_ = wanted;
 		}
-		if (bytes != 0) {
-			staging_block& from = idle_staging(bytes);
-			std::memcpy(from.memory, table.pieces().data(), pieces_bytes);
-			std::memcpy(static_cast<char*>(from.memory) + pieces_bytes, table.blocks().data(), blocks_bytes);
-			throw_if_error(hipMemcpyAsync(device_, from.memory, bytes, hipMemcpyHostToDevice, stream), "copy of a batch's tables to the device");
-			from.in_flight = from.copied != nullptr && hipEventRecord(from.copied, stream) == hipSuccess;
-			if (!from.in_flight) { (void) hipGetLastError(); throw_if_error(hipStreamSynchronize(stream), "waiting for the copy of a batch's tables"); }
-		}
-		view_.pieces = static_cast<const piece_t*>(device_);
-		view_.blocks = reinterpret_cast<const block_t*>(static_cast<const char*>(device_) + pieces_bytes);
-		view_.num_pieces = (uint32_t) table.pieces().size();
-		view_.num_blocks = (uint32_t) table.blocks().size();
-		view_.block_size = table.block_size();
-		view_.dynamic_shared_memory_size = table.dynamic_shared_memory_size();
-		for (unsigned i = 0; i < hints_per_batch; i++) { view_.hints[i] = table.hints[i]; }
+		view_ = upload_into(device_, table, stream);
 	}
 
 	const on_device_t& view() const { return view_; }
 
 private:
-	struct staging_block { void* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; bool in_flight = false; };
-
-	/// a staging block of at least `bytes` that no copy is still reading
-	staging_block& idle_staging(size_t bytes)
-	{
-		for (auto& s : staging_) {
-			if (s.in_flight) {
-				const hipError_t status = hipEventQuery(s.copied);
-				if (status == hipSuccess) { s.in_flight = false; }
-				else if (status != hipErrorNotReady) { (void) hipGetLastError(); }
-			}
-			if (!s.in_flight && s.capacity >= bytes) { return s; }
-		}
-		staging_block fresh;
-		fresh.capacity = bytes + bytes / 4 + 4096;
-		throw_if_error(hipHostMalloc(&fresh.memory, fresh.capacity, hipHostMallocDefault), "hipHostMalloc of a batch's staging");
-		if (hipEventCreateWithFlags(&fresh.copied, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); fresh.copied = nullptr; }
-		staging_.push_back(fresh);
-		return staging_.back();
-	}
-
 	void* device_ = nullptr;
-	size_t device_capacity_ = 0;
-	std::vector<staging_block> staging_;
+	size_t capacity_ = 0;
 	on_device_t view_;
 };
 

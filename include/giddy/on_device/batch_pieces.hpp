@@ -30,9 +30,20 @@ struct piece_view {
 		static_assert(sizeof(T) <= 8, "a launch parameter that does not fit a 64-bit slot");
 		const uint64_t slot = uniform_word(&record->slot[i]);
 		if constexpr (std::is_pointer<T>::value) {
-			// (a pointer made from an integer has no address space and its loads would be FLAT ones, which count against the LDS counter as well: say "global" first)
-			typedef typename std::remove_pointer<T>::type __attribute__((address_space(1)))* global_pointer;
-			return (T) reinterpret_cast<global_pointer>(static_cast<uintptr_t>(slot));
+			// A pointer made from an integer has no address space, and its loads would be FLAT ones (which count against the LDS counter as well): say
+			// where it points first.  INPUT arrays (pointers to const) are named as CONSTANT memory — what `const T* __restrict__` kernel parameters tell
+			// the compiler of an ordinary launch: nothing the kernel stores can change them, so a load at a wave-uniform address (a segment's anchor) is
+			// a SCALAR load, which does not queue behind the wavefront's stores (Delta <4,8,2> in a batch: 62 % of the HBM peak with vector loads of the
+			// anchors, against 77 % for the column's own launch).  The decoders never decode in place (their parameters are __restrict__).
+			using pointee = typename std::remove_pointer<T>::type;
+			if constexpr (std::is_const<pointee>::value) {
+				typedef pointee __attribute__((address_space(4)))* constant_pointer;
+				return (T) reinterpret_cast<constant_pointer>(static_cast<uintptr_t>(slot));
+			}
+			else {
+				typedef pointee __attribute__((address_space(1)))* global_pointer;
+				return (T) reinterpret_cast<global_pointer>(static_cast<uintptr_t>(slot));
+			}
 		}
 		else if constexpr (std::is_same<T, bool>::value) { return (slot & 0xFF) != 0; }
 		else if constexpr (std::is_integral<T>::value || std::is_enum<T>::value) { return (T) slot; }

@@ -7,7 +7,6 @@
 #include <memory>
 #include <exception>
 #include <string>
-#include <thread>
 #include <vector>
 
 #include "../c_abi_internal.hpp"
@@ -93,15 +92,15 @@ void enqueue_rebase(hipStream_t stream, void* out, const void* in, uint64_t coun
 
 // ---- the pipeline ----------------------------------------------------------------------------------------------------------
 
-/// chunks from which the pipeline's per-stream loops run on host threads of their own (GIDDY_PIPELINE_THREADED_FROM in the environment, read once; 0: never)
-uint64_t threaded_from_chunks()
+/// compressed bytes a GROUP of consecutive chunks moves at least, where the wrapper decodes batches: the group's slices cross the link as ONE copy per array and
+/// are decoded by ONE launch with a piece per chunk (GIDDY_PIPELINE_GROUP_BYTES in the environment, read once; 0: a copy and a launch per chunk, as before round 5)
+uint64_t group_bytes_wanted()
 {
-	static const uint64_t from = [] {
-		const char* v = std::getenv("GIDDY_PIPELINE_THREADED_FROM");
-		const uint64_t given = v ? std::strtoull(v, nullptr, 10) : 48;
-		return given == 0 ? ~(uint64_t) 0 : given;
+	static const uint64_t bytes = [] {
+		const char* v = std::getenv("GIDDY_PIPELINE_GROUP_BYTES");
+		return v ? std::strtoull(v, nullptr, 10) : (uint64_t) 4 << 20;
 	}();
-	return from;
+	return bytes;
 }
 
 enum class sliced_by { nothing, elements, segments, units, size_containers, whole_table };
@@ -230,103 +229,174 @@ void decode_from_host(const char* key, int scheme, const giddy_column_shape_t& s
 		}
 	}
 	cuda::throw_if_error(hipEventRecord(pinned.copied, first_stream), "hipEventRecord");
-	ordering_event uploaded;
-	uploaded.record(first_stream);
-	for (size_t k = 1; k < num_streams; k++) { uploaded.make_wait(static_cast<hipStream_t>(streams[k])); }
 
-	// the chunk's slices of the bulk arrays, each 256-byte aligned within ONE block per stream, leased for the whole call: the chunks of a
-	// stream follow each other through it in stream order.  (The wrapper's own scratch — chained Delta tiles, finer anchors of long
-	// segments — is another block of the pool: neither waits for the other.)
-	auto slices_of = [&](const cuda::sharding::shard_t& shard, std::vector<size_t>& offset) {
+	// GROUPS of consecutive chunks.  A chunk used to cost a copy per bulk array and a launch — 3-4 us of host time per enqueued operation, so a run-length
+	// column (ratio 21) cut into 256 / 1024 chunks decoded at 253 / 78 GB/s where 16 chunks reach 830 (profiles/r04_pcie_pipeline.txt).  The slices of
+	// consecutive chunks are consecutive in the column's arrays (a run that straddles a cut belongs to both sides: the ranges overlap by it), so a group of
+	// G chunks crosses the link as ONE copy per array and is decoded by ONE batch launch with a piece per chunk (giddy/batch.hpp) — the cuts, the rebased
+	// anchors and every chunk's own launch configuration stay what they were.  G: enough chunks for `group_bytes_wanted()` compressed bytes, while there are
+	// at least four groups per stream to overlap.  Absolute run positions are rebased per chunk by a launch of their own: those columns keep G = 1.
+	uint64_t bulk_bytes = 0;
+	bool rebases_positions = false;
+	for (size_t i = 0; i < num_arguments; i++) {
+		const role& r = roles[i];
+		if (r.how == sliced_by::elements) { bulk_bytes += shape.length * r.itemsize; }
+		if (r.how == sliced_by::units) { bulk_bytes += shape.num_units * r.itemsize; }
+		if (r.how == sliced_by::size_containers) { bulk_bytes += shards.back().size_containers.end * r.itemsize; }
+	}
+	for (const auto& s : shards) { rebases_positions = rebases_positions || s.position_bias != 0; }
+	uint64_t chunks_per_group = 1;
+	if (wrapper->launches_batches() && !rebases_positions && group_bytes_wanted() != 0 && num_chunks > 1) {
+		const uint64_t per_chunk = std::max<uint64_t>(1, bulk_bytes / num_chunks);
+		chunks_per_group = std::max<uint64_t>(1, std::min<uint64_t>(group_bytes_wanted() / per_chunk, num_chunks / std::max<uint64_t>(1, 4 * num_streams)));
+	}
+	const uint64_t num_groups = (num_chunks + chunks_per_group - 1) / chunks_per_group;
+	// a group's slices: [the first chunk's first entry, the last chunk's end) of every bulk array, each 256-byte aligned within ONE block per stream, leased for
+	// the whole call — the groups of a stream follow each other through it in stream order.  (The wrapper's own scratch — chained Delta tiles, finer anchors
+	// of long segments — and a group's batch tables are other blocks of the pool: none waits for another.)
+	auto range_of = [&](const role& r, uint64_t first_chunk, uint64_t end_chunk) {
+		auto slice_of = [&](const cuda::sharding::shard_t& shard) -> const cuda::sharding::slice_t& {
+			return r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
+		};
+		uint64_t first = ~(uint64_t) 0, end = 0;
+		for (uint64_t c = first_chunk; c < end_chunk; c++) {
+			if (shards[c].length() == 0) { continue; }
+			first = std::min<uint64_t>(first, slice_of(shards[c]).first); end = std::max<uint64_t>(end, slice_of(shards[c]).end);
+		}
+		return first > end ? cuda::sharding::slice_t { 0, 0 } : cuda::sharding::slice_t { first, end };
+	};
+	auto slices_of = [&](uint64_t first_chunk, uint64_t end_chunk, std::vector<size_t>& offset) {
 		size_t total = 0;
 		for (size_t i = 0; i < num_arguments; i++) {
 			const role& r = roles[i];
 			if (r.how != sliced_by::elements && r.how != sliced_by::units && r.how != sliced_by::size_containers) { continue; }
-			const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
 			offset[i] = total;
-			total += (slice.size() * r.itemsize + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of a slice's last chunk)
+			total += (range_of(r, first_chunk, end_chunk).size() * r.itemsize + 255) / 256 * 256 + 256;   // (+ slack: the decoders' 16-byte loads may read up to the end of a slice's last chunk)
 		}
 		return total;
 	};
 	std::vector<size_t> most(num_streams, 256);
 	{
 		std::vector<size_t> offset(num_arguments, 0);
-		for (uint64_t c = 0; c < num_chunks; c++) { if (shards[c].length() != 0) { most[c % num_streams] = std::max(most[c % num_streams], slices_of(shards[c], offset)); } }
+		for (uint64_t g = 0; g < num_groups; g++) {
+			most[g % num_streams] = std::max(most[g % num_streams], slices_of(g * chunks_per_group, std::min(num_chunks, (g + 1) * chunks_per_group), offset));
+		}
 	}
 	std::vector<std::unique_ptr<cuda::stream_scratch::lease>> blocks;
-	for (size_t k = 0; k < num_streams && k < num_chunks; k++) {
+	for (size_t k = 0; k < num_streams && k < num_groups; k++) {
 		blocks.emplace_back(new cuda::stream_scratch::lease(static_cast<hipStream_t>(streams[k])));
 		if (!blocks.back()->take(most[k])) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for a chunk's slices"); }
 	}
-	// The chunks of stream k — k, k + num_streams, ... — by one loop: the wrapper's argument map and the resolver's are built ONCE per loop, a chunk
-	// rewrites the entries that differ in place (no allocation per chunk), and the launch configuration is resolved again only when the
-	// chunk's length differs from the previous chunk's.  A chunk costs two or three enqueued operations (its copies, its launch) at ~2.6-4 us of
-	// host time each: with many chunks the loops run on a host thread per stream (round 4; one thread: 14-17 us per chunk, which
-	// bounded run-length columns — their ratio is 21 — at 256 chunks to a third of their rate at 16).
-	const int device_of_the_call = cuda::device::current::get().id();
-	auto chunks_of_stream = [&](size_t k, bool set_device) {
-		if (set_device) { cuda::device::current::set(device_of_the_call); }
-		hipStream_t stream = static_cast<hipStream_t>(streams[k]);
-		std::vector<giddy_argument_t> chunk_arguments(arguments, arguments + num_arguments);
-		auto map = giddy_internal::to_map(arguments, num_arguments);
-		std::vector<cuda::any*> entry(num_arguments, nullptr);
-		for (size_t i = 0; i < num_arguments; i++) { entry[i] = &map.at(roles[i].name); }
-		// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
-		auto resolution = map;
+	// Every chunk's launch arguments, in the order of the chunks: the wrapper's argument map and the resolver's are built ONCE, a chunk rewrites the entries
+	// that differ in place (no allocation per chunk), and the launch configuration is resolved again only when the chunk's length differs from the
+	// previous chunk's.  `with_chunk(config, map)`: what to do with them.
+	std::vector<std::vector<size_t>> offsets_of_group(num_groups, std::vector<size_t>(num_arguments, 0));
+	std::vector<std::vector<uint64_t>> first_of_group(num_groups, std::vector<uint64_t>(num_arguments, 0));
+	for (uint64_t g = 0; g < num_groups; g++) {
+		const uint64_t first_chunk = g * chunks_per_group, end_chunk = std::min(num_chunks, (g + 1) * chunks_per_group);
+		(void) slices_of(first_chunk, end_chunk, offsets_of_group[g]);
 		for (size_t i = 0; i < num_arguments; i++) {
-			if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
-				resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
-			}
+			const role& r = roles[i];
+			if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) { first_of_group[g][i] = range_of(r, first_chunk, end_chunk).first; }
 		}
-		cuda::any& resolution_length = resolution["length"];
-		cuda::any& resolution_data_length = resolution["data_length"];
+	}
+	struct chunk_walk {
+		std::vector<giddy_argument_t> chunk_arguments;
+		cuda::kernel_t::arguments_type map, resolution;
+		std::vector<cuda::any*> entry;
 		cuda::launch_configuration_t config;
 		uint64_t config_for_length = ~(uint64_t) 0;
-		std::vector<size_t> offset(num_arguments, 0);
-		char* const base = static_cast<char*>(blocks[k]->memory());
-		for (uint64_t c = k; c < num_chunks; c += num_streams) {
-			const auto& shard = shards[c];
-			if (shard.length() == 0) { continue; }
-			(void) slices_of(shard, offset);
-			for (size_t i = 0; i < num_arguments; i++) {
-				const role& r = roles[i];
-				giddy_argument_t& a = chunk_arguments[i];
-				bool changed = false;
-				if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
-					const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
-					const size_t bytes = slice.size() * r.itemsize;
-					if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offset[i], static_cast<const char*>(arguments[i].value.pointer) + slice.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a chunk's slice)"); }
-					a.value.pointer = base + offset[i]; changed = true;
-					if (r.positions && shard.position_bias != 0) { enqueue_rebase(stream, base + offset[i], base + offset[i], shard.units.size(), r.itemsize, shard.position_bias); }
-				}
-				else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; changed = true; }
-				else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; changed = true; }
-				else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; changed = true; }
-				else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; changed = true; } }
-				if (changed) { *entry[i] = giddy_internal::to_any(a); }
+	};
+	chunk_walk walk;
+	walk.chunk_arguments.assign(arguments, arguments + num_arguments);
+	walk.map = giddy_internal::to_map(arguments, num_arguments);
+	walk.entry.assign(num_arguments, nullptr);
+	for (size_t i = 0; i < num_arguments; i++) { walk.entry[i] = &walk.map.at(roles[i].name); }
+	// (launch-configuration resolution reads its sizes as size_t, under the names the wrappers' resolvers use)
+	walk.resolution = walk.map;
+	for (size_t i = 0; i < num_arguments; i++) {
+		if (roles[i].itemsize == 0 && (roles[i].name == "segment_length" || roles[i].name == "num_dictionary_entries" || roles[i].name == "anchoring_period")) {
+			walk.resolution[roles[i].name] = cuda::any((size_t) arguments[i].value.u64);
+		}
+	}
+	auto arguments_of_chunk = [&](uint64_t g, uint64_t c) {   // -> walk.map / walk.config describe chunk c (of group g)
+		const auto& shard = shards[c];
+		char* const base = static_cast<char*>(blocks[g % num_streams]->memory());
+		for (size_t i = 0; i < num_arguments; i++) {
+			const role& r = roles[i];
+			giddy_argument_t& a = walk.chunk_arguments[i];
+			bool changed = false;
+			if (r.how == sliced_by::elements || r.how == sliced_by::units || r.how == sliced_by::size_containers) {
+				const auto& slice = r.how == sliced_by::elements ? shard.elements : r.how == sliced_by::units ? shard.units : shard.size_containers;
+				a.value.pointer = base + offsets_of_group[g][i] + (slice.first - first_of_group[g][i]) * r.itemsize; changed = true;
 			}
-			if (shard.length() != config_for_length) {
-				resolution_length = cuda::any((size_t) shard.length());
-				resolution_data_length = cuda::any((size_t) shard.length());
-				config = wrapper->resolve_launch_configuration(properties, attributes, resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
-				config_for_length = shard.length();
-			}
-			wrapper->enqueue_launch_with(stream, config, map);
+			else if (r.how == sliced_by::segments) { a.value.pointer = whole_base + whole_offset[i] + shard.segments.first * r.itemsize; changed = true; }
+			else if (r.how == sliced_by::whole_table) { a.value.pointer = whole_base + whole_offset[i]; changed = true; }
+			else if (r.output) { a.value.pointer = static_cast<char*>(arguments[i].value.pointer) + shard.elements.first * r.itemsize; changed = true; }
+			else if (r.itemsize == 0) { uint64_t count; if (is_scalar_count(r.name, shard, count)) { a.value.u64 = count; changed = true; } }
+			if (changed) { *walk.entry[i] = giddy_internal::to_any(a); }
+		}
+		if (shard.length() != walk.config_for_length) {
+			walk.resolution["length"] = cuda::any((size_t) shard.length());
+			walk.resolution["data_length"] = cuda::any((size_t) shard.length());
+			walk.config = wrapper->resolve_launch_configuration(properties, attributes, walk.resolution, cuda::launch_configuration_limits_t { cuda::nullopt, cuda::nullopt, cuda::nullopt });
+			walk.config_for_length = shard.length();
 		}
 	};
-	const size_t loops = std::min<uint64_t>(num_streams, num_chunks);
-	if (loops > 1 && num_chunks >= threaded_from_chunks()) {
-		std::vector<std::exception_ptr> failures(loops);
-		std::vector<std::thread> workers;
-		for (size_t k = 1; k < loops; k++) {
-			workers.emplace_back([&, k] { try { chunks_of_stream(k, true); } catch (...) { failures[k] = std::current_exception(); } });
+	// Groups of several chunks: every group's batch tables are built now and cross the link as ONE copy, with the per-segment arrays (a copy per group would
+	// sit between the groups' bulk copies on the link: ~9 us each, measured) — a group then costs a copy per bulk array and its launch.
+	std::vector<cuda::batch::on_device_t> tables_of_group(num_groups);
+	cuda::stream_scratch::lease tables_block(first_stream);
+	if (chunks_per_group > 1) {
+		cuda::batch::table_t all;          // the groups' tables one after the other: pieces and blocks keep their own numbering within each group
+		std::vector<cuda::batch::table_t> tables(num_groups);
+		size_t bytes = 0;
+		std::vector<size_t> at(num_groups, 0);
+		for (uint64_t g = 0; g < num_groups; g++) {
+			for (uint64_t c = g * chunks_per_group; c < std::min(num_chunks, (g + 1) * chunks_per_group); c++) {
+				if (shards[c].length() == 0) { continue; }
+				arguments_of_chunk(g, c);
+				wrapper->add_to_batch(tables[g], walk.config, walk.map);
+			}
+			at[g] = bytes;
+			bytes += (cuda::batch::device_bytes_of(tables[g]) + 255) / 256 * 256;
 		}
-		try { chunks_of_stream(0, false); } catch (...) { failures[0] = std::current_exception(); }
-		for (auto& worker : workers) { worker.join(); }
-		for (const auto& failure : failures) { if (failure) { std::rethrow_exception(failure); } }
+		if (!tables_block.take(std::max<size_t>(bytes, 256))) { throw cuda::runtime_error(hipErrorOutOfMemory, "no device memory for the groups' batch tables"); }
+		cuda::batch::staging_pool::block* staging = cuda::batch::staging_pool::instance().take(std::max<size_t>(bytes, 256));
+		for (uint64_t g = 0; g < num_groups; g++) {
+			tables_of_group[g] = cuda::batch::place(static_cast<char*>(staging->memory) + at[g], static_cast<char*>(tables_block.memory()) + at[g], tables[g]);
+		}
+		const hipError_t status = bytes ? hipMemcpyAsync(tables_block.memory(), staging->memory, bytes, hipMemcpyHostToDevice, first_stream) : hipSuccess;
+		cuda::batch::staging_pool::instance().copy_enqueued(staging, first_stream);
+		cuda::throw_if_error(status, "hipMemcpyAsync (the groups' batch tables)");
 	}
-	else {
-		for (size_t k = 0; k < loops; k++) { chunks_of_stream(k, false); }
+	ordering_event uploaded;
+	uploaded.record(first_stream);
+	for (size_t k = 1; k < num_streams; k++) { uploaded.make_wait(static_cast<hipStream_t>(streams[k])); }
+
+	for (uint64_t g = 0; g < num_groups; g++) {
+		hipStream_t stream = static_cast<hipStream_t>(streams[g % num_streams]);
+		char* const base = static_cast<char*>(blocks[g % num_streams]->memory());
+		const uint64_t first_chunk = g * chunks_per_group, end_chunk = std::min(num_chunks, (g + 1) * chunks_per_group);
+		// the group's slices of the bulk arrays: one copy each
+		for (size_t i = 0; i < num_arguments; i++) {
+			const role& r = roles[i];
+			if (r.how != sliced_by::elements && r.how != sliced_by::units && r.how != sliced_by::size_containers) { continue; }
+			const auto range = range_of(r, first_chunk, end_chunk);
+			const size_t bytes = range.size() * r.itemsize;
+			if (bytes) { cuda::throw_if_error(hipMemcpyAsync(base + offsets_of_group[g][i], static_cast<const char*>(arguments[i].value.pointer) + range.first * r.itemsize, bytes, hipMemcpyHostToDevice, stream), "hipMemcpyAsync (a group's slice)"); }
+		}
+		if (chunks_per_group > 1) {
+			if (tables_of_group[g].num_blocks != 0) { wrapper->enqueue_launch_of_batch(stream, tables_of_group[g]); }
+			continue;
+		}
+		const auto& shard = shards[first_chunk];   // (a group of one chunk: a launch of its own)
+		if (shard.length() == 0) { continue; }
+		arguments_of_chunk(g, first_chunk);
+		for (size_t i = 0; i < num_arguments; i++) {   // (absolute run positions count from the column's first output: rebased where they have just arrived)
+			if (roles[i].positions && shard.position_bias != 0) { enqueue_rebase(stream, walk.chunk_arguments[i].value.pointer, walk.chunk_arguments[i].value.pointer, shard.units.size(), roles[i].itemsize, shard.position_bias); }
+		}
+		wrapper->enqueue_launch_with(stream, walk.config, walk.map);
 	}
 	// the first stream runs on only when every stream has made its last launch of this call: whatever is enqueued on it next — the next
 	// call's uploads into the same kept block among them — comes after all of this call's readers of the per-segment arrays
