@@ -137,6 +137,69 @@ def timed_steps(work, steps, warmup, barrier, per_step_events=True):
     return elapsed, sum(per_launch_ms) / steps
 
 
+def first_call_after_idle(work, idle_seconds=1.0, repetitions=3):
+    """ONE pass of the hot path after the GPU has idled for `idle_seconds` — what a caller's first decode gets, which the steady-state
+    figures above (a settle loop, warm-up steps) never show: by HIP events on the launch stream and by the host's clock around launch +
+    synchronize.  Median of `repetitions`."""
+    import torch
+    stream = torch.cuda.current_stream().cuda_stream
+    by_events, on_host = [], []
+    for _ in range(repetitions):
+        torch.cuda.synchronize()
+        time.sleep(idle_seconds)
+        begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        begin.record(); work.run(stream); end.record()
+        torch.cuda.synchronize()
+        on_host.append((time.perf_counter() - t0) * 1e3); by_events.append(begin.elapsed_time(end))
+    ms = sorted(by_events)[len(by_events) // 2]
+    return {"after_idle_seconds": idle_seconds, "ms_by_events": round(ms, 4), "ms_on_the_hosts_clock": round(sorted(on_host)[len(on_host) // 2], 4),
+            "frac_of_hbm_peak": round(work.algorithmic_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+            "note": "one step after %.1f s of idle (median of %d): clocks and power states have to come up; NOT the steady-state rate of `value`" % (idle_seconds, repetitions)}
+
+
+def small_columns(name, work, device, log2_piece=18, pieces=1024):
+    """`pieces` columns of 2^log2_piece elements — consecutive segment-range shards of the workload's column, decoded into their ranges of its output —
+    (a) a launch each, back to back, (b) as ONE batch launch (giddy_enqueue_batch, include/giddy/batch.hpp): % of the HBM peak over the
+    algorithmic bytes of the pieces, beside the rate of the same bytes as part of the whole column."""
+    import torch
+    from libgiddy_amd import schemes
+    stream = torch.cuda.current_stream().cuda_stream
+    total_pieces = work.n >> log2_piece
+    pieces = min(pieces, total_pieces)
+    if pieces < 2:
+        return None
+    fields = work.column_fields()
+    shards = [work.shard_function(fields, r, total_pieces) for r in range(pieces)]
+    outs = [work.output[s.start:s.stop] for s in shards]
+    nbytes = sum(o.numel() * o.element_size() + sum(v.numel() * v.element_size() for v in s.fields.values() if isinstance(v, torch.Tensor)) for s, o in zip(shards, outs))
+    configs = [work.launch_fields(o, s.fields, stream, None) for o, s in zip(outs, shards)]
+    with schemes.into_batch() as batch:
+        for o, s in zip(outs, shards):
+            work.launch_fields(o, s.fields, stream, None)
+
+    def each():
+        for o, s, c in zip(outs, shards, configs):
+            work.launch_fields(o, s.fields, stream, c)
+
+    def ms_of(run):
+        run(); torch.cuda.synchronize()
+        times = []
+        for _ in range(5):
+            begin, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            begin.record(); run(); end.record(); torch.cuda.synchronize()
+            times.append(begin.elapsed_time(end))
+        return sorted(times)[len(times) // 2]
+
+    frac = lambda ms: round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    ms_each, ms_batch = ms_of(each), ms_of(lambda: batch.enqueue(stream))
+    return {"columns": pieces, "elements_each": 1 << log2_piece, "algorithmic_bytes": nbytes,
+            "a_launch_per_column": {"ms": round(ms_each, 4), "frac_of_hbm_peak": frac(ms_each), "us_per_column": round(ms_each * 1e3 / pieces, 2)},
+            "one_batch_launch": {"ms": round(ms_batch, 4), "frac_of_hbm_peak": frac(ms_batch), "workgroups": batch.num_blocks},
+            "note": "giddy_enqueue_batch: every column a piece of ONE launch (the columns' bytes are re-read from the Infinity Cache between repetitions when they fit it; "
+                    "cold figures per size: profiles/r05_size_sweep.txt)"}
+
+
 def roofline(work, mean_launch_ms, traffic):
     """`traffic`: None, or (bytes, source) as committed_traffic returns"""
     achieved = work.algorithmic_bytes / (mean_launch_ms * 1e-3) / 1e9
@@ -345,6 +408,7 @@ def modes_of_use(n, device, steps):
     import torch
     import modes
     import workloads as w
+    modes.shim(build_if_missing=False)   # (never a compiler from inside the benchmark: absent -> "skipped" in the line)
     stream = torch.cuda.current_stream()
     out = {"note": "A and B reach the same typed launch (include/giddy/kernel_wrapper.hpp); C is the bare kernel of the reference's signature"}
 
@@ -461,6 +525,14 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
                                              "decompressed_GBps": round(eighth.decompressed_bytes * steps / el8 / 1e9, 1),
                                              "shard_rate_over_column_rate": round(eighth.decompressed_bytes * steps / el8 / column_rate, 4)}
             del eighth
+        # what the one optional collective WOULD move per GPU for this column cut 8 ways: the decoded shards (gather_decoded) against the compressed ones (gather_compressed)
+        eighths = [w.Sharded(whole, r8, 8) for r8 in range(8)]
+        entry["bytes_a_gather_into_rank_0_would_move_at_8"] = {
+            "decoded_per_rank": [int(e.decompressed_bytes) for e in eighths],
+            "compressed_per_rank": [int(e.algorithmic_bytes - e.decompressed_bytes) for e in eighths],
+            "decoded_over_compressed": round(sum(e.decompressed_bytes for e in eighths) / max(1, sum(e.algorithmic_bytes - e.decompressed_bytes for e in eighths)), 2),
+            "note": "7 of the 8 shards cross xGMI into rank 0 (~153 GB/s per link): libgiddy_amd.distributed.gather_compressed moves the second row and decodes at the root; UNMEASURED on hardware"}
+        del eighths
         entry["shard_of_8_alone_on_this_gpu"] = predicted
         entry["predicted_strong_efficiency_at_8"] = min(v["shard_rate_over_column_rate"] for v in predicted.values())
         entry["predicted_strong_efficiency_note"] = ("min over ranks 0, 3, 7 of (that rank's shard-of-8 decoded alone, rate) / (the whole column, rate), both on this one GPU: "
@@ -537,6 +609,7 @@ def main():
     work = make_workload(args.workload, n, device)
     work.run(torch.cuda.current_stream().cuda_stream)
     work.verify(oracle)                                   # bit-exact before anything is reported
+    first_call = first_call_after_idle(work) if world == 1 else None
     elapsed, mean_launch_ms = timed_steps(work, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -559,6 +632,10 @@ def main():
         "roofline": roofline(work, mean_launch_ms, committed_traffic(work.kernel, work.algorithmic_bytes, getattr(work, "workload_name", None))),
     }
 
+    if first_call is not None:
+        line["first_call"] = first_call
+    if rank == 0 and world == 1 and args.schemes != "none" and hasattr(work, "shard_function"):
+        line["small_columns"] = {args.workload: small_columns(args.workload, work, device)}
     if args.gather and world > 1:
         count = min(n, 1 << args.gather_log2n)
         line["gather"] = time_gather(work.output.view(-1)[:count], [count] * world, rank, world, device, barrier)
@@ -605,6 +682,8 @@ def main():
                 entry["decompressed_GBps_input_in_infinity_cache"], entry["ms_per_step_input_in_infinity_cache"] = entry["decompressed_GBps"], entry["ms_per_step"]
                 entry["decompressed_GBps"] = round(w.decompressed_bytes / (pc["ms_three_columns_in_turn"] * 1e-3) / 1e9, 1)
                 entry["ms_per_step"] = pc["ms_three_columns_in_turn"]
+            if name in ("frame_of_reference", "delta_patched", "run_length_encoding", "discard_zero_bytes_variable"):
+                line.setdefault("small_columns", {})[name] = small_columns(name, w, device)
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
             schemes_out[name] = entry
@@ -631,6 +710,10 @@ def main():
             entry = strong_scaling_leg(name, min(log2_total, args.log2n + 1), args, rank, world, device, backend, barrier, oracle, gather=with_gather)
             entry["roofline_rank0"] = entry.pop("this_rank_roofline")
             line["sharded"][name] = entry
+        if world == 1:
+            line["predicted_strong_efficiency_at_8"] = {name: entry.get("predicted_strong_efficiency_at_8") for name, entry in line["sharded"].items()}
+            line["predicted_strong_efficiency_at_8"]["note"] = ("shard-of-8 rate / column rate on ONE GPU (sharded.*.predicted_strong_efficiency_note): a prediction of what the decode "
+                                                                "itself would scale like.  The scaling curve at N = 2, 4, 8 is UNMEASURED: no multi-GPU node has been available to any round")
 
     if rank == 0:
         print(json.dumps(line))

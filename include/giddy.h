@@ -256,8 +256,9 @@ int          giddy_enqueue_rebase(void* hip_stream, void* out, const void* in, u
  * `shards[i]` on device `devices[i]`, written by work enqueued on `hip_streams[i]` — into one contiguous buffer at `destination` on
  * `root_device`, shard after shard.  Each shard's copy is enqueued on its own stream (it crosses its xGMI link once, behind its decode);
  * `root_stream` (a stream of the root device) then waits for all of them: work enqueued on it afterwards sees the whole column.  Peer access
- * between each shard's device and the root is checked and enabled (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess; an error where they
- * cannot reach each other directly — the copy would silently be staged through the host).  The
+ * between each shard's device and the root is checked and enabled once per pair (hipDeviceCanAccessPeer / hipDeviceEnablePeerAccess); where they
+ * cannot reach each other directly the copies are staged through the host by the runtime — slower, said once on stderr — unless
+ * GIDDY_REQUIRE_PEER_ACCESS=1 is in the environment, which makes it an error.  The
  * counterpart of libgiddy_amd.distributed.gather_decoded (one process per GPU, RCCL) for callers who drive all devices themselves. */
 int          giddy_enqueue_gather_on_node(void* destination, int root_device, void* root_stream, const void* const* shards, const int* devices,
                                           void* const* hip_streams, const uint64_t* bytes, size_t num_shards);
@@ -268,7 +269,8 @@ int          giddy_enqueue_gather_on_node(void* destination, int root_device, vo
  * shard's own stream has enqueued so far) and decoded there, by the wrapper `key` names, to where its "decompressed" argument points ON THE
  * ROOT — shard i + 1's copy overlaps shard i's decode when there are two root streams or more.  root_streams[0] then waits for the others.
  * For discard-zero-bytes columns that is 2.9 x fewer bytes over xGMI than gathering decoded shards.  Peer access is checked and enabled
- * (an error where the devices cannot reach each other directly).  Cut a shard finer (giddy_shard) for more overlap. */
+ * as for giddy_enqueue_gather_on_node (staged through the host where there is none; GIDDY_SHARD_DECODE_IN_PLACE needs it and is an error without).
+ * Cut a shard finer (giddy_shard) for more overlap. */
 #define GIDDY_SHARD_COPY_EVEN_IF_LOCAL 1u    /* copy the arrays into the root's scratch even when the shard already lies on the root (tests on one GPU) */
 #define GIDDY_SHARD_DECODE_IN_PLACE    2u    /* no copy: the root's decoder reads the shard's arrays where they lie, over the link (peer access) — every byte crosses once, nothing is staged */
 typedef struct giddy_compressed_shard {

@@ -1,12 +1,15 @@
 // giddy_shard / giddy_enqueue_rebase / giddy_decode_from_host (include/giddy.h): a column's cuts, the rebasing of a shard's anchors on
 // the device, and the chunked host-to-device pipeline, for callers of the C ABI.  The cuts are include/giddy/sharding.hpp's.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
 #include <map>
 #include <memory>
-#include <exception>
+#include <mutex>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../c_abi_internal.hpp"
@@ -30,18 +33,37 @@ struct ordering_event {
 	void make_wait(hipStream_t stream) { cuda::throw_if_error(hipStreamWaitEvent(stream, event, 0), "hipStreamWaitEvent"); }
 };
 
-/// `from`'s copies to and from `to` go device to device (over xGMI) rather than staged through the host: checked, and switched on — once;
-/// a second request is answered hipErrorPeerAccessAlreadyEnabled, which is success here.  Throws where the devices cannot reach each other.
-void enable_peer_access(int from, int to)
+/// `from`'s copies to and from `to` should go device to device (over xGMI) rather than staged through the host: checked, and switched on — ONCE per pair
+/// and process (the answer is kept: the launch path does not repeat the two runtime calls).  Where the devices cannot reach each other directly (no
+/// P2P: virtual machines, ACS / IOMMU set-ups, mixed hives) hipMemcpyPeerAsync still works — the runtime stages the copy through the host —, so the
+/// gathers go on, slower, and say so once on stderr; GIDDY_REQUIRE_PEER_ACCESS=1 in the environment makes that an error instead (a benchmark that
+/// must not silently measure the host's memory).  Returns whether the pair has direct access.
+bool enable_peer_access(int from, int to)
 {
-	if (from == to) { return; }
-	int can = 0;
-	cuda::throw_if_error(hipDeviceCanAccessPeer(&can, from, to), "hipDeviceCanAccessPeer");
-	if (!can) { throw cuda::runtime_error(hipErrorPeerAccessUnsupported, "device " + std::to_string(from) + " cannot access device " + std::to_string(to) + " directly: the gather would be staged through the host"); }
-	cuda::device::current::scoped_override_t<> on(from);
-	const hipError_t status = hipDeviceEnablePeerAccess(to, 0);
-	if (status == hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); return; }
-	cuda::throw_if_error(status, "hipDeviceEnablePeerAccess");
+	if (from == to) { return true; }
+	static std::mutex mutex;
+	static std::map<std::pair<int, int>, bool> known;
+	static const bool required = [] { const char* v = std::getenv("GIDDY_REQUIRE_PEER_ACCESS"); return v != nullptr && v[0] == '1'; }();
+	std::lock_guard<std::mutex> lock(mutex);
+	auto found = known.find({ from, to });
+	if (found == known.end()) {
+		int can = 0;
+		cuda::throw_if_error(hipDeviceCanAccessPeer(&can, from, to), "hipDeviceCanAccessPeer");
+		if (can) {
+			cuda::device::current::scoped_override_t<> on(from);
+			const hipError_t status = hipDeviceEnablePeerAccess(to, 0);
+			if (status == hipErrorPeerAccessAlreadyEnabled) { (void) hipGetLastError(); }
+			else { cuda::throw_if_error(status, "hipDeviceEnablePeerAccess"); }
+		}
+		else if (!required) {
+			std::fprintf(stderr, "libgiddy_amd: device %d cannot access device %d directly: copies between them are staged through the host (GIDDY_REQUIRE_PEER_ACCESS=1 makes this an error)\n", from, to);
+		}
+		found = known.emplace(std::make_pair(from, to), can != 0).first;
+	}
+	if (!found->second && required) {
+		throw cuda::runtime_error(hipErrorPeerAccessUnsupported, "device " + std::to_string(from) + " cannot access device " + std::to_string(to) + " directly (GIDDY_REQUIRE_PEER_ACCESS=1): the gather would be staged through the host");
+	}
+	return found->second;
 }
 
 uint64_t anchor_value(const giddy_column_shape_t& shape, uint64_t index)
@@ -474,7 +496,9 @@ int giddy_enqueue_gather_compressed_on_node(const char* key, int root_device, vo
 			// (GIDDY_SHARD_DECODE_IN_PLACE: no copy at all — the root's decoder reads the shard's arrays where they lie, over the link, as it reads
 			// pinned host memory in libgiddy_amd.pipeline.decode_directly_from_pinned_host: peer access makes a peer's memory addressable)
 			const bool in_place = (shard.flags & GIDDY_SHARD_DECODE_IN_PLACE) != 0;
-			if (in_place) { enable_peer_access(root_device, shard.device); }
+			if (in_place && !enable_peer_access(root_device, shard.device)) {   // (a kernel cannot read a peer's memory through the host)
+				throw cuda::runtime_error(hipErrorPeerAccessUnsupported, "GIDDY_SHARD_DECODE_IN_PLACE: device " + std::to_string(root_device) + " cannot access device " + std::to_string(shard.device) + " directly");
+			}
 			const bool moves = !in_place && (shard.device != root_device || (shard.flags & GIDDY_SHARD_COPY_EVEN_IF_LOCAL) != 0);
 			// the root's stream waits for what the shard's device has enqueued on the shard's stream so far (its arrays being written, say)
 			{

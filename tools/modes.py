@@ -30,10 +30,14 @@ def build_shim():
                            "-o", SHIM, "-L" + lib, "-lgiddy_amd", "-Wl,-rpath," + lib])
 
 
-def shim():
+def shim(build_if_missing=True):
+    """`build_if_missing=False`: a process that has initialised the GPU (bench.py, anything under rocprofv3) never starts a compiler — it reports the shim as absent
+    (build it beforehand: __graft_entry__.build_cpp_test_tools())"""
     global _shim
     if _shim is None:
         if not os.path.exists(SHIM):
+            if not build_if_missing:
+                raise FileNotFoundError("tests/cpp/bin/libmodes_shim.so is not built (python -c 'import __graft_entry__ as g; g.build_cpp_test_tools()')")
             build_shim()
         _shim = ctypes.CDLL(SHIM, mode=ctypes.RTLD_GLOBAL)
         _shim.modes_last_error.restype = ctypes.c_char_p
