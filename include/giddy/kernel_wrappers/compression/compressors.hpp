@@ -155,9 +155,9 @@ void kernel_t<I, U, CS>::enqueue_launch_with(stream::id_t stream, const launch_c
 	// chained by a decoupled look-back (the column read once; 2^28 64-bit elements: 2.66 ms in three launches with a thread per container
 	// -> 1.4 ms by rows -> profiles/r04_compress_bench.txt).  Otherwise: count, offsets, write by a thread per container.
 	const unsigned largest = largest_size_of(min_size, bits, U);
-	const bool by_rows = GIDDY_DZBV_COMPRESS_BY_ROWS && compress_by_rows_applies((unsigned) per, largest, (uint64_t) segment);
+	const bool by_rows = compress_by_rows_applies((unsigned) per, largest, (uint64_t) segment);
 	const shared_memory_size_t staging_bytes = (shared_memory_size_t) (waves_per_block * compress_by_rows_staging_words((unsigned) per, largest) * sizeof(uint32_t));
-	if (by_rows && GIDDY_DZBV_COMPRESS_CHAINED && num_tiles <= 0x7FFFFFFFull) {
+	if (by_rows && num_tiles <= 0x7FFFFFFFull) {
 		const uint64_t num_links = util::div_rounding_up(num_tiles, (uint64_t) 4);   // (compress_by_rows: a workgroup — a link of the chain — takes four consecutive tiles)
 		enqueue_zero(stream, totals, num_links * sizeof(uint64_t));
 		auto chained_config = chained_launch(num_links);

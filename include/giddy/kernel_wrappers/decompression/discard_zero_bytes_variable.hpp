@@ -6,16 +6,15 @@
 #include "giddy/kernels/decompression/discard_zero_bytes_variable.hpp"
 #include "giddy/stream_scratch.hpp"
 
-// output bytes per launch of a long column (see enqueue_launch)
-#ifndef GIDDY_DZBV_LAUNCH_BYTES
-#define GIDDY_DZBV_LAUNCH_BYTES (1ull << 30)
-#endif
 
 namespace cuda {
 namespace kernels {
 namespace decompression {
 namespace discard_zero_bytes {
 namespace variable_width {
+
+/// output bytes per launch of a long column (see launch(): a launch boundary brings the XCDs' write fronts together again; smaller pieces lose more to launch tails than they gain)
+enum : uint64_t { launch_bytes = 1ull << 30 };
 
 /// GIDDY_DZBV_FINE_ANCHORS=0 in the environment: long segments are decoded as they are (measurements)
 inline int fine_from_environment()
@@ -82,7 +81,7 @@ public:
 	/// THE decode of a variable-width discard-zero-bytes column on `stream`: what the type-erased enqueue_launch(),
 	/// cuda::kernel::enqueue_launch(kernel, ...) with typed parameters and variable_width::launch<...>() all run.  `decompress` is the one
 	/// decoder; this function gives long segments finer anchors first (scratch from stream_scratch — none to be had: the segments as
-	/// they are) and cuts a long column into consecutive launches of about GIDDY_DZBV_LAUNCH_BYTES of output.
+	/// they are) and cuts a long column into consecutive launches of about `launch_bytes` of output.
 	static void launch(stream::id_t stream, const launch_configuration_t& launch_config,
 		uncompressed_type* decompressed, const unsigned char* compressed_data, const element_sizes_container_size_type* packed_element_sizes,
 		const uint_t<IndexSize>* position_anchors, size_type segment_length, size_type length,
@@ -117,7 +116,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(st
 	// A long launch loses its compact write front: workgroup b runs on XCD b % 8, the XCDs work through their eighths of the grid at
 	// paces that differ by some 10 %, and once their fronts are tens of MiB apart the memory system serves them at 65-70 % of the HBM peak
 	// instead of 81 % (profiles/r03_dzbv_xcd_drift_2p30.txt).  A launch boundary brings the fronts together again, so a long column
-	// is decoded as consecutive launches of about `GIDDY_DZBV_LAUNCH_BYTES` of output each (2^31 elements: 69 -> 78 %): whole
+	// is decoded as consecutive launches of about `launch_bytes` of output each (2^31 elements: 69 -> 78 %): whole
 	// segments, whole size containers and 16-byte aligned outputs per piece; the anchors are absolute, so compressed_data stays put.
 	// Long segments: anchors for every 1024 elements from the size fields (kernels/..., namespace fine), in stream-ordered scratch memory,
 	// then the decoder on segments of 1024 — where the wide path applies (1-, 2-, 4-bit fields; 4- and 8-byte elements).
@@ -190,7 +189,7 @@ void kernel_t<IndexSize, UncompressedSize, ElementSizesContainerSize>::launch(st
 	const size_t n = length, L = segment_length;
 	const size_t per = bits_per_element_size == 0 ? 1 : (8 * ElementSizesContainerSize) / bits_per_element_size;
 	const size_t segments = L == 0 ? 0 : util::div_rounding_up(n, L);
-	const size_t pieces = std::max<size_t>(1, (n * UncompressedSize + (size_t) GIDDY_DZBV_LAUNCH_BYTES / 2) / (size_t) GIDDY_DZBV_LAUNCH_BYTES);
+	const size_t pieces = std::max<size_t>(1, (n * UncompressedSize + (size_t) launch_bytes / 2) / (size_t) launch_bytes);
 	const size_t granule = std::max<size_t>(per, 1) * 16;
 	const size_t segments_per_piece = pieces <= 1 ? segments : util::round_up(util::div_rounding_up(segments, pieces), granule);
 	for (size_t first = 0; first < std::max<size_t>(segments, 1); first += std::max<size_t>(segments_per_piece, 1)) {

@@ -66,7 +66,7 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
-	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize);
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::delta);
 	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, CompressedSize>), stream, launch_config,
 		decompressed, compressed_input, anchor_values, patch_values, patch_positions,
 		(size_type) length, (size_type) segment_length, (size_type) num_patches);

@@ -85,7 +85,7 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 		launch_config.dynamic_shared_memory_size >= behind + sizeof(dictionary::detail::chunk_key_storage<UncompressedSize, DictionaryIndexSize>);
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
-	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize);
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::dictionary);
 	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, DictionaryIndexSize, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, DictionaryIndexSize>), stream, launch_config,
 		decompressed, compressed_input, dictionary_entries, patch_values, patch_positions,
 		length, num_dictionary_entries, (size_type) num_patches, caching, chunk_key_staging);

@@ -66,7 +66,7 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
-	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed));
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed), sorted_patches::together_from::frame_of_reference);
 	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>), stream, launch_config,
 		decompressed, compressed_input, segment_model_coefficients, patch_values, patch_positions,
 		(size_type) length, (size_type) segment_length, (size_type) num_patches);

@@ -57,7 +57,7 @@ void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch_with(
 	auto num_patches        = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
-	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed));
+	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed), sorted_patches::together_from::model);
 	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, Uncompressed, UnaryModelFunction>), stream, launch_config,
 		decompressed, model_coefficients, patch_values, patch_positions, (size_type) length, (size_type) num_patches);
 }

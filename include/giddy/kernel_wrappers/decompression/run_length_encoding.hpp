@@ -6,10 +6,6 @@
 #include "giddy/kernels/decompression/run_anchors.hpp"
 #include "giddy/stream_scratch.hpp"
 
-#ifndef GIDDY_RUN_DENSE_KERNEL
-#define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -87,7 +83,7 @@ public:
 		constexpr bool has_groups = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled;
 		const uint64_t outputs = tables.hints[0], runs = tables.hints[1];
 		const bool sparse = has_groups && runs != 0 && outputs / runs >= 16;
-		const bool dense = GIDDY_RUN_DENSE_KERNEL && has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
+		const bool dense = has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
 		const void* kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, false, false>>);
 		if constexpr (has_groups) {   // (the other instantiations have the one build)
 			if (dense) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, RunLengthSize, RunIndexSize, true, true>>); }
@@ -136,7 +132,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	const uint64_t n = uncompressed_length, L = segment_length, runs = num_element_runs;
 	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_length_encoding.hpp)
 	const bool sparse = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16;
-	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && !sparse
+	const bool dense = run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && !sparse
 		&& memory_access::is_aligned(run_lengths, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	// (the dense kernel wants all the workgroups a CU holds: the launch parameters' cap of 6 — LDS reserved for nothing, measured on mean runs of 32 —
@@ -158,7 +154,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		const uint64_t group_outputs = per_group * L, finer_per_group = util::div_rounding_up(group_outputs, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_segments, per_group);
 		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) finer_segments_per_workgroup);
-		if (finer_per_group <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES && workgroups >= environment.fused_from && per_group <= 0xFFFFFFFFull
+		if (finer_per_group <= (uint64_t) run_expansion::fused_up_to_fines && workgroups >= environment.fused_from && per_group <= 0xFFFFFFFFull
 			&& runs / groups <= fine::most_runs_per_segment_for_one_launch) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups, 1u << 20), fine::threads),
@@ -187,7 +183,7 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// — segments of up to 8 finer ones (a wavefront decodes two of them, one after the other: with 16 — segments of 131 072 — the separate launches win again,
 		// 2^30 outputs: 75.6 % against 79.0 %; with 4 and 8: 84.2 / 82.5 % against 78.2 / 78.8 %) —
 		const uint64_t workgroups_of_one_kernel = segments * util::div_rounding_up(L / fine::sub, (uint64_t) finer_segments_per_workgroup);
-		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES
+		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) run_expansion::fused_up_to_fines
 			&& workgroups_of_one_kernel >= environment.fused_from && runs / segments <= fine::most_runs_per_segment_for_one_launch;
 		if (fused || (one_launch && environment.force_one_launch && environment.fused && sparse && L / fine::sub <= most_fines_per_long_segment)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,

@@ -8,10 +8,6 @@
 
 #include <cstdlib>
 
-#ifndef GIDDY_RUN_DENSE_KERNEL
-#define GIDDY_RUN_DENSE_KERNEL 1   // columns of mean runs below 16: the kernel with only the groups-of-runs path
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -86,7 +82,7 @@ public:
 		constexpr bool has_groups = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled;
 		const uint64_t outputs = tables.hints[0], runs = tables.hints[1];
 		const bool sparse = has_groups && runs != 0 && outputs / runs >= 16;
-		const bool dense = GIDDY_RUN_DENSE_KERNEL && has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
+		const bool dense = has_groups && runs != 0 && !sparse && tables.hints[2] == 0;
 		const void* kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, false, false>>);
 		if constexpr (has_groups) {   // (the other instantiations have the one build)
 			if (dense) { kernel = reinterpret_cast<const void*>(batch::decode_pieces<piece_body<UncompressedIndexSize, UncompressedSize, PositionOffsetSize, PositionsAreRelative, RunIndexSize, true, true>>); }
@@ -141,7 +137,7 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	// mean runs of 16 or more: the kernel without the groups-of-runs path (kernels/decompression/run_position_encoding.hpp)
 	const bool sparse = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && n / num_element_runs >= 16;
 	// ... below 16, run arrays 16-byte aligned: the kernel with ONLY that path
-	const bool dense = GIDDY_RUN_DENSE_KERNEL && run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && !sparse
+	const bool dense = run_expansion::run_groups<UncompressedSize, PositionOffsetSize>::enabled && num_element_runs != 0 && !sparse
 		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	stream_scratch::lease scratch(stream);
@@ -153,7 +149,7 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		const uint64_t finer_per_group = util::div_rounding_up(per_group * L, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_anchors, per_group);
 		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
-		if (finer_per_group <= (uint64_t) GIDDY_RUN_FUSED_UP_TO_FINES && workgroups >= run_expansion::fine_environment::get().fused_from && per_group <= 0xFFFFFFFFull) {
+		if (finer_per_group <= (uint64_t) run_expansion::fused_up_to_fines && workgroups >= run_expansion::fine_environment::get().fused_from && per_group <= 0xFFFFFFFFull) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups, 1u << 20), fine::threads),
 				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length, (uint32_t) per_group);
@@ -166,7 +162,7 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// decompress_long_segments).  The search is a cheap launch of its own, unlike the run lengths' scan: 2^28 outputs in segments of 32 768: 76.9 % against 74-75 %
 		// (2^30: 82-85 against 79-80), but of 65 536 — a wavefront decodes two finer segments one after the other: 70-72 % against 74-75 % (profiles/r04_run_prepass.txt)
 		const uint64_t workgroups_of_one_kernel = (uint64_t) num_anchors * util::div_rounding_up(L / fine::sub, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
-		if (run_expansion::fine_environment::get().fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) GIDDY_RUN_POSITIONS_FUSED_UP_TO_FINES
+		if (run_expansion::fine_environment::get().fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) run_expansion::positions_fused_up_to_fines
 			&& workgroups_of_one_kernel >= run_expansion::fine_environment::get().fused_from) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),

@@ -9,12 +9,6 @@
 #include "giddy/kernels/compression/common.hpp"
 #include "giddy/kernels/compression/chained.hpp"
 
-#ifndef GIDDY_DZBV_COMPRESS_CHAINED
-#define GIDDY_DZBV_COMPRESS_CHAINED 1   // ... and in one launch, its tiles chained by a decoupled look-back (compress_by_rows<..., true>)
-#endif
-#ifndef GIDDY_DZBV_COMPRESS_BY_ROWS
-#define GIDDY_DZBV_COMPRESS_BY_ROWS 1   // the write pass by rows of 64 elements per wavefront (compress_by_rows) where the shape allows
-#endif
 
 namespace cuda {
 namespace kernels {

@@ -26,22 +26,14 @@ namespace runs {
 
 namespace one_pass {
 
-#ifndef GIDDY_ONE_PASS_WAVES_PER_SIMD
-#define GIDDY_ONE_PASS_WAVES_PER_SIMD 4   // (6 and 8 — the compiler then spills — measured slower: profiles/r03_compress_bench.txt)
-#endif
-#ifndef GIDDY_ONE_PASS_TOGETHER
-#define GIDDY_ONE_PASS_TOGETHER 4   // run values a lane reads again at a time
-#endif
-#ifndef GIDDY_ONE_PASS_BITS_PER_LANE
-#define GIDDY_ONE_PASS_BITS_PER_LANE 64
-#endif
-enum : unsigned { per_lane = GIDDY_ONE_PASS_BITS_PER_LANE, wave_elements = 64 * per_lane, tile = waves_per_block * wave_elements };
+enum : unsigned { per_lane = 64, wave_elements = 64 * per_lane, tile = waves_per_block * wave_elements };
 using mask_t = std::conditional<(per_lane > 32), uint64_t, uint32_t>::type;   // a lane's bits, one per element it saw
-enum : unsigned { staged_runs = 2048 };
-#ifndef GIDDY_ONE_PASS_TILES_PER_LINK
-#define GIDDY_ONE_PASS_TILES_PER_LINK 4
-#endif
-enum : unsigned { tiles_per_link = GIDDY_ONE_PASS_TILES_PER_LINK };   // consecutive tiles a workgroup of encode_run_positions takes as ONE link of the chain   // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
+enum : unsigned {
+	staged_runs = 2048,          // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
+	tiles_per_link = 4,          // consecutive tiles a workgroup of encode_run_positions takes as ONE link of the chain
+	values_read_together = 4,    // run values a lane reads again at a time: one round trip
+	waves_per_simd = 4,          // (6 and 8 — the compiler then spills — measured slower: profiles/r03_compress_bench.txt)
+};
 __device__ __forceinline__ unsigned count_bits(mask_t m) { return (unsigned) __builtin_popcountll((unsigned long long) m); }
 __device__ __forceinline__ unsigned lowest_bit(mask_t m) { return (unsigned) __builtin_ctzll((unsigned long long) m); }
 __device__ __forceinline__ unsigned highest_bit(mask_t m) { return 63u - (unsigned) __builtin_clzll((unsigned long long) m); }
@@ -163,7 +155,7 @@ __device__ __forceinline__ uint64_t segments_past(uint64_t wave_into_segment, ui
 /// Run-position encoding in ONE launch: run k (in order of position) -> run_data[k], run_start_positions[k]; position_anchors[s] =
 /// the run covering s * L; *num_element_runs = the number of runs.  `states`: one zeroed uint64 per tile.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned PositionSize, bool PositionsAreRelative, unsigned RunIndexSize>
-__global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SIMD) encode_run_positions(
+__global__ void __launch_bounds__(threads_per_block, waves_per_simd) encode_run_positions(
 	uint_t<UncompressedSize>*        __restrict__  run_data,
 	uint_t<PositionSize>*            __restrict__  run_start_positions,
 	uint_t<RunIndexSize>*            __restrict__  position_anchors,
@@ -228,7 +220,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		const bool staged = tile_total <= staged_runs;   // (block-uniform)
 		const uint64_t wave_into_segment = wave_base < n ? wave_base % L : 0, wave_segment = wave_base / L;
 		auto for_each_run_of_the_lane = [&](auto&& emit) {   // emit(rank in the tile, offset in the wavefront, value)
-			constexpr unsigned together = GIDDY_ONE_PASS_TOGETHER;   // (values read that many at a time: one round trip)
+			constexpr unsigned together = values_read_together;   // (values read that many at a time: one round trip)
 			for (mask_t rest = starts; rest != 0; ) {
 				uint32_t offset[together]; T value[together]; bool have[together];
 				mask_t walk = rest;
@@ -313,7 +305,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 /// inherited), `count_states` the number of pieces that end before the tile.  Both zeroed, one uint64 per tile each.
 /// Segment s's anchor: the piece holding element s * L and the element's offset into it.
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned RunLengthSize, unsigned RunIndexSize>
-__global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SIMD) encode_run_lengths(
+__global__ void __launch_bounds__(threads_per_block, waves_per_simd) encode_run_lengths(
 	uint_t<UncompressedSize>*        __restrict__  run_data,
 	uint_t<RunLengthSize>*           __restrict__  run_lengths,
 	uint_t<RunIndexSize>*            __restrict__  position_anchors,
@@ -470,7 +462,7 @@ __global__ void __launch_bounds__(threads_per_block, GIDDY_ONE_PASS_WAVES_PER_SI
 		// filled before the look-back (while the tiles before this one are waited for: the write phase was 11 of a tile's 36 microseconds), the others —
 		// tiles of more than `staged_runs` pieces: mean runs below 8 — after it.  One copy of the loop in the code: the window is its only variable.
 		auto stage_window = [&](uint32_t window_first) {
-			constexpr unsigned together = GIDDY_ONE_PASS_TOGETHER;   // (values read that many at a time: one round trip)
+			constexpr unsigned together = values_read_together;   // (values read that many at a time: one round trip)
 			for (mask_t rest = wave_base < n ? ends : 0; rest != 0; ) {
 				T value[together]; uint32_t rank[together]; bool have[together];
 				mask_t walk = rest;

@@ -58,39 +58,20 @@ namespace delta {
 
 namespace detail {
 
-// build-time tuning knobs (defaults measured on MI355X)
-#ifndef GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS
-#define GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS 1   // segments that are not whole rows: rows laid out by the output's cache lines, a segment boundary inside a row (wave_per_ragged_segment_in_aligned_rows)
-#endif
-#ifndef GIDDY_DELTA_ROWS_IN_FLIGHT
-#define GIDDY_DELTA_ROWS_IN_FLIGHT 0   // 0: the measured best per instantiation (rows_in_flight_for below); n > 0: n for all
-#endif
-#ifndef GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO
-#define GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO 4   // bytes of input per lane per row up to which a chunk's input goes through LDS (wave path)
-#endif
-#ifndef GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH
-#define GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH 0   // (measurement aid: what the ragged path's bookkeeping costs where nothing is ragged)
-#endif
-#ifndef GIDDY_DELTA_RAGGED_STAGED
-#define GIDDY_DELTA_RAGGED_STAGED(uncompressed_size) ((uncompressed_size) == 8)   // ragged segments: staging pays for 64-bit elements (<4,8,2>: 69 % against 60; <4,4,1>: 76 % against 80)
-#endif
-#ifndef GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO
-#define GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO 2   // ... of the fused kernels, whose patch windows share the LDS
-#endif
-#ifndef GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP
-#define GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP 8
-#endif
-#ifndef GIDDY_DELTA_ROWS_PER_CHUNK
-#define GIDDY_DELTA_ROWS_PER_CHUNK 32
-#endif
-#ifndef GIDDY_DELTA_WAVE_PATH_THREADS
-#define GIDDY_DELTA_WAVE_PATH_THREADS 256
-#endif
+// What was measured on MI355X and is no longer a build switch (the experiments' numbers are in profiles/r0*_delta_*.txt):
+//   * segments that are not whole rows go by rows laid out on the OUTPUT's cache lines, a segment boundary inside a row (wave_per_ragged_segment_in_aligned_rows;
+//     rows that begin where the segment does leave partial lines at both ends of every row);
+//   * rows in flight per wavefront are per instantiation (rows_in_flight_for) — there is no single best value;
+//   * the whole-row path is not the ragged path with nothing ragged (its bookkeeping costs 2-4 points).
+/// bytes of input per lane per row up to which a chunk's input goes through LDS on the wave path — and in the fused kernels, whose patch windows share the LDS
+enum : unsigned { stage_row_inputs_up_to = 4, patched_stage_row_inputs_up_to = 2 };
+/// ragged segments: staging their input pays for 64-bit elements (<4,8,2>: 69 % of the HBM peak against 60; <4,4,1>: 76 % against 80)
+constexpr bool ragged_segments_staged(unsigned uncompressed_size) { return uncompressed_size == 8; }
 
 enum : unsigned {
-	rows_per_wave_per_sweep = GIDDY_DELTA_ROWS_PER_WAVE_PER_SWEEP,                // block path
-	wave_path_threads = GIDDY_DELTA_WAVE_PATH_THREADS,
-	rows_per_chunk = GIDDY_DELTA_ROWS_PER_CHUNK,                                                          // wave path: rows a wavefront takes per outer-loop trip;
+	rows_per_wave_per_sweep = 8,                                                  // block path
+	wave_path_threads = 256,
+	rows_per_chunk = 32,                                                                                  // wave path: rows a wavefront takes per outer-loop trip;
 	                                                                              // segments of more rows are swept by a whole workgroup
 	max_waves_per_block = 16,
 };
@@ -101,7 +82,6 @@ enum : unsigned {
 template <unsigned UncompressedSize, unsigned CompressedSize>
 constexpr unsigned rows_in_flight_for()
 {
-	if (GIDDY_DELTA_ROWS_IN_FLIGHT > 0) { return GIDDY_DELTA_ROWS_IN_FLIGHT; }
 	if (UncompressedSize == 2) { return 8; }
 	if ((UncompressedSize == 8 && CompressedSize == 1) || (UncompressedSize == 4 && CompressedSize == 2)) { return 1; }
 	return 2;
@@ -194,24 +174,7 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t rows_per_se
 /// (partial cache lines at both ends of every row) and its input loads are 2-8 bytes per lane — 46-68 % of the HBM peak at segments of 5000
 /// and 10000 elements where the wave paths for ragged segments (rows by the output's cache lines, input through LDS) reach 58-74 %.  For
 /// 2- and 4-byte elements the workgroup path is the faster one (78-89 %), and for 2-byte deltas of 64-bit elements too (68 % against 64-67).
-#ifndef GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS
-#define GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS 0
-#endif
-#ifndef GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS
-#define GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS 1
-#endif
-#ifndef GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1
-#define GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1 8   // (28 before a workgroup took several short segments: block_per_segment)
-#endif
-#ifndef GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1
-#define GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1 8
-#endif
-#ifndef GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS
-#define GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS 0   // (see takes_wave_path: what it gains at 2^28 elements is the Infinity Cache's; at 2^30 it loses 5-6 points)
-#endif
-#ifndef GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS
-#define GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS 8192   // 0: never
-#endif
+enum : unsigned { long_ragged_by_wave_from_segments = 8192 };   // (segments of more than rows_per_chunk rows, ragged, 64-bit elements: a wavefront each from this many segments on)
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
 {
@@ -221,34 +184,17 @@ __host__ __device__ inline bool takes_wave_path(uint64_t n, uint64_t L)
 	// eight in flight — a segment of 8 or 16 rows sharing its workgroup with three or one more (block_per_segment).  At 2^28 elements: <4,4,1> at segments of 2048 / 4096 /
 	// 8192: 82 / 82 / 83 -> 89 % of the HBM peak, <4,2,1>: 82 -> 86 %.  At 2^30: 73 / 73 / 71 % against 73 / 78 / 77 % — the 2^28 column's 256 MiB of deltas sit in the
 	// Infinity Cache between repetitions, and the workgroup shape profits from that more than it costs; read from HBM it is the slower one.)
-	if (GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS != 0 && L % traits::row == 0 && rows >= GIDDY_DELTA_WORKGROUP_PATH_FOR_ALL_FROM_ROWS && rows <= rows_per_chunk) { return false; }   // (measurements)
-	if (GIDDY_DELTA_WORKGROUP_PATH_FOR_SOME_SHORTER_SEGMENTS && L % traits::row == 0 && CompressedSize == 1 && rows <= rows_per_chunk
-		&& ((UncompressedSize == 4 && rows >= GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_4_FROM_1) || (UncompressedSize == 2 && rows >= GIDDY_DELTA_WORKGROUP_FROM_ROWS_OF_2_FROM_1))) { return false; }
 	if (rows <= rows_per_chunk) { return true; }
-	return GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS != 0 && UncompressedSize == 8 && CompressedSize != 2 && L % traits::row != 0
-		&& n / GIDDY_DELTA_LONG_RAGGED_BY_WAVE_FROM_SEGMENTS >= L;
+	return UncompressedSize == 8 && CompressedSize != 2 && L % traits::row != 0 && n / long_ragged_by_wave_from_segments >= L;
 }
 
-/// A chunk's anchors, one per lane (a chunk is at most rows_per_chunk <= 64 segments): ONE vector load that goes out ahead of the chunk's first
-/// rows, where `base = anchors[segment]` at every segment's first row is a load the wavefront has to wait for with its stores unissued
-/// (segments of 12 rows: 66 % of the HBM peak where segments of 16 — two per chunk instead of... — reach 73 %).
-#ifndef GIDDY_DELTA_ANCHORS_AHEAD
-#define GIDDY_DELTA_ANCHORS_AHEAD 0   // (measured against the same kernels without it, one box, 2^30 elements in segments of 4096: 2-byte elements -5 points, <8,8,2> -1.5, the rest within noise)
-#endif
+/// A chunk's anchors.  (Tried in round 4 and taken out: ONE vector load of all of a chunk's anchors, a lane each, ahead of the chunk's first rows, instead of a load at every
+/// segment's first row — 2-byte elements -5 points, <8,8,2> -1.5, the rest within noise.)
 template <typename U>
 struct chunk_anchors {
-	U mine;
-	uint64_t first;
 	const U* __restrict__ anchors;
-	__device__ __forceinline__ void load(const U* __restrict__ anchors_, uint64_t first_segment, uint64_t segments_per_chunk, uint64_t start, uint64_t end, uint64_t L, unsigned lane)
-	{
-		anchors = anchors_; first = first_segment;
-		if (GIDDY_DELTA_ANCHORS_AHEAD) { mine = (lane < segments_per_chunk && start + lane * L < end) ? anchors[first_segment + lane] : (U) 0; }
-	}
-	__device__ __forceinline__ U of(uint64_t segment) const
-	{
-		return GIDDY_DELTA_ANCHORS_AHEAD ? wave64::read_lane(mine, (unsigned) (segment - first)) : anchors[segment];
-	}
+	__device__ __forceinline__ void load(const U* __restrict__ anchors_, uint64_t, uint64_t, uint64_t, uint64_t, uint64_t, unsigned) { anchors = anchors_; }
+	__device__ __forceinline__ U of(uint64_t segment) const { return anchors[segment]; }
 };
 
 /// wave path: this wavefront decompresses whole segments on its own (several short ones per chunk)
@@ -508,18 +454,11 @@ __device__ __forceinline__ void wave_per_ragged_segment_in_aligned_rows(
 /// segment's anchor less the row's prefix before lane b (one ds_bpermute); if it began in an earlier row they go on from where that row ended.
 /// The anchors are gathered per lane with the row's own loads (lanes of one segment read one address).  A chunk is as many whole segments
 /// as fill `rows_per_chunk` rows (short_segments_per_wave_chunk; kernel and launch parameters agree).
-#ifndef GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS
-#define GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS 1
-#endif
-#ifndef GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS
-#define GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS 1   // ... and ragged segments of a row or more go the same way (0: wave_per_ragged_segment_in_aligned_rows)
-#endif
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __host__ __device__ inline bool short_segments_share_rows(uint64_t L)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
-	return GIDDY_DELTA_SHORT_SEGMENTS_SHARE_ROWS && L % traits::E == 0 && L % traits::row != 0
-		&& (L < traits::row || (GIDDY_DELTA_PLACE_LANES_IN_ALL_RAGGED_ROWS && (L + traits::row - 1) / traits::row <= rows_per_chunk));
+	return L % traits::E == 0 && L % traits::row != 0 && (L < traits::row || (L + traits::row - 1) / traits::row <= rows_per_chunk);
 }
 /// segments per wavefront chunk, of any length (the wave path)
 template <unsigned UncompressedSize, unsigned CompressedSize>
@@ -531,19 +470,17 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk_of(uint64_t L)
 }
 
 /// Chunks of the lane-placed path.  A wavefront's chunk had better be EXACTLY rows_per_chunk rows (measured, tools/run_ragged_delta.sh with
-/// GIDDY_DELTA_ROWS_PER_CHUNK builds: chunks of 16 or 32 rows 73 % of the HBM peak, of 21, 24, 30, 31, 33, 48 rows 62-66 % — whole-row segments
+/// builds with other values of rows_per_chunk: chunks of 16 or 32 rows 73 % of the HBM peak, of 21, 24, 30, 31, 33, 48 rows 62-66 % — whole-row segments
 /// of 10 or 12 rows, three or two to a chunk, sit there too; neither the base addresses' alignment nor the number of workgroups explains it,
 /// and the bytes moved are the same).  So where whole segments do not make such a chunk the chunks are WINDOWS of rows_per_chunk rows of the column
 /// whatever the segments do: a window that begins inside a segment first adds up that segment's deltas before the window (at most one segment's
-/// worth of input read a second time — segments of up to GIDDY_DELTA_WINDOWS_UP_TO_ROWS rows go this way).
-#ifndef GIDDY_DELTA_WINDOWS_UP_TO_ROWS
-#define GIDDY_DELTA_WINDOWS_UP_TO_ROWS 4   // 0: chunks of whole segments always (measured with 16: segments of 8-12 rows lose 3-4 points to the second read, of up to 4 rows gain 5-13)
-#endif
+/// worth of input read a second time — segments of up to windows_up_to_rows rows go this way).
+enum : unsigned { windows_up_to_rows = 4 };   // (measured with 16: segments of 8-12 rows lose 3-4 points to the second read, of up to 4 rows gain 5-13)
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __host__ __device__ inline bool chunks_are_windows(uint64_t L)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
-	return short_segments_share_rows<UncompressedSize, CompressedSize>(L) && L <= (uint64_t) GIDDY_DELTA_WINDOWS_UP_TO_ROWS * traits::row
+	return short_segments_share_rows<UncompressedSize, CompressedSize>(L) && L <= (uint64_t) windows_up_to_rows * traits::row
 		&& segments_per_wave_chunk_of<UncompressedSize, CompressedSize>(L) * L != (uint64_t) rows_per_chunk * traits::row;
 }
 /// elements per wavefront chunk on the wave path, for segments of any length
@@ -762,15 +699,12 @@ __device__ __forceinline__ void wave_per_ragged_segment_with_staged_input(
 /// the row's loads) leaves `anchor - the row's prefix before it` in a wave-private LDS table indexed by the segment's number within the row; every element
 /// then reads its segment's entry — or, if its segment began before the row, goes on from where the previous row ended.  A window that begins inside a
 /// segment first adds up that segment's deltas before it (the input from the segment's start to the window: read twice).
-#ifndef GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS
-#define GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS 1
-#endif
 enum : unsigned { any_length_waves = 4 };   // wavefronts per workgroup the LDS tables exist for
 template <unsigned UncompressedSize, unsigned CompressedSize>
 __host__ __device__ inline bool any_length_by_windows(uint64_t L)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
-	return GIDDY_DELTA_ANY_SEGMENT_LENGTH_BY_WINDOWS && L % traits::E != 0 && L <= (uint64_t) rows_per_chunk * traits::row;
+	return L % traits::E != 0 && L <= (uint64_t) rows_per_chunk * traits::row;
 }
 
 /// `AnyAlignment` (decompress_at_any_alignment): `out` and `in` aligned for their elements only.  Rows follow the output's 1 KiB boundaries as before — every row but the
@@ -928,7 +862,7 @@ __device__ __forceinline__ void block_per_segment(
 	// taken by 1 or 2 of its wavefronts in one sweep — the same barrier, the totals added up within a segment's wavefronts only
 	const uint64_t rows_per_segment = (L + traits::row - 1) / traits::row;
 	const unsigned waves_per_segment = (unsigned) ((rows_per_segment + R - 1) / R);
-	if (GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS && waves_per_segment * 2 <= num_waves) {
+	if (waves_per_segment * 2 <= num_waves) {
 		const unsigned segments_per_block = num_waves / waves_per_segment;
 		const unsigned mine_of_block = w / waves_per_segment, part = w % waves_per_segment;
 		for (uint64_t first = (uint64_t) grid.block() * segments_per_block; first < num_segments; first += (uint64_t) grid.blocks() * segments_per_block) {
@@ -1067,7 +1001,7 @@ namespace detail {
 /// whether an instantiation's wave path brings a chunk's input in through LDS, and the bytes of LDS a wavefront needs for it
 template <unsigned UncompressedSize, unsigned CompressedSize, bool Patched> constexpr bool stages_row_inputs()
 {
-	return row_traits<UncompressedSize, CompressedSize>::E * CompressedSize <= (Patched ? GIDDY_DELTA_PATCHED_STAGE_ROW_INPUTS_UP_TO : GIDDY_DELTA_STAGE_ROW_INPUTS_UP_TO);
+	return row_traits<UncompressedSize, CompressedSize>::E * CompressedSize <= (Patched ? patched_stage_row_inputs_up_to : stage_row_inputs_up_to);
 }
 template <unsigned UncompressedSize, unsigned CompressedSize> constexpr unsigned staged_chunk_bytes()
 {
@@ -1110,7 +1044,7 @@ __device__ __forceinline__ void decompress(
 				return;
 			}
 			// (segments sharing rows, in chunks of exactly the staging area's size: staged too)
-			if (GIDDY_DELTA_RAGGED_STAGED(UncompressedSize) && staging != nullptr && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
+			if (ragged_segments_staged(UncompressedSize) && staging != nullptr && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
 				&& short_segments_share_rows<UncompressedSize, CompressedSize>(L)
 				&& wave_chunk_length_of<UncompressedSize, CompressedSize>(L) == (uint64_t) rows_per_chunk * traits::row) {
 				wave_rows_of_short_segments<UncompressedSize, CompressedSize, true>(
@@ -1119,7 +1053,7 @@ __device__ __forceinline__ void decompress(
 				return;
 			}
 			// (ragged segments of at least a row, the chunk's bytes 16-byte aligned: staged as well, rows by the output's cache lines)
-			if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && GIDDY_DELTA_RAGGED_STAGED(UncompressedSize) && staging != nullptr && L >= traits::row && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
+			if (ragged_segments_staged(UncompressedSize) && staging != nullptr && L >= traits::row && wave64::per_block() <= 4 && memory_access::is_aligned(compressed_input, 16)
 				&& (rows_per_segment > rows_per_chunk || segments_per_wave_chunk(rows_per_segment) * L * CompressedSize + 16 <= staged_chunk_bytes<UncompressedSize, CompressedSize>())) {
 				wave_per_ragged_segment_with_staged_input<UncompressedSize, CompressedSize>(
 					decompressed, compressed_input, anchor_values, n, L, patches,
@@ -1127,9 +1061,9 @@ __device__ __forceinline__ void decompress(
 				return;
 			}
 		}
-		if (L % traits::row == 0 && !GIDDY_DELTA_WHOLE_ROWS_BY_THE_RAGGED_PATH) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
+		if (L % traits::row == 0) { wave_per_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
 		else if (short_segments_share_rows<UncompressedSize, CompressedSize>(L)) { wave_rows_of_short_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, nullptr, grid); }
-		else if (GIDDY_DELTA_RAGGED_IN_ALIGNED_ROWS && L >= traits::row) { wave_per_ragged_segment_in_aligned_rows<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
+		else if (L >= traits::row) { wave_per_ragged_segment_in_aligned_rows<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
 		else { wave_per_ragged_segment<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, patches, grid); }
 	}
 	else if (vector_access && wave64::per_block() <= max_waves_per_block) {
@@ -1211,22 +1145,14 @@ __global__ void decompress_at_any_alignment(
 // Nothing here depends on the order in which workgroups are dispatched: a tile that does not see its predecessors' states
 // within `chained::patience` polls adds up the deltas before it itself (from the segment's start — correct, just slow), so the
 // launch completes under any schedule; with the dispatcher's in-order habit it never happens.
-#ifndef GIDDY_DELTA_LOOKBACK_WINDOWS
-#define GIDDY_DELTA_LOOKBACK_WINDOWS 1
-#endif
-#ifndef GIDDY_DELTA_CHAINED_ROWS_PER_WAVE
-#define GIDDY_DELTA_CHAINED_ROWS_PER_WAVE 0   // 0: by the deltas' width (rows_per_wave below)
-#endif
-#ifndef GIDDY_DELTA_CHAINED_ROWS_TOGETHER
-#define GIDDY_DELTA_CHAINED_ROWS_TOGETHER 2   // rows of the second pass the instruction scheduler may interleave
-#endif
 
 namespace chained {
 
 enum : unsigned {
 	aggregate = 1, prefix = 2,
 	patience = 1u << 16,       // polls (~1 us each) that bring nothing new before a tile stops waiting
-	lookback_windows = GIDDY_DELTA_LOOKBACK_WINDOWS,   // predecessors read per poll, in 64s
+	lookback_windows = 1,   // predecessors read per poll, in 64s
+	rows_of_the_second_pass_together = 2,   // rows of the second pass the instruction scheduler may interleave
 };
 
 /// Rows a wavefront takes of its tile: as many as it can keep the DELTAS of in registers between the two passes over them (totals
@@ -1237,7 +1163,6 @@ enum : unsigned {
 template <unsigned UncompressedSize, unsigned CompressedSize>
 constexpr unsigned rows_per_wave()
 {
-	if (GIDDY_DELTA_CHAINED_ROWS_PER_WAVE > 0) { return GIDDY_DELTA_CHAINED_ROWS_PER_WAVE; }
 	return detail::row_traits<UncompressedSize, CompressedSize>::E * CompressedSize <= 4 ? 32 : (detail::row_traits<UncompressedSize, CompressedSize>::E * CompressedSize <= 8 ? 16 : 8);
 }
 /// A tile is a workgroup of `Waves` wavefronts (4, 8 or 16 — the wrapper picks by the number of tiles in a segment: the longer the chain,
@@ -1432,7 +1357,7 @@ __global__ void __launch_bounds__(Waves * 64) decompress(
 				memory_access::store_group<memory_access::wide_output_policy<sizeof(U)>(GIDDY_DELTA_STORE_POLICY)>(
 					decompressed + my_start + (uint64_t) k * traits::row + (uint64_t) lane * traits::E, values);
 				base += (U) row.total;
-				if (k % GIDDY_DELTA_CHAINED_ROWS_TOGETHER == GIDDY_DELTA_CHAINED_ROWS_TOGETHER - 1) { __builtin_amdgcn_sched_barrier(0); }   // (left alone the scheduler scans all the rows first)
+				if (k % rows_of_the_second_pass_together == rows_of_the_second_pass_together - 1) { __builtin_amdgcn_sched_barrier(0); }   // (left alone the scheduler scans all the rows first)
 			}
 		}
 		else {
@@ -1512,7 +1437,7 @@ public:
 				util::div_rounding_up(rows_per_segment, (size_t) detail::rows_per_wave_per_sweep));
 			grid_construction_resolution = block;
 			length = num_segments;
-			if (GIDDY_DELTA_WORKGROUP_TAKES_SEVERAL_SEGMENTS && waves <= 2) {   // (segments of 8 or 16 rows: 4 or 2 of them to a workgroup of 4 wavefronts — block_per_segment)
+			if (waves <= 2) {   // (segments of 8 or 16 rows: 4 or 2 of them to a workgroup of 4 wavefronts — block_per_segment)
 				length = util::div_rounding_up(num_segments, (size_t) (4 / waves));
 				waves = 4;
 			}

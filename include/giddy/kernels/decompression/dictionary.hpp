@@ -59,7 +59,7 @@ template <bool Patched, unsigned UncompressedSize = 0, unsigned DictionaryIndexS
 	// (plain 8-byte values with 2-byte or wider keys as well where every workgroup re-stages the dictionary: 32 KiB are then staged
 	// per 128 KiB of output instead of per 32 KiB tile — <4,8,2> 60-64 -> 75, <4,8,4> 71 -> 78 % of HBM peak; staged once or looked up
 	// through L2, tiles are 3 points better; 4-byte values lose 2-5 points by chunks)
-	return Patched || GIDDY_STREAM_BY_WAVE_CHUNKS || (RestagedDictionary && UncompressedSize == 8 && DictionaryIndexSize >= 2);
+	return Patched || (RestagedDictionary && UncompressedSize == 8 && DictionaryIndexSize >= 2);
 }
 /// ... whose chunks' keys come in through LDS when a row takes at most this many key bytes per lane: 4 for 8-byte values (1- and
 /// 2-byte keys: 55-58 -> 81-83 % and 69 -> 80 % of HBM peak, at 2 resident workgroups per CU), 2 otherwise (4-byte values with

@@ -51,56 +51,20 @@ namespace variable_width {
 
 using element_size_t = native_word_t;
 
-// build-time tuning knob (default measured on MI355X)
-#ifndef GIDDY_DZBV_ROWS_IN_FLIGHT
-#define GIDDY_DZBV_ROWS_IN_FLIGHT 2
-#endif
-
-// the wide path (see detail::decompress_wide): 1 = on where it applies
-#ifndef GIDDY_DZBV_PAIRS
-#define GIDDY_DZBV_PAIRS 1   // two-byte elements are cut out of the staged bytes two at a time, by a table of byte permutations (detail::pair_entry)
-#endif
-#ifndef GIDDY_DZBV_WIDE
-#define GIDDY_DZBV_WIDE 1
-#endif
-// 1 KiB pieces of a super-row's bytes requested before the first is written to LDS (measured: 2 >= 3 > 4, which costs a wavefront of occupancy)
-#ifndef GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT
-#define GIDDY_DZBV_WIDE_PIECES_IN_FLIGHT 2
-#endif
-// wavefronts per SIMD the register allocator must leave room for; 0 = its own choice (65-67 vector registers, 7 wavefronts:
-// measured 1-3 points FASTER than forcing 64 registers, which turns scalar spills into extra vector work)
-#ifndef GIDDY_DZBV_WAVES_PER_SIMD
-#define GIDDY_DZBV_WAVES_PER_SIMD 6
-#endif
-#if GIDDY_DZBV_WAVES_PER_SIMD > 0
-#define GIDDY_DZBV_OCCUPANCY __attribute__((amdgpu_waves_per_eu(GIDDY_DZBV_WAVES_PER_SIMD)))
-#else
-#define GIDDY_DZBV_OCCUPANCY
-#endif
-// a wavefront's chunks within its workgroup's span: 1 = interleaved with the other wavefronts', 0 = consecutive
-#ifndef GIDDY_DZBV_INTERLEAVE_SPANS
-#define GIDDY_DZBV_INTERLEAVE_SPANS 1
-#endif
-#ifndef GIDDY_DZBV_SGPRS
-#define GIDDY_DZBV_SGPRS 102
-#endif
-// chunks (anchored segments, or batches of short ones) a wavefront takes when the column has plenty (launch_config_resolution_params_t)
-// cache policy of the 16-byte output stores on the fast paths (memory_access::store_policy): 1 = nt, 2 = sc1 nt (write-through)
-#ifndef GIDDY_DZBV_STORE_POLICY
-#define GIDDY_DZBV_STORE_POLICY 1
-#endif
-#ifndef GIDDY_DZBV_BUSY_FACTOR
-#define GIDDY_DZBV_BUSY_FACTOR 1024
-#endif
-#ifndef GIDDY_DZBV_CHUNKS_PER_WAVE
-#define GIDDY_DZBV_CHUNKS_PER_WAVE 1
-#endif
+// What this decoder's tuning settled on (MI355X; DESIGN.md section 4, "DZB-variable, round 2", "What a long launch loses"); no longer build switches:
+// the wide path wherever it applies, two-byte elements cut out in pairs by a table of byte permutations, a wavefront's chunks interleaved with its
+// workgroup's other wavefronts', `nt` stores (write-through: -1...-4 points), one chunk per wavefront (K > 1, software-pipelined: slower at every size).
+/// 1 KiB pieces of a super-row's bytes requested before the first is written to LDS (measured: 2 >= 3 > 4, which costs a wavefront of occupancy)
+enum : unsigned { wide_pieces_in_flight = 2 };
+/// Register budget of the two kernels: room for 6 wavefronts per SIMD (the allocator's own choice — 65-67 vector registers, 7 wavefronts — measured 1-3 points
+/// faster than forcing 64 registers, which turns scalar spills into vector work; 5 or 7 per SIMD: 74-77 % against 77-79), 102 scalar registers
+#define GIDDY_DZBV_KERNEL_ATTRIBUTES __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(102))) __attribute__((amdgpu_waves_per_eu(6)))
 
 namespace detail {
 
 enum : unsigned {
 	max_waves_per_block = 4,          // the launch parameters cap the workgroup at 256 threads
-	rows_in_flight = GIDDY_DZBV_ROWS_IN_FLIGHT,
+	rows_in_flight = 2,
 	rows_per_chunk = 8,               // a wavefront batches short segments up to this many rows per outer-loop trip
 	staging_bytes = 1024 + 16 + 16,   // a row's bytes + head misalignment + over-read slack for the aligned dword reads
 	staging_words = staging_bytes / 4,
@@ -226,13 +190,10 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 /// segments: one can decompress it without using the anchors at all, with no change of semantics" (the reference's discard_zero_bytes_variable.cuh:366-369):
 /// an anchor is a checkpoint of the ONE running sum of element sizes, so every k-th anchor with segments of k x segment_length is the same column.
 /// k makes the coarser segments whole "super-rows" of the wide path (64 size words) when that takes at most 2^16 elements, else whole rows, else
-/// stays 1.  Kernel and launch parameters agree (coalescing_of); GIDDY_DZBV_COALESCE_SHORT_SEGMENTS=0: never.
-#ifndef GIDDY_DZBV_COALESCE_SHORT_SEGMENTS
-#define GIDDY_DZBV_COALESCE_SHORT_SEGMENTS 1
-#endif
+/// stays 1.  Kernel and launch parameters agree (coalescing_of).
 __host__ __device__ inline unsigned coalescing_of(uint64_t segment_length, unsigned row, unsigned bits)
 {
-	if (!GIDDY_DZBV_COALESCE_SHORT_SEGMENTS || segment_length == 0 || segment_length >= row) { return 1; }
+	if (segment_length == 0 || segment_length >= row) { return 1; }
 	const unsigned L = (unsigned) segment_length;
 	unsigned low_zeros = 0;
 	while (((L >> low_zeros) & 1u) == 0) { low_zeros++; }
@@ -342,7 +303,7 @@ struct row_group {
 						values.words[d] = __builtin_amdgcn_perm(0u, four_bytes, entry.selector);
 						at += entry.bytes;
 					}
-					memory_access::store_group<GIDDY_DZBV_STORE_POLICY>(decompressed + i0, values);
+					memory_access::store_group<memory_access::non_temporal>(decompressed + i0, values);
 					continue;
 				}
 			}
@@ -353,7 +314,7 @@ struct row_group {
 				values[j] = (U) cut<UncompressedSize>(row_stage[word], row_stage[word + 1], UncompressedSize == 8 ? row_stage[word + 2] : 0u, at & 3, size, masks);
 				at += size;
 			}
-			memory_access::store_group<GIDDY_DZBV_STORE_POLICY>(decompressed + i0, values);
+			memory_access::store_group<memory_access::non_temporal>(decompressed + i0, values);
 		}
 		wave64::lds_fence();   // the staging area may be rewritten after this
 	}
@@ -500,7 +461,7 @@ template <> __device__ __forceinline__ unsigned sum_of_fields<4>(uint32_t x)
 __host__ __device__ inline bool wide_path_applies(unsigned bits, unsigned container_size, unsigned E)
 {
 	// (3-bit fields: two steps per 1024-element segment, no faster than the row-wise path; 2-byte elements, E = 8: 6 points slower)
-	if (!GIDDY_DZBV_WIDE || bits < 1 || bits > 4 || bits == 3 || E > 4) { return false; }
+	if (bits < 1 || bits > 4 || bits == 3 || E > 4) { return false; }
 	return (32 / bits) % E == 0;
 }
 
@@ -673,7 +634,7 @@ __device__ __forceinline__ void decompress_wide(
 			values[j] = (U) cut<UncompressedSize>(words[0], words[1], UncompressedSize == 8 ? words[2] : 0u, position & 3, size, masks);
 			position += size;
 		}
-		store_group<GIDDY_DZBV_STORE_POLICY>(out + (uint64_t) k * row, values);
+		store_group<non_temporal>(out + (uint64_t) k * row, values);
 	};
 
 	auto rows_of = [&](const wide_step& s, const located& at) {
@@ -742,7 +703,7 @@ __device__ __forceinline__ void decompress_full_groups(
 	group_t current, next;
 	container_type after_next[R];
 	// (two-byte elements, size fields of at most 4 bits: pairs of elements by table — pair_entry)
-	const pair_entry* const pairs = (UncompressedSize == 2 && GIDDY_DZBV_PAIRS && bits <= 4) ? static_cast<const size_masks_and_pairs&>(masks).pairs : nullptr;
+	const pair_entry* const pairs = (UncompressedSize == 2 && bits <= 4) ? static_cast<const size_masks_and_pairs&>(masks).pairs : nullptr;
 	// wave-uniform position of the next group's first size field
 	uint64_t container_base = divide(rows_start, per);
 	unsigned field_base = (unsigned) (rows_start - container_base * per);
@@ -781,7 +742,7 @@ namespace detail {
 
 template <unsigned UncompressedSize>
 struct block_storage {
-	enum : unsigned { R = rows_in_flight, words_per_wave = GIDDY_DZBV_WIDE && wide_staging_words > R * staging_words ? (unsigned) wide_staging_words : R * staging_words };
+	enum : unsigned { R = rows_in_flight, words_per_wave = wide_staging_words > R * staging_words ? (unsigned) wide_staging_words : R * staging_words };
 	uint32_t staging[max_waves_per_block][words_per_wave];
 	typename std::conditional<UncompressedSize == 2, size_masks_and_pairs, size_masks>::type masks;   // (two-byte elements: + the table of pairs)
 };
@@ -839,16 +800,10 @@ __device__ __forceinline__ void decompress_as_block(
 	const uint64_t K = detail::divide_any(total_chunks + num_waves - 1, num_waves);
 	const uint64_t block_first = block_index * working_waves * K;
 	const uint64_t block_limit = block_first + working_waves * K < total_chunks ? block_first + working_waves * K : total_chunks;
-#if GIDDY_DZBV_INTERLEAVE_SPANS == 2
-	// (grid stride: wavefront g of all W takes chunks g, g + W, g + 2 W ... — with a grid of resident workgroups the chip as a whole sweeps the column once)
-	const unsigned stride = (unsigned) num_waves;
-	const uint64_t first_chunk = block_index * working_waves + wave64::index_in_block();
-	const uint64_t span_limit = total_chunks;
-#else
-	const unsigned stride = GIDDY_DZBV_INTERLEAVE_SPANS ? working_waves : 1u;
-	const uint64_t first_chunk = block_first + (GIDDY_DZBV_INTERLEAVE_SPANS ? (uint64_t) wave64::index_in_block() : wave64::index_in_block() * K);
-	const uint64_t span_limit = GIDDY_DZBV_INTERLEAVE_SPANS ? block_limit : (first_chunk + K < block_limit ? first_chunk + K : block_limit);
-#endif
+	// (a wavefront's chunks are interleaved with the other wavefronts' of its workgroup; consecutive ones, or a grid stride over all wavefronts, measured slower)
+	const unsigned stride = working_waves;
+	const uint64_t first_chunk = block_first + (uint64_t) wave64::index_in_block();
+	const uint64_t span_limit = block_limit;
 	if (first_chunk >= span_limit) { return; }
 	const uint64_t my_chunks = detail::divide_any(span_limit - first_chunk + stride - 1, stride);
 
@@ -944,7 +899,7 @@ __device__ __forceinline__ void decompress_as_block(
 } // namespace detail
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress(
+__global__ void GIDDY_DZBV_KERNEL_ATTRIBUTES decompress(
 	uint_t<UncompressedSize>*  __restrict__  decompressed,
 	const uint8_t*             __restrict__  compressed_data,
 	const uint_t<ElementSizesContainerSize>*
@@ -967,7 +922,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV
 /// The pieces of a batch launch (giddy/batch.hpp): `decompress` with its parameters out of the calling workgroup's piece's record, as that piece's block
 /// (a kernel of its own rather than batch::decode_pieces<>: the register and occupancy attributes above are part of how this decoder was tuned)
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned ElementSizesContainerSize>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_num_sgpr(GIDDY_DZBV_SGPRS))) GIDDY_DZBV_OCCUPANCY decompress_pieces(
+__global__ void GIDDY_DZBV_KERNEL_ATTRIBUTES decompress_pieces(
 	const batch::piece_t* __restrict__ pieces, const batch::block_t* __restrict__ blocks)
 {
 	const batch::located_piece mine = batch::piece_of_this_block(pieces, blocks);
@@ -1152,21 +1107,11 @@ public:
 		segment_length               *= detail::coalescing_of(segment_length, 64 * (16 / UncompressedSize), 2);
 		const size_t chunks           = util::div_rounding_up(util::div_rounding_up(length_in_elements, segment_length),
 		                                    (size_t) detail::segments_per_wave_chunk(segment_length, 64 * (16 / UncompressedSize)));
-		length                        = util::div_rounding_up(chunks, chunks_per_wavefront(chunks, device_properties_));
+		length                        = chunks;             // (one chunk per wavefront: K > 1, software-pipelined across chunks, was slower at every size — profiles/r03_dzbv_segments_per_wavefront.txt)
 		serialization_option          = auto_maximized;    // spans of (batches of short) segments; the kernel covers the column with any grid
 		quanta.threads_in_block       = warp_size;
 		upper_limits.threads_in_block = 256;
-		keep_gpu_busy_factor          = GIDDY_DZBV_BUSY_FACTOR;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
-	}
-
-	/// A wavefront that takes several chunks pays its prologue once and overlaps one chunk's loads with the previous one's stores
-	/// (the kernel's wide path) — as long as the column still gives every compute unit a dozen rounds of wavefronts.
-	static size_t chunks_per_wavefront(size_t chunks, const device::properties_t& device)
-	{
-		const size_t resident_wavefronts = (size_t) device.multiProcessorCount * 24;
-		size_t k = GIDDY_DZBV_CHUNKS_PER_WAVE;
-		while (k > 1 && chunks / k < 8 * resident_wavefronts) { k /= 2; }
-		return k < 1 ? 1 : k;
+		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t length_in_elements, size_t segment_length)

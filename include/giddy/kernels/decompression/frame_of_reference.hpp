@@ -117,7 +117,7 @@ __device__ __forceinline__ void decompress(
 		divide<IndexSize>(position, L, segment, within);
 		return predict(segment_model_coefficients[segment], within, offset);
 	};
-	if constexpr (Patches::enabled || GIDDY_STREAM_BY_WAVE_CHUNKS) {
+	if constexpr (Patches::enabled) {   // (the plain decoder in this wave-chunk shape, with 4, 8 or 16 rows per chunk: -1...-7 points)
 		// (8 rows in flight — a 4-byte column's whole chunk at once — measured 3-9 points faster than 4 for this decoder; Dictionary is best at 4)
 		constexpr unsigned stage_up_to = GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO;
 		constexpr bool stages = stream_tiles::stages_chunk_input<Compressed, Uncompressed, stage_up_to>();
@@ -222,8 +222,7 @@ public:
 		if (segment_length % sizeof(native_word_t) != 0) {
 			throw std::invalid_argument("The segment length must be aligned with the GPU's native word size");
 		}
-		constexpr unsigned elements_per_thread_per_tile = GIDDY_STREAM_BY_WAVE_CHUNKS ? stream_tiles::elements_per_thread_per_chunk<Uncompressed>()
-			: stream_tiles::elements_per_thread_per_tile<Uncompressed, detail::steps_per_tile<Uncompressed, Compressed>()>();
+		constexpr unsigned elements_per_thread_per_tile = stream_tiles::elements_per_thread_per_tile<Uncompressed, detail::steps_per_tile<Uncompressed, Compressed>()>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
 		serialization_option          = auto_maximized;   // tiles at grid stride

@@ -50,9 +50,6 @@ struct alignas(16) plane_set { uint32_t plane[planes]; };   // bit j of plane[k]
 
 } // namespace detail
 
-#ifndef GIDDY_IB_STORE_POLICY
-#define GIDDY_IB_STORE_POLICY 2   // memory_access::store_policy of the 16-byte output stores, for 4-8-byte elements (wave64.hpp)
-#endif
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned BitmapAlignmentInInts, bool UseDictionary = true>
 __global__ void decompress(
@@ -144,7 +141,7 @@ __global__ void decompress(
 						}
 					}
 					U* where = decompressed + chunk_first_element + e0;
-					if (aligned) { store_group<memory_access::wide_output_policy<UncompressedSize>(GIDDY_IB_STORE_POLICY)>(where, values); }   // (write-through: +3 / +7 points for 4- / 8-byte elements)
+					if (aligned) { store_group<memory_access::wide_output_policy<UncompressedSize>(memory_access::streaming)>(where, values); }   // (write-through: +3 / +7 points for 4- / 8-byte elements)
 					else {
 						#pragma unroll
 						for (unsigned j = 0; j < E; j++) { where[j] = values[j]; }

@@ -28,24 +28,17 @@
 #include "giddy/common.hpp"
 #include "giddy/on_device/wave64.hpp"
 
-#ifndef GIDDY_RUN_FINE_SUB
-#define GIDDY_RUN_FINE_SUB 8192   // outputs per finer anchor: segments of 4096-8192 are where the decoders do best (profiles/r03_run_long_segments.txt)
-#endif
-
-#ifndef GIDDY_RUN_FUSED_FROM_SEGMENTS
-#define GIDDY_RUN_FUSED_FROM_SEGMENTS 2048   // long segments of run lengths: pre-pass and decoder in one kernel from this many segments on
-#endif
-#ifndef GIDDY_RUN_POSITIONS_FUSED_UP_TO_FINES
-#define GIDDY_RUN_POSITIONS_FUSED_UP_TO_FINES 4   // run POSITIONS: the search for finer anchors and the decoder in one kernel for segments of up to this many finer ones
-#endif
-#ifndef GIDDY_RUN_FUSED_UP_TO_FINES
-#define GIDDY_RUN_FUSED_UP_TO_FINES 16   // ... of up to this many finer segments (of 8192 outputs) each (64 — what the kernel's LDS holds the anchors of — measured: eight workgroups each scanning a 524 288-segment's 16 384 run lengths lose 5-7 points to the separate launches)
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
 namespace run_expansion {
+/// The finer anchors' thresholds (measured: profiles/r03_run_long_segments.txt, r04_run_prepass.txt)
+enum : unsigned {
+	outputs_per_finer_anchor    = 8192,   // segments of 4096-8192 outputs are where the decoders do best
+	fused_from_segments         = 2048,   // long segments of run lengths: pre-pass and decoder in one kernel from this many workgroups on
+	positions_fused_up_to_fines = 4,      // run POSITIONS: the search for finer anchors and the decoder in one kernel for segments of up to this many finer ones
+	fused_up_to_fines           = 16,     // run lengths: ... of up to this many (64 — what the kernel's LDS holds the anchors of — measured: eight workgroups each scanning a 524 288-segment's 16 384 run lengths lose 5-7 points to the separate launches)
+};
 /// Segments at least this long get finer anchors (the wrappers ask); GIDDY_RUN_FINER_ANCHORS_FROM in the environment: another
 /// threshold (0: never — measurements).  Default: two finer segments' worth.
 /// switches for measurements, read from the environment once per process: GIDDY_RUN_FINE_ONE_LAUNCH=0 — the three-launch pre-pass for
@@ -56,7 +49,7 @@ struct fine_environment {
 	bool force_one_launch = false;   // GIDDY_RUN_FINE_ONE_LAUNCH=2: ... by the one-launch pre-pass
 	uint64_t min_mean_run = 0;
 	bool fused = true;               // GIDDY_RUN_FUSED_PREPASS=0: the one-launch pre-pass stays a launch of its own (run lengths)
-	uint64_t fused_from = GIDDY_RUN_FUSED_FROM_SEGMENTS;   // GIDDY_RUN_FUSED_FROM=n: the one-kernel builds from n workgroups on (tests: 1)
+	uint64_t fused_from = fused_from_segments;   // GIDDY_RUN_FUSED_FROM=n: the one-kernel builds from n workgroups on (tests: 1)
 	bool group_all = false;          // GIDDY_RUN_GROUP_ALL=1 (measurements): groups of segments through the long segments' kernel for whole-tile segment lengths too
 	static const fine_environment& get()
 	{
@@ -78,7 +71,7 @@ inline uint64_t finer_anchors_from()
 {
 	static const uint64_t from = [] {
 		const char* v = std::getenv("GIDDY_RUN_FINER_ANCHORS_FROM");
-		const uint64_t given = v ? std::strtoull(v, nullptr, 10) : 2 * (uint64_t) GIDDY_RUN_FINE_SUB;
+		const uint64_t given = v ? std::strtoull(v, nullptr, 10) : 2 * (uint64_t) outputs_per_finer_anchor;
 		return given == 0 ? ~(uint64_t) 0 : given;
 	}();
 	return from;
@@ -108,7 +101,7 @@ inline uint64_t segments_per_group_for(uint64_t segment_length, unsigned element
 namespace fine {
 
 enum : unsigned {
-	sub = GIDDY_RUN_FINE_SUB,
+	sub = outputs_per_finer_anchor,
 	threads = 256,
 	runs_per_tile = 64,
 	tiles_per_block = 1024,

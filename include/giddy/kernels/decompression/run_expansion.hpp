@@ -29,62 +29,25 @@ namespace kernels {
 namespace decompression {
 namespace run_expansion {
 
-#ifndef GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST
-#define GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST 2   // segments shorter than a tile are taken at least this many at a time
-#endif
-#ifndef GIDDY_RUN_STAGE_ALL_VALUES
-#define GIDDY_RUN_STAGE_ALL_VALUES 1   // 1: 4-byte values of kernels with 1-2-byte run descriptors go through LDS too (0: sparse tiles gather them from L1/L2 — faster while stores were `nt`)
-#endif
-#ifndef GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE
-#define GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE 2   // element sizes from which the next tile's descriptors are requested ahead of the stores
-#endif
-#ifndef GIDDY_RUN_STAGED_LOOKUPS_TOGETHER
-#define GIDDY_RUN_STAGED_LOOKUPS_TOGETHER 1
-#endif
-#ifndef GIDDY_RUN_NONTEMPORAL_DESCRIPTORS
-#define GIDDY_RUN_NONTEMPORAL_DESCRIPTORS 0   // 1: run lengths / positions — read once — are loaded around the L1, which the run values' look-ups live in
-#endif
-#ifndef GIDDY_RUN_STAGE_WIDE_DESCRIPTORS
-#define GIDDY_RUN_STAGE_WIDE_DESCRIPTORS 1   // 4-byte values of kernels with 4-8-byte run descriptors go through LDS in every tile
-#endif
-#ifndef GIDDY_RUN_DESCRIPTORS_PER_LANE
-#define GIDDY_RUN_DESCRIPTORS_PER_LANE 4
-#endif
-#ifndef GIDDY_RUN_RESIDENT_BLOCKS_CAP
-#define GIDDY_RUN_RESIDENT_BLOCKS_CAP 6   // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (0: no cap); DESIGN.md section 4
-#endif
-#ifndef GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP
-#define GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP 0   // ... and for 32-bit values with 8-byte run descriptors: with nt stores 4 was best (RPE <8,4,8,false,8>: 67 -> 73 %); with write-through stores none (78 %)
-#endif
-#ifndef GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS
-#define GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS 0   // 1: the dense-only instantiations load run values next to the descriptors in every tile (used in dense ones only)
-#endif
-#ifndef GIDDY_RUN_NARROW_CHUNK_BYTES
-#define GIDDY_RUN_NARROW_CHUNK_BYTES 8192   // output a wavefront of a 1-byte column takes per trip when segments are at least a tile long (two segments of 4096: +2-5 points for RLE, 16384: mixed; not for relative run positions: -15)
-#endif
-#ifndef GIDDY_RUN_WIDE_CHUNK_BYTES
-#define GIDDY_RUN_WIDE_CHUNK_BYTES 0   // output a wavefront of a 4- or 8-byte column takes per trip when segments are at least a tile long (0: one segment)
-#endif
-#ifndef GIDDY_RUN_TOUCH_ANCHORS_AHEAD
-#define GIDDY_RUN_TOUCH_ANCHORS_AHEAD 0   // chunks ahead (a multiple of 32: the same XCD's L2) whose anchor a wavefront touches when it starts — the anchor of a chunk is the first of two dependent round trips
-#endif
-#ifndef GIDDY_RUN_ROW_PADDING
-#define GIDDY_RUN_ROW_PADDING 1   // rows of a tile begin on 512-byte boundaries of the output (expand)
-#endif
-#ifndef GIDDY_RUN_CHUNKS_BY_ADDRESS
-#define GIDDY_RUN_CHUNKS_BY_ADDRESS 1   // a workgroup's chunks share an aligned window of the output (first_chunk_by_address)
-#endif
-#ifndef GIDDY_RUN_GROUPS
-#define GIDDY_RUN_GROUPS 1   // chunks of many runs take their descriptors and values from LDS, a group of 512 runs at a time (run_groups below)
-#endif
-#ifndef GIDDY_RUN_TILE_WORDS_PER_LANE
-#define GIDDY_RUN_TILE_WORDS_PER_LANE 2
-#endif
+// What the run decoders' tuning settled on (MI355X; DESIGN.md section 4 has each measurement).  No longer build switches:
+//   * every tile's run values go through wave-private LDS, whatever the widths of values and descriptors (with write-through stores: staging wins for all);
+//   * a lane's 2 or 4 look-ups of wide staged values go out together; rows of a tile begin on 512-byte boundaries of the output; a workgroup's chunks share
+//     an aligned window of the output; chunks of many runs take their descriptors and values from LDS in groups; a batch of segments is a whole number of
+//     64-byte blocks of output;
+//   * tried and taken out: descriptors loaded around the L1 (-37 points), an anchor touched some thousand chunks ahead (-6...7 cold), 16 or 32 KiB of whole
+//     segments per trip for 4- and 8-byte columns (-10), run values next to the descriptors in the dense-only builds, a residency cap for 8-byte descriptors.
 enum : unsigned {
-	words_per_lane      = GIDDY_RUN_TILE_WORDS_PER_LANE,
+	segments_per_trip_at_least   = 2,      // segments shorter than a tile are taken at least this many at a time
+	prefetch_from_element_size   = 2,      // element sizes from which the next tile's descriptors are requested ahead of the stores (1-byte columns: the registers are worth more)
+	narrow_chunk_bytes           = 8192,   // output a wavefront of a 1-byte column takes per trip when segments are at least a tile long (two segments of 4096: +2-5 points for run lengths; 16384: mixed; not for relative run positions: -15)
+	resident_blocks_cap          = 6,      // resident workgroups per CU for 32-bit values with 1-2-byte run descriptors (warm 5 is better, cold 6-8: the column that is decoded once decides)
+};
+
+enum : unsigned {
+	words_per_lane      = 2,
 	tile_words          = 64 * words_per_lane,     // 128
 	tile_length         = 32 * tile_words,         // 4096 outputs per tile
-	runs_per_lane       = GIDDY_RUN_DESCRIPTORS_PER_LANE,   // run descriptors examined per lane per batch
+	runs_per_lane       = 4,                       // run descriptors examined per lane per batch (6 / 8: +1...+3 / -4...-14 points)
 	runs_per_batch      = 64 * runs_per_lane,
 	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
 };
@@ -98,24 +61,18 @@ enum : unsigned {
 __device__ __forceinline__ uint64_t first_chunk_by_address(const void* output, uint64_t chunk_bytes, unsigned working_waves, uint64_t wave, uint64_t num_waves)
 {
 	const uint64_t group_bytes = chunk_bytes * working_waves;
-	if (!GIDDY_RUN_CHUNKS_BY_ADDRESS || chunk_bytes == 0 || (group_bytes & (group_bytes - 1)) != 0 || group_bytes > (1u << 20)) { return wave; }
+	if (chunk_bytes == 0 || (group_bytes & (group_bytes - 1)) != 0 || group_bytes > (1u << 20)) { return wave; }
 	// (chunk_bytes and working_waves are powers of two as well: shifts and masks — two 64-bit divisions here cost the one- and two-byte
 	// columns, whose wavefronts live for a 4 KiB tile, 5 to 15 points: profiles/r03_sweep_all_instantiations.txt against its successor)
 	const uint64_t shift = ((reinterpret_cast<uintptr_t>(output) & (group_bytes - 1)) >> __builtin_ctzll(chunk_bytes)) & (working_waves - 1);
 	return wave >= shift ? wave - shift : wave + num_waves - shift;
 }
 
-/// One load whose value nobody needs: the line is in this XCD's L2 when the wavefront that does need it comes along.  Returns the value — keep it
-/// alive with keep_alive() after the wavefront's own first loads, or the compiler drops the load.
-template <typename T>
-__device__ __forceinline__ uint32_t touch(const T* p) { return (uint32_t) *reinterpret_cast<const volatile uint8_t*>(p); }
-__device__ __forceinline__ void keep_alive(uint32_t value) { asm volatile("" :: "v"(value)); }
-
 /// a run descriptor (length or position): read once
 template <typename T>
 __device__ __forceinline__ T load_descriptor(const T* p)
 {
-	return GIDDY_RUN_NONTEMPORAL_DESCRIPTORS ? __builtin_nontemporal_load(p) : *p;
+	return *p;   // (through the L1: a lane's four narrow loads of one line hit it — around it: -37 points)
 }
 
 struct tile_entry {
@@ -160,7 +117,7 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 ///    descriptors (lengths or positions) are 1-2 bytes wide — 79.5 vs 75.9 % of peak for RLE <4,4,2> — and 12-15 points slower
 ///    when they are 4-8 bytes wide.  A tile expanded from staged values issues no load between its stores, so its stores can be
 ///    write-through (`staged_store_policy`), which the look-up path cannot afford; with that, staging wins for both (C4: RLE 84.7 ->
-///    85.6 %, mean run 6: 68 -> 72 %) and is what every instantiation does now (`GIDDY_RUN_STAGE_ALL_VALUES`).
+///    85.6 %, mean run 6: 68 -> 72 %) and is what every instantiation does now.
 /// Tiles with more runs than fit fall back to gathers through L1/L2.
 ///
 /// DENSE tiles (run_length_encoding.hpp / run_position_encoding.hpp): when the first batch of run descriptors does not reach the
@@ -171,12 +128,12 @@ __device__ __forceinline__ uint32_t rank(tile_entry* table, unsigned lane)
 /// for such tiles alone (the instantiations whose sparse tiles are faster through L1/L2).
 template <unsigned ElementSize, unsigned RunDescriptorSize = 2>
 struct value_staging {
-	enum : unsigned { always = GIDDY_RUN_STAGE_ALL_VALUES || ElementSize != 4 || (GIDDY_RUN_STAGE_WIDE_DESCRIPTORS && RunDescriptorSize >= 4), dense_only = !always, enabled = 1,
+	enum : unsigned { always = 1, dense_only = !always, enabled = 1,
 		bytes = 1024 * words_per_lane, capacity = bytes / ElementSize,
 		allocated = capacity + 16 / ElementSize,   // (the permuting expansions read up to 11 bytes past a lane's first run)
 		// wide values are staged by the loop that loads the run descriptors (one dependent round trip less per tile: +1...4 points);
 		// narrow ones by one sweep of their own inside expand() (element-sized loads next to every descriptor cost them 2-7 points)
-		with_descriptors = (always || GIDDY_RUN_DENSE_VALUES_WITH_DESCRIPTORS) && ElementSize >= 4,
+		with_descriptors = always && ElementSize >= 4,
 		dense_granule = 128 / ElementSize };   // a tile that is cut short ends on a multiple of this many outputs
 };
 
@@ -184,12 +141,9 @@ struct value_staging {
 /// chunks of 40 segments of 100, 4 of 900 or 2 of 2000 — 14 400 or 16 000 bytes — 70 % of the HBM peak; of 13 segments of 300, 5 of 700 or 3 of 1100 — 15 600,
 /// 14 000, 13 200 bytes — 65-66 %): `count` rounded down to the multiple that makes it so, where there is one (kernel and launch parameters agree; rounding UP to the first multiple, within
 /// two tiles, gained 2 points at 1100 and 1500 and broke the relative positions' search over a chunk's anchors: not kept).
-#ifndef GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS
-#define GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS 1
-#endif
 __host__ __device__ inline uint64_t whole_64_byte_blocks(uint64_t count, uint64_t segment_length, unsigned element_size)
 {
-	if (!GIDDY_RUN_CHUNKS_OF_WHOLE_64_BYTE_BLOCKS || count <= 1) { return count; }
+	if (count <= 1) { return count; }
 	uint64_t unit = 64, rest = (segment_length * element_size) % 64;
 	while (rest != 0) { const uint64_t t = unit % rest; unit = rest; rest = t; }   // gcd(64, bytes per segment)
 	const uint64_t multiple = 64 / unit;
@@ -204,7 +158,7 @@ __host__ __device__ inline uint64_t whole_64_byte_blocks(uint64_t count, uint64_
 template <unsigned ElementSize, unsigned RunDescriptorSize, bool Allowed = true>
 struct run_groups {
 	enum : unsigned {
-		enabled = Allowed && GIDDY_RUN_GROUPS && ElementSize == 4 && (RunDescriptorSize == 2 || RunDescriptorSize == 4),
+		enabled = Allowed && ElementSize == 4 && (RunDescriptorSize == 2 || RunDescriptorSize == 4),
 		group_runs = 512,
 		descriptors_per_lane = 16 / RunDescriptorSize, values_per_lane = 16 / ElementSize,
 		descriptor_loads = (group_runs + 64 * descriptors_per_lane - 1) / (64 * descriptors_per_lane),   // 1 or 2 loads per lane of descriptors
@@ -300,7 +254,7 @@ __device__ __forceinline__ void expand(
 	// points with rows laid from the tile's start (every 512-byte block written by two instructions); 512 bytes on, nothing.
 	// (4- and 8-byte elements: for 1- and 2-byte columns — 16 and 8 outputs per lane, tiles of 4 and 8 KiB — the bookkeeping costs 1-3 points even where
 	// the pad is 0, and a displaced output was never their problem)
-	const uint32_t pad = (GIDDY_RUN_ROW_PADDING && ElementSize >= 4 && aligned) ? (uint32_t) ((reinterpret_cast<uintptr_t>(out) & 511u) / ElementSize) : 0u;
+	const uint32_t pad = (ElementSize >= 4 && aligned) ? (uint32_t) ((reinterpret_cast<uintptr_t>(out) & 511u) / ElementSize) : 0u;
 	for (uint32_t row_start = 0; row_start < tile_len + pad; row_start += 64 * E) {
 		const uint32_t p = row_start + lane * E - pad;   // (wraps below zero for the first row's idle lanes)
 		if (p >= tile_len) { continue; }
@@ -360,8 +314,8 @@ __device__ __forceinline__ void expand(
 		else if (use_staged) {
 			// one output dword (4 / ElementSize elements) at a time, so that at most that many ranks and looked-up
 			// values are alive at once (all 16 of a 1-byte column at once cost two wavefronts per SIMD of occupancy)
-			// (wide elements: a lane's 2 or 4 look-ups all at once — GIDDY_RUN_STAGED_LOOKUPS_TOGETHER — instead of one LDS round trip after the other)
-			constexpr unsigned per_dword = (GIDDY_RUN_STAGED_LOOKUPS_TOGETHER && ElementSize >= 4) ? E : 4 / (ElementSize > 4 ? 4 : ElementSize);
+			// (wide elements: a lane's 2 or 4 look-ups all at once instead of one LDS round trip after the other)
+			constexpr unsigned per_dword = ElementSize >= 4 ? E : 4 / (ElementSize > 4 ? 4 : ElementSize);
 			#pragma unroll
 			for (unsigned first = 0; first < E; first += per_dword) {
 				#pragma unroll

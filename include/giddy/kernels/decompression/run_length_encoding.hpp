@@ -36,15 +36,14 @@ namespace detail {
 __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, unsigned element_size = 4)
 {
 	// (1-byte columns: a tile is 4 KiB of output, and a wavefront that lives for one of them spends its life on its first loads — several
-	// segments in a row, entered once: GIDDY_RUN_NARROW_CHUNK_BYTES of output per trip)
+	// segments in a row, entered once: run_expansion::narrow_chunk_bytes of output per trip)
 	if (segment_length >= run_expansion::tile_length) {
-		const uint64_t fit = element_size == 1 ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length
-			: element_size >= 4 ? (uint64_t) GIDDY_RUN_WIDE_CHUNK_BYTES / (segment_length * element_size) : 1;
+		const uint64_t fit = element_size == 1 ? (uint64_t) run_expansion::narrow_chunk_bytes / segment_length : 1;   // (wider columns: one segment — two per trip +0.5 cold, four -10)
 		return fit > 1 ? fit : 1;
 	}
 	// (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile — 52 -> 66 % at 3000)
 	uint64_t fit = run_expansion::tile_length / segment_length;
-	fit = fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST ? GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST : fit;
+	fit = fit < run_expansion::segments_per_trip_at_least ? run_expansion::segments_per_trip_at_least : fit;
 	return run_expansion::whole_64_byte_blocks(fit, segment_length, element_size);
 }
 
@@ -119,12 +118,6 @@ __device__ __forceinline__ void decompress(
 		const uint64_t chunk_outputs = segments_per_chunk * L;
 		const uint64_t column_or_group_end = n < mine.outputs_until ? n : mine.outputs_until;
 		const uint64_t segment_end = (segment_start + chunk_outputs < column_or_group_end) ? segment_start + chunk_outputs : column_or_group_end;
-		// (the anchor of the chunk some thousand wavefronts ahead, into this XCD's L2: GIDDY_RUN_TOUCH_ANCHORS_AHEAD)
-		uint32_t touched = 0;
-		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
-			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
-			touched = touch(segment_position_anchors + (ahead < num_segments ? ahead : s));
-		}
 		uint64_t first_run = segment_position_anchors[s - mine.anchors_from];
 		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
 		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s - mine.anchors_from];
@@ -260,7 +253,7 @@ __device__ __forceinline__ void decompress(
 					next_first_run = first_run + runs_from_here;
 					entering = true; skipped_of_first_run = 0;
 				}
-				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+				if (UncompressedSize >= prefetch_from_element_size && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
 					const uint32_t runs_from_there = run_limit - next_first_run > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t) (run_limit - next_first_run);   // >= 1
 					uint32_t k[runs_per_lane];
 					#pragma unroll
@@ -292,7 +285,6 @@ __device__ __forceinline__ void decompress(
 			}
 			first_run = next_first_run; left_in_first_run = next_left_in_first_run;
 		}
-		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0) { keep_alive(touched); }
 	}
 }
 
@@ -445,8 +437,7 @@ public:
 		upper_limits.threads_in_block = 256;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		// 32-bit values, narrow run lengths: 6 resident workgroups per CU are 3-7 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
-		if (UncompressedSize == 4 && RunLengthSize <= 2 && GIDDY_RUN_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_RESIDENT_BLOCKS_CAP; }
-		if (UncompressedSize == 4 && RunLengthSize == 8 && GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP; }
+		if (UncompressedSize == 4 && RunLengthSize <= 2) { resident_blocks_per_multiprocessor_cap = (unsigned) run_expansion::resident_blocks_cap; }
 	}
 
 	launch_config_resolution_params_t(

@@ -38,12 +38,12 @@ namespace detail {
 __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_length, bool positions_are_relative, unsigned element_size = 4)
 {
 	if (segment_length >= run_expansion::tile_length) {   // (1-byte columns: run_length_encoding.hpp)
-		const uint64_t fit = element_size == 1 && !positions_are_relative ? (uint64_t) GIDDY_RUN_NARROW_CHUNK_BYTES / segment_length   // (relative positions: a search over the chunk's anchors per candidate costs more than the trip saves)
-			: element_size >= 4 ? (uint64_t) GIDDY_RUN_WIDE_CHUNK_BYTES / (segment_length * element_size) : 1;
+		const uint64_t fit = element_size == 1 && !positions_are_relative ? (uint64_t) run_expansion::narrow_chunk_bytes / segment_length   // (relative positions: a search over the chunk's anchors per candidate costs more than the trip saves)
+			: 1;
 		return fit > 1 ? fit : 1;
 	}
 	uint64_t fit = run_expansion::tile_length / segment_length;
-	if (fit < GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST) { fit = GIDDY_RUN_SEGMENTS_PER_TRIP_AT_LEAST; }   // (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile)
+	if (fit < run_expansion::segments_per_trip_at_least) { fit = run_expansion::segments_per_trip_at_least; }   // (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile)
 	fit = (positions_are_relative && fit > 32) ? 32 : fit;
 	return run_expansion::whole_64_byte_blocks(fit, segment_length, element_size);
 }
@@ -113,11 +113,6 @@ __device__ __forceinline__ void decompress(
 		const uint64_t positions_origin = relative_to == L ? segment_start : segment_start / relative_to * relative_to;
 		const uint64_t segment_stride = regrouped ? relative_to : L;   // from one segment's start to the next one's, for the positions
 		const unsigned segments_here = regrouped ? (unsigned) ((segment_end - 1) / relative_to - segment_start / relative_to + 1) : (unsigned) segments_per_chunk;
-		uint32_t touched = 0;   // (GIDDY_RUN_TOUCH_ANCHORS_AHEAD: run_length_encoding.hpp)
-		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0 && lane == 0) {
-			const uint64_t ahead = s + (uint64_t) GIDDY_RUN_TOUCH_ANCHORS_AHEAD * segments_per_chunk;
-			touched = touch(position_anchors + (ahead < (uint64_t) num_anchors ? ahead : s));
-		}
 		uint64_t first_run = position_anchors[s - mine.anchors_from];
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
 		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk - mine.anchors_from] : num_runs - 1;
@@ -264,7 +259,7 @@ __device__ __forceinline__ void decompress(
 			if (need_carry) {
 				uint32_t furthest = wave64::read_last_lane(wave64::inclusive_max(last_at_or_before_end));
 				if (furthest != 0) { next_first_run = first_run + furthest - 1; }
-				if (UncompressedSize >= GIDDY_RUN_PREFETCH_FROM_ELEMENT_SIZE && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
+				if (UncompressedSize >= prefetch_from_element_size && !use_groups) {   // (1-byte columns: 16 outputs per lane, the registers are worth more)
 					const uint32_t candidates_there = last_candidate - next_first_run > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) (last_candidate - next_first_run);
 					uint32_t r[runs_per_lane];
 					#pragma unroll
@@ -297,7 +292,6 @@ __device__ __forceinline__ void decompress(
 			}
 			first_run = next_first_run;
 		}
-		if (GIDDY_RUN_TOUCH_ANCHORS_AHEAD != 0) { keep_alive(touched); }
 	}
 }
 
@@ -471,8 +465,7 @@ public:
 		upper_limits.threads_in_block = 256;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		// 32-bit values, 16-bit positions: 6 resident workgroups per CU are 5-6 points faster than 8 (measured per instantiation, tools/occupancy_sweep.py)
-		if (UncompressedSize == 4 && PositionOffsetSize <= 2 && GIDDY_RUN_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_RESIDENT_BLOCKS_CAP; }
-		if (UncompressedSize == 4 && PositionOffsetSize == 8 && GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP) { resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_RUN_WIDEST_RESIDENT_BLOCKS_CAP; }
+		if (UncompressedSize == 4 && PositionOffsetSize <= 2) { resident_blocks_per_multiprocessor_cap = (unsigned) run_expansion::resident_blocks_cap; }
 	}
 
 	launch_config_resolution_params_t(

@@ -8,9 +8,6 @@
 #ifndef GIDDY_STREAM_THREADS_PER_BLOCK
 #define GIDDY_STREAM_THREADS_PER_BLOCK 256 // workgroup size cap for streaming kernels
 #endif
-#ifndef GIDDY_STREAM_BY_WAVE_CHUNKS
-#define GIDDY_STREAM_BY_WAVE_CHUNKS 0      // 1: FOR and Dictionary without patches also run by wavefront chunks (stream_tiles.hpp)
-#endif
 #ifndef GIDDY_FOR_STEPS_PER_TILE
 #define GIDDY_FOR_STEPS_PER_TILE GIDDY_STREAM_STEPS_PER_TILE     // Frame of Reference's own tile depth
 #endif

@@ -21,7 +21,7 @@
 #include "giddy/on_device/wave64.hpp"
 
 #ifndef GIDDY_PATCHES_TOGETHER_FROM
-#define GIDDY_PATCHES_TOGETHER_FROM 6   // patches per row of 64 lanes' elements, on the column's average, from which the wrappers launch the ManyPatches builds
+#define GIDDY_PATCHES_TOGETHER_FROM -1   // >= 0 (measurements): patches per row from which EVERY fused wrapper launches its ManyPatches build, instead of the table below
 #endif
 
 namespace cuda {
@@ -66,10 +66,20 @@ struct none {
 	template <typename T> __device__ __forceinline__ T patched(uint64_t, T value) const { return value; }
 };
 
+/// Patches per row of 64 lanes' elements, on the column's average, from which a fused decoder's ManyPatches build is the faster one — per decoder family,
+/// where the two builds' rates cross (profiles/r05_patch_density.txt: both builds forced over 0.3 ... 3 % of patches, 2^28 elements; round 4 had one
+/// constant, 6, and a dent under it: at 2 % of patches Dictionary ran at 54 % of the HBM peak where its other build does 63, fixed-width
+/// discard-zero-bytes 58 against 72, Model 32 against 46).  The walk that patches one at a time costs the whole wavefront a trip around a loop of LDS
+/// reads per patch; how soon that loses to a binary search per lane depends on what else the decoder's row loop has to hide it behind.
+namespace together_from {
+constexpr float delta = 3.2f, dictionary = 3.0f, discard_zero_bytes_fixed = 2.0f, frame_of_reference = 4.5f, model = 2.5f;
+}
+
 /// whether a column of `length` elements with `num_patches` patches, decoded in rows of 64 lanes x `elements_per_lane`, is one for the ManyPatches builds
-inline bool many_patches_per_row(uint64_t num_patches, uint64_t length, unsigned elements_per_lane)
+inline bool many_patches_per_row(uint64_t num_patches, uint64_t length, unsigned elements_per_lane, float from)
 {
-	return length != 0 && (double) num_patches * (double) (64 * elements_per_lane) >= (double) GIDDY_PATCHES_TOGETHER_FROM * (double) length;
+	const double threshold = GIDDY_PATCHES_TOGETHER_FROM >= 0 ? (double) GIDDY_PATCHES_TOGETHER_FROM : (double) from;
+	return length != 0 && (double) num_patches * (double) (64 * elements_per_lane) >= threshold * (double) length;
 }
 
 /// Wave-private LDS for the cursors of a workgroup's wavefronts: a window of 64 patches each.  Declared __shared__
@@ -211,7 +221,7 @@ struct cursor_t {
 		while (position < row_start) { advance(lane); }
 		// Round 4: MANY patches in a row.  One at a time (below) a patch is a trip around a loop of LDS reads for the whole wavefront: fine for the one patch
 		// in four rows of a 0.1 % column, 13 trips per row at 5 % (Dictionary: 31 % of the HBM peak), 128 at 50 % (6 %).  The window is sorted, so a LANE's
-		// patches are a contiguous stretch of it: where the column has GIDDY_PATCHES_TOGETHER_FROM patches or more to a row ON AVERAGE (decided once, by the
+		// patches are a contiguous stretch of it: where the column has `together_from` patches or more to a row ON AVERAGE (decided once, by the
 		// wrapper, from the column's counts — and as a build of its own: finding out row by row cost the 1 % columns 7 points, and the registers of this path
 		// in the same kernel cost the 0.1 % ones 2-5) every lane finds its own — a binary search over the row's entries in
 		// the window (at most 6 LDS reads), then as many steps as it has patches (equal positions: the last wins).

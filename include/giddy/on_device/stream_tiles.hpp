@@ -180,19 +180,13 @@ __device__ __forceinline__ void transform(
 // as fast as the tile loop above decodes it without (0.87-0.90 ms for 2^30 elements); 32 rows / 2 in flight
 // — the Delta shape — is 8 % slower, 4 rows 17-40 % slower.
 
-#ifndef GIDDY_PATCHED_ROWS_PER_CHUNK
-#define GIDDY_PATCHED_ROWS_PER_CHUNK 0   // 0: by output width (below); n > 0: n rows for every instantiation
-#endif
-#ifndef GIDDY_PATCHED_ROWS_IN_FLIGHT
-#define GIDDY_PATCHED_ROWS_IN_FLIGHT 4
-#endif
-enum : unsigned { rows_in_flight = GIDDY_PATCHED_ROWS_IN_FLIGHT };
+enum : unsigned { rows_in_flight = 4 };
 
 /// rows a wavefront takes per chunk: 8 — except for 8-byte outputs, whose rows hold only 128 elements (measured at 8, 16 and 32
 /// rows: Dictionary <4,8,1> 40 / 47 / 51 % of peak, <4,8,2> 58 / 66 / 69 %; 4-byte outputs lose 5-9 points going from 8 to 16+)
 template <typename Out> constexpr unsigned rows_per_chunk_for()
 {
-	return GIDDY_PATCHED_ROWS_PER_CHUNK > 0 ? GIDDY_PATCHED_ROWS_PER_CHUNK : (sizeof(Out) >= 8 ? 32 : 8);
+	return sizeof(Out) >= 8 ? 32 : 8;
 }
 
 /// elements one thread produces per chunk — what the patched launch parameters divide the column length by
