@@ -228,3 +228,54 @@ def test_round_4_entry_points_fail_politely_without_a_device():
     handle = kernel.prepare(arguments)
     handle.update({"length": r.size_t(1 << 21)})
     del handle
+
+
+def test_batches_are_built_on_the_host_alone():
+    """giddy_batch_* (include/giddy/batch.hpp) with the nominal device: pieces are added and counted without touching a GPU — a piece brings the workgroups
+    its own resolved configuration has, an empty piece brings none —, the wrappers that launch batches say so, the others refuse, a piece's argument map is
+    checked like a launch's, a batch for the nominal device cannot be uploaded, and null handles are status codes."""
+    lib = _native.lib
+    lengths = (0, 1, 4097, 1 << 20, 300000)
+    for key, resolve, launch in (
+            (schemes.key_dictionary(4, 4, 1), lambda n: {"num_dictionary_entries": r.size_t(256), "data_length": r.size_t(n)},
+             lambda n: {"decompressed": r.pointer(0x10000000, "u32"), "compressed_input": r.const_pointer(0x20000000, "u8"), "dictionary_entries": r.const_pointer(0x30000000, "u32"),
+                        "length": r.uint32(n), "num_dictionary_entries": r.uint32(256)}),
+            (schemes.key_run_length_encoding(4, 4, 2, 4), lambda n: {"length": r.size_t(n), "segment_length": r.size_t(4096)},
+             lambda n: {"decompressed": r.pointer(0x10000000, "u32"), "run_data": r.const_pointer(0x20000000, "u32"), "run_lengths": r.const_pointer(0x30000000, "u16"),
+                        "position_anchors": r.const_pointer(0x40000000, "u32"), "intra_run_anchor_offsets": r.const_pointer(0x50000000, "u16"),
+                        "segment_length": r.uint32(4096), "num_segments": r.uint32(-(-n // 4096)), "num_element_runs": r.uint32(max(1, n // 32)), "length": r.uint32(n)})):
+        kernel = r.kernel_t.produceSubclass(key)
+        assert kernel.launches_batches()
+        batch = kernel.batch(r.NOMINAL_MI355X)
+        expected_blocks = 0
+        for n in lengths:
+            batch.add(launch(n), resolve(n))
+            expected_blocks += kernel.resolve_launch_configuration(r.NOMINAL_MI355X, resolve(n)).grid_dimensions[0]
+        assert batch.num_pieces == len(lengths) and batch.num_blocks == expected_blocks > 0
+        with pytest.raises(r.LogicError):
+            batch.upload(0)
+        with pytest.raises(r.LogicError):
+            batch.tables()
+        with pytest.raises(r.OutOfRange):      # a required argument is missing: as enqueue_launch
+            batch.add({"decompressed": r.pointer(0x10000000, "u32")}, resolve(100))
+        with pytest.raises(r.BadAnyCast):      # ... or holds another type
+            wrong = launch(100); wrong["length"] = r.uint64(100)
+            batch.add(wrong, resolve(100))
+        assert batch.num_pieces == len(lengths)   # (the failed pieces were not added)
+        batch.clear()
+        assert batch.num_pieces == 0 and batch.num_blocks == 0
+    # every registration of the seven families launches batches; nothing else does
+    families = ("decompression::dictionary::kernel_t", "decompression::frame_of_reference::kernel_t", "decompression::delta::kernel_t",
+                "decompression::discard_zero_bytes::fixed_width::kernel_t", "decompression::discard_zero_bytes::variable_width::kernel_t",
+                "decompression::run_length_encoding::kernel_t", "decompression::run_position_encoding::kernel_t")
+    batching = [k for k in r.kernel_t.registered_keys() if r.kernel_t.produceSubclass(k).launches_batches()]
+    assert len(batching) == 20 + 8 + 12 + 12 + 9 + 18 + 10 and all(k.startswith(families) for k in batching)
+    scatter = r.kernel_t.produceSubclass(schemes.key_scatter(4, 8, 4))
+    with pytest.raises(r.LogicError):
+        scatter.batch(r.NOMINAL_MI355X)
+    handle = ctypes.c_void_p()
+    assert lib.giddy_batch_create(None, -1, ctypes.byref(handle)) == -1
+    assert lib.giddy_batch_add(None, None, 0, None, 0) == -1 and lib.giddy_enqueue_batch(None, None) == -1 and lib.giddy_batch_upload(None, None) == -1
+    assert lib.giddy_batch_num_pieces(None) == 0 and lib.giddy_can_launch_batches(None) == 0
+    assert lib.giddy_enqueue_batch_of_device_tables(scatter._handle, None, None) == -1
+    lib.giddy_batch_release(None)
