@@ -284,10 +284,13 @@ const device_function_t kernel_t<I, U, D>::get_device_function() const { return 
 namespace dictionary {
 namespace construction {
 
-/// The column's distinct values, sorted ascending, for dictionaries of up to 65 536 entries.  Launch keys: "input", "length";
+/// The column's distinct values, sorted ascending.  Launch keys: "input", "length";
 /// output "dictionary_entries" uint_t<U>* (room for 65 536); scratch, ZEROED by the caller: "slot_states" unsigned* (2^18 entries),
 /// "status" unsigned* (2 entries: [0] = distinct values found — compare with the key width's limit —, [1] = entries written);
-/// scratch: "slot_values" uint64_t* (2^18 entries), "unsorted_entries" uint_t<U>* (65 536 entries)
+/// scratch: "slot_values" uint64_t* (2^18 entries), "unsorted_entries" uint_t<U>* (65 536 entries).
+/// LARGER dictionaries (4- and 8-byte keys): "capacity" (unsigned: entries there is room for; more than 65 536) and "hash_slots" (unsigned: a power of two,
+/// at least twice the capacity — four times keeps the probes short) size the arrays instead: "slot_states" / "slot_values" of hash_slots entries,
+/// "dictionary_entries" of the capacity rounded up to a power of two ("unsorted_entries" is not used: the entries are sorted in place).
 template <unsigned IndexSize, unsigned UncompressedSize>
 class kernel_t : public cuda::registered::kernel_t {
 public:
@@ -309,14 +312,39 @@ void kernel_t<I, U>::enqueue_launch_with(stream::id_t stream, const launch_confi
 	auto states   = argument<unsigned*>(arguments, "slot_states");
 	auto values   = argument<uint64_t*>(arguments, "slot_values");
 	auto status   = argument<unsigned*>(arguments, "status");
-	auto unsorted = argument<uint_t<U>*>(arguments, "unsorted_entries");
 	auto length   = (size_type_by_index_size<I>) argument<uint_t<I>>(arguments, "length");
+	const unsigned capacity = optional_argument<unsigned>(arguments, "capacity").value_or((unsigned) max_entries);
+	const unsigned slots = optional_argument<unsigned>(arguments, "hash_slots").value_or((unsigned) hash_slots);
+	if (capacity == 0 || (slots & (slots - 1)) != 0 || slots < capacity || (capacity > max_entries && (uint64_t) slots < 2 * (uint64_t) capacity)) {
+		throw std::invalid_argument("dictionary construction: hash_slots must be a power of two, at least twice the capacity");
+	}
 	if (length == 0) { return; }
-	cuda::kernel::enqueue_launch(*this, stream, launch_config, states, values, status, argument<const uint_t<U>*>(arguments, "input"), length);
-	cuda::enqueue_launch(reinterpret_cast<const void*>(collect_distinct<U>), stream, launch_configuration_t(hash_slots / threads_per_block, threads_per_block),
-		unsorted, status, static_cast<const unsigned*>(states), static_cast<const uint64_t*>(values), (unsigned) max_entries);
-	cuda::enqueue_launch(reinterpret_cast<const void*>(place_by_rank<U>), stream, launch_configuration_t(max_entries / threads_per_block, threads_per_block),
-		argument<uint_t<U>*>(arguments, "dictionary_entries"), static_cast<const uint_t<U>*>(unsorted), static_cast<const unsigned*>(status), (unsigned) max_entries);
+	cuda::kernel::enqueue_launch(*this, stream, launch_config, states, values, status, argument<const uint_t<U>*>(arguments, "input"), length, slots, capacity);
+	auto* entries = argument<uint_t<U>*>(arguments, "dictionary_entries");
+	const launch_configuration_t over_slots((grid_dimension_t) std::min<unsigned>(slots / threads_per_block, 1u << 16), threads_per_block);
+	if (capacity <= max_entries) {
+		auto unsorted = argument<uint_t<U>*>(arguments, "unsorted_entries");
+		cuda::enqueue_launch(reinterpret_cast<const void*>(collect_distinct<U>), stream, over_slots,
+			unsorted, status, static_cast<const unsigned*>(states), static_cast<const uint64_t*>(values), capacity, slots);
+		cuda::enqueue_launch(reinterpret_cast<const void*>(place_by_rank<U>), stream, launch_configuration_t(max_entries / threads_per_block, threads_per_block),
+			entries, static_cast<const uint_t<U>*>(unsorted), static_cast<const unsigned*>(status), capacity);
+		return;
+	}
+	// more than 65 536 entries: collected into the entries array itself, padded to a power of two with the largest value, sorted in place by a bitonic network
+	unsigned padded = 1;
+	while (padded < capacity) { padded <<= 1; }
+	cuda::enqueue_launch(reinterpret_cast<const void*>(collect_distinct<U>), stream, over_slots,
+		entries, status, static_cast<const unsigned*>(states), static_cast<const uint64_t*>(values), capacity, slots);
+	const launch_configuration_t over_entries((grid_dimension_t) std::min<unsigned>(std::max<unsigned>(padded / 2 / threads_per_block, 1), 1u << 16), threads_per_block);
+	const launch_configuration_t over_tiles((grid_dimension_t) std::min<unsigned>(std::max<unsigned>(padded / sorted_in_lds, 1), 1u << 16), threads_per_block);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(pad_for_sorting<U>), stream, over_entries, entries, static_cast<const unsigned*>(status), capacity, padded);
+	cuda::enqueue_launch(reinterpret_cast<const void*>(bitonic_steps_in_lds<U>), stream, over_tiles, entries, padded, 0u, true);   // every stage up to sorted_in_lds
+	for (unsigned k = 2 * sorted_in_lds; k <= padded && k != 0; k <<= 1) {
+		for (unsigned j = k / 2; j >= sorted_in_lds; j >>= 1) {
+			cuda::enqueue_launch(reinterpret_cast<const void*>(bitonic_step<U>), stream, over_entries, entries, padded, j, k);
+		}
+		cuda::enqueue_launch(reinterpret_cast<const void*>(bitonic_steps_in_lds<U>), stream, over_tiles, entries, padded, k, false);   // this stage's j < sorted_in_lds
+	}
 }
 
 template <unsigned I, unsigned U>

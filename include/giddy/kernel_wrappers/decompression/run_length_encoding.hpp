@@ -141,20 +141,27 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 	if (dense) { launch_config.dynamic_shared_memory_size = 0; }
 	stream_scratch::lease scratch(stream);
 	const auto& environment = run_expansion::fine_environment::get();
-	// Segments that are not whole tiles of 4096 outputs (1000, 3000, 10 000, 50 000 ...): a wavefront's chunk of whole segments is then 15.6 or 31.2 KiB, not 16 or 32 —
-	// the chunk-size effect of DESIGN.md section 4 — and a tile is cut at every segment's end: 64-70 % of the HBM peak where whole tiles give 77-79.  Anchors are only entry
-	// points, so GROUPS of such segments — about 32 768 outputs each, whatever that is in segments — go through the long segments' one kernel: the workgroup finds the entry
-	// point of every 8192nd output of its group and decodes from there (kernels/decompression/run_length_encoding.hpp, decompress_long_segments).
+	// GROUPS of segments through the long segments' one kernel (kernels/decompression/run_length_encoding.hpp, decompress_long_segments): anchors are only entry points,
+	// so a workgroup may take a group of consecutive segments — about 32 768 outputs —, find the entry point of every 8192nd output of its group and decode from there.
+	// Round 5, by the regret grid with the compressed input COLD (tools/regret.py, profiles/r05_regret.txt): taken for sparse columns (mean run >= 16) in whole-tile
+	// segments of MORE than one finer segment and fewer than four — 12 288, 16 384, 24 576 ...: 63-66 -> 69-76 % of the HBM peak at 2^28 outputs, 37-40 -> 56-60 % at 2^26,
+	// where the three-launch pre-pass used to run (its launches cost a small column more than its finer anchors gain).  NOT any more for segment lengths that are not
+	// whole tiles (1000, 3000, 10 000 ...: round 4 took those this way on figures measured with one column decoded again and again — its run arrays, which the group's
+	// workgroup reads twice, then come out of the Infinity Cache; from HBM the ordinary path is 5-16 points faster at 2^30 and 2^26 and equal at 2^28).
+	// GIDDY_RUN_GROUP_ALL=1 in the environment: groups for every segment length (measurements).
 	// (instantiations without the groups-of-runs path — other than 4-byte elements — have one build only: whatever their mean run)
-	// — 8-byte elements: +2-3 points; 2-byte: 46 -> 58 % for segments of 3000 and 10 000, but 75 -> 58 for segments of 1000 (taken from 2048 outputs on); 1-byte: never (61 -> 31)
+	// — 8-byte elements: +2-3 points; 2-byte: from 2048 outputs on; 1-byte: never (61 -> 31)
 	const bool one_kernel_build_applies = sparse || (!run_expansion::run_groups<UncompressedSize, RunLengthSize>::enabled && runs != 0 && n / runs >= 16
 		&& (UncompressedSize >= 4 || (UncompressedSize == 2 && L >= 2048)));
-	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && ((L % run_expansion::tile_length != 0 && run_expansion::tile_length % L != 0 && L >= run_expansion::tile_length / 2) || (environment.group_all && L > 0)) && memory_access::is_aligned(run_lengths, 16)) {   // (shorter segments: +2-7 points at 2^28 outputs, -2 at 2^30 — left to the ordinary path)
+	const bool whole_tiles_between_one_and_four_finer_segments = L % run_expansion::tile_length == 0 && L > (uint64_t) fine::sub && L < 4 * (uint64_t) fine::sub;
+	if (environment.fused && one_kernel_build_applies && n > 0 && runs > 0 && (whole_tiles_between_one_and_four_finer_segments || (environment.group_all && L > 0)) && memory_access::is_aligned(run_lengths, 16)) {
 		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);   // (run_anchors.hpp)
 		const uint64_t group_outputs = per_group * L, finer_per_group = util::div_rounding_up(group_outputs, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_segments, per_group);
 		const uint64_t workgroups = groups * util::div_rounding_up(finer_per_group, (uint64_t) finer_segments_per_workgroup);
+		// (up to fused_up_to_workgroups of them, as below: 2^30 outputs in segments of 24 576 at mean run 32 — 43 690 workgroups —, cold: 55 % where the three launches do 75)
 		if (finer_per_group <= (uint64_t) run_expansion::fused_up_to_fines && workgroups >= environment.fused_from && per_group <= 0xFFFFFFFFull
+			&& (workgroups <= run_expansion::fused_up_to_workgroups || environment.group_all)
 			&& runs / groups <= fine::most_runs_per_segment_for_one_launch) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups, 1u << 20), fine::threads),
@@ -175,7 +182,9 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		const uint64_t segments = util::div_rounding_up(n, L);
 		const bool one_launch = environment.one_launch && (environment.force_one_launch
 			|| (sparse && L >= 4 * (uint64_t) fine::sub && segments <= fine::most_segments_for_one_launch && runs / segments <= fine::most_runs_per_segment_for_one_launch));
-		const bool worth_it = environment.force || one_launch || n / runs >= 8 || L >= 16 * (uint64_t) fine::sub;
+		// (dense columns — mean runs below 8 — from segments of four finer ones on: round 5's regret grid, cold: 32 768 / 65 536 at mean runs of 2-4: 48-50 -> 53-55 %
+		// at 2^28 outputs, 19-31 -> 40 % at 2^26; round 4 had it from 131 072 on)
+		const bool worth_it = environment.force || one_launch || n / runs >= 8 || L >= 4 * (uint64_t) fine::sub;
 		// ... and then pre-pass and decode are ONE kernel: the workgroup that scanned a segment's lengths decodes the segment, its finer anchors never leave LDS
 		// (kernels/decompression/run_length_encoding.hpp, decompress_long_segments; profiles/r04_run_prepass.txt)
 		// — where there are enough segments for a workgroup each to fill the chip (2^28 outputs, mean run 32, segments of 32 768 / 65 536: 75.7 / 74.9 % against 68.9 / 71.8 %;
@@ -183,8 +192,10 @@ void GIDDY_RLE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// — segments of up to 8 finer ones (a wavefront decodes two of them, one after the other: with 16 — segments of 131 072 — the separate launches win again,
 		// 2^30 outputs: 75.6 % against 79.0 %; with 4 and 8: 84.2 / 82.5 % against 78.2 / 78.8 %) —
 		const uint64_t workgroups_of_one_kernel = segments * util::div_rounding_up(L / fine::sub, (uint64_t) finer_segments_per_workgroup);
+		// — and not so many that the launch outlasts what keeps its write front together (2^30 outputs in segments of 32 768, cold: 70 % against the three launches' 76) —
 		const bool fused = environment.fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) run_expansion::fused_up_to_fines
-			&& workgroups_of_one_kernel >= environment.fused_from && runs / segments <= fine::most_runs_per_segment_for_one_launch;
+			&& workgroups_of_one_kernel >= environment.fused_from && (workgroups_of_one_kernel <= run_expansion::fused_up_to_workgroups || environment.force_one_launch)
+			&& runs / segments <= fine::most_runs_per_segment_for_one_launch;
 		if (fused || (one_launch && environment.force_one_launch && environment.fused && sparse && L / fine::sub <= most_fines_per_long_segment)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),

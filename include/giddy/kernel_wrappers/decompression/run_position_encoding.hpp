@@ -141,10 +141,10 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		&& memory_access::is_aligned(run_start_positions, 16) && memory_access::is_aligned(run_data, 16);
 	const void* const decoder = sparse ? sparse_kernel() : dense ? dense_kernel() : base_kernel();
 	stream_scratch::lease scratch(stream);
-	// Segment lengths that are not whole tiles of 4096 outputs: groups of segments through the long segments' one kernel, as for run lengths
-	// (kernel_wrappers/decompression/run_length_encoding.hpp; relative positions: a piece of a group finds each run's segment among the column's own anchors)
-	if (run_expansion::fine_environment::get().fused && sparse && UncompressedSize >= 4 && n > 0 && num_element_runs > 0 && (PositionsAreRelative ? L >= 256 : L > 0)   // (a piece of 4096 outputs: within 17 segments of relative positions)
-		&& ((L % run_expansion::tile_length != 0 && run_expansion::tile_length % L != 0 && L >= run_expansion::tile_length / 2) || (run_expansion::fine_environment::get().group_all && L > 0))) {   // (shorter segments: 70 -> 64 % at 2^30)
+	// Groups of segments through the long segments' one kernel: round 4 took segment lengths that are not whole tiles this way, on figures measured with the run
+	// arrays in the Infinity Cache; with them COLD (round 5, tools/regret.py) the ordinary path is the faster one — relative positions in segments of 8200: 58 -> 67-70 % of
+	// the HBM peak, absolute: 63 -> 69 — so only GIDDY_RUN_GROUP_ALL=1 (measurements) still does
+	if (run_expansion::fine_environment::get().fused && run_expansion::fine_environment::get().group_all && sparse && UncompressedSize >= 4 && n > 0 && num_element_runs > 0 && (PositionsAreRelative ? L >= 256 : L > 0)) {   // (a piece of 4096 outputs: within 17 segments of relative positions)
 		const uint64_t per_group = run_expansion::segments_per_group_for(L, UncompressedSize, fine::sub);
 		const uint64_t finer_per_group = util::div_rounding_up(per_group * L, (uint64_t) fine::sub);
 		const uint64_t groups = util::div_rounding_up((uint64_t) num_anchors, per_group);
@@ -156,7 +156,8 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 			return;
 		}
 	}
-	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0) {
+	// (relative positions of DENSE columns — mean runs below 16 — in segments of fewer than four finer ones keep their segments: 16 384 / 24 576 at mean runs of 2-4: 47-51 -> 54-57 %, cold)
+	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && !(PositionsAreRelative && n / num_element_runs < 16 && L < 4 * (uint64_t) fine::sub && !run_expansion::fine_environment::get().force)) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
 		// ... in ONE kernel where segments are of 4 finer ones and there are enough of them for 2048 workgroups (kernels/decompression/run_position_encoding.hpp,
 		// decompress_long_segments).  The search is a cheap launch of its own, unlike the run lengths' scan: 2^28 outputs in segments of 32 768: 76.9 % against 74-75 %

@@ -125,18 +125,30 @@ def frame_of_reference(column, segment_length, compressed_dtype=np.int16, model=
 
 
 def dictionary_entries(column, limit=1 << 16, index_size=4):
-    """the column's distinct values, sorted ascending (unsigned order) — numpy.unique on the device; at most `limit` <= 65 536 of them"""
+    """the column's distinct values, sorted ascending (unsigned order) — numpy.unique on the device; at most `limit` of them (Unrepresentable beyond).
+    Up to 65 536: a hash set of 2^18 slots, sorted by rank; more (4- and 8-byte keys): a hash set of four slots per entry of `limit`, the entries
+    sorted in place by a bitonic network (include/giddy/kernels/compression/dictionary_construction.hpp)"""
     n, usize = column.numel(), column.element_size()
     device = column.device
-    states = torch.zeros(1 << 18, dtype=torch.int32, device=device)
+    large = limit > (1 << 16)
+    capacity = int(limit) if large else 1 << 16
+    if capacity >= 1 << 29:
+        raise ValueError("a dictionary of 2^29 entries or more is not built on the device")
+    padded = 1 << max(0, (capacity - 1).bit_length())
+    slots = max(1 << 18, 4 * padded) if large else 1 << 18
+    states = torch.zeros(slots, dtype=torch.int32, device=device)
     status = torch.zeros(2, dtype=torch.int32, device=device)
-    values = torch.empty(1 << 18, dtype=torch.int64, device=device)
-    unsorted, entries = torch.empty(1 << 16, dtype=column.dtype, device=device), torch.empty(1 << 16, dtype=column.dtype, device=device)
+    values = torch.empty(slots, dtype=torch.int64, device=device)
+    entries = torch.empty(padded, dtype=column.dtype, device=device)
     if n:
-        _launch("compression::dictionary::construction::kernel_t<%du, %du>" % (index_size, usize), {"length": r.size_t(n)},
-                {"input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "dictionary_entries": r.pointer(entries, "u%d" % (8 * usize)),
-                 "slot_states": r.pointer(states, "u32"), "status": r.pointer(status, "u32"), "slot_values": r.pointer(values, "u64"),
-                 "unsorted_entries": r.pointer(unsorted, "u%d" % (8 * usize))})
+        arguments = {"input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "dictionary_entries": r.pointer(entries, "u%d" % (8 * usize)),
+                     "slot_states": r.pointer(states, "u32"), "status": r.pointer(status, "u32"), "slot_values": r.pointer(values, "u64")}
+        if large:
+            arguments.update({"capacity": r.uint32(capacity), "hash_slots": r.uint32(slots)})
+        else:
+            unsorted = torch.empty(1 << 16, dtype=column.dtype, device=device)
+            arguments["unsorted_entries"] = r.pointer(unsorted, "u%d" % (8 * usize))
+        _launch("compression::dictionary::construction::kernel_t<%du, %du>" % (index_size, usize), {"length": r.size_t(n)}, arguments)
     found = int(status[0])
     if found > limit:
         raise Unrepresentable("too many distinct values for the key type")
@@ -145,12 +157,11 @@ def dictionary_entries(column, limit=1 << 16, index_size=4):
 
 def dictionary(column, key_dtype=np.uint8, entries=None, index_size=4):
     """`entries`: the dictionary, sorted ascending and distinct, on the device.  Not given: the column's distinct values, found and
-    sorted on the device (dictionary_entries()), for key types of 1 or 2 bytes."""
+    sorted on the device (dictionary_entries())."""
     n, usize, ksize = column.numel(), column.element_size(), _size(key_dtype)
     if entries is None:
-        if ksize > 2:
-            raise NotImplementedError("device-side dictionary construction holds up to 65 536 entries (1- and 2-byte keys): pass `entries`")
-        entries = dictionary_entries(column, limit=1 << (8 * ksize), index_size=index_size)
+        # (wide keys: room for as many entries as the column could have, up to 2^24 — a dictionary of more is no compression; pass `entries` for one)
+        entries = dictionary_entries(column, limit=min(1 << (8 * ksize), max(1, n), 1 << 24) if ksize > 2 else 1 << (8 * ksize), index_size=index_size)
     if entries.numel() > (1 << (8 * ksize)):
         raise Unrepresentable("too many distinct values for the key type")
     out = {"compressed_input": torch.empty(n, dtype=_SIGNED[ksize], device=column.device), "dictionary_entries": entries, "length": n,

@@ -225,6 +225,34 @@ def test_dictionary_construction(usize):
             compressors.dictionary_entries(dev(np.arange(70000, dtype=ud)))
         with pytest.raises(compressors.Unrepresentable):
             compressors.dictionary_entries(dev(np.arange(300, dtype=ud)), limit=256)
+        # more than 65 536 entries (4- and 8-byte keys; round 5): a hash set sized by the limit, the entries sorted by a bitonic network — limits that are and are not
+        # powers of two, fewer entries than a workgroup sorts in LDS, the largest value among the entries (what the network pads with), every element distinct
+        for n, distinct, limit in [(1 << 21, 300000, 1 << 19), (1 << 20, 70000, 100000), (500000, 500000, 500000), (1 << 20, 1000, 1 << 17), (3000000, 2000000, 3000000)]:
+            rng = cases.rng(n + distinct)
+            pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=distinct, dtype=np.uint64, endpoint=True).astype(ud))
+            pool[-1] = np.iinfo(ud).max
+            column = pool[rng.integers(0, len(pool), size=n)] if distinct < n else rng.permutation(pool)[:n]
+            got = compressors.dictionary_entries(dev(column), limit=limit).cpu().numpy().view(ud)
+            assert np.array_equal(got, np.unique(column)), (usize, n, distinct, limit, len(got))
+        with pytest.raises(compressors.Unrepresentable):
+            compressors.dictionary_entries(dev(np.arange(200000, dtype=ud)), limit=100000)
+
+
+@pytest.mark.parametrize("usize,ksize", [(4, 4), (8, 4)])
+def test_dictionary_with_wide_keys_built_and_encoded_on_the_device(usize, ksize):
+    """compressors.dictionary with 4-byte keys and no dictionary given: construction (more than 65 536 entries), encoding, and the decode back"""
+    from libgiddy_amd import compressors, schemes
+    ud = np.dtype("u%d" % usize)
+    rng = cases.rng(usize)
+    pool = np.unique(rng.integers(0, np.iinfo(ud).max, size=150000, dtype=np.uint64, endpoint=True).astype(ud))
+    column = pool[rng.integers(0, len(pool), size=1 << 21)]
+    want = formats.dictionary(column, "u%d" % ksize)
+    got = compressors.dictionary(dev(column), "u%d" % ksize)
+    same(got, want, ("dictionary with wide keys", usize, ksize))
+    out = torch.empty(len(column), dtype=got["dictionary_entries"].dtype, device="cuda")
+    schemes.dictionary(out, got["compressed_input"], got["dictionary_entries"], len(column), got["num_dictionary_entries"], uncompressed_size=usize, dictionary_index_size=ksize,
+                       stream=torch.cuda.current_stream().cuda_stream)
+    assert (out.cpu().numpy().view(ud) == column).all()
 
 
 @pytest.mark.parametrize("usize,use_dictionary", [(1, True), (2, True), (4, True), (8, True), (1, False)])

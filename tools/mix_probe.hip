@@ -50,6 +50,40 @@ __global__ void stream(u32x4* __restrict__ out, const uint8_t* __restrict__ in, 
 	}
 }
 
+// The same stream by a PERSISTENT grid: workgroup b takes tiles b, b + grid, ... and requests tile t + grid's input before it stores tile t — the reads run a whole
+// sweep ahead of the stores, so the stores' window can be as narrow as K allows without the loads' latency being exposed (if the workgroups keep pace)
+template <int K, int R, int Policy>
+__global__ void stream_persistent(u32x4* __restrict__ out, const uint8_t* __restrict__ in, uint64_t groups)
+{
+	extern __shared__ uint8_t pad[];
+	const uint64_t per_tile = (uint64_t) blockDim.x * K;
+	uint32_t got[K], next[K];
+	auto load = [&](uint64_t tile, uint32_t (&into)[K]) {
+		#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const uint64_t g = tile * per_tile + threadIdx.x + (uint64_t) k * blockDim.x;
+			into[k] = 0;
+			if (g >= groups) { continue; }
+			if (R == 4) { into[k] = reinterpret_cast<const uint32_t*>(in)[g]; }
+			if (R == 8) { const u32x2 v = reinterpret_cast<const u32x2*>(in)[g]; into[k] = v.x ^ v.y; }
+			if (R == 16) { const u32x4 v = reinterpret_cast<const u32x4*>(in)[g]; into[k] = v.x ^ v.y ^ v.z ^ v.w; }
+		}
+	};
+	load(blockIdx.x, got);
+	for (uint64_t tile = blockIdx.x; tile * per_tile < groups; tile += gridDim.x) {
+		load(tile + gridDim.x, next);
+		#pragma unroll
+		for (int k = 0; k < K; k++) {
+			const uint64_t g = tile * per_tile + threadIdx.x + (uint64_t) k * blockDim.x;
+			if (g >= groups) { continue; }
+			const uint32_t base = (uint32_t) g * 4u + got[k];
+			store16<Policy>(out + g, u32x4 { base, base + 1, base + 2, base + 3 });
+		}
+		#pragma unroll
+		for (int k = 0; k < K; k++) { got[k] = next[k]; }
+	}
+}
+
 // R bytes per group read and nothing written but one dword per workgroup (so that the loads cannot be dropped)
 template <int K, int R>
 __global__ void read_only(uint32_t* __restrict__ sink, const uint8_t* __restrict__ in, uint64_t groups)
@@ -97,6 +131,16 @@ void line(u32x4* out, const uint8_t* in, uint64_t groups, int resident)
 	fflush(stdout);
 }
 
+template <int K, int R, int Policy>
+void persistent_line(u32x4* out, const uint8_t* in, uint64_t groups, int per_cu)
+{
+	const double ms = time_ms([&] { stream_persistent<K, R, Policy><<<256 * per_cu, 256, 0>>>(out, in, groups); });
+	const double bytes = (16.0 + R) * groups;
+	printf("PERSISTENT grid of %d workgroups per CU, reads a sweep ahead: stores %d per lane per tile, %2d bytes read per 16 written, %s: %7.3f ms  %7.1f GB/s = %4.1f %% of 8 TB/s\n",
+		per_cu, K, R, Policy == 2 ? "sc1 nt" : "nt    ", ms, bytes / ms / 1e6, bytes / ms / 1e6 / 80);
+	fflush(stdout);
+}
+
 template <int K, int R>
 void lines(u32x4* out, const uint8_t* in, uint64_t groups)
 {
@@ -120,6 +164,16 @@ int main(int argc, char** argv)
 	lines<4, 8>(out, in, groups);
 	lines<4, 16>(out, in, groups);   // the copy
 	lines<4, 2>(out, in, groups);
+	lines<1, 4>(out, in, groups);    // ... with tiles of ONE store per lane, as Model's
+	lines<2, 4>(out, in, groups);
+	lines<1, 8>(out, in, groups);
+	lines<1, 16>(out, in, groups);
+	lines<8, 4>(out, in, groups);
+	for (int per_cu : { 4, 6, 8 }) {
+		persistent_line<1, 4, 2>(out, in, groups, per_cu); persistent_line<2, 4, 2>(out, in, groups, per_cu); persistent_line<4, 4, 2>(out, in, groups, per_cu);
+		persistent_line<1, 8, 2>(out, in, groups, per_cu); persistent_line<2, 8, 2>(out, in, groups, per_cu);
+		persistent_line<1, 16, 2>(out, in, groups, per_cu); persistent_line<4, 16, 2>(out, in, groups, per_cu);
+	}
 	for (int resident : { 0 }) {
 		(void) resident;
 		const uint64_t tiles = (groups + 1023) / 1024;

@@ -5,14 +5,14 @@ once per process: every forced configuration is a child process decoding the who
     python tools/regret.py [SCHEME,...|all] [log2n,...=26,28]          the driver: prints chosen / best / regret per shape, and the worst
     python tools/regret.py --worker SCHEME LOG2N                       (a child: one line per shape — % of the 8 TB/s HBM peak)
 
-Schemes: run_length_encoding, run_position_encoding_relative, run_position_encoding_absolute (segment lengths 64 ... 2^20 incl. 2052 / 4100 / 8200 x mean
+Schemes: run_length_encoding, run_position_encoding_relative, run_position_encoding_absolute (segment lengths 64 ... 2^20 incl. 2052 / 4100 / 8200, 3000 / 10 000 and the whole tiles between 8192 and 65 536 x mean
 runs 2, 4, 32, 200), delta (<4,8,2>: segment lengths 1024 ... 2^22 and one segment), discard_zero_bytes_variable (segment lengths 64 ... 2^20).
 """
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-RUN_SEGMENTS = (64, 1024, 2052, 4096, 4100, 8200, 16384, 65536, 1 << 20)
+RUN_SEGMENTS = (64, 1024, 2052, 3000, 4096, 4100, 8200, 10000, 12288, 16384, 24576, 32768, 65536, 1 << 20)
 RUN_MEANS = (2, 4, 32, 200)
 SHAPES = {
     "run_length_encoding": [(L, m) for L in RUN_SEGMENTS for m in RUN_MEANS],
@@ -44,23 +44,30 @@ def worker(scheme, log2n):
     n = 1 << log2n
     for L, mean in SHAPES[scheme]:
         try:
-            if scheme == "run_length_encoding": work = w.RunLength(n, device, segment_length=L, mean_run=mean)
-            elif scheme.startswith("run_position_encoding"): work = w.RunPosition(n, device, segment_length=L, mean_run=mean, relative=scheme.endswith("relative"))
-            elif scheme == "delta": work = w.DeltaPatched(n, device, segment_length=L or n)
-            else: work = w.DiscardZeroBytesVariable(n, device, segment_length=L)
-            run = (lambda: work.launch_fields(work.output, work.column_fields(), stream, work.config))
-            for _ in range(3): run()
+            # THREE columns of different seeds decoded in turn: what a column's compressed arrays cost when they come from HBM, not from the Infinity Cache
+            # (one column repeated flatters every path that reads its run arrays twice: the groups of segments at C4 are 86 % warm and 70 % cold)
+            works = []
+            for seed in (0, 1000, 2000):
+                w.SEED_OFFSET = seed
+                if scheme == "run_length_encoding": work = w.RunLength(n, device, segment_length=L, mean_run=mean)
+                elif scheme.startswith("run_position_encoding"): work = w.RunPosition(n, device, segment_length=L, mean_run=mean, relative=scheme.endswith("relative"))
+                elif scheme == "delta": work = w.DeltaPatched(n, device, segment_length=L or n)
+                else: work = w.DiscardZeroBytesVariable(n, device, segment_length=L)
+                works.append(work)
+            def run():
+                for work in works: work.launch_fields(work.output, work.column_fields(), stream, work.config)
+            for _ in range(2): run()
             torch.cuda.synchronize()
             times = []
             for _ in range(5):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 a.record()
-                for _ in range(4): run()
+                for _ in range(2): run()
                 b.record(); torch.cuda.synchronize()
-                times.append(a.elapsed_time(b) / 4)
+                times.append(a.elapsed_time(b) / (2 * len(works)))
             ms = sorted(times)[len(times) // 2]
-            print("SHAPE %d %d %.2f" % (L, mean, work.algorithmic_bytes / ms / 1e6 / 80), flush=True)
-            del work
+            print("SHAPE %d %d %.2f" % (L, mean, sum(work.algorithmic_bytes for work in works) / len(works) / ms / 1e6 / 80), flush=True)
+            del works, work
         except Exception as problem:
             print("SHAPE %d %d nan  # %s" % (L, mean, str(problem).splitlines()[0][:100]), flush=True)
         torch.cuda.empty_cache()
@@ -79,7 +86,7 @@ def driver(schemes, sizes):
                         L, mean, pct = line.split()[1:4]
                         results.setdefault((int(L), int(mean)), {})[label] = float(pct)
             labels = list(CONFIGURATIONS[scheme])
-            print("# %s, 2^%d outputs — %% of the HBM peak (algorithmic bytes; one column decoded repeatedly: run arrays that fit the Infinity Cache come from it) by path: %s" % (scheme, log2n, " | ".join(labels)))
+            print("# %s, 2^%d outputs — %% of the HBM peak (algorithmic bytes; three columns of different seeds in turn: inputs from HBM) by path: %s" % (scheme, log2n, " | ".join(labels)))
             for (L, mean), by in sorted(results.items()):
                 rates = [by.get(label, float("nan")) for label in labels]
                 valid = [r for r in rates if r == r]
