@@ -30,7 +30,7 @@ enum : unsigned { per_lane = 64, wave_elements = 64 * per_lane, tile = waves_per
 using mask_t = std::conditional<(per_lane > 32), uint64_t, uint32_t>::type;   // a lane's bits, one per element it saw
 enum : unsigned {
 	staged_runs = 2048,          // runs (pieces) of a tile whose values and descriptors wait in LDS for the tile's base
-	tiles_per_link = 4,          // consecutive tiles a workgroup of encode_run_positions takes as ONE link of the chain
+	tiles_per_link = 4,          // consecutive tiles a workgroup of encode_run_positions takes as ONE link of the chain (round 5, 2^28 elements: 2 / 4 / 8 / 16 tiles: 0.46 / 0.45 / 0.46-0.50 / 0.53 ms)
 	values_read_together = 4,    // run values a lane reads again at a time: one round trip
 	waves_per_simd = 4,          // (6 and 8 — the compiler then spills — measured slower: profiles/r03_compress_bench.txt)
 };
