@@ -230,11 +230,7 @@ public:
 		upper_limits.threads_in_block = GIDDY_STREAM_THREADS_PER_BLOCK;
 		keep_gpu_busy_factor          = 1024;  // in practice: one tile per workgroup — the dispatcher hands tiles out in address order, which HBM likes best
 		// 6 resident workgroups per CU are 1-9 points faster than 8, for every registered width (tools/occupancy_sweep.py)
-#ifdef GIDDY_FOR_RESIDENT_BLOCKS_CAP_EXPERIMENT
-		resident_blocks_per_multiprocessor_cap = (unsigned) GIDDY_FOR_RESIDENT_BLOCKS_CAP_EXPERIMENT;
-#else
 		resident_blocks_per_multiprocessor_cap = 6u;
-#endif
 	}
 
 	launch_config_resolution_params_t(device::properties_t device_properties_, size_t data_length, size_t segment_length)
