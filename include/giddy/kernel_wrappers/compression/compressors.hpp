@@ -19,6 +19,7 @@
 #include "giddy/kernels/compression/incidence_bitmaps.hpp"
 #include "giddy/kernels/compression/patches.hpp"
 #include "giddy/kernels/compression/runs.hpp"
+#include "giddy/kernels/compression/listed_runs.hpp"
 
 namespace cuda {
 namespace kernels {
@@ -33,6 +34,62 @@ inline size_t discard_zero_bytes_variable_scratch_entries(size_t length, size_t 
 {
 	return std::max(scratch_entries(length), util::div_rounding_up(length, (size_t) threads_per_block * std::max<size_t>(fields_per_container, 1)) + 3);
 }
+
+/// "run_scratch" (uint64_t*, with "run_scratch_entries", size_t — both optional) of the run encodings' compressors: with it they take five or six small launches, one of which reads the column, and no
+/// workgroup waits for another (kernels/compression/listed_runs.hpp; run lengths in 1-byte fields: always the chained kernel); `staged_per_wave`
+/// (a multiple of 16, at most 512): the runs per 4096 elements the scratch holds — a wavefront of more is read a second time.
+inline size_t run_scratch_entries(size_t length, unsigned element_size, unsigned staged_per_wave = 256)
+{
+	return (size_t) runs::listed::scratch_layout(util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::wave_elements), element_size, staged_per_wave).entries;
+}
+
+namespace detail {
+
+/// what the launches share: the scratch cut up; the first launch (the one that reads the column) and the last of phase 2 made by members
+template <unsigned U>
+struct listed_runs {
+	uint64_t num_waves, num_blocks;
+	unsigned staged_per_wave;
+	uint64_t *headers, *bases, *previous_starts, *next_starts;
+	uint64_t *block_sums, *block_bases, *block_first_starts, *block_last_starts, *block_next_starts, *block_previous_starts;
+	uint16_t* offsets;
+	uint_t<U>* values;
+	launch_configuration_t per_wavefronts, relisting, per_blocks;
+
+	listed_runs(stream::id_t stream, uint64_t* scratch, size_t scratch_entries, const uint_t<U>* input, uint64_t length)
+	: num_waves(util::div_rounding_up(length, (uint64_t) runs::one_pass::wave_elements)),
+	  num_blocks(util::div_rounding_up(num_waves, (uint64_t) runs::listed::block_waves)),
+	  staged_per_wave(runs::listed::staged_per_wave_that_fits(scratch_entries, num_waves, U)),
+	  per_wavefronts(tile_launch(util::div_rounding_up(num_waves, (uint64_t) waves_per_block))),
+	  relisting(tile_launch(std::min<uint64_t>(util::div_rounding_up(num_waves, (uint64_t) waves_per_block), runs::listed::relisting_workgroups))),
+	  per_blocks(tile_launch(num_blocks))
+	{
+		if (staged_per_wave == 0) { throw std::invalid_argument("\"run_scratch\" is too small for this column: see run_scratch_entries()"); }
+		if (reinterpret_cast<uintptr_t>(scratch) % 16 != 0) { throw std::invalid_argument("\"run_scratch\" must be 16-byte aligned"); }
+		if (num_blocks > 0x7FFFFFFFull) { throw std::invalid_argument("the column has more blocks of wavefronts than a grid has workgroups"); }
+		const runs::listed::scratch_layout layout(num_waves, U, staged_per_wave);
+		headers = scratch + layout.headers; bases = scratch + layout.bases; previous_starts = scratch + layout.previous_starts; next_starts = scratch + layout.next_starts;
+		uint64_t* const blocks = scratch + layout.blocks;
+		block_sums = blocks; block_bases = blocks + layout.blocks_stride; block_first_starts = blocks + 2 * layout.blocks_stride; block_last_starts = blocks + 3 * layout.blocks_stride;
+		block_next_starts = blocks + 4 * layout.blocks_stride; block_previous_starts = blocks + 5 * layout.blocks_stride;
+		offsets = reinterpret_cast<uint16_t*>(scratch + layout.offsets); values = reinterpret_cast<uint_t<U>*>(scratch + layout.values);
+		cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::list_runs<U>), stream, per_wavefronts, headers, offsets, values, input, length, (uint32_t) staged_per_wave);
+	}
+
+	void place_blocks(stream::id_t stream, uint64_t* grand_total) const
+	{
+		cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::place_blocks), stream, launch_configuration_t(1, threads_per_block),
+			block_bases, (const uint64_t*) block_sums, num_blocks, grand_total);
+	}
+};
+
+/// (a caller that names the chain's test arguments wants the chain)
+inline bool chain_is_asked_for(const cuda::registered::kernel_t::arguments_type& arguments)
+{
+	return optional_argument<uint32_t>(arguments, "chain_patience") || optional_argument<uint64_t>(arguments, "chain_fault_tile");
+}
+
+} // namespace detail
 
 /// The chained kernels' grid: EXACTLY a workgroup per tile.  A smaller grid walking the tiles at grid stride deadlocks as soon as it is larger
 /// than what the device holds at once: a resident workgroup's second tile waits for the first tile of a workgroup that cannot start
@@ -414,15 +471,39 @@ void kernel_t<I, U, RL, RI>::enqueue_launch_with(stream::id_t stream, const laun
 	auto input     = argument<const uint_t<U>*>(arguments, "input");
 	auto length    = (size_type) argument<uint_t<I>>(arguments, "length");
 	auto segment   = (size_type) argument<uint_t<I>>(arguments, "segment_length");
-	auto totals    = argument<uint64_t*>(arguments, "tile_totals");
 	auto num_runs  = argument<uint64_t*>(arguments, "num_element_runs");
 	if (length == 0) { return; }
-	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once; "run_starts_scratch" is not used any more
+	// with "run_scratch": three launches (below); otherwise ONE launch (kernels/compression/runs.hpp, one_pass) — the column is read once either way
 	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
 	const uint64_t max_run_length = ~(uint64_t) 0 >> (64 - 8 * RL);   // the largest value a length field holds
 	// "capacity" (optional, size_t): pieces the output arrays have room for — the true count is reported all the same, so that a caller
 	// who sized by an estimate can tell and come back with bigger buffers
 	const uint64_t capacity = optional_argument<size_t>(arguments, "capacity").value_or((size_t) length);
+	if constexpr (RL >= 2) {
+		const auto scratch = optional_argument<uint64_t*>(arguments, "run_scratch");
+		if (scratch && !detail::chain_is_asked_for(arguments)) {   // three launches, no chain (kernels/compression/listed_runs.hpp)
+			const detail::listed_runs<U> listed(stream, scratch.value(), argument<size_t>(arguments, "run_scratch_entries"), input, (uint64_t) length);
+			cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::summarize_wavefronts<true>), stream, listed.per_blocks,
+				listed.bases, listed.previous_starts, listed.next_starts, listed.block_sums, listed.block_first_starts, listed.block_last_starts, (const uint64_t*) listed.headers, listed.num_waves);
+			cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::count_pieces), stream, listed.per_blocks,
+				listed.bases, listed.block_sums, listed.block_next_starts, listed.block_previous_starts, (const uint64_t*) listed.next_starts,
+				(const uint64_t*) listed.block_first_starts, (const uint64_t*) listed.block_last_starts, (const uint64_t*) listed.headers, listed.num_waves, listed.num_blocks,
+				(uint64_t) length, max_run_length);
+			listed.place_blocks(stream, num_runs);
+			auto place = [&](const void* kernel, const launch_configuration_t& grid) {
+				cuda::enqueue_launch(kernel, stream, grid,
+					argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
+					argument<uint_t<RI>*>(arguments, "position_anchors"), argument<uint_t<RL>*>(arguments, "intra_run_anchor_offsets"), input,
+					(const uint64_t*) listed.headers, (const uint64_t*) listed.bases, (const uint64_t*) listed.block_bases,
+					(const uint64_t*) listed.previous_starts, (const uint64_t*) listed.next_starts, (const uint64_t*) listed.block_previous_starts, (const uint64_t*) listed.block_next_starts,
+					(const uint16_t*) listed.offsets, (const uint_t<U>*) listed.values, (uint32_t) listed.staged_per_wave, segment, length, max_run_length, capacity);
+			};
+			place(reinterpret_cast<const void*>(runs::listed::place_run_lengths<I, U, RL, RI, false>), listed.per_wavefronts);
+			place(reinterpret_cast<const void*>(runs::listed::place_run_lengths<I, U, RL, RI, true>), listed.relisting);
+			return;
+		}
+	}
+	auto totals = argument<uint64_t*>(arguments, "tile_totals");
 	enqueue_zero(stream, totals, 2 * num_tiles * sizeof(uint64_t));
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_lengths<I, U, RL, RI>), stream, chained_launch(num_tiles),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<RL>*>(arguments, "run_lengths"),
@@ -463,11 +544,27 @@ void kernel_t<I, U, P, R, RI>::enqueue_launch_with(stream::id_t stream, const la
 	auto input   = argument<const uint_t<U>*>(arguments, "input");
 	auto length  = (size_type) argument<uint_t<I>>(arguments, "length");
 	auto segment = (size_type) argument<uint_t<I>>(arguments, "segment_length");
-	auto totals  = argument<uint64_t*>(arguments, "tile_totals");
 	if (length == 0) { return; }
+	const auto scratch = optional_argument<uint64_t*>(arguments, "run_scratch");
+	if (scratch && !detail::chain_is_asked_for(arguments)) {   // three launches, no chain (kernels/compression/listed_runs.hpp)
+		const detail::listed_runs<U> listed(stream, scratch.value(), argument<size_t>(arguments, "run_scratch_entries"), input, (uint64_t) length);
+		cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::summarize_wavefronts<false>), stream, listed.per_blocks,
+			listed.bases, (uint64_t*) nullptr, (uint64_t*) nullptr, listed.block_sums, (uint64_t*) nullptr, (uint64_t*) nullptr, (const uint64_t*) listed.headers, listed.num_waves);
+		listed.place_blocks(stream, argument<uint64_t*>(arguments, "num_element_runs"));
+		auto place = [&](const void* kernel, const launch_configuration_t& grid) {
+			cuda::enqueue_launch(kernel, stream, grid,
+				argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"), argument<uint_t<RI>*>(arguments, "position_anchors"), input,
+				(const uint64_t*) listed.headers, (const uint64_t*) listed.bases, (const uint64_t*) listed.block_bases, (const uint16_t*) listed.offsets, (const uint_t<U>*) listed.values,
+				(uint32_t) listed.staged_per_wave, segment, length, (uint64_t) optional_argument<size_t>(arguments, "capacity").value_or((size_t) length));
+		};
+		place(reinterpret_cast<const void*>(runs::listed::place_run_positions<I, U, P, R, RI, false>), listed.per_wavefronts);
+		place(reinterpret_cast<const void*>(runs::listed::place_run_positions<I, U, P, R, RI, true>), listed.relisting);
+		return;
+	}
 	// ONE launch (kernels/compression/runs.hpp, one_pass): the column is read once
 	const uint64_t num_tiles = util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::tile);
 	const uint64_t num_links = util::div_rounding_up(num_tiles, (uint64_t) runs::one_pass::tiles_per_link);   // (a workgroup — a link of the chain — takes that many consecutive tiles)
+	auto totals = argument<uint64_t*>(arguments, "tile_totals");
 	enqueue_zero(stream, totals, num_links * sizeof(uint64_t));
 	cuda::enqueue_launch(reinterpret_cast<const void*>(runs::one_pass::encode_run_positions<I, U, P, R, RI>), stream, chained_launch(num_links),
 		argument<uint_t<U>*>(arguments, "run_data"), argument<uint_t<P>*>(arguments, "run_start_positions"),

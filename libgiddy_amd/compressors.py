@@ -40,6 +40,25 @@ def _scratch(n, device):
     return LAST_SCRATCH
 
 
+LAST_RUN_SCRATCH = None
+STAGED_PER_WAVE = 256   # runs per 4096 elements the run compressors' scratch has room for (a wavefront of more is read a second time); a multiple of 16, <= 512
+
+
+def _run_scratch(n, usize, device, chain, staged_per_wave=None):
+    """"run_scratch" / "run_scratch_entries" of the run compressors (kernel_wrappers/compression/compressors.hpp, run_scratch_entries()): with it
+    they take three launches and no workgroup waits for another (kernels/compression/listed_runs.hpp); a caller who sets `chain` gets the one launch."""
+    if chain:
+        return {}
+    staged = STAGED_PER_WAVE if staged_per_wave is None else staged_per_wave
+    waves = -(-n // 4096)
+    even = (waves + 1) // 2 * 2
+    blocks = -(-waves // 1024)
+    entries = 4 * even + 6 * ((blocks + 1) // 2 * 2) + (waves * staged * 2 + 15) // 16 * 2 + (waves * staged * usize + 15) // 16 * 2
+    global LAST_RUN_SCRATCH
+    LAST_RUN_SCRATCH = torch.empty(entries, dtype=torch.int64, device=device)
+    return {"run_scratch": r.pointer(LAST_RUN_SCRATCH, "u64"), "run_scratch_entries": r.size_t(entries)}
+
+
 def _launch(key, resolve, launch, counter=None, what="elements"):
     kernel = schemes.kernel(key)
     config = kernel.resolve_launch_configuration(r.CURRENT_DEVICE, resolve)
@@ -233,7 +252,7 @@ def _count_of(runs, capacity):
     return count
 
 
-def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None, chain=None):
+def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, index_size=4, capacity=None, chain=None, staged_per_wave=None):
     """`capacity`: runs the output buffers have room for (default: as many as elements, the worst case).  The kernels are told, store nothing
     beyond it and still report the true number of runs: CapacityExceeded carries it."""
     n, usize, lsize = column.numel(), column.element_size(), _size(run_length_dtype)
@@ -251,14 +270,15 @@ def run_length_encoding(column, segment_length, run_length_dtype=np.uint16, inde
                  "intra_run_anchor_offsets": r.pointer(buffers["intra_run_anchor_offsets"], "u%d" % (8 * lsize)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
                  "tile_totals": r.pointer(_scratch(n, device), "u64"),
-                 "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain)})
+                 "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain),
+                 **(_run_scratch(n, usize, device, chain, staged_per_wave) if lsize >= 2 else {})})
     count = _count_of(runs, capacity)
     return {"run_data": buffers["run_data"][:count], "run_lengths": buffers["run_lengths"][:count], "position_anchors": buffers["position_anchors"],
             "intra_run_anchor_offsets": buffers["intra_run_anchor_offsets"], "segment_length": segment_length, "num_segments": nseg,
             "num_element_runs": count, "length": n}
 
 
-def run_position_encoding(column, segment_length, position_dtype=np.uint16, relative=True, index_size=4, capacity=None, chain=None):
+def run_position_encoding(column, segment_length, position_dtype=np.uint16, relative=True, index_size=4, capacity=None, chain=None, staged_per_wave=None):
     n, usize, psize = column.numel(), column.element_size(), _size(position_dtype)
     device = column.device
     capacity = capacity or max(n, 1)
@@ -272,7 +292,8 @@ def run_position_encoding(column, segment_length, position_dtype=np.uint16, rela
                 {"run_data": r.pointer(buffers["run_data"], "u%d" % (8 * usize)), "run_start_positions": r.pointer(buffers["run_start_positions"], "u%d" % (8 * psize)),
                  "position_anchors": r.pointer(buffers["position_anchors"], "u%d" % (8 * index_size)),
                  "input": r.const_pointer(column, "u%d" % (8 * usize)), "length": r.uint_t(index_size)(n), "segment_length": r.uint_t(index_size)(segment_length),
-                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain)})
+                 "tile_totals": r.pointer(_scratch(n, device), "u64"), "num_element_runs": r.pointer(runs, "u64"), "capacity": r.size_t(capacity), **_chain_arguments(chain),
+                 **_run_scratch(n, usize, device, chain, staged_per_wave)})
     count = _count_of(runs, capacity)
     return {"run_data": buffers["run_data"][:count], "run_start_positions": buffers["run_start_positions"][:count], "position_anchors": buffers["position_anchors"],
             "segment_length": segment_length, "num_anchors": nseg, "num_element_runs": count, "length": n}

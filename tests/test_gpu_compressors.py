@@ -195,6 +195,49 @@ def test_run_position_encoding(index_size, usize, psize, relative):
         assert (out.cpu().numpy().view(ud) == column).all(), ("rpe round trip", n, L, mean_run)
 
 
+@pytest.mark.parametrize("usize", [1, 2, 4, 8])
+def test_run_compressors_by_three_launches_and_by_the_chain_agree(usize):
+    """The run compressors take three launches and no chain when they are given "run_scratch" (kernels/compression/listed_runs.hpp) and the one chained launch
+    otherwise: both against the format writers — with a scratch that holds 16 runs per 4096 elements (nearly every wavefront of the dense columns is listed a
+    second time), 64, and the most there is (512); columns of one run, of runs longer than a 2-byte length holds, with segments that begin inside later pieces."""
+    from libgiddy_amd import compressors
+    ud = np.dtype("u%d" % usize)
+    columns = [(cases.runs_column(n, mean_run, ud, seed=5 * n + mean_run), L) for n, L, mean_run in RUN_COLUMNS + [(50000, 333, 2), (12289, 4096, 1)]]
+    columns += [(np.repeat(np.array([5, 6, 5, 9, 200], dtype=ud), [70000, 1, 140001, 3, 66000]), L) for L in (64, 4096, 100000)]
+    columns += [(np.full(300000, 7, dtype=ud), 1000), (np.arange(9000, dtype=np.uint64).astype(ud), 4096)]
+    for column, L in columns:
+        want_lengths = formats.run_length_encoding(column, L, np.uint16, 4)
+        want_positions = formats.run_position_encoding(column, L, np.uint32, False, 4)
+        want_relative = formats.run_position_encoding(column, L, np.uint16, True, 4) if L <= 65536 else None
+        for staged, chain in ((16, None), (64, None), (512, None), (None, {"patience": 1 << 23})):
+            what = ("three launches, %d staged" % staged) if chain is None else "chained"
+            same(compressors.run_length_encoding(dev(column), L, np.uint16, 4, chain=chain, staged_per_wave=staged), want_lengths, ("rle", what, len(column), L))
+            same(compressors.run_position_encoding(dev(column), L, np.uint32, False, 4, chain=chain, staged_per_wave=staged), want_positions, ("rpe absolute", what, len(column), L))
+            if want_relative is not None:
+                same(compressors.run_position_encoding(dev(column), L, np.uint16, True, 4, chain=chain, staged_per_wave=staged), want_relative, ("rpe relative", what, len(column), L))
+        # ... and the column handed over one element past a 16-byte boundary (every wavefront reads element by element)
+        displaced = dev(np.concatenate((column[:1], column)))[1:]
+        same(compressors.run_length_encoding(displaced, L, np.uint16, 4), want_lengths, ("rle, displaced", len(column), L))
+        same(compressors.run_position_encoding(displaced, L, np.uint32, False, 4, staged_per_wave=16), want_positions, ("rpe absolute, displaced", len(column), L))
+
+
+def test_a_run_scratch_that_is_too_small_is_refused():
+    from libgiddy_amd import compressors, registered as r, schemes
+    n = 1 << 20
+    column = dev(cases.runs_column(n, 32, np.dtype("u4"), seed=3))
+    k = schemes.kernel("compression::run_position_encoding::kernel_t<4u, 4u, 2u, true, 4u>")
+    out = {name: torch.empty(n, dtype=dtype, device="cuda") for name, dtype in (("run_data", torch.int32), ("run_start_positions", torch.int16), ("position_anchors", torch.int32))}
+    count = torch.zeros(1, dtype=torch.int64, device="cuda")
+    scratch = torch.empty(4 * 256 + 100, dtype=torch.int64, device="cuda")   # the per-wavefront tables fit; not even 16 runs per wavefront do
+    with pytest.raises(Exception, match="run_scratch"):
+        k.enqueue_launch(torch.cuda.current_stream().cuda_stream, k.resolve_launch_configuration(r.CURRENT_DEVICE, {"length": r.size_t(n), "segment_length": r.size_t(4096)}),
+                         {"run_data": r.pointer(out["run_data"], "u32"), "run_start_positions": r.pointer(out["run_start_positions"], "u16"),
+                          "position_anchors": r.pointer(out["position_anchors"], "u32"), "input": r.const_pointer(column, "u32"), "length": r.uint_t(4)(n),
+                          "segment_length": r.uint_t(4)(4096), "num_element_runs": r.pointer(count, "u64"), "capacity": r.size_t(n),
+                          "run_scratch": r.pointer(scratch, "u64"), "run_scratch_entries": r.size_t(scratch.numel())})
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("index_size,esize", [(4, 1), (4, 4), (4, 8), (8, 2), (8, 8)])
 def test_patches(index_size, esize):
     from libgiddy_amd import compressors

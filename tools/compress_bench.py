@@ -47,6 +47,21 @@ x.run(st); torch.cuda.synchronize()
 column = x.output.clone()
 truth_runs = x.num_runs
 del x; torch.cuda.empty_cache()
+def by_events(fn, reps=5):
+    """the launches alone (HIP events around them; the Python call's allocations and its read-back of the count are on the host's clock above)"""
+    times = []
+    for _ in range(reps):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); a.record(); fn(); b.record(); torch.cuda.synchronize()
+        times.append(a.elapsed_time(b))
+    return sorted(times)[len(times) // 2]
+
+CHAIN = {"patience": 1 << 23}   # (naming the chain's arguments asks for the one-launch kernels of round 3-4)
+for name, call in (("run lengths", compressors.run_length_encoding), ("run positions", compressors.run_position_encoding)):
+    for staged in (None, 512, 64):
+        print("#   %-13s listed (no chain), %3s runs staged per wavefront: %6.3f ms by events (incl. the count's read-back)" % (
+            name, staged or compressors.STAGED_PER_WAVE, by_events(lambda: call(column, 4096, np.uint16, capacity=n // 8, staged_per_wave=staged))), flush=True)
+    print("#   %-13s ONE launch, chained tiles (rounds 3-4):            %6.3f ms by events" % (name, by_events(lambda: call(column, 4096, np.uint16, capacity=n // 8, chain=CHAIN))), flush=True)
 f, t = timed(lambda: compressors.run_length_encoding(column, 4096, np.uint16, capacity=n // 8))
 out = torch.empty_like(column)
 schemes.run_length_encoding(out, f["run_data"], f["run_lengths"], f["position_anchors"], f["intra_run_anchor_offsets"], 4096, f["num_segments"], f["num_element_runs"], n, stream=st)
