@@ -38,7 +38,7 @@ inline size_t discard_zero_bytes_variable_scratch_entries(size_t length, size_t 
 /// "run_scratch" (uint64_t*, with "run_scratch_entries", size_t — both optional) of the run encodings' compressors: with it they take five or six small launches, one of which reads the column, and no
 /// workgroup waits for another (kernels/compression/listed_runs.hpp; run lengths in 1-byte fields: always the chained kernel); `staged_per_wave`
 /// (a multiple of 16, at most 512): the runs per 4096 elements the scratch holds — a wavefront of more is read a second time.
-inline size_t run_scratch_entries(size_t length, unsigned element_size, unsigned staged_per_wave = 256)
+inline size_t run_scratch_entries(size_t length, unsigned element_size, unsigned staged_per_wave = runs::listed::staged_per_wave_at_most)
 {
 	return (size_t) runs::listed::scratch_layout(util::div_rounding_up((uint64_t) length, (uint64_t) runs::one_pass::wave_elements), element_size, staged_per_wave).entries;
 }

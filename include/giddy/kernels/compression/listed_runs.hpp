@@ -437,7 +437,7 @@ __device__ __forceinline__ uint32_t starts_up_to(const uint16_t* list, uint32_t 
 template <typename T, bool Relisted>
 struct wavefront_lists {
 	// (ONE launch for both kinds — 8 KiB of LDS a wavefront for all — was measured: 44-46 / 62 us against 31 + 6 / 45 + 6, run positions / lengths at 2^28 elements)
-	enum : unsigned { list_entries = Relisted ? (unsigned) wave_elements : (unsigned) staged_per_wave_at_most, values_ahead = 4 };
+	enum : unsigned { list_entries = Relisted ? (unsigned) wave_elements : (unsigned) staged_per_wave_at_most, values_ahead = 4, offsets_ahead = 64 * values_ahead };
 	typedef uint32_t sixteen_bytes __attribute__((ext_vector_type(4)));
 
 	template <typename Emit>
@@ -452,14 +452,16 @@ struct wavefront_lists {
 			for (uint64_t w = (uint64_t) blockIdx.x * waves_per_block + wave; w < num_waves; w += (uint64_t) gridDim.x * waves_per_block) {
 				// the lists are asked for before the wavefront knows how long they are: one round trip for the header, the offsets and the first values
 				const uint64_t header = headers[w];
+				// (the first 256 of each: what a wavefront of mean runs of 16 or more has; a longer list's rest is asked for once its length is known)
 				sixteen_bytes piece = { };
-				if (lane * 8 < staged_per_wave) { piece = *reinterpret_cast<const sixteen_bytes*>(staged_offsets + w * staged_per_wave + lane * 8); }
+				if (lane * 8 < (staged_per_wave < offsets_ahead ? staged_per_wave : (uint32_t) offsets_ahead)) { piece = *reinterpret_cast<const sixteen_bytes*>(staged_offsets + w * staged_per_wave + lane * 8); }
 				T ahead[values_ahead];
 				#pragma unroll
 				for (unsigned q = 0; q < values_ahead; q++) { ahead[q] = lane + 64 * q < staged_per_wave ? staged_values[w * staged_per_wave + lane + 64 * q] : (T) 0; }
 				const uint32_t count = count_in(header);
 				if (count > staged_per_wave) { continue; }   // (wave-uniform: the other launch's)
 				{
+					if (count > offsets_ahead && lane * 8 >= offsets_ahead && lane * 8 < count) { piece = *reinterpret_cast<const sixteen_bytes*>(staged_offsets + w * staged_per_wave + lane * 8); }
 					*reinterpret_cast<sixteen_bytes*>(list + lane * 8) = piece;
 					wave64::lds_fence();
 					emit(w, (const uint16_t*) list, count, [&](auto&& run) {

@@ -227,7 +227,7 @@ __device__ __forceinline__ group<T, N> load_group(const T* __restrict__ p)
 /// (Non-temporal LOADS — round 5, tools/read_probe.hip: a read stream alone gets 83-87 % of the HBM peak with them and 74-78 % with plain loads, and the run compressors' one
 /// pass over the column takes 190-198 us with them against 205-225 — were tried for every load_group of the decoders, beside their stores, at 2^30 elements: Dictionary
 /// -1.3 ... -2 points, Frame of Reference, the run decoders and both discard-zero-bytes forms +-0.3, Delta +1 over its unpatched instantiations and +-3 — noise — over the
-/// fused ones: the decoders keep plain loads.)
+/// fused ones: the decoders keep plain loads.  Nor did the other compressors gain: DZB-variable 1.22-1.26 ms against 1.17-1.19, dictionary encoding and construction the same.)
 
 /// ... from an address aligned for T only (a column handed over at an odd element offset; gfx950 takes wide loads of global memory at any address — at
 /// the price of the second line a piece may lie across)

@@ -41,7 +41,7 @@ def _scratch(n, device):
 
 
 LAST_RUN_SCRATCH = None
-STAGED_PER_WAVE = 256   # runs per 4096 elements the run compressors' scratch has room for (a wavefront of more is read a second time); a multiple of 16, <= 512
+STAGED_PER_WAVE = 512   # runs per 4096 elements the run compressors' scratch has room for (a wavefront of more is read a second time); a multiple of 16, <= 512
 
 
 def _run_scratch(n, usize, device, chain, staged_per_wave=None):

@@ -58,7 +58,7 @@ def by_events(fn, reps=5):
 
 CHAIN = {"patience": 1 << 23}   # (naming the chain's arguments asks for the one-launch kernels of round 3-4)
 for name, call in (("run lengths", compressors.run_length_encoding), ("run positions", compressors.run_position_encoding)):
-    for staged in (None, 512, 64):
+    for staged in (None, 256, 64):
         print("#   %-13s listed (no chain), %3s runs staged per wavefront: %6.3f ms by events (incl. the count's read-back)" % (
             name, staged or compressors.STAGED_PER_WAVE, by_events(lambda: call(column, 4096, np.uint16, capacity=n // 8, staged_per_wave=staged))), flush=True)
     print("#   %-13s ONE launch, chained tiles (rounds 3-4):            %6.3f ms by events" % (name, by_events(lambda: call(column, 4096, np.uint16, capacity=n // 8, chain=CHAIN))), flush=True)
