@@ -22,7 +22,7 @@ static void register_for_index_size()
 	// dictionary encoding: <IndexSize, UncompressedSize, DictionaryIndexSize>
 	dictionary::kernel_t<I, 1, 1>::registerInSubclassFactory(); dictionary::kernel_t<I, 2, 1>::registerInSubclassFactory(); dictionary::kernel_t<I, 2, 2>::registerInSubclassFactory();
 	dictionary::kernel_t<I, 4, 1>::registerInSubclassFactory(); dictionary::kernel_t<I, 4, 2>::registerInSubclassFactory(); dictionary::kernel_t<I, 4, 4>::registerInSubclassFactory();
-	dictionary::kernel_t<I, 8, 1>::registerInSubclassFactory(); dictionary::kernel_t<I, 8, 2>::registerInSubclassFactory(); dictionary::kernel_t<I, 8, 4>::registerInSubclassFactory();
+	dictionary::kernel_t<I, 8, 1>::registerInSubclassFactory(); dictionary::kernel_t<I, 8, 2>::registerInSubclassFactory(); dictionary::kernel_t<I, 8, 4>::registerInSubclassFactory(); dictionary::kernel_t<I, 8, 8>::registerInSubclassFactory();
 	// dictionary construction (distinct values, sorted; up to 65 536 of them): <IndexSize, UncompressedSize>
 	dictionary::construction::kernel_t<I, 1>::registerInSubclassFactory(); dictionary::construction::kernel_t<I, 2>::registerInSubclassFactory();
 	dictionary::construction::kernel_t<I, 4>::registerInSubclassFactory(); dictionary::construction::kernel_t<I, 8>::registerInSubclassFactory();

@@ -131,7 +131,7 @@ int main()
 		CHECK(reference_registrations == 163);
 		CHECK(fused_patch_extensions == 12 + 20 + 8 + 5 + 12);
 		CHECK(position_expansions == 8);
-		CHECK(compressors == 110);
+		CHECK(compressors == 112);
 		const char* key = "decompression::frame_of_reference::kernel_t<4u, int, short, cuda::functors::unary::parametric_model::constant<4u, int> >";
 		CHECK(factory.canProduce(key));
 		auto k = registered::kernel_t::produceSubclass(key);

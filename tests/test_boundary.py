@@ -39,7 +39,7 @@ def test_factory_has_the_163_reference_registrations():
     assert sorted(expansions) == sorted(schemes.key_compressed_indices_positions(o, i) for o in (4, 8) for i in (1, 2, 4, 8))
     # ... and the device-side compressors (the reference has none), under "compression::..."
     compressors = [k for k in all_keys if k.startswith("compression::")]
-    assert len(compressors) == 110
+    assert len(compressors) == 112
     keys = [k for k in all_keys if "::patched::" not in k and "::positions::" not in k and not k.startswith("compression::")]
     assert len(keys) == 163
     counts = {}

@@ -281,7 +281,7 @@ def test_dictionary_construction(usize):
             compressors.dictionary_entries(dev(np.arange(200000, dtype=ud)), limit=100000)
 
 
-@pytest.mark.parametrize("usize,ksize", [(4, 4), (8, 4)])
+@pytest.mark.parametrize("usize,ksize", [(4, 4), (8, 4), (8, 8)])
 def test_dictionary_with_wide_keys_built_and_encoded_on_the_device(usize, ksize):
     """compressors.dictionary with 4-byte keys and no dictionary given: construction (more than 65 536 entries), encoding, and the decode back"""
     from libgiddy_amd import compressors, schemes
