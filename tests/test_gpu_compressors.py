@@ -221,6 +221,40 @@ def test_run_compressors_by_three_launches_and_by_the_chain_agree(usize):
         same(compressors.run_position_encoding(displaced, L, np.uint32, False, 4, staged_per_wave=16), want_positions, ("rpe absolute, displaced", len(column), L))
 
 
+def test_run_compressors_over_random_shapes():
+    """the run compressors without a chain over 240 random shapes — lengths of 1 ... 300 000 elements, segment lengths of 1 ... 100 000, mean runs of 1 ... the whole column, every
+    element size, length fields of 2 / 4 / 8 bytes, positions relative and absolute, 16 / 48 / 512 runs staged per wavefront — against the format writers"""
+    from libgiddy_amd import compressors
+    rng = cases.rng(20251003)
+    segment_lengths = (1, 2, 3, 64, 100, 1000, 4096, 5000, 65536, 100000)
+    for trial in range(240):
+        n = int(rng.integers(1, 300001)) if trial % 4 else int(rng.integers(1, 9000))
+        L = int(segment_lengths[rng.integers(0, len(segment_lengths))])
+        if L < 64 and n > 40000:
+            n = n % 40000 + 1   # (an anchor per element or two: keep the host writer quick)
+        mean_run = int((1, 2, 5, 40, 3000, n)[rng.integers(0, 6)])
+        usize = int((1, 2, 4, 8)[rng.integers(0, 4)])
+        staged = int((16, 48, 512)[rng.integers(0, 3)])
+        ud = np.dtype("u%d" % usize)
+        column = cases.runs_column(n, mean_run, ud, seed=1000 + trial, max_run=1 << 40)
+        what = (trial, n, L, mean_run, usize, staged)
+        lsize = int((2, 4, 8)[rng.integers(0, 3)])
+        index_size = 8 if lsize == 8 else 4
+        from libgiddy_amd import registered as r
+        if "compression::run_length_encoding::kernel_t<%du, %du, %du, %du>" % (index_size, usize, lsize, index_size) in r.kernel_t.registered_keys():
+            same(compressors.run_length_encoding(dev(column), L, np.dtype("u%d" % lsize), index_size, staged_per_wave=staged),
+                 formats.run_length_encoding(column, L, np.dtype("u%d" % lsize), index_size), ("rle", lsize) + what)
+        relative = bool(rng.integers(0, 2))
+        psize = 2 if relative and L <= 65536 else (4 if rng.integers(0, 2) else 8)
+        relative = relative and L <= 65536
+        index_size = 8 if psize == 8 else 4
+        key = "compression::run_position_encoding::kernel_t<%du, %du, %du, %s, %du>" % (index_size, usize, psize, "true" if relative else "false", index_size)
+        if key not in r.kernel_t.registered_keys():
+            continue
+        same(compressors.run_position_encoding(dev(column), L, np.dtype("u%d" % psize), relative, index_size, staged_per_wave=staged),
+             formats.run_position_encoding(column, L, np.dtype("u%d" % psize), relative, index_size), ("rpe", relative, psize) + what)
+
+
 def test_a_run_scratch_that_is_too_small_is_refused():
     from libgiddy_amd import compressors, registered as r, schemes
     n = 1 << 20
