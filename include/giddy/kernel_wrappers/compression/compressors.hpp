@@ -78,7 +78,7 @@ struct listed_runs {
 
 	void place_blocks(stream::id_t stream, uint64_t* grand_total) const
 	{
-		cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::place_blocks), stream, launch_configuration_t(1, threads_per_block),
+		cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::place_blocks<>), stream, launch_configuration_t(1, threads_per_block),
 			block_bases, (const uint64_t*) block_sums, num_blocks, grand_total);
 	}
 };
@@ -485,7 +485,7 @@ void kernel_t<I, U, RL, RI>::enqueue_launch_with(stream::id_t stream, const laun
 			const detail::listed_runs<U> listed(stream, scratch.value(), argument<size_t>(arguments, "run_scratch_entries"), input, (uint64_t) length);
 			cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::summarize_wavefronts<true>), stream, listed.per_blocks,
 				listed.bases, listed.previous_starts, listed.next_starts, listed.block_sums, listed.block_first_starts, listed.block_last_starts, (const uint64_t*) listed.headers, listed.num_waves);
-			cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::count_pieces), stream, listed.per_blocks,
+			cuda::enqueue_launch(reinterpret_cast<const void*>(runs::listed::count_pieces<>), stream, listed.per_blocks,
 				listed.bases, listed.block_sums, listed.block_next_starts, listed.block_previous_starts, (const uint64_t*) listed.next_starts,
 				(const uint64_t*) listed.block_first_starts, (const uint64_t*) listed.block_last_starts, (const uint64_t*) listed.headers, listed.num_waves, listed.num_blocks,
 				(uint64_t) length, max_run_length);

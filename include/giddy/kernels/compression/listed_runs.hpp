@@ -357,6 +357,7 @@ __global__ void __launch_bounds__(threads_per_block) summarize_wavefronts(
 
 /// Phase 2, run lengths' second launch: the same blocks.  block_next_starts[b] / block_previous_starts[b] = the first start in a later block (the column's
 /// length: none) / the last in an earlier one (1 + a position; 0: none); bases[w] = the PIECES of the block's wavefronts before w; block_sums[b] = the block's.
+template <typename = void>   // (a template only so that the header may be included by several translation units)
 __global__ void __launch_bounds__(threads_per_block) count_pieces(
 	uint64_t*        __restrict__  bases,
 	uint64_t*        __restrict__  block_sums,
@@ -405,6 +406,7 @@ __global__ void __launch_bounds__(threads_per_block) count_pieces(
 }
 
 /// Phase 2, last launch — ONE workgroup: block_bases[b] = the runs (pieces) of the blocks before b; *grand_total = of all.
+template <typename = void>
 __global__ void __launch_bounds__(threads_per_block) place_blocks(uint64_t* __restrict__ block_bases, const uint64_t* __restrict__ block_sums, uint64_t num_blocks, uint64_t* __restrict__ grand_total)
 {
 	__shared__ uint64_t table[waves_per_block];
