@@ -12,8 +12,9 @@ import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 
-RUN_SEGMENTS = (64, 1024, 2052, 3000, 4096, 4100, 8200, 10000, 12288, 16384, 24576, 32768, 65536, 1 << 20)
-RUN_MEANS = (2, 4, 32, 200)
+# (REGRET_SEGMENTS / REGRET_MEANS / REGRET_PATHS in the environment: another grid, or only some of the forced paths — e.g. where a rule's thresholds lie)
+RUN_SEGMENTS = tuple(int(x) for x in os.environ["REGRET_SEGMENTS"].split(",")) if "REGRET_SEGMENTS" in os.environ else (64, 1024, 2052, 3000, 4096, 4100, 8200, 10000, 12288, 16384, 24576, 32768, 65536, 1 << 20)
+RUN_MEANS = tuple(int(x) for x in os.environ["REGRET_MEANS"].split(",")) if "REGRET_MEANS" in os.environ else (2, 4, 32, 200)
 SHAPES = {
     "run_length_encoding": [(L, m) for L in RUN_SEGMENTS for m in RUN_MEANS],
     "run_position_encoding_relative": [(L, m) for L in RUN_SEGMENTS if L <= 65536 for m in RUN_MEANS],
@@ -47,7 +48,7 @@ def worker(scheme, log2n):
             # THREE columns of different seeds decoded in turn: what a column's compressed arrays cost when they come from HBM, not from the Infinity Cache
             # (one column repeated flatters every path that reads its run arrays twice: the groups of segments at C4 are 86 % warm and 70 % cold)
             works = []
-            for seed in (0, 1000, 2000):
+            for seed in range(0, 1000 * int(os.environ.get("REGRET_COLUMNS", "3")), 1000):   # (REGRET_COLUMNS: more of them, where three columns' run arrays still fit the Infinity Cache)
                 w.SEED_OFFSET = seed
                 if scheme == "run_length_encoding": work = w.RunLength(n, device, segment_length=L, mean_run=mean)
                 elif scheme.startswith("run_position_encoding"): work = w.RunPosition(n, device, segment_length=L, mean_run=mean, relative=scheme.endswith("relative"))
@@ -78,14 +79,16 @@ def driver(schemes, sizes):
     for scheme in schemes:
         for log2n in sizes:
             results = {}
+            wanted = os.environ["REGRET_PATHS"].split(",") if "REGRET_PATHS" in os.environ else list(CONFIGURATIONS[scheme])
             for label, switches in CONFIGURATIONS[scheme].items():
+                if label not in wanted: continue
                 out = subprocess.run([sys.executable, os.path.abspath(__file__), "--worker", scheme, str(log2n)], env=dict(os.environ, **switches),
                                      capture_output=True, text=True, timeout=3000).stdout
                 for line in out.splitlines():
                     if line.startswith("SHAPE "):
                         L, mean, pct = line.split()[1:4]
                         results.setdefault((int(L), int(mean)), {})[label] = float(pct)
-            labels = list(CONFIGURATIONS[scheme])
+            labels = [label for label in CONFIGURATIONS[scheme] if label in wanted]
             print("# %s, 2^%d outputs — %% of the HBM peak (algorithmic bytes; three columns of different seeds in turn: inputs from HBM) by path: %s" % (scheme, log2n, " | ".join(labels)))
             for (L, mean), by in sorted(results.items()):
                 rates = [by.get(label, float("nan")) for label in labels]
