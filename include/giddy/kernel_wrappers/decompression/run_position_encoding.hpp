@@ -164,7 +164,11 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		// (2^30: 82-85 against 79-80), but of 65 536 — a wavefront decodes two finer segments one after the other: 70-72 % against 74-75 % (profiles/r04_run_prepass.txt)
 		const uint64_t workgroups_of_one_kernel = (uint64_t) num_anchors * util::div_rounding_up(L / fine::sub, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
 		if (run_expansion::fine_environment::get().fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) run_expansion::positions_fused_up_to_fines
-			&& workgroups_of_one_kernel >= run_expansion::fine_environment::get().fused_from) {
+			&& workgroups_of_one_kernel >= run_expansion::fine_environment::get().fused_from
+			// — and, as for run lengths, not more workgroups than keep a launch's write front together: round 5, the regret grid at 2^30 outputs with the input COLD
+			// (profiles/r05_regret.txt): segments of 32 768 at mean runs of 32-64, relative 57-62 % against the search as a launch of its own 69-70 %, absolute 62-65 against 75-76
+			// (round 4's 82-85 % were measured with one column decoded again and again)
+			&& (workgroups_of_one_kernel <= run_expansion::fused_up_to_workgroups || run_expansion::fine_environment::get().force_one_launch)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
 				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length, (uint32_t) 1);
