@@ -156,8 +156,14 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 			return;
 		}
 	}
-	// (relative positions of DENSE columns — mean runs below 16 — in segments of fewer than four finer ones keep their segments: 16 384 / 24 576 at mean runs of 2-4: 47-51 -> 54-57 %, cold)
-	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && !(PositionsAreRelative && n / num_element_runs < 16 && L < 4 * (uint64_t) fine::sub && !run_expansion::fine_environment::get().force)) {
+	// (relative positions of DENSE columns — mean runs below 16 — in segments of fewer than four finer ones keep their segments: 16 384 / 24 576 at mean runs of 2-4: 47-51 -> 54-57 %, cold;
+	// and in longer ones where there are segments enough to fill the chip with a wavefront each — 16 384: 2^30 outputs in segments of 32 768 / 65 536 at mean runs of 2-4, cold:
+	// 50-56 -> 56-60 %; 2^28 outputs, 8192 / 4096 segments: the finer anchors win by 1-4 points)
+	// (... at mean runs of 2-4: at 8 the finer anchors win there, 62 % against 56-59)
+	const uint64_t mean_run = n / std::max<uint64_t>(num_element_runs, 1);
+	const bool dense_relative_as_it_is = PositionsAreRelative && ((mean_run < 16 && L < 4 * (uint64_t) fine::sub) || (mean_run < 6 && (uint64_t) num_anchors >= 16384))
+		&& !run_expansion::fine_environment::get().force;
+	if (n > 0 && num_element_runs > 0 && L >= run_expansion::finer_anchors_from() && L % fine::sub == 0 && !dense_relative_as_it_is) {
 		const uint64_t num_fine = util::div_rounding_up(n, (uint64_t) fine::sub);
 		// ... in ONE kernel where segments are of 4 finer ones and there are enough of them for 2048 workgroups (kernels/decompression/run_position_encoding.hpp,
 		// decompress_long_segments).  The search is a cheap launch of its own, unlike the run lengths' scan: 2^28 outputs in segments of 32 768: 76.9 % against 74-75 %
@@ -165,10 +171,10 @@ void GIDDY_RPE_KERNEL::launch(stream::id_t stream, const launch_configuration_t&
 		const uint64_t workgroups_of_one_kernel = (uint64_t) num_anchors * util::div_rounding_up(L / fine::sub, (uint64_t) run_length_encoding::finer_segments_per_workgroup);
 		if (run_expansion::fine_environment::get().fused && sparse && L >= 4 * (uint64_t) fine::sub && L / fine::sub <= (uint64_t) run_expansion::positions_fused_up_to_fines
 			&& workgroups_of_one_kernel >= run_expansion::fine_environment::get().fused_from
-			// — and, as for run lengths, not more workgroups than keep a launch's write front together: round 5, the regret grid at 2^30 outputs with the input COLD
+			// — and, as for run lengths, not more workgroups than keep a launch's write front together (8192: run_anchors.hpp): round 5, the regret grid at 2^29 and 2^30 outputs with the input COLD
 			// (profiles/r05_regret.txt): segments of 32 768 at mean runs of 32-64, relative 57-62 % against the search as a launch of its own 69-70 %, absolute 62-65 against 75-76
 			// (round 4's 82-85 % were measured with one column decoded again and again)
-			&& (workgroups_of_one_kernel <= run_expansion::fused_up_to_workgroups || run_expansion::fine_environment::get().force_one_launch)) {
+			&& (workgroups_of_one_kernel <= run_expansion::positions_fused_up_to_workgroups || run_expansion::fine_environment::get().force_one_launch)) {
 			cuda::enqueue_launch(long_segments_kernel(), stream,
 				launch_configuration_t((grid_dimension_t) std::min<uint64_t>(workgroups_of_one_kernel, 1u << 20), fine::threads),
 				decompressed, run_data, run_start_positions, position_anchors, L, (run_index_size_type) num_anchors, num_element_runs, uncompressed_length, (uint32_t) 1);

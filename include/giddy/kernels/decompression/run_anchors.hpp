@@ -37,6 +37,7 @@ enum : unsigned {
 	outputs_per_finer_anchor    = 8192,   // segments of 4096-8192 outputs are where the decoders do best
 	fused_from_segments         = 512,    // long segments: pre-pass and decoder in one kernel from this many workgroups on (round 5: 2048 left a 2^26-output column in segments of 65 536 — 1024 workgroups — at 50 % where the one kernel does 64)
 	fused_up_to_workgroups      = 16384,  // ... and, run lengths, up to this many
+	positions_fused_up_to_workgroups = 8192,   // ... run positions: up to this many (16 384 — 2^29 outputs in segments of 32 768, cold: 62.6 % against 70-72 % for the search as a launch of its own; 8192 — 2^28: 73 against 72-75)
 	positions_fused_up_to_fines = 4,      // run POSITIONS: the search for finer anchors and the decoder in one kernel for segments of up to this many finer ones
 	fused_up_to_fines           = 16,     // run lengths: ... of up to this many (64 — what the kernel's LDS holds the anchors of — measured: eight workgroups each scanning a 524 288-segment's 16 384 run lengths lose 5-7 points to the separate launches)
 };
