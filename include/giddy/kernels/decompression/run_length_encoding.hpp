@@ -118,16 +118,18 @@ __device__ __forceinline__ void decompress(
 		const uint64_t chunk_outputs = segments_per_chunk * L;
 		const uint64_t column_or_group_end = n < mine.outputs_until ? n : mine.outputs_until;
 		const uint64_t segment_end = (segment_start + chunk_outputs < column_or_group_end) ? segment_start + chunk_outputs : column_or_group_end;
-		uint64_t first_run = segment_position_anchors[s - mine.anchors_from];
+		// (both anchors asked for at once — the second at an index that always exists — and ONE wait: a conditional second load is a second round trip, and with the
+		// compressed input cold a round trip is 2 microseconds of a wavefront's 17; round 5)
+		const bool a_chunk_follows = s + segments_per_chunk < num_segments;
+		const uint64_t this_anchor = segment_position_anchors[s - mine.anchors_from], next_anchor = segment_position_anchors[(a_chunk_follows ? s + segments_per_chunk : s) - mine.anchors_from];
+		uint64_t first_run = this_anchor;
 		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
 		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s - mine.anchors_from];
 		length_type left_in_first_run = 0;
 		bool entering = true;   // the chunk's first tile: the first run's length is not known yet
-		uint64_t run_limit = num_runs;   // exclusive
-		if (s + segments_per_chunk < num_segments) {
-			uint64_t through = (uint64_t) segment_position_anchors[s + segments_per_chunk - mine.anchors_from] + 1;
-			if (through < run_limit) { run_limit = through; }
-		}
+		// (a select, not a branch around the use: the compiler sinks a load that only one side of a branch uses back into it — and the second round trip is back)
+		const uint64_t through = a_chunk_follows ? next_anchor + 1 : num_runs;
+		uint64_t run_limit = through < num_runs ? through : num_runs;   // exclusive
 
 		// groups of runs through LDS (see above) when the chunk has more runs than one batch and the arrays allow 16-byte loads
 		// (`GroupsAlways`: the wrapper's launch for dense columns, arrays 16-byte aligned: every chunk by groups — the other path is compiled out)

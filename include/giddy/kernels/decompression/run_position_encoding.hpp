@@ -113,9 +113,13 @@ __device__ __forceinline__ void decompress(
 		const uint64_t positions_origin = relative_to == L ? segment_start : segment_start / relative_to * relative_to;
 		const uint64_t segment_stride = regrouped ? relative_to : L;   // from one segment's start to the next one's, for the positions
 		const unsigned segments_here = regrouped ? (unsigned) ((segment_end - 1) / relative_to - segment_start / relative_to + 1) : (unsigned) segments_per_chunk;
-		uint64_t first_run = position_anchors[s - mine.anchors_from];
+		// (both anchors asked for at once — the second at an index that always exists — and ONE wait: a conditional second load is a second round trip, and with the
+		// compressed input cold a round trip is 2 microseconds of a wavefront's 17; round 5)
+		const bool a_chunk_follows = s + segments_per_chunk < num_anchors;
+		const uint64_t this_anchor = position_anchors[s - mine.anchors_from], next_anchor = position_anchors[(a_chunk_follows ? s + segments_per_chunk : s) - mine.anchors_from];
+		uint64_t first_run = this_anchor;
 		// candidates for runs starting inside this chunk: first_run+1 .. last_candidate (inclusive)
-		const uint64_t last_candidate = (s + segments_per_chunk < num_anchors) ? (uint64_t) position_anchors[s + segments_per_chunk - mine.anchors_from] : num_runs - 1;
+		const uint64_t last_candidate = a_chunk_follows ? next_anchor : num_runs - 1;
 		// lane j: the anchor of the chunk's j-th segment (past the chunk / the column: no run index reaches it)
 		const uint64_t chunk_anchor = regrouped
 			? (lane < segments_here ? (uint64_t) static_cast<const uint_t<RunIndexSize>*>(mine.segment_anchors)[segment_start / relative_to + lane] : ~(uint64_t) 0)
@@ -151,7 +155,6 @@ __device__ __forceinline__ void decompress(
 			bool dense = false, values_staged = false;
 			if (use_groups && next_group_base <= first_run) { take_group(); }   // (the tile before was cut at the old group's end)
 			clear(table, lane);
-			if (!use_groups && staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
 			if (!staging::with_descriptors && prefetched && values_prefetched && lane == 0) { staged[0] = prefetched_first_value; }
 
 			// Candidates are addressed RELATIVE to the tile's first run from here on (candidate k is run first_run + 1 + k; 32 bits: a
@@ -196,6 +199,9 @@ __device__ __forceinline__ void decompress(
 						if (staging::with_descriptors) { values[j] = values_from_here[r]; }   // the runs' values travel with their positions
 					}
 				}
+				// the tile's first run's value — the run that reaches into the tile is no candidate —: asked for here, behind the batch's loads, not ahead of them (there it
+				// was a round trip of its own before the batch's: the other half of what run positions lost against run lengths with the input cold)
+				if (batch_base == 0 && !use_groups && staging::with_descriptors && lane == 0) { staged[0] = prefetched ? prefetched_first_value : run_data[first_run]; }
 				#pragma unroll
 				for (unsigned j = 0; j < runs_per_lane; j++) {
 					const uint32_t k = lane_base + j;
