@@ -72,7 +72,8 @@ template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr boo
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
-template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do, typename Grid = launch_grid::whole>
+/// (`LooksUpThroughMemory`: the dictionary is not in LDS — a tile's look-ups all go out before its first store)
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, bool LooksUpThroughMemory = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void translate(
 	uint_t<UncompressedSize>*           __restrict__  decompressed,
 	const uint_t<DictionaryIndexSize>*  __restrict__  compressed_input,
@@ -95,7 +96,7 @@ __device__ __forceinline__ void translate(
 		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging, grid);
 	}
 	else {
-		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);
+		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment, LooksUpThroughMemory>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);
 	}
 }
 
@@ -176,7 +177,8 @@ __device__ __forceinline__ void decompress(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stream_tiles::nothing_to_do(), grid);
 	}
 	else {
-		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment>(
+		// (through L2 / HBM: a tile's 16 look-ups per lane in flight together — round 5: they went out four at a time, each four waited for before their store)
+		translate<UncompressedSize, DictionaryIndexSize, false, AnyAlignment, true>(
 			decompressed, compressed_input, length, [dictionary_entries](key_type key) { return dictionary_entries[key]; }, patches, chunk_staging, stream_tiles::nothing_to_do(), grid);
 	}
 }

@@ -69,7 +69,9 @@ __host__ __forceinline__ bool wants_any_alignment_build(const Out* out, const In
 /// boundary of the OUTPUT — the elements before it go one at a time with the column's last ones — and the input's loads are wide at whatever address that leaves
 /// them.  A build of its own, chosen by the wrapper from the addresses: inside the one kernel the extra address arithmetic cost the aligned column 2 points.
 /// (only for a produce_group that does not care where a group starts: positions are passed as they are in the column, but a group may lie across any boundary)
-template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, bool AnyAlignment = false,
+/// `ProduceAllFirst`: a whole tile's K groups are produced before the first of them is stored — for a produce_group that LOADS (a dictionary looked up through L2 / HBM): its
+/// K x G look-ups are then in flight together, where produce-store-produce-store waits for each group's (the stores are inline assembly the compiler moves nothing across).
+template <typename In, typename Out, unsigned Steps = steps_per_tile, int Stores = memory_access::non_temporal, bool AnyAlignment = false, bool ProduceAllFirst = false,
 	typename ProduceGroup, typename ProduceOne, typename AfterLoads = nothing_to_do, typename Prepare = nothing_to_prepare, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void transform(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one,
@@ -129,6 +131,14 @@ __device__ __forceinline__ void transform(
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) { contexts[k] = prepare((first_group + (uint64_t) k * blockDim.x) * G); }
 			after_loads();
+			if constexpr (ProduceAllFirst) {
+				group<Out, G> outputs[K];
+				#pragma unroll
+				for (unsigned k = 0; k < K; k++) { produce_with(produce_group, (first_group + (uint64_t) k * blockDim.x) * G, inputs[k], outputs[k], contexts[k]); }
+				#pragma unroll
+				for (unsigned k = 0; k < K; k++) { store_group<Stores>(out + (first_group + (uint64_t) k * blockDim.x) * G, outputs[k]); }
+			}
+			else {
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) {
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
@@ -138,6 +148,7 @@ __device__ __forceinline__ void transform(
 				// narrow elements: G look-ups per step — keep the steps' work from being hoisted above one another
 				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
 				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
+			}
 			}
 #if defined(GIDDY_STREAM_STAMP_PROBE)
 			// (experiment: when was this tile finished, and on which XCD — in place of the tile's first 8 bytes of output; tools/stream_stamp_probe.py)
