@@ -49,7 +49,7 @@ enum : unsigned {
 	tile_length         = 32 * tile_words,         // 4096 outputs per tile
 	runs_per_lane       = 4,                       // run descriptors examined per lane per batch (6 / 8: +1...+3 / -4...-14 points)
 	runs_per_batch      = 64 * runs_per_lane,
-	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup
+	max_waves_per_block = 4,                       // LDS is provisioned for this many wavefronts per workgroup (round 5: workgroups of 1 or 2 wavefronts, LDS and residency to match: 81 -> 72-73 % at 2^30, 73 -> 68 at 2^27)
 };
 
 /// Which chunk a wavefront starts with, chosen by where the OUTPUT lies.  A workgroup's wavefronts write `working_waves` consecutive
