@@ -442,9 +442,11 @@ struct wavefront_lists {
 	enum : unsigned { list_entries = Relisted ? (unsigned) wave_elements : (unsigned) staged_per_wave_at_most, values_ahead = 4, offsets_ahead = 64 * values_ahead };
 	typedef uint32_t sixteen_bytes __attribute__((ext_vector_type(4)));
 
-	template <typename Emit>
+	/// `prepare(w)`: what the scheme needs to know of wavefront w from the tables of phase 2 — asked for together with the header and the lists (scalar loads that are
+	/// consumed one after the other are ISSUED one after the other, a round trip each: the first version's placing of run lengths made three of them behind the lists')
+	template <typename Prepare, typename Emit>
 	__device__ static __forceinline__ void for_each_wavefront(const T* __restrict__ input, const uint64_t* __restrict__ headers, const uint16_t* __restrict__ staged_offsets,
-		const T* __restrict__ staged_values, uint32_t staged_per_wave, uint64_t n, Emit&& emit)
+		const T* __restrict__ staged_values, uint32_t staged_per_wave, uint64_t n, Prepare&& prepare, Emit&& emit)
 	{
 		__shared__ alignas(16) uint16_t lists[waves_per_block][list_entries];
 		const unsigned lane = wave64::lane_id(), wave = wave64::index_in_block();
@@ -454,6 +456,7 @@ struct wavefront_lists {
 			for (uint64_t w = (uint64_t) blockIdx.x * waves_per_block + wave; w < num_waves; w += (uint64_t) gridDim.x * waves_per_block) {
 				// the lists are asked for before the wavefront knows how long they are: one round trip for the header, the offsets and the first values
 				const uint64_t header = headers[w];
+				const auto placed = prepare(w);
 				// (the first 256 of each: what a wavefront of mean runs of 16 or more has; a longer list's rest is asked for once its length is known)
 				sixteen_bytes piece = { };
 				if (lane * 8 < (staged_per_wave < offsets_ahead ? staged_per_wave : (uint32_t) offsets_ahead)) { piece = *reinterpret_cast<const sixteen_bytes*>(staged_offsets + w * staged_per_wave + lane * 8); }
@@ -466,7 +469,7 @@ struct wavefront_lists {
 					if (count > offsets_ahead && lane * 8 >= offsets_ahead && lane * 8 < count) { piece = *reinterpret_cast<const sixteen_bytes*>(staged_offsets + w * staged_per_wave + lane * 8); }
 					*reinterpret_cast<sixteen_bytes*>(list + lane * 8) = piece;
 					wave64::lds_fence();
-					emit(w, (const uint16_t*) list, count, [&](auto&& run) {
+					emit(w, placed, (const uint16_t*) list, count, [&](auto&& run) {
 						#pragma unroll
 						for (unsigned q = 0; q < values_ahead; q++) { if (lane + 64 * q < count) { run(lane + 64 * q, ahead[q]); } }
 						for (uint32_t i = lane + 64 * values_ahead; i < count; i += 64) { run(i, staged_values[w * staged_per_wave + i]); }
@@ -485,9 +488,10 @@ struct wavefront_lists {
 					const unsigned which = (unsigned) __builtin_ctzll(todo);
 					const uint64_t w = first + which;
 					const uint32_t count = wave64::read_lane(of_lane, which);
+					const auto placed = prepare(w);
 					uint32_t last;
 					(void) list_run_starts<T, false>(input, w * wave_elements, n, lane, list, (T*) nullptr, (unsigned char*) nullptr, (uint32_t) wave_elements, last);
-					emit(w, (const uint16_t*) list, count, [&](auto&& run) { for (uint32_t i = lane; i < count; i += 64) { run(i, input[w * wave_elements + list[i]]); } });
+					emit(w, placed, (const uint16_t*) list, count, [&](auto&& run) { for (uint32_t i = lane; i < count; i += 64) { run(i, input[w * wave_elements + list[i]]); } });
 					wave64::lds_fence();   // (the list is rewritten for the next wavefront's elements)
 				}
 			}
@@ -516,8 +520,9 @@ __global__ void __launch_bounds__(threads_per_block, one_pass::waves_per_simd) p
 	const unsigned lane = wave64::lane_id();
 	const uint64_t n = length, L = segment_length;
 	wavefront_lists<T, Relisted>::for_each_wavefront(input, headers, staged_offsets, staged_values, staged_per_wave, n,
-		[&](uint64_t w, const uint16_t* list, uint32_t count, auto&& for_each_run) {
-			const uint64_t wave_base = w * wave_elements, base = bases[w] + block_bases[w / block_waves];
+		[&](uint64_t w) { const uint64_t within = bases[w], of_blocks = block_bases[w / block_waves]; return within + of_blocks; },
+		[&](uint64_t w, uint64_t base, const uint16_t* list, uint32_t count, auto&& for_each_run) {
+			const uint64_t wave_base = w * wave_elements;
 			const uint64_t wave_into_segment = wave_base % L, wave_segment = wave_base / L;
 			for_each_run([&](uint32_t i, T value) {
 				const uint32_t offset = list[i];
@@ -563,12 +568,18 @@ __global__ void __launch_bounds__(threads_per_block, one_pass::waves_per_simd) p
 	using T = uint_t<UncompressedSize>;
 	const unsigned lane = wave64::lane_id();
 	const uint64_t n = length, L = segment_length, M = max_run_length;
+	struct placed_wavefront { uint64_t base, next_start, previous_start; };
 	wavefront_lists<T, Relisted>::for_each_wavefront(input, headers, staged_offsets, staged_values, staged_per_wave, n,
-		[&](uint64_t w, const uint16_t* list, uint32_t count, auto&& for_each_run) {
-			const uint64_t wave_base = w * wave_elements, block = w / block_waves, base = bases[w] + block_bases[block];
-			const uint64_t next_within = next_starts[w], next_beyond = block_next_starts[block], next_start = next_within < next_beyond ? next_within : next_beyond;
+		[&](uint64_t w) {
+			const uint64_t block = w / block_waves;
+			// (all six asked for before any is used)
+			const uint64_t within = bases[w], of_blocks = block_bases[block], next_within = next_starts[w], next_beyond = block_next_starts[block];
 			const uint64_t previous_within = previous_starts[w], previous_beyond = block_previous_starts[block];
-			const uint64_t previous_plus_one = previous_within > previous_beyond ? previous_within : previous_beyond, previous_start = previous_plus_one != 0 ? previous_plus_one - 1 : 0;
+			const uint64_t previous_plus_one = previous_within > previous_beyond ? previous_within : previous_beyond;
+			return placed_wavefront { within + of_blocks, next_within < next_beyond ? next_within : next_beyond, previous_plus_one != 0 ? previous_plus_one - 1 : 0 };
+		},
+		[&](uint64_t w, const placed_wavefront& placed, const uint16_t* list, uint32_t count, auto&& for_each_run) {
+			const uint64_t wave_base = w * wave_elements, base = placed.base, next_start = placed.next_start, previous_start = placed.previous_start;
 			for_each_run([&](uint32_t i, T value) {
 				const uint32_t offset = list[i];
 				const uint64_t k = base + i;
