@@ -268,6 +268,24 @@ __global__ void __launch_bounds__(threads) anchors_from_sums(
 	}
 }
 
+
+/// The last run of [low, high] that starts at or before `target` (run `low` does) — by a WAVEFRONT: all 64 lanes call it with the same arguments and probe 64 places a
+/// round, so 4096 candidates are two dependent round trips where a thread's binary search is twelve.
+template <typename Position>
+__device__ __forceinline__ uint64_t last_start_at_most(const Position* __restrict__ starts, uint64_t low, uint64_t high, uint64_t target, unsigned lane)
+{
+	while (high > low) {
+		const uint64_t span = high - low, step = (span + 63) / 64;   // probe k looks at run low + min(span, (k + 1) * step): the 64th at `high`
+		auto probe = [&](uint64_t k) { return low + (k * step < span ? k * step : span); };
+		const unsigned at_most = (unsigned) __builtin_popcountll(wave64::ballot((uint64_t) starts[probe(lane + 1)] <= target));   // (ones, then zeros: the starts ascend)
+		// (probe(at_most + 1) > probe(at_most) whenever at_most < 64: were both clamped to `high`, run `high` would start at or before the target and every probe with it.
+		// No `max(new_high, new_low)` here: hipcc 7.2 compiles that uniform 64-bit select to an s_cselect on a stale SCC — tools/experiments/search_probe.hip caught it)
+		const uint64_t new_low = probe(at_most), new_high = at_most == 64 ? high : probe(at_most + 1) - 1;
+		low = new_low; high = new_high;
+	}
+	return low;
+}
+
 /// Run-length encoding, ONE launch (round 4): a workgroup per anchored segment streams the segment's run lengths ONCE — chunks of
 /// threads x (16 / RunLengthSize) runs as 16-byte loads, the next chunk requested before this one is worked on —, scans them (in-lane
 /// sums, a 64-lane DPP scan, the wavefronts' totals through LDS), leaves the runs' END positions relative to the segment's start in
@@ -313,8 +331,11 @@ __device__ __forceinline__ void finer_anchors_of_one_segment(
 		return lengths;
 	};
 
+	// (the next segment's anchor asked for with this one's — at an index that always exists — and selected: loaded under the condition it is a round trip of its own)
+	const bool a_segment_follows = s + 1 < num_segments;
 	const uint64_t anchor = position_anchors[s * anchor_stride], offset = intra_run_anchor_offsets[s * anchor_stride];
-	const uint64_t last_run = s + 1 < num_segments ? (uint64_t) position_anchors[(s + 1) * anchor_stride] : num_runs - 1;   // the last run the segment can touch
+	const uint64_t next_anchor = position_anchors[(a_segment_follows ? s + 1 : s) * anchor_stride];
+	const uint64_t last_run = a_segment_follows ? next_anchor : num_runs - 1;   // the last run the segment can touch
 	const uint64_t segment_outputs = (s + 1) * segment_length <= length ? segment_length : length - s * segment_length;
 	const uint64_t fines = (segment_outputs + sub - 1) / sub;   // finer anchors of this segment; number 0 is the segment's own
 	if (threadIdx.x == 0) { anchors_out[0] = (uint_t<RunIndexSize>) anchor; offsets_out[0] = (uint_t<RunLengthSize>) offset; }

@@ -395,13 +395,15 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 		const uint64_t g = work / parts, part = work - g * parts;
 		const uint64_t group_begin = g * group_outputs, group_end = group_begin + group_outputs < n ? group_begin + group_outputs : n;
 		const uint64_t fines = (group_end - group_begin + fine::sub - 1) / fine::sub;
+		// (the entry after the group's last: the next group's own anchor — where the last finer segment's runs end; asked for BEFORE the scan of the group's run lengths, not
+		// behind its waits)
+		const bool has_next = g + 1 < num_groups;
+		const uint64_t next_group_at = (has_next ? g + 1 : g) * segments_per_group;
+		const uint_t<RunIndexSize> next_group_anchor = segment_position_anchors[next_group_at];
+		const uint_t<RunLengthSize> next_group_offset = segment_position_anchor_intra_run_offsets[next_group_at];
 		fine::finer_anchors_of_one_segment<RunLengthSize, RunIndexSize>(finer_anchors, finer_offsets, storage,
 			run_lengths, segment_position_anchors, segment_position_anchor_intra_run_offsets, g, group_outputs, num_groups, num_element_runs, n, segments_per_group);
-		// (the entry after the group's last: the next group's own anchor — where the last finer segment's runs end)
-		const bool has_next = g + 1 < num_groups;
-		if (threadIdx.x == 0 && has_next) {
-			finer_anchors[fines] = segment_position_anchors[(g + 1) * segments_per_group]; finer_offsets[fines] = segment_position_anchor_intra_run_offsets[(g + 1) * segments_per_group];
-		}
+		if (threadIdx.x == 0 && has_next) { finer_anchors[fines] = next_group_anchor; finer_offsets[fines] = next_group_offset; }
 		__syncthreads();
 		detail::chunks_to_take mine;
 		const uint64_t numbering_from = g * per_group;   // (the finer segments' numbers only have to be this workgroup's own)

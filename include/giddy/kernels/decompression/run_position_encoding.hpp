@@ -416,24 +416,28 @@ __global__ void __launch_bounds__(run_expansion::fine::threads) decompress_long_
 		const uint64_t group_begin = g * group_outputs, group_end = group_begin + group_outputs < n ? group_begin + group_outputs : n;
 		const uint64_t fines = (group_end - group_begin + fine::sub - 1) / fine::sub;
 		const bool has_next = g + 1 < num_groups;
-		for (uint64_t j = threadIdx.x; j < fines; j += blockDim.x) {   // (fine::anchors_by_search, for this group)
-			uint64_t low = position_anchors[g * segments_per_group];
+		// fine::anchors_by_search for this group — a WAVEFRONT per finer anchor, 64 probes a round (fine::last_start_at_most): a thread's binary search over a segment's
+		// ~1000 runs was ten dependent round trips at the head of every workgroup's life
+		const uint64_t group_anchor = position_anchors[g * segments_per_group];
+		const uint64_t next_group_anchor = position_anchors[(has_next ? g + 1 : g) * segments_per_group];
+		for (uint64_t j = wave64::index_in_block(); j < fines; j += wave64::per_block()) {
+			uint64_t low = group_anchor;
 			if (j != 0) {
 				// (relative positions restart in every segment of the column: the search is among the runs of the segment the finer anchor's output lies in)
 				const uint64_t output = group_begin + j * fine::sub, segment = PositionsAreRelative ? output / anchoring_period : g * segments_per_group;
-				if (PositionsAreRelative) { low = position_anchors[segment]; }
-				uint64_t high = PositionsAreRelative ? (segment + 1 < (uint64_t) num_anchors ? (uint64_t) position_anchors[segment + 1] : num_runs - 1)
-					: (has_next ? (uint64_t) position_anchors[(g + 1) * segments_per_group] : num_runs - 1);
-				if (PositionsAreRelative && high > low && run_start_positions[high] == 0) { high--; }
-				const uint64_t target = PositionsAreRelative ? output - segment * anchoring_period : output;
-				while (low < high) {
-					const uint64_t middle = low + (high - low + 1) / 2;
-					if ((uint64_t) run_start_positions[middle] <= target) { low = middle; } else { high = middle - 1; }
+				uint64_t high = has_next ? next_group_anchor : num_runs - 1;
+				if (PositionsAreRelative) {
+					const bool a_segment_follows = segment + 1 < (uint64_t) num_anchors;
+					const uint64_t this_anchor = position_anchors[segment], following_anchor = position_anchors[a_segment_follows ? segment + 1 : segment];
+					low = this_anchor; high = a_segment_follows ? following_anchor : num_runs - 1;
+					if (high > low && run_start_positions[high] == 0) { high--; }
 				}
+				const uint64_t target = PositionsAreRelative ? output - segment * anchoring_period : output;
+				low = fine::last_start_at_most(run_start_positions, low, high, target, wave64::lane_id());
 			}
-			finer_anchors[j] = (uint_t<RunIndexSize>) low;
+			if (wave64::lane_id() == 0) { finer_anchors[j] = (uint_t<RunIndexSize>) low; }
 		}
-		if (threadIdx.x == 0 && has_next) { finer_anchors[fines] = position_anchors[(g + 1) * segments_per_group]; }   // (where the last finer segment's candidates end)
+		if (threadIdx.x == 0 && has_next) { finer_anchors[fines] = (uint_t<RunIndexSize>) next_group_anchor; }   // (where the last finer segment's candidates end)
 		__syncthreads();
 		run_length_encoding::detail::chunks_to_take mine;
 		const uint64_t numbering_from = g * per_group;
