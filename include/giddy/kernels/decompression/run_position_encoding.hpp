@@ -126,6 +126,12 @@ __device__ __forceinline__ void decompress(
 			: (PositionsAreRelative && segments_per_chunk > 1 && lane < segments_per_chunk && s + lane < num_anchors)
 				? (uint64_t) position_anchors[s + lane - mine.anchors_from] : ~(uint64_t) 0;
 
+		// (... as 32-bit distances from the chunk's first anchor — a chunk's anchors lie within a chunk's runs of each other —: the search below moves them between lanes with
+		// one ds_bpermute a step, not two, and takes as many steps as the chunk has segments to tell apart: two for four segments of 1024, not five)
+		const uint64_t first_anchor_of_chunk = wave64::read_first_lane(chunk_anchor);
+		const uint32_t chunk_anchor_distance = chunk_anchor == ~(uint64_t) 0 || chunk_anchor - first_anchor_of_chunk > 0xFFFFFFF0ull ? 0xFFFFFFFFu : (uint32_t) (chunk_anchor - first_anchor_of_chunk);
+		const unsigned first_search_step = segments_here > 1 ? 1u << (31 - __builtin_clz(segments_here - 1)) : 0u;   // (wave-uniform)
+
 		// groups of runs through LDS when the chunk has more runs than one batch and the arrays allow 16-byte loads
 		const uint64_t run_limit = last_candidate + 1;   // (exclusive: the runs this chunk may look at)
 		// (`GroupsAlways`: the wrapper's launch for dense columns, arrays 16-byte aligned: every chunk by groups — the other path is compiled out)
@@ -212,13 +218,18 @@ __device__ __forceinline__ void decompress(
 						// the anchors held one per lane
 						unsigned segment_in_chunk = 0;
 						if (segments_here > 1) {   // wave-uniform
-							const uint64_t r = first_run + 1 + k;
-							#pragma unroll
-							for (unsigned step = 16; step >= 1; step >>= 1) {
+							const uint64_t r = first_run + 1 + k - first_anchor_of_chunk;
+							const uint32_t distance = r > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t) r;
+							auto search_step = [&](unsigned step) {
 								const unsigned probe = segment_in_chunk + step;
-								const uint64_t anchor = __shfl(chunk_anchor, (int) (probe < 64 ? probe : 63), 64);
-								if (probe < segments_here && anchor < r) { segment_in_chunk = probe; }
+								const uint32_t anchor = (uint32_t) __shfl((int) chunk_anchor_distance, (int) (probe < 64 ? probe : 63), 64);
+								if (probe < segments_here && anchor < distance) { segment_in_chunk = probe; }
+							};
+							if (first_search_step == 16) {   // (17 ... 32 segments — of 128 outputs and fewer —: all five steps, unrolled: as a loop they cost such columns 1-3 points)
+								#pragma unroll
+								for (unsigned step = 16; step >= 1; step >>= 1) { search_step(step); }
 							}
+							else { for (unsigned step = first_search_step; step >= 1; step >>= 1) { search_step(step); } }   // (a wave-uniform number of turns)
 						}
 						// ... and at relative position 0 it starts the NEXT segment
 						start = positions_origin + (uint64_t) segment_in_chunk * segment_stride + (positions[j] != 0 ? (uint64_t) positions[j] : relative_to);
