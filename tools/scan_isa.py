@@ -1,0 +1,67 @@
+"""Two scans of the built library's gfx950 code objects (no GPU needed):
+    python tools/scan_isa.py [libgiddy_amd/libgiddy_amd.so]
+
+1. SERIALIZED SCALAR LOADS: `s_load ... s_waitcnt lgkmcnt(0) ... s_load` within a couple of dozen instructions, past a kernel's first 60 (its arguments) — a load that was issued
+   only after the wait for an earlier one, i.e. a round trip of its own.  Round 5 found the run decoders' chunk prologue that way: a conditional
+   `anchors[s + 1]` lands in another basic block, behind the wait for `anchors[s]`.  Some are inherent (a batch piece's record, then what it points to).
+2. A uniform select on a STALE SCC: hipcc 7.2 compiled `high = new_high < new_low ? new_low : new_high` (wave-uniform 64-bit values) to `v_cmp_gt_u64 vcc, ...` followed by
+   `s_cselect_b32` with SCC last written by the `s_addc_u32` of an address computation (tools/experiments/search_probe.hip).  Signature: an s_cselect whose last SCC writer is an
+   arithmetic instruction, with a VOPC compare into VCC in between.
+"""
+import collections, glob, os, re, shutil, subprocess, sys, tempfile
+LLVM = "/opt/rocm/lib/llvm/bin"
+library = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libgiddy_amd", "libgiddy_amd.so")
+SCC_WRITER = re.compile(r"^s_(and|or|xor|andn2|orn2|nand|nor|xnor|add|sub|addc|subb|cmp|bitcmp|lshl|lshr|ashr|bfe|abs|min|max|not|wqm|bcnt|ff|flbit|absdiff|cmpk|addk|mulk|quadmask)[a-z0-9_]*\b")
+ARITHMETIC = re.compile(r"^s_(add|sub|addc|subb|lshl|lshr|ashr|addk|mulk|bfe|abs|min|max|absdiff)[a-z0-9_]*\b")
+
+
+def demangled(name):
+    return subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip()
+
+
+def family(name):
+    return re.sub(r"<.*", "", demangled(name).replace("void ", ""))
+
+
+serialized, stale = collections.defaultdict(list), collections.defaultdict(list)
+kernels = 0
+with tempfile.TemporaryDirectory() as scratch:
+    copy = os.path.join(scratch, os.path.basename(library))
+    shutil.copy(library, copy)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", copy], check=True, capture_output=True)
+    for code_object in sorted(glob.glob(os.path.join(scratch, "*gfx950*"))):
+        text = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", code_object], capture_output=True, text=True).stdout
+        kernel = None
+        for line in text.splitlines():
+            m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
+            if m:
+                kernel, index, last_load, waited, last_scc, compared = m.group(1), 0, -99, -99, None, False
+                kernels += 1
+                continue
+            instruction = line.strip().split("//")[0].strip()
+            if kernel is None or not instruction:
+                continue
+            index += 1
+            if instruction.startswith(("s_load", "s_buffer_load")):
+                if index > 60 and waited > last_load and index - waited <= 20 and waited - last_load <= 8:
+                    serialized[kernel].append(index)
+                last_load = index
+            elif instruction.startswith("s_waitcnt") and "lgkmcnt(0)" in instruction:
+                waited = index
+            if instruction.startswith("s_cselect") and last_scc and ARITHMETIC.match(last_scc) and compared:
+                stale[kernel].append((index, last_scc, instruction))
+            if SCC_WRITER.match(instruction) and not instruction.startswith("s_cselect"):
+                last_scc, compared = instruction, False
+            elif instruction.startswith("v_cmp") and len(instruction.split()) > 1 and instruction.split()[1].startswith("vcc"):
+                compared = True
+
+print("%d kernels in %s" % (kernels, library))
+print("1. scalar loads issued behind the wait for an earlier one (kernels by family; occurrences in one of them):")
+by_family = collections.Counter(family(k) for k in serialized)
+for name, count in by_family.most_common():
+    example = next(k for k in serialized if family(k) == name)
+    print("   %3d kernels  %2d  %s" % (count, len(serialized[example]), name))
+print("2. s_cselect on an SCC last written by arithmetic, a VOPC compare in between: %d kernels" % len(stale))
+for k, found in list(stale.items())[:10]:
+    print("   %s: %s" % (demangled(k)[:120], found[0]))
+sys.exit(1 if stale else 0)
