@@ -121,10 +121,11 @@ __device__ __forceinline__ void decompress(
 		// (both anchors asked for at once — the second at an index that always exists — and ONE wait: a conditional second load is a second round trip, and with the
 		// compressed input cold a round trip is 2 microseconds of a wavefront's 17; round 5)
 		const bool a_chunk_follows = s + segments_per_chunk < num_segments;
+		// (the first run's length arrives with the first batch of lengths: no round trip of its own; how far into it the segment begins: asked for FIRST — with 4- and
+		// 8-byte lengths it is a scalar load like the anchors', and behind them it was issued behind their wait)
+		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s - mine.anchors_from];
 		const uint64_t this_anchor = segment_position_anchors[s - mine.anchors_from], next_anchor = segment_position_anchors[(a_chunk_follows ? s + segments_per_chunk : s) - mine.anchors_from];
 		uint64_t first_run = this_anchor;
-		// (the first run's length arrives with the first batch of lengths: no round trip of its own)
-		length_type skipped_of_first_run = segment_position_anchor_intra_run_offsets[s - mine.anchors_from];
 		length_type left_in_first_run = 0;
 		bool entering = true;   // the chunk's first tile: the first run's length is not known yet
 		// (a select, not a branch around the use: the compiler sinks a load that only one side of a branch uses back into it — and the second round trip is back)
