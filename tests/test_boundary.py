@@ -279,3 +279,17 @@ def test_batches_are_built_on_the_host_alone():
     assert lib.giddy_batch_num_pieces(None) == 0 and lib.giddy_can_launch_batches(None) == 0
     assert lib.giddy_enqueue_batch_of_device_tables(scatter._handle, None, None) == -1
     lib.giddy_batch_release(None)
+
+
+def test_no_uniform_select_on_a_stale_scc_in_the_built_library():
+    """Round 5 met a hipcc 7.2 miscompile: `high = new_high < new_low ? new_low : new_high` on wave-uniform 64-bit values became a VOPC compare followed by an s_cselect whose
+    SCC had last been written by the s_addc of an address computation (run positions' wave-wide search returned after its first round).  tools/scan_isa.py looks for that
+    signature in every kernel of the built library; it also lists scalar loads issued behind the wait for an earlier one (informative only)."""
+    import subprocess
+    import sys
+    library = os.path.join(ROOT, "libgiddy_amd", "libgiddy_amd.so")
+    if not os.path.exists(library):
+        pytest.skip("the library is not built")
+    result = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_isa.py"), library], capture_output=True, text=True, timeout=900)
+    assert result.returncode == 0, result.stdout[-3000:] + result.stderr[-2000:]
+    assert "a VOPC compare in between: 0 kernels" in result.stdout
