@@ -148,7 +148,8 @@ struct cursor_t {
 		const bool have = mine < num;
 		// (Tried in round 4: the NEXT window's entries requested here, into registers, so that a column with a patch in every few elements does not wait
 		// a memory round trip per window — loads in flight across the row loops make every wait the compiler places a wait for everything, as the note
-		// above says: Delta with 0.1 % patches 72.6 -> 57.9 % of the HBM peak, nothing gained at 20-50 %.  Not kept.)
+		// above says: Delta with 0.1 % patches 72.6 -> 57.9 % of the HBM peak, nothing gained at 20-50 %.  Not kept.  Round 5: a window of TWO or FOUR pages of 64 patches,
+		// refilled by one round trip — at 1-20 % of patches two pages +-1-2 points, four -15 ... -20 (their LDS costs the occupancy): the refills are not what the dense columns wait for.)
 		const position_type p = have ? positions[mine] : no_patch;
 		const Value v = have ? values[mine] : Value();
 		wave64::lds_fence();   // (earlier reads of the window are done)
