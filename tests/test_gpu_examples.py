@@ -8,7 +8,7 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PROGRAMS = ["factory_provided_type_erased_wrapper", "instantiation_of_wrapper", "direct_use_of_kernel", "fused_decode_and_patch", "sharded_decode_on_all_devices"]
+PROGRAMS = ["factory_provided_type_erased_wrapper", "instantiation_of_wrapper", "direct_use_of_kernel", "fused_decode_and_patch", "sharded_decode_on_all_devices", "batch_of_small_columns"]
 
 
 @pytest.mark.parametrize("program", PROGRAMS)
