@@ -24,13 +24,16 @@ public:
 
 	launch_configuration_t resolve_launch_configuration(
 		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
-		size_t length, launch_configuration_limits_t limits) const
+		size_t length, launch_configuration_limits_t limits, size_t num_patches = 0) const
 	{
 		model::launch_config_resolution_params_t<IndexSize, Uncompressed, UnaryModelFunction> params(
 			device_properties, kernel_function_attributes, length);
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(length, (size_t) stream_tiles::group_size<Uncompressed>::value * GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK);
-		params.resident_blocks_per_multiprocessor_cap = GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP > 0
+		// (a store stream with few patches likes few wavefronts; one whose every row waits for a window of patches from memory wants them all: a caller that
+		// states "num_patches" when resolving gets the residency for its density — 16 patches to a row of 64 lanes' elements and more: no throttle)
+		const bool dense = (uint64_t) num_patches * (64 * stream_tiles::group_size<Uncompressed>::value) >= 16 * (uint64_t) length;
+		params.resident_blocks_per_multiprocessor_cap = (GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP > 0 && !dense)
 			? optional<unsigned>(GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP) : optional<unsigned>(nullopt);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
@@ -42,7 +45,8 @@ launch_configuration_t kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::re
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
 	auto length = argument<size_t>(extra_arguments, "length");
-	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
+	auto num_patches = optional_argument<size_t>(extra_arguments, "num_patches");   // (optional: see above)
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits, num_patches.value_or(0));
 }
 
 template <unsigned IndexSize, typename Uncompressed, typename UnaryModelFunction>

@@ -122,7 +122,7 @@ __device__ __forceinline__ void decompress(
 		constexpr unsigned stage_up_to = GIDDY_FOR_PATCHED_STAGE_INPUT_UP_TO;
 		constexpr bool stages = stream_tiles::stages_chunk_input<Compressed, Uncompressed, stage_up_to>();
 		__shared__ stream_tiles::chunk_input_storage<Compressed, Uncompressed, stages> chunk_staging;
-		stream_tiles::transform_and_patch<Compressed, Uncompressed, 8, stage_up_to>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches,
+		stream_tiles::transform_and_patch<Compressed, Uncompressed, Patches::many ? GIDDY_FOR_MANY_PATCHED_ROWS_IN_FLIGHT : 8, stage_up_to>(decompressed, compressed_input, length, produce_group_unprepared, produce_one, patches,
 			stream_tiles::nothing_to_do(), &chunk_staging, grid);
 	}
 	else {
@@ -198,9 +198,10 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>  num_patches)
 {
 	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
+	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0> patch_rows;
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows, patch_rows));
 }
 
 } // namespace patched

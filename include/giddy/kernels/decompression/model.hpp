@@ -58,6 +58,7 @@ __global__ void decompress(
 	using model_index_type = typename UnaryModelFunction::index_type;
 	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
+	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0> patch_rows;
 	UnaryModelFunction model(model_coefficients);
 	stream_tiles::generate_and_patch<Uncompressed, GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {
@@ -65,7 +66,7 @@ __global__ void decompress(
 			for (unsigned j = 0; j < G; j++) { out[j] = static_cast<Uncompressed>(model((model_index_type) (first_position + j))); }
 		},
 		[&](uint64_t position) { return static_cast<Uncompressed>(model((model_index_type) position)); },
-		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows));
+		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows, patch_rows));
 }
 
 } // namespace patched

@@ -57,7 +57,7 @@ __device__ __forceinline__ uint64_t find_last(const uint_t<PositionSize>* __rest
 
 /// No patches: what the plain decoders are instantiated with.
 struct none {
-	enum : bool { enabled = false };
+	enum : bool { enabled = false, many = false };
 	__device__ __forceinline__ void begin_seek(uint64_t, unsigned) { }
 	__device__ __forceinline__ void finish_seek(unsigned) { }
 	__device__ __forceinline__ void seek(uint64_t, unsigned) { }
@@ -67,12 +67,12 @@ struct none {
 };
 
 /// Patches per row of 64 lanes' elements, on the column's average, from which a fused decoder's ManyPatches build is the faster one — per decoder family,
-/// where the two builds' rates cross (profiles/r05_patch_density.txt: both builds forced over 0.3 ... 3 % of patches, 2^28 elements; round 4 had one
-/// constant, 6, and a dent under it: at 2 % of patches Dictionary ran at 54 % of the HBM peak where its other build does 63, fixed-width
-/// discard-zero-bytes 58 against 72, Model 32 against 46).  The walk that patches one at a time costs the whole wavefront a trip around a loop of LDS
-/// reads per patch; how soon that loses to a binary search per lane depends on what else the decoder's row loop has to hide it behind.
+/// where the two builds' rates cross (both builds forced, 2^28 elements: profiles/r05_patch_density.txt; round 4 had one constant, 6, and a dent under it).
+/// The walk that patches one at a time costs the whole wavefront a trip around a loop of LDS reads per patch; the ManyPatches builds pay five LDS operations
+/// per row whatever its patches (cursor_t::apply_to_row) — since they pass a row's patches through a row area in LDS the crossings are at 1 ... 3 patches per
+/// row (with the search per lane they did before: 2 ... 4.5).
 namespace together_from {
-constexpr float delta = 3.2f, dictionary = 3.0f, discard_zero_bytes_fixed = 2.0f, frame_of_reference = 4.5f, model = 2.5f;
+constexpr float delta = 1.5f, dictionary = 1.7f, discard_zero_bytes_fixed = 2.0f, frame_of_reference = 3.0f, model = 1.0f;
 }
 
 /// whether a column of `length` elements with `num_patches` patches, decoded in rows of 64 lanes x `elements_per_lane`, is one for the ManyPatches builds
@@ -91,11 +91,25 @@ struct window_storage {
 	Value values[max_waves_per_block][64];
 };
 
+/// The `ManyPatches` builds' second wave-private area: ONE ROW of the output as LDS addresses — a value and a byte "a patch lies here" per element of a row
+/// of 64 lanes' elements (16 bytes per lane: 1 KiB of values, 64 ... 1024 bytes of marks) — through which a row's patches reach the lanes that hold their
+/// elements (cursor_t::apply_to_row).  `MaxWaves` 0: the other builds, which have no use for it.
+template <typename Value, unsigned MaxWaves, unsigned ElementsPerLane = 16 / sizeof(Value)>
+struct row_storage {
+	enum : unsigned { max_waves_per_block = MaxWaves, row_elements = 64 * ElementsPerLane };
+	Value values[MaxWaves][row_elements];
+	unsigned char marks[MaxWaves][row_elements];
+};
+template <typename Value, unsigned ElementsPerLane>
+struct row_storage<Value, 0, ElementsPerLane> {
+	enum : unsigned { max_waves_per_block = 0, row_elements = 0 };
+};
+
 /// `ManyPatches`: apply_to_row has every lane look for its own patches (columns with several patches to a row: the wrappers launch the kernels'
 /// `ManyPatches` builds for them) instead of walking the patches one at a time
-template <unsigned PositionSize, typename Value, bool ManyPatches = false>
+template <unsigned PositionSize, typename Value, bool ManyPatches = false, unsigned RowElementsPerLane = 16 / sizeof(Value)>
 struct cursor_t {
-	enum : bool { enabled = true };
+	enum : bool { enabled = true, many = ManyPatches };
 	enum : unsigned { guess_probes = 16 };
 	using position_type = uint_t<PositionSize>;
 	using storage_type = window_storage<PositionSize, Value>;
@@ -118,12 +132,41 @@ struct cursor_t {
 	uint64_t position;                          // the current patch; ~0 once the patches are exhausted
 	Value value;
 	uint64_t seek_target, seek_base, probed_position;
+	Value* row_values = nullptr;                // LDS (ManyPatches): this wavefront's row_storage
+	unsigned char* row_marks = nullptr;
 
 	/// `length`: the column's length in elements (only used to guess where a position's patches are)
 	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage)
 	: cursor_t(values_, positions_, num_, length,
 		storage.positions[wave64::index_in_block() % storage_type::max_waves_per_block],
 		storage.values[wave64::index_in_block() % storage_type::max_waves_per_block]) { }
+
+	/// ... and the ManyPatches builds' row area
+	template <unsigned MaxWaves, unsigned ElementsPerLane>
+	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage, row_storage<Value, MaxWaves, ElementsPerLane>& rows)
+	: cursor_t(values_, positions_, num_, length, storage)
+	{
+		with_rows(rows);
+	}
+	/// (for the callers that place the windows themselves)
+	template <unsigned MaxWaves, unsigned ElementsPerLane>
+	__device__ __forceinline__ cursor_t& with_rows(row_storage<Value, MaxWaves, ElementsPerLane>& rows)
+	{
+		if constexpr (MaxWaves != 0) {
+			static_assert(ElementsPerLane >= RowElementsPerLane, "the row area holds the rows this cursor takes through it");
+			// (a workgroup's first `MaxWaves` wavefronts have a row area — the wrappers launch workgroups of four; the wavefronts of a larger workgroup that a caller
+			// of the bare kernel may launch find their patches by the search below)
+			const unsigned w = wave64::index_in_block(), lane = wave64::lane_id();
+			if (w < MaxWaves) {
+				row_values = rows.values[w];
+				row_marks = rows.marks[w];
+				constexpr unsigned row_elements = row_storage<Value, MaxWaves, ElementsPerLane>::row_elements;
+				for (unsigned i = lane * 4; i < row_elements; i += 256) { *reinterpret_cast<uint32_t*>(row_marks + i) = 0; }   // no patch anywhere, to begin with
+				wave64::lds_fence();
+			}
+		}
+		return *this;
+	}
 
 	/// ... with this wavefront's window (64 positions, 64 values of LDS) placed by the caller
 	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length,
@@ -221,12 +264,49 @@ struct cursor_t {
 	{
 		while (position < row_start) { advance(lane); }
 		// Round 4: MANY patches in a row.  One at a time (below) a patch is a trip around a loop of LDS reads for the whole wavefront: fine for the one patch
-		// in four rows of a 0.1 % column, 13 trips per row at 5 % (Dictionary: 31 % of the HBM peak), 128 at 50 % (6 %).  The window is sorted, so a LANE's
-		// patches are a contiguous stretch of it: where the column has `together_from` patches or more to a row ON AVERAGE (decided once, by the
-		// wrapper, from the column's counts — and as a build of its own: finding out row by row cost the 1 % columns 7 points, and the registers of this path
-		// in the same kernel cost the 0.1 % ones 2-5) every lane finds its own — a binary search over the row's entries in
-		// the window (at most 6 LDS reads), then as many steps as it has patches (equal positions: the last wins).
+		// in four rows of a 0.1 % column, 13 trips per row at 5 % (Dictionary: 31 % of the HBM peak), 128 at 50 % (6 %).  Where the column has `together_from`
+		// patches or more to a row ON AVERAGE (decided once, by the wrapper, from the column's counts — and as a build of its own: finding out row by row cost the
+		// 1 % columns 7 points, and the registers of this path in the same kernel cost the 0.1 % ones 2-5) a row's patches are taken together.
 		if constexpr (ManyPatches) {
+			// Round 5, second form: the row as LDS addresses.  The window's entry l belongs to lane l; the lanes whose entries lie in this row put their value and a mark at the
+			// element's place in the wavefront's row area, every lane then reads the marks of its own E elements (one LDS read) and the values behind the set ones, and the
+			// owners take their marks back: five LDS operations per row whatever the number of patches, no loop whose trip count differs between lanes.  (The first form: every
+			// lane a binary search over the row's entries in the window — up to 6 dependent LDS reads — and then a step per patch of its own.)
+			if constexpr (E <= RowElementsPerLane) {
+				if (row_values != nullptr) {
+					while (position < row_end) {
+						const position_type in_my_slot = window_positions[lane];
+						const position_type in_the_next_slot = window_positions[lane < 63 ? lane + 1 : lane];
+						const bool in_row = lane >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
+						const unsigned count = (unsigned) __builtin_popcountll(wave64::ballot(in_row));   // (>= 1: the current patch is one of them)
+						// (equal positions: the last wins — an entry whose successor in the window has the same position stands back; a successor in the NEXT window comes a turn later)
+						const bool mine_to_place = in_row && !(lane < 63 && in_the_next_slot == in_my_slot);
+						const unsigned slot = (unsigned) ((uint64_t) in_my_slot - row_start);
+						if (mine_to_place) { row_values[slot] = window_values[lane]; row_marks[slot] = 1; }
+						wave64::lds_fence();
+						if constexpr (E % 4 == 0) {
+							#pragma unroll
+							for (unsigned q = 0; q < E / 4; q++) {
+								const uint32_t marks = reinterpret_cast<const uint32_t*>(row_marks)[lane * (E / 4) + q];
+								if (marks != 0) {
+									#pragma unroll
+									for (unsigned j = 0; j < 4; j++) { if ((marks >> (8 * j)) & 0xFFu) { row[4 * q + j] = row_values[lane * E + 4 * q + j]; } }
+								}
+							}
+						}
+						else {
+							#pragma unroll
+							for (unsigned j = 0; j < E; j++) { if (row_marks[lane * E + j]) { row[j] = row_values[lane * E + j]; } }
+						}
+						wave64::lds_fence();
+						if (mine_to_place) { row_marks[slot] = 0; }
+						index_in_window += count - 1;
+						advance(lane);   // (to the entry after the row's last in this window: refills the window when that was its last)
+					}
+					return;
+				}
+			}
+			// ... the first form: rows longer than the row area was made for (Delta's any-length rows of 64 x 4 eight-byte elements), wavefronts without one
 			while (position < row_end) {
 				const position_type in_my_slot = window_positions[lane];
 				const bool in_row = lane >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;

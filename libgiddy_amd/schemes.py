@@ -249,7 +249,8 @@ def patched_model(decompressed, model_coefficients, patch_values, patch_position
               "model_coefficients": r.coefficients(model_coefficients, "i%d" % (8 * uncompressed_size)),
               "length": r.uint_t(index_size)(length)}
     launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "i%d" % (8 * uncompressed_size), index_size))
-    return _run(key_patched(key_model(index_size, uncompressed_size, model)), {"length": r.size_t(length)}, launch,
+    resolve = {"length": r.size_t(length), "num_patches": r.size_t(num_patches)}   # (the count is optional when resolving: it picks the residency)
+    return _run(key_patched(key_model(index_size, uncompressed_size, model)), resolve, launch,
                 stream, device, limits, launch_config)
 
 

@@ -198,6 +198,58 @@ def test_patched_dictionary(usize, dsize, index_size):
                 assert len(bad) == 0, (n, how, cache, bad[:5], got[bad[:5]], expect[bad[:5]])
 
 
+@pytest.mark.parametrize("usize", [1, 2, 4, 8])
+@pytest.mark.parametrize("how", ["dense", "duplicates", "all", "clustered"])
+def test_many_patches_in_workgroups_larger_than_the_row_areas(usize, how):
+    """The ManyPatches builds pass a row's patches to the lanes through a wave-private row area in LDS, provisioned for the four wavefronts of the
+    workgroups the wrappers launch; a caller of the kernels may launch workgroups of up to 1024 threads: wavefronts 4 ... 15 find their patches
+    by the search over the window instead.  Both forms in one launch, against the oracle."""
+    schemes, r, g = _imports()
+    ud = np.dtype("u%d" % usize)
+    n = 700001
+    narrow = cases.rng(n + usize).integers(0, 255, size=n, endpoint=True).astype(np.uint8)
+    positions, values = _patches(n, how, ud, 4, seed=usize + len(how))
+    d_values, d_positions = g.dev(values), g.dev(positions)
+
+    def both(launch, decoded):
+        expect = _expected(decoded, positions, values)
+        out = g.dev_empty(n, ud)
+        resolved = launch(out, None)
+        assert np.array_equal(g.host(out, ud, n), expect)
+        for threads, blocks in ((1024, 40), (512, 97), (320, 64)):
+            out = g.dev_empty(n, ud)
+            launch(out, r.launch_configuration_t((blocks, 1, 1), (threads, 1, 1), resolved.dynamic_shared_memory_size))
+            got = g.host(out, ud, n)
+            bad = np.flatnonzero(got != expect)
+            assert len(bad) == 0, (threads, blocks, bad[:5], got[bad[:5]], expect[bad[:5]])
+
+    if usize > 1:
+        d_in = g.dev(narrow)
+        both(lambda out, config: schemes.patched_discard_zero_bytes_fixed(out, d_in, d_values, d_positions, n, len(positions), uncompressed_size=usize, compressed_size=1,
+                                                                           index_size=4, stream=g.stream(), launch_config=config), narrow.astype(ud))
+    f = cases.dictionary_case(n, 256, ud, np.dtype("u1"), seed=n + usize)
+    d_keys, d_dict = g.dev(f["compressed_input"]), g.dev(f["dictionary_entries"])
+    both(lambda out, config: schemes.patched_dictionary(out, d_keys, d_dict, d_values, d_positions, n, 256, len(positions), uncompressed_size=usize, dictionary_index_size=1,
+                                                         index_size=4, stream=g.stream(), launch_config=config), oracle.dictionary(f["compressed_input"], f["dictionary_entries"]))
+    if usize in (2, 4):
+        sd = np.dtype("i%d" % usize)
+        coefficients = np.array([-12345, 37], dtype=sd)
+        decoded = oracle.model(coefficients, n, sd, "linear", model_index_size=4)
+        signed_values = values.view(sd)
+        d_signed = g.dev(signed_values)
+
+        def model_both():
+            expect = _expected(decoded, positions, signed_values)
+            out = g.dev_empty(n, sd)
+            resolved = schemes.patched_model(out, coefficients, d_signed, d_positions, n, len(positions), uncompressed_size=usize, model="linear", index_size=4, stream=g.stream())
+            assert np.array_equal(g.host(out, sd, n), expect)
+            out = g.dev_empty(n, sd)
+            schemes.patched_model(out, coefficients, d_signed, d_positions, n, len(positions), uncompressed_size=usize, model="linear", index_size=4, stream=g.stream(),
+                                  launch_config=r.launch_configuration_t((40, 1, 1), (1024, 1, 1), resolved.dynamic_shared_memory_size))
+            assert np.array_equal(g.host(out, sd, n), expect)
+        model_both()
+
+
 def test_patched_kernels_equal_the_two_launch_pipeline_on_the_golden_fixture():
     """C3 in miniature, fused: same golden fixture as the two-launch pipeline test"""
     import os
