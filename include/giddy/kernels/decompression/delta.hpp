@@ -1399,13 +1399,13 @@ __global__ void decompress(
 	constexpr bool stages = detail::stages_row_inputs<UncompressedSize, CompressedSize, true>();
 	constexpr unsigned staging_bytes = stages ? 4 * detail::staged_chunk_bytes<UncompressedSize, CompressedSize>() : 0;
 	__shared__ sorted_patches::window_storage<IndexSize, value_type, 4> first_windows;
-	__shared__ sorted_patches::row_storage<value_type, ManyPatches ? 4 : 0> patch_rows;
+	__shared__ sorted_patches::row_storage<value_type, ManyPatches ? 4 : 0, 16 / sizeof(value_type), IndexSize, 1> patch_rows;   // (one page of patches: sorted_patches.hpp)
 	__shared__ __attribute__((aligned(16))) uint8_t overlay[staging_bytes > sizeof(more_windows) ? staging_bytes : sizeof(more_windows)];
 	const unsigned w = wave64::index_in_block() % 16;
 	more_windows& later_windows = *reinterpret_cast<more_windows*>(overlay);
 	detail::decompress<IndexSize, UncompressedSize, CompressedSize>(
 		decompressed, compressed_input, anchor_values, length, segment_length,
-		sorted_patches::cursor_t<IndexSize, value_type, ManyPatches>(patch_values, patch_positions, num_patches, length,
+		sorted_patches::cursor_t<IndexSize, value_type, ManyPatches, 16 / sizeof(value_type), 1>(patch_values, patch_positions, num_patches, length,
 			w < 4 ? first_windows.positions[w] : later_windows.positions[w - 4], w < 4 ? first_windows.values[w] : later_windows.values[w - 4]).with_rows(patch_rows),
 		stages ? overlay : nullptr);
 }

@@ -251,7 +251,7 @@ __global__ void decompress(
 	bool                                              chunk_key_staging_in_dynamic_lds)   // room for detail::chunk_key_storage behind the dictionary
 {
 	__shared__ sorted_patches::window_storage<IndexSize, uint_t<UncompressedSize>> patch_windows;
-	__shared__ sorted_patches::row_storage<uint_t<UncompressedSize>, ManyPatches ? 4 : 0> patch_rows;
+	__shared__ sorted_patches::row_storage<uint_t<UncompressedSize>, ManyPatches ? 4 : 0, 16 / UncompressedSize, IndexSize> patch_rows;
 	detail::decompress<UncompressedSize, DictionaryIndexSize>(decompressed, compressed_input, dictionary_entries,
 		length, num_dictionary_entries, cache_dictionary_in_shared_memory,
 		sorted_patches::cursor_t<IndexSize, uint_t<UncompressedSize>, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows, patch_rows),

@@ -124,7 +124,7 @@ __global__ void decompress(
 	using C = uint_t<CompressedSize>;
 	constexpr unsigned G = stream_tiles::group_size<U>::value;
 	__shared__ sorted_patches::window_storage<IndexSize, U> patch_windows;
-	__shared__ sorted_patches::row_storage<U, ManyPatches ? 4 : 0> patch_rows;
+	__shared__ sorted_patches::row_storage<U, ManyPatches ? 4 : 0, 16 / sizeof(U), IndexSize> patch_rows;
 	__shared__ stream_tiles::chunk_input_storage<C, U, stages_chunk_input<UncompressedSize, CompressedSize>()> chunk_staging;
 	pad_high_bytes<UncompressedSize, CompressedSize, UncompressedEndianness> widen;
 	stream_tiles::transform_and_patch<C, U, stream_tiles::rows_in_flight, stage_input_up_to<UncompressedSize>()>(decompressed, compressed_input, length,

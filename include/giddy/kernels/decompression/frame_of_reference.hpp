@@ -198,7 +198,7 @@ __global__ void decompress(
 	size_type_by_index_size<IndexSize>  num_patches)
 {
 	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
-	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0> patch_rows;
+	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0, 16 / sizeof(Uncompressed), IndexSize> patch_rows;
 	detail::decompress<IndexSize, Uncompressed, Compressed, UnaryModelFunction>(
 		decompressed, compressed_input, segment_model_coefficients, length, segment_length,
 		sorted_patches::cursor_t<IndexSize, Uncompressed, ManyPatches>(patch_values, patch_positions, num_patches, length, patch_windows, patch_rows));

@@ -58,7 +58,7 @@ __global__ void decompress(
 	using model_index_type = typename UnaryModelFunction::index_type;
 	constexpr unsigned G = stream_tiles::group_size<Uncompressed>::value;
 	__shared__ sorted_patches::window_storage<IndexSize, Uncompressed> patch_windows;
-	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0> patch_rows;
+	__shared__ sorted_patches::row_storage<Uncompressed, ManyPatches ? 4 : 0, 16 / sizeof(Uncompressed), IndexSize> patch_rows;
 	UnaryModelFunction model(model_coefficients);
 	stream_tiles::generate_and_patch<Uncompressed, GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK>(decompressed, length,
 		[&](uint64_t first_position, memory_access::group<Uncompressed, G>& out) {

@@ -20,6 +20,9 @@
 #include "giddy/common.hpp"
 #include "giddy/on_device/wave64.hpp"
 
+#ifndef GIDDY_PATCH_WINDOW_PAGES
+#define GIDDY_PATCH_WINDOW_PAGES 2   // ManyPatches builds: pages of 64 patches in the window of a wavefront that has a row area (one memory round trip refills them all).  1 | 2 | 4 at 5 % of patches: Dictionary 66.6 | 70.0 | 47.4 % of the HBM peak, at 50 %: 55.5 | 63.8 | 48.3; DZB-fixed, FOR, Model: +1 ... +6 with two; Delta 69.1 | 63.3 | 42.0 (its registers: one page there)
+#endif
 #ifndef GIDDY_PATCHES_TOGETHER_FROM
 #define GIDDY_PATCHES_TOGETHER_FROM -1   // >= 0 (measurements): patches per row from which EVERY fused wrapper launches its ManyPatches build, instead of the table below
 #endif
@@ -94,23 +97,26 @@ struct window_storage {
 /// The `ManyPatches` builds' second wave-private area: ONE ROW of the output as LDS addresses — a value and a byte "a patch lies here" per element of a row
 /// of 64 lanes' elements (16 bytes per lane: 1 KiB of values, 64 ... 1024 bytes of marks) — through which a row's patches reach the lanes that hold their
 /// elements (cursor_t::apply_to_row).  `MaxWaves` 0: the other builds, which have no use for it.
-template <typename Value, unsigned MaxWaves, unsigned ElementsPerLane = 16 / sizeof(Value)>
+/// ... and, with `WindowPages` > 1, a window of that many pages of 64 patches for the same wavefronts, in place of their one-page window of window_storage.
+template <typename Value, unsigned MaxWaves, unsigned ElementsPerLane = 16 / sizeof(Value), unsigned PositionSize = 4, unsigned WindowPages = GIDDY_PATCH_WINDOW_PAGES>
 struct row_storage {
-	enum : unsigned { max_waves_per_block = MaxWaves, row_elements = 64 * ElementsPerLane };
+	enum : unsigned { max_waves_per_block = MaxWaves, row_elements = 64 * ElementsPerLane, window_pages = WindowPages, wide_entries = WindowPages > 1 ? 64 * WindowPages : 1 };
 	Value values[MaxWaves][row_elements];
 	unsigned char marks[MaxWaves][row_elements];
+	uint_t<PositionSize> window_positions[MaxWaves][wide_entries];
+	Value window_values[MaxWaves][wide_entries];
 };
-template <typename Value, unsigned ElementsPerLane>
-struct row_storage<Value, 0, ElementsPerLane> {
-	enum : unsigned { max_waves_per_block = 0, row_elements = 0 };
+template <typename Value, unsigned ElementsPerLane, unsigned PositionSize, unsigned WindowPages>
+struct row_storage<Value, 0, ElementsPerLane, PositionSize, WindowPages> {
+	enum : unsigned { max_waves_per_block = 0, row_elements = 0, window_pages = 1 };
 };
 
 /// `ManyPatches`: apply_to_row has every lane look for its own patches (columns with several patches to a row: the wrappers launch the kernels'
 /// `ManyPatches` builds for them) instead of walking the patches one at a time
-template <unsigned PositionSize, typename Value, bool ManyPatches = false, unsigned RowElementsPerLane = 16 / sizeof(Value)>
+template <unsigned PositionSize, typename Value, bool ManyPatches = false, unsigned RowElementsPerLane = 16 / sizeof(Value), unsigned MaxWindowPages = (ManyPatches ? GIDDY_PATCH_WINDOW_PAGES : 1)>
 struct cursor_t {
 	enum : bool { enabled = true, many = ManyPatches };
-	enum : unsigned { guess_probes = 16 };
+	enum : unsigned { guess_probes = 16, max_window_pages = MaxWindowPages };
 	using position_type = uint_t<PositionSize>;
 	using storage_type = window_storage<PositionSize, Value>;
 	static constexpr position_type no_patch = (position_type) ~(position_type) 0;   // (no column has an element at the all-ones index)
@@ -129,6 +135,7 @@ struct cursor_t {
 	Value* window_values;
 	uint64_t window_start;
 	unsigned index_in_window;
+	unsigned window_entries = 64;               // 64 x the pages of this wavefront's window
 	uint64_t position;                          // the current patch; ~0 once the patches are exhausted
 	Value value;
 	uint64_t seek_target, seek_base, probed_position;
@@ -142,15 +149,15 @@ struct cursor_t {
 		storage.values[wave64::index_in_block() % storage_type::max_waves_per_block]) { }
 
 	/// ... and the ManyPatches builds' row area
-	template <unsigned MaxWaves, unsigned ElementsPerLane>
-	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage, row_storage<Value, MaxWaves, ElementsPerLane>& rows)
+	template <unsigned MaxWaves, unsigned ElementsPerLane, unsigned WindowPages>
+	__device__ __forceinline__ cursor_t(const Value* values_, const position_type* positions_, uint64_t num_, uint64_t length, storage_type& storage, row_storage<Value, MaxWaves, ElementsPerLane, PositionSize, WindowPages>& rows)
 	: cursor_t(values_, positions_, num_, length, storage)
 	{
 		with_rows(rows);
 	}
 	/// (for the callers that place the windows themselves)
-	template <unsigned MaxWaves, unsigned ElementsPerLane>
-	__device__ __forceinline__ cursor_t& with_rows(row_storage<Value, MaxWaves, ElementsPerLane>& rows)
+	template <unsigned MaxWaves, unsigned ElementsPerLane, unsigned WindowPages>
+	__device__ __forceinline__ cursor_t& with_rows(row_storage<Value, MaxWaves, ElementsPerLane, PositionSize, WindowPages>& rows)
 	{
 		if constexpr (MaxWaves != 0) {
 			static_assert(ElementsPerLane >= RowElementsPerLane, "the row area holds the rows this cursor takes through it");
@@ -160,7 +167,13 @@ struct cursor_t {
 			if (w < MaxWaves) {
 				row_values = rows.values[w];
 				row_marks = rows.marks[w];
-				constexpr unsigned row_elements = row_storage<Value, MaxWaves, ElementsPerLane>::row_elements;
+				constexpr unsigned row_elements = row_storage<Value, MaxWaves, ElementsPerLane, PositionSize, WindowPages>::row_elements;
+				if constexpr (WindowPages > 1) {
+					static_assert(WindowPages <= max_window_pages, "fill_window() loads at most max_window_pages pages");
+					window_positions = rows.window_positions[w];
+					window_values = rows.window_values[w];
+					window_entries = 64 * WindowPages;
+				}
 				for (unsigned i = lane * 4; i < row_elements; i += 256) { *reinterpret_cast<uint32_t*>(row_marks + i) = 0; }   // no patch anywhere, to begin with
 				wave64::lds_fence();
 			}
@@ -187,22 +200,32 @@ struct cursor_t {
 	}
 	__device__ __forceinline__ void fill_window(unsigned lane)
 	{
-		const uint64_t mine = window_start + lane;
-		const bool have = mine < num;
 		// (Tried in round 4: the NEXT window's entries requested here, into registers, so that a column with a patch in every few elements does not wait
 		// a memory round trip per window — loads in flight across the row loops make every wait the compiler places a wait for everything, as the note
 		// above says: Delta with 0.1 % patches 72.6 -> 57.9 % of the HBM peak, nothing gained at 20-50 %.  Not kept.  Round 5: a window of TWO or FOUR pages of 64 patches,
 		// refilled by one round trip — at 1-20 % of patches two pages +-1-2 points, four -15 ... -20 (their LDS costs the occupancy): the refills are not what the dense columns wait for.)
-		const position_type p = have ? positions[mine] : no_patch;
-		const Value v = have ? values[mine] : Value();
+		// (a window of several pages: all its loads go out before any is waited for — one round trip)
+		position_type p[max_window_pages];
+		Value v[max_window_pages];
+		#pragma unroll
+		for (unsigned k = 0; k < max_window_pages; k++) {
+			if (k == 0 || 64 * k < window_entries) {
+				const uint64_t mine = window_start + 64 * k + lane;
+				const bool have = mine < num;
+				p[k] = have ? positions[mine] : no_patch;
+				v[k] = have ? values[mine] : Value();
+			}
+		}
 		wave64::lds_fence();   // (earlier reads of the window are done)
-		window_positions[lane] = p;
-		window_values[lane] = v;
+		#pragma unroll
+		for (unsigned k = 0; k < max_window_pages; k++) {
+			if (k == 0 || 64 * k < window_entries) { window_positions[64 * k + lane] = p[k]; window_values[64 * k + lane] = v[k]; }
+		}
 		wave64::lds_fence();
 	}
 	__device__ __forceinline__ void advance(unsigned lane)
 	{
-		if (++index_in_window == 64) { window_start += 64; index_in_window = 0; fill_window(lane); }
+		if (++index_in_window == window_entries) { window_start += window_entries; index_in_window = 0; fill_window(lane); }
 		read_current();
 	}
 
@@ -275,14 +298,16 @@ struct cursor_t {
 			if constexpr (E <= RowElementsPerLane) {
 				if (row_values != nullptr) {
 					while (position < row_end) {
-						const position_type in_my_slot = window_positions[lane];
-						const position_type in_the_next_slot = window_positions[lane < 63 ? lane + 1 : lane];
-						const bool in_row = lane >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
+						const unsigned my_slot = (index_in_window & ~63u) + lane;   // (the page the current patch is in: a row's patches beyond it come a turn later)
+						const position_type in_my_slot = window_positions[my_slot];
+						const bool has_successor = my_slot + 1 < window_entries;
+						const position_type in_the_next_slot = window_positions[has_successor ? my_slot + 1 : my_slot];
+						const bool in_row = my_slot >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
 						const unsigned count = (unsigned) __builtin_popcountll(wave64::ballot(in_row));   // (>= 1: the current patch is one of them)
 						// (equal positions: the last wins — an entry whose successor in the window has the same position stands back; a successor in the NEXT window comes a turn later)
-						const bool mine_to_place = in_row && !(lane < 63 && in_the_next_slot == in_my_slot);
+						const bool mine_to_place = in_row && !(has_successor && in_the_next_slot == in_my_slot);
 						const unsigned slot = (unsigned) ((uint64_t) in_my_slot - row_start);
-						if (mine_to_place) { row_values[slot] = window_values[lane]; row_marks[slot] = 1; }
+						if (mine_to_place) { row_values[slot] = window_values[my_slot]; row_marks[slot] = 1; }
 						wave64::lds_fence();
 						if constexpr (E % 4 == 0) {
 							#pragma unroll
@@ -308,8 +333,9 @@ struct cursor_t {
 			}
 			// ... the first form: rows longer than the row area was made for (Delta's any-length rows of 64 x 4 eight-byte elements), wavefronts without one
 			while (position < row_end) {
-				const position_type in_my_slot = window_positions[lane];
-				const bool in_row = lane >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
+				const unsigned my_slot = (index_in_window & ~63u) + lane;
+				const position_type in_my_slot = window_positions[my_slot];
+				const bool in_row = my_slot >= index_in_window && in_my_slot != no_patch && (uint64_t) in_my_slot < row_end;
 				const unsigned count = (unsigned) __builtin_popcountll(wave64::ballot(in_row));   // (>= 1: the current patch is one of them)
 				const uint64_t my_first = row_start + (uint64_t) lane * E;
 				const unsigned row_entries_end = index_in_window + count;
