@@ -31,10 +31,11 @@ public:
 		// a thread of the patched kernel covers a wavefront chunk's share of elements rather than a tile's
 		params.length = util::div_rounding_up(length, (size_t) stream_tiles::group_size<Uncompressed>::value * GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK);
 		// (a store stream with few patches likes few wavefronts; one whose every row waits for a window of patches from memory wants them all: a caller that
-		// states "num_patches" when resolving gets the residency for its density — 16 patches to a row of 64 lanes' elements and more: no throttle)
-		const bool dense = (uint64_t) num_patches * (64 * stream_tiles::group_size<Uncompressed>::value) >= 16 * (uint64_t) length;
+		// states "num_patches" when resolving gets the residency for its density — from 3 patches to a row of 64 lanes' elements on: 5 workgroups per CU, from 16: no throttle)
+		const uint64_t patches_x_row = (uint64_t) num_patches * (64 * stream_tiles::group_size<Uncompressed>::value);
+		const bool many = patches_x_row >= 3 * (uint64_t) length, dense = patches_x_row >= 16 * (uint64_t) length;
 		params.resident_blocks_per_multiprocessor_cap = (GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP > 0 && !dense)
-			? optional<unsigned>(GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP) : optional<unsigned>(nullopt);
+			? optional<unsigned>(many ? 5u : (unsigned) GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP) : optional<unsigned>(nullopt);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };

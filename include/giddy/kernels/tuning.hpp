@@ -21,7 +21,7 @@
 #define GIDDY_FOR_MANY_PATCHED_ROWS_IN_FLIGHT 4   // fused FOR, ManyPatches build: rows whose inputs are in registers at a time (the other build: 8; here 8 | 4 | 2 at 2 % of patches: 58.5 | 65.3 | 57.8 % of the HBM peak, at 20 %: 48.8 | 57.3 | 55.1)
 #endif
 #ifndef GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP
-#define GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP 5   // fused Model: resident workgroups per CU (0: no throttle).  3 | 5 | 8 at 0.1 % of patches: 68.8 | 68.8 | 67.9 % of the HBM peak, at 3 %: 62.8 | 71.8 | 69.7, at 10 %: 52.7 | 72.2 | 74.3, at 50 %: 31 | 45 | 62 (tools/experiments/model_patched_caps.sh; columns that state their patch count when resolving and have 6 % of patches or more are not throttled)
+#define GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP 3   // fused Model: resident workgroups per CU for columns with few patches (0: no throttle).  3 | 5 | 8 at 0.1 % of patches: 72-73 | 69 | 68 % of the HBM peak (2^30 elements), at 3 %: 62.8 | 71.8 | 69.7, at 10 %: 52.7 | 72.2 | 74.3, at 50 %: 31 | 45 | 62 (tools/experiments/model_patched_caps.sh): the wrapper takes 5 from 3 patches per row on (1.2 %: with 3 | 5 at 0.5 % 72 | 65, at 2 % 67 | 72) and none from 16, for callers that state their patch count when resolving
 #endif
 #ifndef GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK
 #define GIDDY_MODEL_PATCHED_ROWS_PER_CHUNK 32  // fused Model: rows of 1 KiB a wavefront produces per seek (8 / 32 / 128 measured: 71-73 / 74-76 / 68-70 % at the best residency)
