@@ -53,7 +53,8 @@ namespace detail {
 /// out[p] = lookup(keys[p]) over the shared streaming tile loop
 /// whether an instantiation runs by wavefront chunks (stream_tiles::transform_and_patch) rather than by workgroup tiles: the
 /// fused ones do.  (Their 1-byte keys of 8-byte values come in with 16-byte loads through LDS instead of 2 bytes per lane and
-/// row: 57 -> 81 % of HBM peak with 2 resident workgroups per CU.  The plain kernel in the same shape stays at its tiles' 70-73 %.)
+/// row: 57 -> 81 % of HBM peak with 2 resident workgroups per CU.  The plain kernel in the same shape stays at its tiles' 70-73 %;
+/// round 5, the headline column <4,4,1> at 2^30 through the fused kernel with NO patches: 74 % against the tiles' 80 — tools/experiments/dictionary_plain_vs_fused.py.)
 template <bool Patched, unsigned UncompressedSize = 0, unsigned DictionaryIndexSize = 0, bool RestagedDictionary = false> constexpr bool by_wave_chunks()
 {
 	// (plain 8-byte values with 2-byte or wider keys as well where every workgroup re-stages the dictionary: 32 KiB are then staged
