@@ -81,7 +81,10 @@ constexpr float delta = 1.5f, dictionary = 1.7f, discard_zero_bytes_fixed = 2.0f
 /// whether a column of `length` elements with `num_patches` patches, decoded in rows of 64 lanes x `elements_per_lane`, is one for the ManyPatches builds
 inline bool many_patches_per_row(uint64_t num_patches, uint64_t length, unsigned elements_per_lane, float from)
 {
-	const double threshold = GIDDY_PATCHES_TOGETHER_FROM >= 0 ? (double) GIDDY_PATCHES_TOGETHER_FROM : (double) from;
+	// (`from` was measured on 4- and 8-byte outputs — rows of 256 and 128 elements.  The rows of 2- and 1-byte outputs are 512 and 1024 elements long and their builds cross at about
+	// twice as many patches per row — Dictionary <4,2,1> / <4,1,1>: 3.8 / 3.6 against 1.7, Delta <4,2,1>: 3.6 against 1.5, Model -> short 2.0 against 1.0; taken at `from` they lost
+	// 6-13 points between 0.25 and 0.7 % of patches: profiles/r05_patch_density.txt, last table)
+	const double threshold = GIDDY_PATCHES_TOGETHER_FROM >= 0 ? (double) GIDDY_PATCHES_TOGETHER_FROM : (double) from * (elements_per_lane >= 8 ? 2.0 : 1.0);
 	return length != 0 && (double) num_patches * (double) (64 * elements_per_lane) >= threshold * (double) length;
 }
 
