@@ -33,7 +33,7 @@ public:
 		// (a store stream with few patches likes few wavefronts; one whose every row waits for a window of patches from memory wants them all: a caller that
 		// states "num_patches" when resolving gets the residency for its density — from 3 patches to a row of 64 lanes' elements on: 5 workgroups per CU, from 16: no throttle)
 		const uint64_t patches_x_row = (uint64_t) num_patches * (64 * stream_tiles::group_size<Uncompressed>::value);
-		const bool many = patches_x_row >= 3 * (uint64_t) length, dense = patches_x_row >= 16 * (uint64_t) length;
+		const bool many = patches_x_row >= (stream_tiles::group_size<Uncompressed>::value >= 8 ? 2 : 3) * (uint64_t) length, dense   /* (2-byte outputs: wherever their ManyPatches build is taken - at 1 % of patches 3 | 5 workgroups: 41-44 | 58-62 % of the HBM peak) */ = patches_x_row >= 16 * (uint64_t) length;
 		params.resident_blocks_per_multiprocessor_cap = (GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP > 0 && !dense)
 			? optional<unsigned>(many ? 5u : (unsigned) GIDDY_MODEL_PATCHED_RESIDENT_BLOCKS_CAP) : optional<unsigned>(nullopt);
 		return cuda::kernels::resolve_launch_configuration(params, limits);
