@@ -8,6 +8,10 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/dictionary.hpp"
 
+#ifndef GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY
+#define GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -31,7 +35,8 @@ public:
 		size_t                            num_dictionary_entries,
 		size_t                            data_length,
 		optional<bool>                    cache_input_data_in_shared_mem,
-		launch_configuration_limits_t     limits) const
+		launch_configuration_limits_t     limits,
+		size_t                            num_patches = 0) const
 	{
 		dictionary::launch_config_resolution_params_t<IndexSize, UncompressedSize, DictionaryIndexSize> params(
 			device_properties, kernel_function_attributes, num_dictionary_entries, data_length,
@@ -40,6 +45,11 @@ public:
 		params.length = util::div_rounding_up(data_length, (size_t) stream_tiles::elements_per_thread_per_chunk<uncompressed_type>());
 		params.resident_blocks_per_multiprocessor_cap = nullopt;   // (the plain kernel's occupancy throttle was not measured for this one)
 		params.reserve_chunk_key_staging();   // (narrow keys of 8-byte values: staged through LDS, 2 resident workgroups per CU)
+		// (... for columns with few patches: where the ManyPatches build will be launched — known when the caller states "num_patches" when resolving — the rows wait for
+		// windows of patches from memory and want every wavefront they can have; as fused fixed-width discard-zero-bytes, patched/discard_zero_bytes_fixed.hpp)
+		if (GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) data_length, 16 / UncompressedSize, sorted_patches::together_from::dictionary)) {
+			params.resident_blocks_per_multiprocessor_cap = nullopt;
+		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };
@@ -54,8 +64,9 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize
 	auto num_dictionary_entries = argument<size_t>(extra_arguments, "num_dictionary_entries");
 	auto data_length            = argument<size_t>(extra_arguments, "data_length");
 	auto cache_input_data_in_shared_mem = optional_argument<bool>(extra_arguments, "cache_input_data_in_shared_mem");
+	auto num_patches = optional_argument<size_t>(extra_arguments, "num_patches");   // (optional: picks the residency)
 	return resolve_launch_configuration(device_properties, kernel_function_attributes,
-		num_dictionary_entries, data_length, cache_input_data_in_shared_mem, limits);
+		num_dictionary_entries, data_length, cache_input_data_in_shared_mem, limits, num_patches.value_or(0));
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned DictionaryIndexSize>

@@ -8,6 +8,10 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/discard_zero_bytes_fixed.hpp"
 
+#ifndef GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY
+#define GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -31,7 +35,7 @@ public:
 
 	launch_configuration_t resolve_launch_configuration(
 		device::properties_t device_properties, device_function::attributes_t kernel_function_attributes,
-		size_t length, launch_configuration_limits_t limits) const
+		size_t length, launch_configuration_limits_t limits, size_t num_patches = 0) const
 	{
 		fixed_width::launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize, translate(UncompressedEndianness), SerializationFactor>
 			params(device_properties, kernel_function_attributes, length);
@@ -42,6 +46,12 @@ public:
 		params.resident_blocks_per_multiprocessor_cap = nullopt;
 		if (UncompressedSize == 8) { params.resident_blocks_per_multiprocessor_cap = 2u; }
 		else if (!(UncompressedSize == 4 && CompressedSize == 1)) { params.resident_blocks_per_multiprocessor_cap = 4u; }
+		// (... for columns with few patches.  One whose rows wait for windows of patches from memory wants every wavefront it can have: a caller that states "num_patches"
+		// when resolving is not throttled where the ManyPatches build will be launched — <4,2,1> at 2 / 5 / 20 % of patches: 51 -> 69 / 45 -> 63 / 33 -> 47 % of the HBM peak,
+		// <4,8,1> at 5 / 20 %: 45 -> 70 / 41 -> 67, <4,4,2>: 66 -> 77 / 57 -> 70 — tools/experiments/dzbf_patched_residency.sh)
+		if (GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::discard_zero_bytes_fixed)) {
+			params.resident_blocks_per_multiprocessor_cap = nullopt;
+		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };
@@ -55,7 +65,8 @@ launch_configuration_t GIDDY_DZBFP_KERNEL::resolve_launch_configuration(
 	arguments_type extra_arguments, launch_configuration_limits_t limits) const
 {
 	auto length = argument<size_t>(extra_arguments, "length");
-	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits);
+	auto num_patches = optional_argument<size_t>(extra_arguments, "num_patches");   // (optional: picks the residency)
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, limits, num_patches.value_or(0));
 }
 
 GIDDY_DZBFP_TEMPLATE

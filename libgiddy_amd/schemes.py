@@ -261,7 +261,7 @@ def patched_discard_zero_bytes_fixed(decompressed, compressed_input, patch_value
               "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * compressed_size)),
               "length": r.uint_t(index_size)(length)}
     launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "u%d" % (8 * uncompressed_size), index_size))
-    return _run(key_patched(key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size)), {"length": r.size_t(length)}, launch,
+    return _run(key_patched(key_discard_zero_bytes_fixed(index_size, uncompressed_size, compressed_size)), {"length": r.size_t(length), "num_patches": r.size_t(num_patches)}, launch,
                 stream, device, limits, launch_config)
 
 
@@ -286,7 +286,7 @@ def patched_dictionary(decompressed, compressed_input, dictionary_entries, patch
                        uncompressed_size=4, dictionary_index_size=1, index_size=4, cache_dictionary_in_shared_mem=None,
                        stream=0, device=r.CURRENT_DEVICE, limits=None, launch_config=None):
     """dictionary() followed by scatter(), in one kernel"""
-    resolve = {"num_dictionary_entries": r.size_t(num_dictionary_entries), "data_length": r.size_t(length)}
+    resolve = {"num_dictionary_entries": r.size_t(num_dictionary_entries), "data_length": r.size_t(length), "num_patches": r.size_t(num_patches)}
     launch = {"decompressed": r.pointer(decompressed, "u%d" % (8 * uncompressed_size)),
               "compressed_input": r.const_pointer(compressed_input, "u%d" % (8 * dictionary_index_size)),
               "dictionary_entries": r.const_pointer(dictionary_entries, "u%d" % (8 * uncompressed_size)),
