@@ -8,6 +8,10 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 
+#ifndef GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY
+#define GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
+#endif
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -30,10 +34,16 @@ public:
 		device_function::attributes_t  kernel_function_attributes,
 		size_t                         length,
 		size_t                         segment_length,
-		launch_configuration_limits_t  limits) const
+		launch_configuration_limits_t  limits,
+		size_t                         num_patches = 0) const
 	{
 		delta::launch_config_resolution_params_t<IndexSize, UncompressedSize, CompressedSize> params(
 			device_properties, kernel_function_attributes, length, segment_length, limits.dynamic_shared_memory);
+		// (the plain kernel's throttle — 1-byte deltas of 8-byte elements: 4 resident workgroups per CU — suits columns with few patches; where the ManyPatches build will be
+		// launched, known when the caller states "num_patches" when resolving, the rows wait for windows of patches from memory and want every wavefront: as the other fused wrappers)
+		if (GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::delta)) {
+			params.resident_blocks_per_multiprocessor_cap = nullopt;
+		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);
 	}
 };
@@ -47,7 +57,8 @@ launch_configuration_t kernel_t<IndexSize, UncompressedSize, CompressedSize>::re
 {
 	auto length         = argument<size_t>(extra_arguments, "length");
 	auto segment_length = argument<size_t>(extra_arguments, "segment_length");
-	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits);
+	auto num_patches    = optional_argument<size_t>(extra_arguments, "num_patches");   // (optional: picks the residency)
+	return resolve_launch_configuration(device_properties, kernel_function_attributes, length, segment_length, limits, num_patches.value_or(0));
 }
 
 template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>

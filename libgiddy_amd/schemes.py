@@ -238,7 +238,7 @@ def patched_delta(decompressed, compressed_input, anchor_values, patch_values, p
               "length": r.uint_t(index_size)(length), "segment_length": r.uint_t(index_size)(segment_length)}
     launch.update(_patch_arguments(patch_values, patch_positions, num_patches, "u%d" % (8 * uncompressed_size), index_size))
     return _run(key_patched(key_delta(index_size, uncompressed_size, compressed_size)),
-                {"length": r.size_t(length), "segment_length": r.size_t(segment_length)}, launch,
+                {"length": r.size_t(length), "segment_length": r.size_t(segment_length), "num_patches": r.size_t(num_patches)}, launch,
                 stream, device, limits, launch_config)
 
 
