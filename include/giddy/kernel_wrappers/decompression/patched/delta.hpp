@@ -8,10 +8,6 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 
-#ifndef GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY
-#define GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -41,7 +37,7 @@ public:
 			device_properties, kernel_function_attributes, length, segment_length, limits.dynamic_shared_memory);
 		// (the plain kernel's throttle — 1-byte deltas of 8-byte elements: 4 resident workgroups per CU — suits columns with few patches; where the ManyPatches build will be
 		// launched, known when the caller states "num_patches" when resolving, the rows wait for windows of patches from memory and want every wavefront: as the other fused wrappers)
-		if (GIDDY_DELTA_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::delta)) {
+		if (sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::delta)) {
 			params.resident_blocks_per_multiprocessor_cap = nullopt;
 		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);

@@ -8,10 +8,6 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/dictionary.hpp"
 
-#ifndef GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY
-#define GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -47,7 +43,7 @@ public:
 		params.reserve_chunk_key_staging();   // (narrow keys of 8-byte values: staged through LDS, 2 resident workgroups per CU)
 		// (... for columns with few patches: where the ManyPatches build will be launched — known when the caller states "num_patches" when resolving — the rows wait for
 		// windows of patches from memory and want every wavefront they can have; as fused fixed-width discard-zero-bytes, patched/discard_zero_bytes_fixed.hpp)
-		if (GIDDY_DICT_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) data_length, 16 / UncompressedSize, sorted_patches::together_from::dictionary)) {
+		if (sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) data_length, 16 / UncompressedSize, sorted_patches::together_from::dictionary)) {
 			params.resident_blocks_per_multiprocessor_cap = nullopt;
 		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);

@@ -8,10 +8,6 @@
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernels/decompression/discard_zero_bytes_fixed.hpp"
 
-#ifndef GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY
-#define GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY 1   // (0: the residency of sparse columns whatever the patches — measurements)
-#endif
-
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -49,7 +45,7 @@ public:
 		// (... for columns with few patches.  One whose rows wait for windows of patches from memory wants every wavefront it can have: a caller that states "num_patches"
 		// when resolving is not throttled where the ManyPatches build will be launched — <4,2,1> at 2 / 5 / 20 % of patches: 51 -> 69 / 45 -> 63 / 33 -> 47 % of the HBM peak,
 		// <4,8,1> at 5 / 20 %: 45 -> 70 / 41 -> 67, <4,4,2>: 66 -> 77 / 57 -> 70 — tools/experiments/dzbf_patched_residency.sh)
-		if (GIDDY_DZBF_PATCHED_UNTHROTTLED_WHERE_MANY && sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::discard_zero_bytes_fixed)) {
+		if (sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::discard_zero_bytes_fixed)) {
 			params.resident_blocks_per_multiprocessor_cap = nullopt;
 		}
 		return cuda::kernels::resolve_launch_configuration(params, limits);
