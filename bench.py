@@ -40,12 +40,15 @@ def parse():
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=20)
-    p.add_argument("--warmup", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=5)
     p.add_argument("--log2n", type=int, default=30)
     p.add_argument("--workload", default="dictionary")
     p.add_argument("--schemes", default="all", help="extra per-scheme measurements at N=1: all (the BASELINE configs) | "
                    "coverage (all + DZB-fixed, Model, incidence bitmaps) | none | comma list")
     p.add_argument("--no-cpu-baseline", action="store_true")
+    p.add_argument("--extras", choices=("all", "none"), default="all", help="none: without the blocks that are not a BASELINE measurement (first call after idle, small columns, "
+                   "the three modes of use) — what tools/profile_round.sh runs under rocprofv3, so that a kernel's dispatches in the trace are its timed steps")
+    p.add_argument("--details", default=None, help="where the whole record goes (default: bench_details.json beside bench.py); the final stdout line is the compact one")
     p.add_argument("--gather", action="store_true", help="N > 1: after the timed region also time the one optional collective — the RCCL "
                    "point-to-point gather of every rank's decoded shard into one contiguous buffer on rank 0 (reported separately, never part of `value`)")
     p.add_argument("--gather-log2n", type=int, default=28, help="elements of each rank's decoded shard that are gathered")
@@ -210,20 +213,68 @@ def roofline(work, mean_launch_ms, traffic):
             "mean_launch_ms": round(mean_launch_ms, 4)}
 
 
+DETAILS_FILE = "bench_details.json"
+FINAL_LINE_LIMIT = 4096   # bytes: the driver recovers the line from the tail of stdout (round 5's 22 kB line came back `parsed: null`)
+
+
+def _fracs(entries, cold_first=True):
+    """{name: roofline.frac} of a `schemes` / `sharded` block of the full record"""
+    out = {}
+    for name, entry in (entries or {}).items():
+        r = entry.get("roofline") or entry.get("roofline_rank0") or {}
+        if "frac" in r:
+            out[name] = r["frac"]
+    return out
+
+
+def compact_line(line, details_file=DETAILS_FILE):
+    """The FINAL stdout line: the contract's keys + roofline + cpu_baseline + one flat map of roofline fractions per scheme.
+    Everything else of the record (`schemes`, `modes`, `sharded`, `small_columns`, `first_call`, the predictions) is in `details_file`."""
+    pick = lambda d, keys: {k: d[k] for k in keys if k in d}
+    out = pick(line, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    out["config"] = pick(line.get("config", {}), ("workload", "instantiation", "elements_per_gpu", "elements_total", "launch"))
+    if "roofline" in line:
+        out["roofline"] = pick(line["roofline"], ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "mean_launch_ms",
+                                                  "measured_copy_GBps", "frac_of_measured_copy"))
+    if "cpu_baseline" in line:
+        out["cpu_baseline"] = pick(line["cpu_baseline"], ("value", "unit", "cores", "kind", "single_thread_value", "cpu", "sample"))
+    if line.get("schemes"):
+        out["schemes_frac"] = _fracs(line["schemes"])
+    if line.get("sharded"):
+        out["sharded_frac"] = _fracs(line["sharded"])
+        predicted = {name: entry["predicted_strong_efficiency_at_8"] for name, entry in line["sharded"].items() if "predicted_strong_efficiency_at_8" in entry}
+        if predicted:
+            out["predicted_strong_efficiency_at_8"] = predicted
+    out["details"] = details_file
+    return out
+
+
+def emit(line, details_path=None):
+    """rank 0: the whole record -> bench_details.json (and stderr, for the log); the compact line LAST on stdout"""
+    details_path = details_path or os.path.join(ROOT, DETAILS_FILE)
+    text = json.dumps(line, allow_nan=False)
+    try:
+        with open(details_path, "w") as f:
+            f.write(text + "\n")
+    except OSError as problem:   # (a read-only checkout must not cost the line)
+        print("bench.py: could not write %s: %r" % (details_path, problem), file=sys.stderr)
+    print(text, file=sys.stderr)
+    sys.stderr.flush()
+    final = json.dumps(compact_line(line, os.path.basename(details_path)), allow_nan=False)
+    assert len(final) < FINAL_LINE_LIMIT, "the final line has grown to %d bytes" % len(final)
+    print(final)
+    sys.stdout.flush()
+
+
 def measured_copy_ceiling():
-    """what this box sustains on a plain device-to-device copy of 4 GiB (hipMemcpy D2D via torch), read + write GB/s"""
-    import torch
-    a = torch.empty(1 << 30, dtype=torch.int32, device="cuda")
-    b = torch.empty_like(a)
-    b.copy_(a); torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
-    for begin, end in events:
-        begin.record(); b.copy_(a); end.record()
-    torch.cuda.synchronize()
-    ms = sorted(x.elapsed_time(y) for x, y in events)[2]
-    del a, b
-    torch.cuda.empty_cache()
-    return round(2 * 4 * (1 << 30) / ms / 1e6, 1)
+    """What this box sustains on the library's own streaming loop with the identity in place of a decoder (tools/stream_ceiling.py,
+    tests/cpp/stream_ceiling.hip: 16 bytes a lane, the decoders' non-temporal stores): a plain copy, and the headline's 1 B in : 4 B out shape.
+    bytes read + written per second.  None when the measurement library is not built."""
+    import stream_ceiling
+    try:
+        return stream_ceiling.measure()
+    except (FileNotFoundError, OSError) as problem:
+        return {"skipped": repr(problem)}
 
 
 def cpu_model():
@@ -600,7 +651,7 @@ def main():
             "roofline": entry.pop("this_rank_roofline"), "sharded": {args.workload: entry},
         }
         if rank == 0:
-            print(json.dumps(line))
+            emit(line, args.details)
         if world > 1:
             dist.destroy_process_group()
         return
@@ -609,7 +660,7 @@ def main():
     work = make_workload(args.workload, n, device)
     work.run(torch.cuda.current_stream().cuda_stream)
     work.verify(oracle)                                   # bit-exact before anything is reported
-    first_call = first_call_after_idle(work) if world == 1 else None
+    first_call = first_call_after_idle(work) if world == 1 and args.extras == "all" else None
     elapsed, mean_launch_ms = timed_steps(work, args.steps, args.warmup, barrier)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
@@ -634,7 +685,7 @@ def main():
 
     if first_call is not None:
         line["first_call"] = first_call
-    if rank == 0 and world == 1 and args.schemes != "none" and hasattr(work, "shard_function"):
+    if rank == 0 and world == 1 and args.schemes != "none" and args.extras == "all" and hasattr(work, "shard_function"):
         line["small_columns"] = {args.workload: small_columns(args.workload, work, device)}
     if args.gather and world > 1:
         count = min(n, 1 << args.gather_log2n)
@@ -642,8 +693,14 @@ def main():
 
     if rank == 0 and world == 1:
         ceiling = measured_copy_ceiling()
-        line["roofline"]["measured_d2d_copy_GBps"] = ceiling
-        line["roofline"]["frac_of_measured_copy"] = round(line["roofline"]["achieved"] / ceiling, 4)
+        if "copy_GBps" in ceiling:
+            line["roofline"]["measured_copy_GBps"] = ceiling["copy_GBps"]
+            line["roofline"]["frac_of_measured_copy"] = round(line["roofline"]["achieved"] / ceiling["copy_GBps"], 4)
+            line["roofline"]["measured_widening_stream_GBps"] = ceiling["widen_1_to_4_GBps"]
+            line["roofline"]["measured_ceiling_note"] = ("the library's tile loop (stream_tiles::transform, 16 B per lane, non-temporal stores) with the identity in place of a decoder, "
+                                                         "2^30 elements, median of 10 launches: a 4 B : 4 B copy, and a 1 B : 4 B widening stream (the headline's traffic shape)")
+        else:
+            line["roofline"]["measured_copy"] = ceiling
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(work, min(n, 1 << args.cpu_sample_log2))
 
@@ -682,7 +739,7 @@ def main():
                 entry["decompressed_GBps_input_in_infinity_cache"], entry["ms_per_step_input_in_infinity_cache"] = entry["decompressed_GBps"], entry["ms_per_step"]
                 entry["decompressed_GBps"] = round(w.decompressed_bytes / (pc["ms_three_columns_in_turn"] * 1e-3) / 1e9, 1)
                 entry["ms_per_step"] = pc["ms_three_columns_in_turn"]
-            if name in ("frame_of_reference", "delta_patched", "run_length_encoding", "discard_zero_bytes_variable"):
+            if args.extras == "all" and name in ("frame_of_reference", "delta_patched", "run_length_encoding", "discard_zero_bytes_variable"):
                 line.setdefault("small_columns", {})[name] = small_columns(name, w, device)
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
@@ -692,7 +749,7 @@ def main():
         line["schemes"] = schemes_out
 
     # ---- the reference's three modes of use on two of the columns whose wrappers pick among several kernels (N = 1 only) ----
-    if world == 1 and args.schemes != "none":
+    if world == 1 and args.schemes != "none" and args.extras == "all":
         try:
             line["modes"] = modes_of_use(n, device, max(5, args.steps // 2))
         except Exception as problem:   # (the C++ shim is test infrastructure: its absence must not cost the bench line)
@@ -716,7 +773,7 @@ def main():
                                                                 "itself would scale like.  The scaling curve at N = 2, 4, 8 is UNMEASURED: no multi-GPU node has been available to any round")
 
     if rank == 0:
-        print(json.dumps(line))
+        emit(line, args.details)
     if world > 1:
         dist.destroy_process_group()
 

@@ -1,0 +1,42 @@
+// What this box sustains on the library's OWN streaming loop (giddy/on_device/stream_tiles.hpp: 16 bytes per lane, K steps a tile, non-temporal
+// stores, one tile a workgroup) with the identity in place of a decoder — the measured ceiling bench.py reports beside the 8 TB/s paper peak
+// ("a measured on-box copy ceiling").  Two shapes:
+//   stream_copy      4 bytes in : 4 bytes out per element   (a plain copy)
+//   stream_widen     1 byte  in : 4 bytes out per element   (Dictionary<4,4,1>'s and DZB-fixed<4,4,1>'s traffic without their arithmetic)
+// Measurement infrastructure behind ctypes (tools/stream_ceiling.py); not part of libgiddy_amd.so.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "giddy/on_device/stream_tiles.hpp"
+
+namespace {
+
+template <typename In, typename Out>
+__global__ void __launch_bounds__(256) identity_stream(Out* __restrict__ out, const In* __restrict__ in, uint64_t n)
+{
+	using namespace cuda;
+	constexpr unsigned G = stream_tiles::group_size<Out>::value;
+	stream_tiles::transform<In, Out>(out, in, n,
+		[](uint64_t, const memory_access::group<In, G>& a, memory_access::group<Out, G>& b) {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { b[j] = (Out) a[j]; }
+		},
+		[](uint64_t, In x) { return (Out) x; });
+}
+
+template <typename In, typename Out>
+int launch(void* out, const void* in, uint64_t n, void* stream)
+{
+	constexpr uint64_t per_block = 256 * cuda::stream_tiles::elements_per_thread_per_tile<Out>();
+	const uint64_t blocks = (n + per_block - 1) / per_block;
+	if (blocks == 0) { return 0; }
+	if (blocks > 0x7fffffffull) { return (int) hipErrorInvalidConfiguration; }
+	identity_stream<In, Out><<<dim3((unsigned) blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(static_cast<Out*>(out), static_cast<const In*>(in), n);
+	return (int) hipGetLastError();
+}
+
+} // namespace
+
+extern "C" int stream_copy(void* out, const void* in, uint64_t elements_of_4_bytes, void* stream) { return launch<uint32_t, uint32_t>(out, in, elements_of_4_bytes, stream); }
+extern "C" int stream_widen(void* out, const void* in, uint64_t elements, void* stream) { return launch<uint8_t, uint32_t>(out, in, elements, stream); }

@@ -14,3 +14,6 @@ el, ms = bench.timed_steps(w, steps, 2, lambda: None)
 print("%-34s %-28s %8.4f ms (whole step %8.4f ms)  %7.1f GB/s algorithmic (%.1f%% of 8 TB/s)  cfg=%s" % (
     os.path.basename(os.environ.get("GIDDY_LIBRARY_PATH", "default")), name, ms, el * 1e3 / steps, w.algorithmic_bytes / ms / 1e6,
     w.algorithmic_bytes / ms / 1e6 / 80.0, w.config))
+# (tools/summarize_profiles.py reads this line out of the --pmc passes' logs: algorithmic bytes of every workload, whether or not a bench line carries it)
+print("WORKLOAD_RECORD " + json.dumps({"workload": name, "elements": w.n, "algorithmic_bytes_per_launch": w.algorithmic_bytes, "kernel": w.kernel,
+                                       "instantiation": w.name, "mean_launch_ms": round(ms, 4)}))

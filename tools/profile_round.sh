@@ -11,9 +11,9 @@ if [ -z "${SKIP_PMC:-}" ]; then rm -rf $OUT; fi; mkdir -p $OUT; rm -rf $OUT/trac
 hipcc --offload-arch=gfx950 -O3 tools/pmc_calibrate.hip -o /tmp/pmc_calibrate
 # 1. kernel trace + stats of the bench command itself (ONLY_PMC=1 skips it)
 if [ -z "${ONLY_PMC:-}" ]; then
-timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --sharded none > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+timeout 1200 rocprofv3 --kernel-trace --stats -d $OUT/trace -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sharded none --extras none --schemes coverage --details $OUT/bench_under_rocprof.details.json > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 # ... and the headline workload ALONE (the Zipf entry of the full line launches the same kernel: its dispatches would mix into "the last 20")
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_headline -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline --sharded none --schemes none > $OUT/bench_headline_under_rocprof.json 2> $OUT/bench_headline_under_rocprof.err
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_headline -o bench --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sharded none --extras none --schemes none --details $OUT/bench_headline_under_rocprof.details.json > $OUT/bench_headline_under_rocprof.json 2> $OUT/bench_headline_under_rocprof.err
 fi
 # 2. PMC passes (separate runs); WORKLOADS="a b" overrides the list; SKIP_PMC=1 keeps the passes of an earlier call
 if [ -n "${SKIP_PMC:-}" ]; then exit 0; fi

@@ -1,0 +1,61 @@
+"""The measured streaming ceiling of this box (tests/cpp/stream_ceiling.hip): the library's own tile loop with the identity in place of a decoder,
+as a plain copy (4 B in : 4 B out) and as Dictionary<4,4,1>'s traffic shape (1 B in : 4 B out).  GB/s of bytes read + written, by HIP events on the launch stream."""
+import ctypes
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SHIM = os.path.join(ROOT, "tests", "cpp", "bin", "libstream_ceiling.so")
+_shim = None
+
+
+def build_shim():
+    os.makedirs(os.path.dirname(SHIM), exist_ok=True)
+    subprocess.check_call(["hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "cpp", "stream_ceiling.hip"), "-o", SHIM])
+
+
+def shim():
+    """never a compiler from a process that has initialised the GPU: absent -> FileNotFoundError (__graft_entry__.build() builds it)"""
+    global _shim
+    if _shim is None:
+        if not os.path.exists(SHIM):
+            raise FileNotFoundError("tests/cpp/bin/libstream_ceiling.so is not built (python -c 'import __graft_entry__ as g; g.build_cpp_test_tools()')")
+        _shim = ctypes.CDLL(SHIM)
+        for f in (_shim.stream_copy, _shim.stream_widen):
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            f.restype = ctypes.c_int
+    return _shim
+
+
+def measure(log2n=30, repetitions=10):
+    """{"copy_GBps", "widen_1_to_4_GBps"}: medians of `repetitions` launches over 2^log2n elements"""
+    import torch
+    s = shim()
+    n = 1 << log2n
+    stream = torch.cuda.current_stream().cuda_stream
+    out = torch.empty(n, dtype=torch.int32, device="cuda")
+    results = {}
+    for name, fn, in_bytes in (("copy_GBps", s.stream_copy, 4), ("widen_1_to_4_GBps", s.stream_widen, 1)):
+        source = torch.randint(0, 127, (n * in_bytes,), dtype=torch.int8, device="cuda")
+        for _ in range(3):
+            assert fn(out.data_ptr(), source.data_ptr(), n, stream) == 0
+        torch.cuda.synchronize()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repetitions)]
+        for begin, end in events:
+            begin.record(); fn(out.data_ptr(), source.data_ptr(), n, stream); end.record()
+        torch.cuda.synchronize()
+        ms = sorted(b.elapsed_time(e) for b, e in events)[repetitions // 2]
+        if in_bytes == 1:   # (the identity is checked once: what was timed is a copy)
+            assert bool((out[: 1 << 20] == source[: 1 << 20].to(torch.int32)).all())
+        else:
+            assert bool((out[: 1 << 20] == source.view(torch.int32)[: 1 << 20]).all())
+        results[name] = round((in_bytes + 4) * n / ms / 1e6, 1)
+        del source
+    del out
+    torch.cuda.empty_cache()
+    return results
+
+
+if __name__ == "__main__":
+    print(measure())

@@ -48,6 +48,79 @@ def launches_per_step(workload, elements):
     return max(1, (8 * int(elements) + (1 << 29)) >> 30)
 
 
+def details_of(stdout_path, details_path):
+    """the whole record of a bench run: its --details file (since round 6 the final stdout line is the compact one), else the last stdout line"""
+    try:
+        return open(details_path).read().strip().splitlines()[-1]
+    except OSError:
+        return open(stdout_path).read().strip().splitlines()[-1]
+
+
+def timed_region(durations, steps):
+    """The dispatches of a kernel that belong to a timed region of the bench command: of the FULL-SIZE column — at least half the kernel's longest
+    dispatch, which leaves out the thousands of 2^18-element columns `small_columns` launches afterwards and the pre-passes' tiny launches (round 5 took
+    "the last N dispatches" and reported those: 3.8 us for FOR) — and of those the last `steps` (the headline runs 20 timed steps, the others 10; DZB-variable
+    2^28 x 8 bytes is two launches per step; a run decoder's entry ends with 3 x 10 launches of three columns in turn)."""
+    if not durations:
+        return []
+    longest = max(durations)
+    full_size = [x for x in durations if 2 * x >= longest]
+    return full_size[-steps:]
+
+
+# which of a scheme's kernels a workload's step launches, where the scheme's name alone does not say (template arguments as rocprofv3 prints them)
+ROW_FILTERS = {
+    "run_position_encoding_relative": lambda name: ", true," in name.split("(")[0],
+    "run_position_encoding_absolute": lambda name: ", false," in name.split("(")[0],
+    "delta_patched": lambda name: "patched" not in name,
+}
+
+
+def roofline_from_the_trace(timed_rows, bench):
+    """<round>_roofline_from_rocprof.md: every workload of the bench line under rocprofv3 — algorithmic bytes per launch (the line's) over the mean
+    duration of the kernel's timed-region dispatches in the KERNEL TRACE, beside the fraction the line itself reports from HIP events."""
+    entries = [("dictionary", bench["roofline"], None)] + [(n, e["roofline"], e.get("elements")) for n, e in bench.get("schemes", {}).items()]
+    out = ["# Roofline fractions recomputed from the rocprofv3 kernel trace (%s)\n" % ROUND,
+           "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sharded none --extras none --schemes coverage` (tools/profile_round.sh);",
+           "timed region = the last 10 (headline, DZB-variable: 20) dispatches of the kernel that last at least half its longest dispatch (`%s_kernel_stats.csv`, TimedRegionAverageNs);" % ROUND,
+           "fraction = algorithmic bytes per step / (launches per step x that mean) / 8 TB/s.  `events` = the same fraction as bench.py reports it from HIP events in the same run.\n",
+           "| workload | kernel row | launches/step | timed-region mean ns | algorithmic bytes/step | frac (trace) | frac (events) | trace/events |", "|---|---|---|---|---|---|---|---|"]
+    for workload, roofline, elements in entries:
+        scheme = KERNELS.get("dictionary" if workload == "dictionary_zipf" else workload)
+        if scheme is None:
+            continue
+        namespace = scheme.rsplit("::", 1)[0] + "::"
+        patched = "::patched::" in scheme
+        accept = ROW_FILTERS.get(workload, lambda name: True)
+        if workload in ("dictionary", "dictionary_zipf"):
+            accept = lambda name, zipf=(workload == "dictionary_zipf"): name.startswith("zipf-keyed column: ") == zipf
+        rows = [r for r in timed_rows if namespace in r[0] and ("::patched::" in r[0]) == patched and "decode_pieces" not in r[0] and "_pieces<" not in r[0] and accept(r[0]) and r[1] > 0]
+        if not rows:
+            continue
+        name, calls, mean_ns, _ = max(rows, key=lambda r: r[3])   # the kernel of the scheme the run spent most time in: the step's decoder, not a pre-pass
+        per_step = launches_per_step(workload, elements)
+        frac = roofline["algorithmic_bytes_per_launch"] / (per_step * mean_ns * 1e-9) / 8e12
+        short = name.replace("void cuda::kernels::", "").split("(")[0]
+        out.append("| %s | `%s` | %d | %.1f | %d | %.4f | %.4f | %.3f |" % (workload, short, per_step, mean_ns, roofline["algorithmic_bytes_per_launch"], frac, roofline["frac"], frac / roofline["frac"]))
+    with open(os.path.join(OUT, ROUND + "_roofline_from_rocprof.md"), "w") as f:
+        f.write("\n".join(out) + "\n")
+    print("\n".join(out))
+
+
+def records_of_the_passes():
+    """{workload: WORKLOAD_RECORD of tools/bench_one.py} out of the --pmc passes' logs"""
+    found = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        for workload in KERNELS:
+            try:
+                for line in open(os.path.join(RAW, "pmc_%s_%s.log" % (counter, workload))):
+                    if line.startswith("WORKLOAD_RECORD "):
+                        found[workload] = json.loads(line[len("WORKLOAD_RECORD "):])
+            except (OSError, ValueError):
+                pass
+    return found
+
+
 def mean_counter(path, kernel_substring):
     values = [float(r["Counter_Value"]) for r in csv.DictReader(open(path)) if kernel_substring in r["Kernel_Name"]]
     return (sum(values) / len(values), len(values)) if values else (None, 0)
@@ -74,16 +147,22 @@ def main():
     with open(os.path.join(OUT, ROUND + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "TimedRegionCalls", "TimedRegionAverageNs"])
+        timed_rows = []
         for r in ours:
             d = durations_by_kernel.get("headline alone: " + r["Name"]) or durations_by_kernel.get(r["Name"], [])
-            # (the headline runs 20 timed steps, the others 10; DZB-variable 2^28 x 8 bytes: two launches per step; since round 4 the run decoders' entries end
-            # with 3 x 10 launches of three columns in turn and the `modes` block follows: their "timed region" here is the trace's last dispatches of the kernel)
-            timed = d[-20:] if "dictionary" in r["Name"] else (d[-20:] if "variable_width" in r["Name"] else d[-10:])
+            timed = timed_region(d, 20 if ("dictionary::decompress" in r["Name"] or "variable_width" in r["Name"]) else 10)
             w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
                         len(timed), "%.1f" % (sum(timed) / max(len(timed), 1))])
-    bench_line = open(os.path.join(RAW, "bench_under_rocprof.json")).read().strip().splitlines()[-1]
+            timed_rows.append((r["Name"], len(timed), sum(timed) / max(len(timed), 1), float(r["TotalDurationNs"])))
+            if "dictionary::decompress" in r["Name"] and durations_by_kernel.get("headline alone: " + r["Name"]):
+                # (in the full trace the kernel's last dispatches are the Zipf-keyed column's timed steps: the same kernel, the entry after the headline's)
+                zipf = timed_region(durations_by_kernel.get(r["Name"], []), 10)
+                timed_rows.append(("zipf-keyed column: " + r["Name"], len(zipf), sum(zipf) / max(len(zipf), 1), float(r["TotalDurationNs"])))
+    bench_line = details_of(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(RAW, "bench_under_rocprof.details.json"))
     with open(os.path.join(OUT, ROUND + "_bench_under_rocprof.json"), "w") as f:
         f.write(bench_line + "\n")
+
+    roofline_from_the_trace(timed_rows, json.loads(bench_line))
 
     # ---- calibration ---------------------------------------------------------------------------------
     known_kib = (1 << 30) / 1024.0
@@ -113,6 +192,9 @@ def main():
             algorithmic.setdefault(name, entry["roofline"]["algorithmic_bytes_per_launch"])
     except (OSError, ValueError, KeyError):
         pass
+    for name, record in records_of_the_passes().items():   # every workload of the passes says its own algorithmic bytes
+        algorithmic.setdefault(name, record["algorithmic_bytes_per_launch"])
+        elements.setdefault(name, record["elements"])
     traffic, lines = {}, []
     for workload, kernel in KERNELS.items():
         try:
