@@ -151,21 +151,17 @@ __device__ __forceinline__ void decompress(
 			const uint64_t at = (uint64_t) i * blockDim.x + threadIdx.x;
 			if (at < num_dictionary_entries) { my_entries[i] = dictionary_entries[at]; }
 		}
-		// (Every thread gets here exactly once, so every wavefront takes the barrier inside exactly once — but from different call
-		// sites of the tile loop.  That relies on what s_barrier IS on CDNA — a count of arriving wavefronts, whatever their program
-		// counters — not on the textual convergence HIP's __syncthreads contract asks for; hoisting it in front of the loop costs the
-		// overlap this arrangement exists for.  If the workgroup is smaller than the launch parameters assumed — a caller's block-size
-		// limit — the test above fails and the plain staging loop below runs instead: correct, with several tiles per workgroup.)
-		bool staged_yet = false;
+		// (stream_tiles calls the hook once per thread, from one place outside its loops — behind the loads of the workgroup's first tile /
+		// the wavefront's first chunk: one textual __syncthreads() that every thread of the workgroup reaches on the same path.  If the
+		// workgroup is smaller than the launch parameters assumed — a caller's block-size limit — the test above fails and the plain
+		// staging loop below runs instead: correct, with several tiles per workgroup.)
 		auto stage = [&]() {
-			if (staged_yet) { return; }
 			#pragma unroll
 			for (unsigned i = 0; i < entries_per_thread; i++) {
 				const uint64_t at = (uint64_t) i * blockDim.x + threadIdx.x;
 				if (at < num_dictionary_entries) { staged[at] = my_entries[i]; }
 			}
 			__syncthreads();
-			staged_yet = true;
 		};
 		translate<UncompressedSize, DictionaryIndexSize, true, AnyAlignment>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage, grid);

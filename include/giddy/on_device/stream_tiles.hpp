@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <type_traits>
 
 #include "giddy/kernels/tuning.hpp"
 #include "giddy/on_device/launch_grid.hpp"
@@ -30,9 +31,12 @@ struct nothing_to_do { __device__ __forceinline__ void operator()() const { } };
 
 /// out[p] = produce(p, in[p]) for p < n.  `produce_group(first_position, inputs, outputs)` handles G
 /// consecutive elements at once (it may hoist per-group work such as a segment lookup).
-/// `after_loads()` is called by every thread of the workgroup — the same number of times — once a tile's loads
-/// have been issued and before the first produce (and once before the scalar tail): the place for a side table's
-/// trip through LDS, so that its latency overlaps the tile's own loads.  It must be idempotent.
+/// `after_loads()` is called by every thread of the workgroup EXACTLY ONCE, from ONE place in the function that is not inside a loop
+/// or a condition — behind the loads of the workgroup's first tile (if it has one), before the first produce: the place for a side
+/// table's trip through LDS with its barrier, so that the table's latency overlaps the tile's own loads.  (A decoder that passes one
+/// gets the loop in its software-pipelined form, `pipelined_tiles` below: the same order of memory operations, with the call hoisted
+/// out of the loop — until round 6 the hook ran per tile, guarded by a flag, and its __syncthreads() was reached from three call
+/// sites, which is outside what HIP promises for a barrier.)
 struct no_context { };
 struct nothing_to_prepare { __device__ __forceinline__ no_context operator()(uint64_t) const { return no_context(); } };
 
@@ -61,6 +65,67 @@ __host__ __forceinline__ bool wants_any_alignment_build(const Out* out, const In
 	return (reinterpret_cast<uintptr_t>(out) & 127) != 0 || (reinterpret_cast<uintptr_t>(in) & (in_bytes - 1)) != 0;
 }
 
+/// transform()'s tile loop for a decoder with an `after_loads` hook, software-pipelined so that the hook is called from one place: the first tile's loads,
+/// the hook, then { produce and store the tile; the next tile's loads } while there are tiles.  Every quantity the loop branches on (the tile index, whether a
+/// tile is whole) is the same for all the threads of a workgroup.  `lead`: elements in front of the first group (the AnyAlignment build), else 0.
+template <typename In, typename Out, unsigned K, int Stores, bool AnyAlignment, typename ProduceGroup, typename AfterLoads, typename Grid>
+__device__ __forceinline__ void pipelined_tiles(
+	Out* __restrict__ out, const In* __restrict__ in, uint64_t lead, uint64_t num_groups, ProduceGroup& produce_group, AfterLoads& after_loads, const Grid& grid)
+{
+	using namespace memory_access;
+	constexpr unsigned G = group_size<Out>::value;
+	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+	group<In, G> inputs[K];
+	auto load = [&](uint64_t g) { if constexpr (AnyAlignment) { return load_group_at_any_alignment<In, G>(in + g * G); } else { return load_group<In, G>(in + g * G); } };
+	auto load_tile = [&](uint64_t tile) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		if ((tile + 1) * groups_per_tile <= num_groups) {
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { inputs[k] = load(first_group + (uint64_t) k * blockDim.x); }
+		}
+		else {
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				if (g < num_groups) { inputs[k] = load(g); }
+			}
+		}
+	};
+	uint64_t tile = grid.block();
+	bool more = tile * groups_per_tile < num_groups;
+	if (more) { load_tile(tile); }
+	after_loads();
+	while (more) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		if ((tile + 1) * groups_per_tile <= num_groups) {
+			// a whole tile (every tile but possibly the last): no per-step bounds checks
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				group<Out, G> outputs;
+				produce_group(lead + g * G, inputs[k], outputs);
+				store_group<Stores>(out + g * G, outputs);
+				// narrow elements: G look-ups per step — keep the steps' work from being hoisted above one another
+				// (all K x 16 look-ups of a 1-byte column in flight at once cost half the occupancy)
+				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
+			}
+		}
+		else {
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				if (g >= num_groups) { continue; }
+				group<Out, G> outputs;
+				produce_group(lead + g * G, inputs[k], outputs);
+				store_group<Stores>(out + g * G, outputs);
+			}
+		}
+		tile += grid.blocks();
+		more = tile * groups_per_tile < num_groups;
+		if (more) { load_tile(tile); }
+	}
+}
+
 /// `prepare(first_position)` -> a group's context (say, its segment's record): for a whole tile ALL the contexts are
 /// requested right behind the tile's input loads and before its first store — a load issued between two stores would
 /// have to wait for the earlier store (CDNA4 counts vector memory operations in order).
@@ -81,6 +146,8 @@ __device__ __forceinline__ void transform(
 	constexpr unsigned G = group_size<Out>::value;
 	constexpr unsigned K = Steps;
 	constexpr unsigned in_bytes = G * sizeof(In) >= 16 ? 16 : G * sizeof(In);
+	constexpr bool has_hook = !std::is_same<AfterLoads, nothing_to_do>::value;
+	static_assert(!has_hook || (std::is_same<Prepare, nothing_to_prepare>::value && !ProduceAllFirst), "a decoder with an after_loads hook takes the pipelined loop, which has neither contexts nor ProduceAllFirst");
 
 	if constexpr (AnyAlignment) {
 		// (the first 128-BYTE boundary: a wavefront's store instruction then writes whole lines — from a 16-byte boundary that is not one of those, the same tiles run at 54 % of the HBM peak against 91)
@@ -89,6 +156,10 @@ __device__ __forceinline__ void transform(
 		const In* __restrict__ in_at_boundary = in + lead;
 		const uint64_t num_groups = (n - lead) / G;
 		const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
+		if constexpr (has_hook) {
+			pipelined_tiles<In, Out, K, Stores, true>(out_at_boundary, in_at_boundary, lead, num_groups, produce_group, after_loads, grid);
+		}
+		else
 		for (uint64_t tile = grid.block(); tile * groups_per_tile < num_groups; tile += grid.blocks()) {
 			const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 			group<In, G> inputs[K];
@@ -97,7 +168,6 @@ __device__ __forceinline__ void transform(
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
 				if (g < num_groups) { inputs[k] = load_group_at_any_alignment<In, G>(in_at_boundary + g * G); }
 			}
-			after_loads();
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) {
 				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
@@ -107,7 +177,6 @@ __device__ __forceinline__ void transform(
 				store_group<Stores>(out_at_boundary + g * G, outputs);
 			}
 		}
-		after_loads();
 		const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
 		const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 		for (uint64_t p = global_thread; p < lead; p += num_threads) { out[p] = produce_one(p, in[p]); }
@@ -119,6 +188,10 @@ __device__ __forceinline__ void transform(
 	const uint64_t num_groups = vectorizable ? n / G : 0;
 	const uint64_t groups_per_tile = (uint64_t) blockDim.x * K;
 
+	if constexpr (has_hook) {
+		pipelined_tiles<In, Out, K, Stores, false>(out, in, 0, num_groups, produce_group, after_loads, grid);
+	}
+	else
 	for (uint64_t tile = grid.block(); tile * groups_per_tile < num_groups; tile += grid.blocks()) {
 		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 		group<In, G> inputs[K];
@@ -130,7 +203,6 @@ __device__ __forceinline__ void transform(
 			decltype(prepare((uint64_t) 0)) contexts[K];
 			#pragma unroll
 			for (unsigned k = 0; k < K; k++) { contexts[k] = prepare((first_group + (uint64_t) k * blockDim.x) * G); }
-			after_loads();
 			if constexpr (ProduceAllFirst) {
 				group<Out, G> outputs[K];
 				#pragma unroll
@@ -163,7 +235,6 @@ __device__ __forceinline__ void transform(
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
 			if (g < num_groups) { inputs[k] = load_group<In, G>(in + g * G); }
 		}
-		after_loads();
 		#pragma unroll
 		for (unsigned k = 0; k < K; k++) {
 			uint64_t g = first_group + (uint64_t) k * blockDim.x;
@@ -174,7 +245,6 @@ __device__ __forceinline__ void transform(
 		}
 	}
 
-	after_loads();
 	const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
 	const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 	for (uint64_t p = num_groups * G + global_thread; p < n; p += num_threads) { out[p] = produce_one(p, in[p]); }
@@ -218,7 +288,7 @@ template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, uns
 	typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void transform_and_patch(
 	Out* __restrict__ out, const In* __restrict__ in, uint64_t n, ProduceGroup produce_group, ProduceOne produce_one, Patches patches,
-	AfterLoads after_loads = AfterLoads(),   // (as in transform(): here a wavefront may call it a different number of times than its neighbours)
+	AfterLoads after_loads = AfterLoads(),   // (as in transform(): called once per thread, from one place outside the chunk loop)
 	chunk_input_storage<In, Out, stages_chunk_input<In, Out, StageUpToBytesPerLane>()>* staging = nullptr, Grid grid = Grid())
 {
 	using namespace memory_access;
@@ -239,6 +309,81 @@ __device__ __forceinline__ void transform_and_patch(
 	constexpr unsigned chunk_input_bytes = rows_per_chunk * row * sizeof(In);
 	const bool may_stage = stage_chunk_input && staging != nullptr && wave64::index_in_block() < chunk_staging_waves && is_aligned(in, 16);
 
+	constexpr bool has_hook = !std::is_same<AfterLoads, nothing_to_do>::value;
+	if constexpr (has_hook) {
+		// The same chunk loop software-pipelined, so that the hook (a side table's trip through LDS and its BARRIER) is called from one place that every
+		// wavefront of the workgroup passes exactly once, whatever its number of chunks and whichever of the two forms its chunks take: the first chunk's
+		// seek probes and loads, the hook, then { the chunk; the next chunk's probes and loads } while there are chunks.
+		using piece_t = typename chunk<16>::type;
+		constexpr unsigned pieces_per_lane = stage_chunk_input ? chunk_input_bytes / 16 / wave64::size : 1;
+		static_assert(!stage_chunk_input || (pieces_per_lane >= 1 && chunk_input_bytes % (16 * wave64::size) == 0), "a chunk's input is a whole number of 16-byte pieces per lane");
+		piece_t pieces[pieces_per_lane];
+		group<In, G> current[R], next[R];
+		auto end_of = [&](uint64_t first_row) { return first_row + rows_per_chunk < num_rows ? first_row + rows_per_chunk : num_rows; };
+		auto comes_through_lds = [&](uint64_t first_row) { return stage_chunk_input && may_stage && end_of(first_row) - first_row == rows_per_chunk; };   // wave-uniform
+		auto issue = [&](uint64_t c) {
+			const uint64_t first_row = c * rows_per_chunk, end_row = end_of(first_row);
+			patches.begin_seek(first_row * row, lane);   // (its probes go out ahead of the first rows' loads, the rest behind them)
+			if (comes_through_lds(first_row)) {
+				const piece_t* source = reinterpret_cast<const piece_t*>(in + first_row * row);
+				#pragma unroll
+				for (unsigned i = 0; i < pieces_per_lane; i++) { pieces[i] = source[i * wave64::size + lane]; }
+			}
+			else {
+				#pragma unroll
+				for (unsigned k = 0; k < R; k++) {
+					if (first_row + k < end_row) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }
+				}
+			}
+		};
+		uint64_t c = wave;
+		if (c < num_chunks) { issue(c); }
+		after_loads();
+		while (c < num_chunks) {
+			const uint64_t first_row = c * rows_per_chunk, end_row = end_of(first_row);
+			patches.finish_seek(lane);
+			if (comes_through_lds(first_row)) {
+				if constexpr (stage_chunk_input) {
+					In* mine = staging->inputs[wave64::index_in_block()];
+					wave64::lds_fence();   // (the previous chunk's rows have been read)
+					#pragma unroll
+					for (unsigned i = 0; i < pieces_per_lane; i++) { reinterpret_cast<piece_t*>(mine)[i * wave64::size + lane] = pieces[i]; }
+					wave64::lds_fence();
+					for (uint64_t r = first_row; r < end_row; r++) {
+						const uint64_t p = r * row + lane * G;
+						const group<In, G> inputs = load_group<In, G>(mine + (r - first_row) * row + lane * G);
+						group<Out, G> outputs;
+						produce_group(p, inputs, outputs);
+						patches.template apply_to_row<G>(r * row, lane, outputs);
+						store_group(out + p, outputs);
+					}
+				}
+			}
+			else {
+				for (uint64_t r = first_row; r < end_row; r += R) {
+					#pragma unroll
+					for (unsigned k = 0; k < R; k++) {
+						if (r + R + k < end_row) { next[k] = load_group<In, G>(in + (r + R + k) * row + lane * G); }
+					}
+					#pragma unroll
+					for (unsigned k = 0; k < R; k++) {
+						if (r + k >= end_row) { continue; }   // wave-uniform
+						const uint64_t p = (r + k) * row + lane * G;
+						group<Out, G> outputs;
+						produce_group(p, current[k], outputs);
+						patches.template apply_to_row<G>((r + k) * row, lane, outputs);
+						store_group(out + p, outputs);
+						if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }   // (as below)
+					}
+					#pragma unroll
+					for (unsigned k = 0; k < R; k++) { current[k] = next[k]; }
+				}
+			}
+			c += num_waves;
+			if (c < num_chunks) { issue(c); }
+		}
+	}
+	else
 	for (uint64_t c = wave; c < num_chunks; c += num_waves) {
 		const uint64_t first_row = c * rows_per_chunk;
 		const uint64_t end_row = first_row + rows_per_chunk < num_rows ? first_row + rows_per_chunk : num_rows;
@@ -253,7 +398,6 @@ __device__ __forceinline__ void transform_and_patch(
 				patches.begin_seek(first_row * row, lane);
 				#pragma unroll
 				for (unsigned i = 0; i < pieces_per_lane; i++) { pieces[i] = source[i * wave64::size + lane]; }
-				after_loads();
 				patches.finish_seek(lane);
 				wave64::lds_fence();   // (the previous chunk's rows have been read)
 				#pragma unroll
@@ -276,7 +420,6 @@ __device__ __forceinline__ void transform_and_patch(
 		for (unsigned k = 0; k < R; k++) {
 			if (first_row + k < end_row) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }
 		}
-		after_loads();
 		patches.finish_seek(lane);
 		for (uint64_t r = first_row; r < end_row; r += R) {
 			#pragma unroll
@@ -300,7 +443,6 @@ __device__ __forceinline__ void transform_and_patch(
 		}
 	}
 
-	after_loads();
 	const uint64_t global_thread = (uint64_t) grid.block() * blockDim.x + threadIdx.x;
 	const uint64_t num_threads = (uint64_t) grid.blocks() * blockDim.x;
 	for (uint64_t p = num_rows * row + global_thread; p < n; p += num_threads) { out[p] = patches.patched(p, produce_one(p, in[p])); }

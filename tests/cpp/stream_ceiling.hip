@@ -12,12 +12,12 @@
 
 namespace {
 
-template <typename In, typename Out>
+template <typename In, typename Out, int Stores>
 __global__ void __launch_bounds__(256) identity_stream(Out* __restrict__ out, const In* __restrict__ in, uint64_t n)
 {
 	using namespace cuda;
 	constexpr unsigned G = stream_tiles::group_size<Out>::value;
-	stream_tiles::transform<In, Out>(out, in, n,
+	stream_tiles::transform<In, Out, stream_tiles::steps_per_tile, Stores>(out, in, n,
 		[](uint64_t, const memory_access::group<In, G>& a, memory_access::group<Out, G>& b) {
 			#pragma unroll
 			for (unsigned j = 0; j < G; j++) { b[j] = (Out) a[j]; }
@@ -25,18 +25,22 @@ __global__ void __launch_bounds__(256) identity_stream(Out* __restrict__ out, co
 		[](uint64_t, In x) { return (Out) x; });
 }
 
+/// `dynamic_lds`: bytes of LDS a workgroup reserves and does not use — the decoders' residency throttle (resolve_launch_configuration.cpp: 26 KiB = 6 workgroups
+/// per CU, the headline's launch); `stores`: memory_access::store_policy (1 = nt, 2 = sc1 nt: the decoders' of 4-byte and wider outputs)
 template <typename In, typename Out>
-int launch(void* out, const void* in, uint64_t n, void* stream)
+int launch(void* out, const void* in, uint64_t n, void* stream, uint32_t dynamic_lds, int stores)
 {
 	constexpr uint64_t per_block = 256 * cuda::stream_tiles::elements_per_thread_per_tile<Out>();
 	const uint64_t blocks = (n + per_block - 1) / per_block;
 	if (blocks == 0) { return 0; }
 	if (blocks > 0x7fffffffull) { return (int) hipErrorInvalidConfiguration; }
-	identity_stream<In, Out><<<dim3((unsigned) blocks), dim3(256), 0, static_cast<hipStream_t>(stream)>>>(static_cast<Out*>(out), static_cast<const In*>(in), n);
+	auto kernel = stores == 2 ? identity_stream<In, Out, cuda::memory_access::streaming> : identity_stream<In, Out, cuda::memory_access::non_temporal>;
+	if (dynamic_lds > 65536) { (void) hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) dynamic_lds); }
+	kernel<<<dim3((unsigned) blocks), dim3(256), dynamic_lds, static_cast<hipStream_t>(stream)>>>(static_cast<Out*>(out), static_cast<const In*>(in), n);
 	return (int) hipGetLastError();
 }
 
 } // namespace
 
-extern "C" int stream_copy(void* out, const void* in, uint64_t elements_of_4_bytes, void* stream) { return launch<uint32_t, uint32_t>(out, in, elements_of_4_bytes, stream); }
-extern "C" int stream_widen(void* out, const void* in, uint64_t elements, void* stream) { return launch<uint8_t, uint32_t>(out, in, elements, stream); }
+extern "C" int stream_copy(void* out, const void* in, uint64_t elements_of_4_bytes, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint32_t, uint32_t>(out, in, elements_of_4_bytes, stream, dynamic_lds, stores); }
+extern "C" int stream_widen(void* out, const void* in, uint64_t elements, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint8_t, uint32_t>(out, in, elements, stream, dynamic_lds, stores); }

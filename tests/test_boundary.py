@@ -293,3 +293,5 @@ def test_no_uniform_select_on_a_stale_scc_in_the_built_library():
     result = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "scan_isa.py"), library], capture_output=True, text=True, timeout=900)
     assert result.returncode == 0, result.stdout[-3000:] + result.stderr[-2000:]
     assert "a VOPC compare in between: 0 kernels" in result.stdout
+    # (scan 3: the dictionary decoders' staging barrier — one textual site outside the tile / chunk loops since round 6)
+    assert "more than two, or one inside a loop: 0 kernels" in result.stdout

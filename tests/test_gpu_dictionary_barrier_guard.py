@@ -1,12 +1,12 @@
-"""-m gpu: a guard for the one barrier in the library that is reached from different call sites.
+"""-m gpu: every shape of workgroup and column through the dictionary decoders' overlapped staging.
 
-include/giddy/kernels/decompression/dictionary.hpp stages a small dictionary in LDS with a __syncthreads() inside a callback that
-the tile loop calls after issuing the first tile's key loads — every wavefront takes it exactly once, but not at one textual place
-(that buys the overlap of the two memory round trips; it leans on what s_barrier is on CDNA, a count of arriving wavefronts).  If a
-compiler upgrade ever turned that into a hang, the first sign should be a FAILED TEST, not a stuck GPU box: every Dictionary
-instantiation, plain and fused with patches, is launched here with workgroups of 64 ... 1024 threads, grids from one workgroup to
-the natural one, and column lengths that leave some wavefronts of a workgroup without a tile, some with a ragged one and some with
-several — in a CHILD process under a watchdog, which the parent kills (and fails) if it does not finish in time."""
+include/giddy/kernels/decompression/dictionary.hpp stages a small dictionary in LDS with a __syncthreads() inside a hook that
+stream_tiles calls behind the first tile's (first chunk's) key loads.  Until round 6 the hook was called per tile behind a flag, so the
+barrier sat at three call sites; since then the tile and chunk loops are software-pipelined and the hook is called from ONE place outside
+them (tools/scan_isa.py, scan 3, asserts that on the built code objects).  This test stays as the functional side of it: every Dictionary
+instantiation, plain and fused with patches, is launched with workgroups of 64 ... 1024 threads, grids from one workgroup to the natural
+one, and column lengths that leave some wavefronts of a workgroup without a tile, some with a ragged one and some with several — in a
+CHILD process under a watchdog, which the parent kills (and fails) if it does not finish in time."""
 import os
 import subprocess
 import sys

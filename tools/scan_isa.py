@@ -7,6 +7,10 @@
 2. A uniform select on a STALE SCC: hipcc 7.2 compiled `high = new_high < new_low ? new_low : new_high` (wave-uniform 64-bit values) to `v_cmp_gt_u64 vcc, ...` followed by
    `s_cselect_b32` with SCC last written by the `s_addc_u32` of an address computation (tools/experiments/search_probe.hip).  Signature: an s_cselect whose last SCC writer is an
    arithmetic instruction, with a VOPC compare into VCC in between.
+3. BARRIERS OF THE DICTIONARY DECODERS: the staged dictionary's trip through LDS overlaps the first tile's key loads, which until round 6 put its __syncthreads() behind a
+   flag at three call sites of the tile loop (different wavefronts could arrive at different s_barrier instructions).  Now stream_tiles calls the hook from one place outside
+   its loops; the scan asserts what that gives: every dictionary kernel holds at most TWO s_barrier instructions (the overlapped staging's, and the plain staging loop's of
+   the other branch), none of them inside a loop (no backward branch across it).
 """
 import collections, glob, os, re, shutil, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
@@ -24,7 +28,9 @@ def family(name):
 
 
 serialized, stale = collections.defaultdict(list), collections.defaultdict(list)
+listing = collections.defaultdict(list)   # dictionary kernels: (address, instruction, branch target relative to the kernel's symbol or None)
 kernels = 0
+kernel_start = {}
 with tempfile.TemporaryDirectory() as scratch:
     copy = os.path.join(scratch, os.path.basename(library))
     shutil.copy(library, copy)
@@ -36,12 +42,19 @@ with tempfile.TemporaryDirectory() as scratch:
             m = re.match(r"^[0-9a-f]+ <(.*)>:$", line)
             if m:
                 kernel, index, last_load, waited, last_scc, compared = m.group(1), 0, -99, -99, None, False
+                kernel_start[kernel] = int(line.split()[0], 16)
                 kernels += 1
                 continue
             instruction = line.strip().split("//")[0].strip()
             if kernel is None or not instruction:
                 continue
             index += 1
+            if "dictionary" in kernel:
+                comment = line.split("//")[1] if "//" in line else ""
+                address = re.match(r"\s*([0-9A-Fa-f]+):", comment)
+                if address:
+                    target = re.search(r"<[^>]*\+0x([0-9a-fA-F]+)>", comment) if instruction.startswith(("s_cbranch", "s_branch")) else None
+                    listing[kernel].append((int(address.group(1), 16), instruction, int(target.group(1), 16) if target else None))
             if instruction.startswith(("s_load", "s_buffer_load")):
                 if index > 60 and waited > last_load and index - waited <= 20 and waited - last_load <= 8:
                     serialized[kernel].append(index)
@@ -64,4 +77,47 @@ for name, count in by_family.most_common():
 print("2. s_cselect on an SCC last written by arithmetic, a VOPC compare in between: %d kernels" % len(stale))
 for k, found in list(stale.items())[:10]:
     print("   %s: %s" % (demangled(k)[:120], found[0]))
-sys.exit(1 if stale else 0)
+def barriers_in_cycles(start, instructions):
+    """(number of s_barrier instructions, how many of them lie on a cycle of the kernel's control-flow graph)"""
+    addresses = [a for a, _, _ in instructions]
+    leaders = {addresses[0]}
+    for i, (a, text, target) in enumerate(instructions):
+        if text.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+            if i + 1 < len(instructions):
+                leaders.add(addresses[i + 1])
+            if target is not None:
+                leaders.add(start + target)
+    block_of, successors, current = {}, collections.defaultdict(set), None
+    for i, (a, text, target) in enumerate(instructions):
+        if a in leaders:
+            if current is not None and not instructions[i - 1][1].startswith(("s_branch", "s_endpgm")):
+                successors[current].add(a)   # falls through
+            current = a
+        block_of[a] = current
+        if target is not None:
+            successors[current].add(start + target)
+    def on_a_cycle(block):
+        seen, stack = set(), list(successors[block])
+        while stack:
+            b = stack.pop()
+            if b == block:
+                return True
+            if b not in seen:
+                seen.add(b); stack.extend(successors[b])
+        return False
+    found = [a for a, text, _ in instructions if text.startswith("s_barrier")]
+    return len(found), sum(1 for a in found if on_a_cycle(block_of[a]))
+
+
+bad_barriers, barrier_counts = [], collections.Counter()
+dictionary_kernels = [k for k in listing if "decompress" in demangled(k).split("(")[0] or "piece_body" in demangled(k).split("(")[0]]
+for k in dictionary_kernels:
+    count, in_cycles = barriers_in_cycles(kernel_start[k], listing[k])
+    barrier_counts[count] += 1
+    if count > 2 or in_cycles:
+        bad_barriers.append((k, count, in_cycles))
+print("3. dictionary decoders: %d kernels, s_barrier instructions per kernel %s; more than two, or one inside a loop: %d kernels" % (
+    len(dictionary_kernels), sorted(barrier_counts.items()), len(bad_barriers)))
+for k, count, inside in bad_barriers[:10]:
+    print("   %s: %d s_barrier, %d inside a loop" % (demangled(k)[:140], count, inside))
+sys.exit(1 if stale or bad_barriers else 0)

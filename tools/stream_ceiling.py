@@ -23,34 +23,45 @@ def shim():
             raise FileNotFoundError("tests/cpp/bin/libstream_ceiling.so is not built (python -c 'import __graft_entry__ as g; g.build_cpp_test_tools()')")
         _shim = ctypes.CDLL(SHIM)
         for f in (_shim.stream_copy, _shim.stream_widen):
-            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]
+            f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
             f.restype = ctypes.c_int
     return _shim
 
 
+# (reserved LDS per workgroup -> resident workgroups per CU; store policy) the loop is tried with: the decoders' own launch shapes
+SHAPES = [(0, 1), (0, 2), (26624, 2), (39936, 2), (53248, 2)]
+
+
 def measure(log2n=30, repetitions=10):
-    """{"copy_GBps", "widen_1_to_4_GBps"}: medians of `repetitions` launches over 2^log2n elements"""
+    """{"copy_GBps", "widen_1_to_4_GBps", ...}: for each traffic shape the BEST of the launch shapes the decoders use (residency throttle x store policy),
+    each the median of `repetitions` launches over 2^log2n elements"""
     import torch
     s = shim()
     n = 1 << log2n
     stream = torch.cuda.current_stream().cuda_stream
     out = torch.empty(n, dtype=torch.int32, device="cuda")
     results = {}
-    for name, fn, in_bytes in (("copy_GBps", s.stream_copy, 4), ("widen_1_to_4_GBps", s.stream_widen, 1)):
+    for name, fn, in_bytes in (("copy", s.stream_copy, 4), ("widen_1_to_4", s.stream_widen, 1)):
         source = torch.randint(0, 127, (n * in_bytes,), dtype=torch.int8, device="cuda")
-        for _ in range(3):
-            assert fn(out.data_ptr(), source.data_ptr(), n, stream) == 0
-        torch.cuda.synchronize()
-        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repetitions)]
-        for begin, end in events:
-            begin.record(); fn(out.data_ptr(), source.data_ptr(), n, stream); end.record()
-        torch.cuda.synchronize()
-        ms = sorted(b.elapsed_time(e) for b, e in events)[repetitions // 2]
-        if in_bytes == 1:   # (the identity is checked once: what was timed is a copy)
-            assert bool((out[: 1 << 20] == source[: 1 << 20].to(torch.int32)).all())
-        else:
-            assert bool((out[: 1 << 20] == source.view(torch.int32)[: 1 << 20]).all())
-        results[name] = round((in_bytes + 4) * n / ms / 1e6, 1)
+        by_shape = {}
+        for lds, stores in SHAPES:
+            for _ in range(3):
+                status = fn(out.data_ptr(), source.data_ptr(), n, stream, lds, stores)
+                assert status == 0, status
+            torch.cuda.synchronize()
+            events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(repetitions)]
+            for begin, end in events:
+                begin.record(); fn(out.data_ptr(), source.data_ptr(), n, stream, lds, stores); end.record()
+            torch.cuda.synchronize()
+            ms = sorted(b.elapsed_time(e) for b, e in events)[repetitions // 2]
+            by_shape["lds=%d,stores=%s" % (lds, "sc1_nt" if stores == 2 else "nt")] = round((in_bytes + 4) * n / ms / 1e6, 1)
+        # (the identity is checked once: what was timed is a copy)
+        expected = source[: 1 << 20].to(torch.int32) if in_bytes == 1 else source.view(torch.int32)[: 1 << 20]
+        assert bool((out[: 1 << 20] == expected).all())
+        best = max(by_shape, key=by_shape.get)
+        results[name + "_GBps"] = by_shape[best]
+        results[name + "_best_shape"] = best
+        results[name + "_by_shape"] = by_shape
         del source
     del out
     torch.cuda.empty_cache()
