@@ -89,6 +89,16 @@ def make_workload(name, n, device, per_rank_seed=True, cap=1 << 28, seed_offset=
     }
     work = table[name]()
     work.workload_name = name
+    # how often the step has been launched in this process (tools/summarize_profiles.py finds a workload's dispatches in the rocprofv3 kernel trace by it,
+    # where two workloads of one run launch the same kernel: DZB-variable with 2- and 3-bit sizes, Delta with plain and compressed patch positions)
+    import functools
+    work.step_runs = 0
+    uncounted = work.run
+    @functools.wraps(uncounted)
+    def counted(*args, **kwargs):
+        work.step_runs += 1
+        return uncounted(*args, **kwargs)
+    work.run = counted
     return work
 
 
@@ -716,6 +726,7 @@ def main():
                       "delta_compressed_patches", "delta_fused_compressed_patches", "model_fused_patches", "discard_zero_bytes_fixed_fused_patches"]
         elif args.schemes != "all":
             names = [s for s in args.schemes.split(",") if s]
+        line["step_runs"] = work.step_runs
         del work
         torch.cuda.empty_cache()
         schemes_out = {}
@@ -745,6 +756,7 @@ def main():
                 line.setdefault("small_columns", {})[name] = small_columns(name, w, device)
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
+            entry["step_runs"] = w.step_runs
             schemes_out[name] = entry
             del w
             torch.cuda.empty_cache()

@@ -76,32 +76,59 @@ ROW_FILTERS = {
 }
 
 
-def roofline_from_the_trace(timed_rows, bench):
-    """<round>_roofline_from_rocprof.md: every workload of the bench line under rocprofv3 — algorithmic bytes per launch (the line's) over the mean
-    duration of the kernel's timed-region dispatches in the KERNEL TRACE, beside the fraction the line itself reports from HIP events."""
-    entries = [("dictionary", bench["roofline"], None)] + [(n, e["roofline"], e.get("elements")) for n, e in bench.get("schemes", {}).items()]
+def roofline_from_the_trace(durations_by_kernel, bench):
+    """<round>_roofline_from_rocprof.md: every workload of the bench line under rocprofv3 — algorithmic bytes per step (the line's) over the mean duration of
+    the kernel's timed-region dispatches in the KERNEL TRACE, beside the fraction the line itself reports from HIP events.  Where consecutive workloads launch
+    the same kernel, the kernel's full-size dispatches are dealt out to them in order by the number of steps each says it launched (`step_runs`)."""
+    entries = [("dictionary", bench["roofline"], None, bench.get("step_runs"))] + \
+              [(n, e["roofline"], e.get("elements"), e.get("step_runs")) for n, e in bench.get("schemes", {}).items()]
     out = ["# Roofline fractions recomputed from the rocprofv3 kernel trace (%s)\n" % ROUND,
            "`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --sharded none --extras none --schemes coverage` (tools/profile_round.sh);",
-           "timed region = the last 10 (headline, DZB-variable: 20) dispatches of the kernel that last at least half its longest dispatch (`%s_kernel_stats.csv`, TimedRegionAverageNs);" % ROUND,
-           "fraction = algorithmic bytes per step / (launches per step x that mean) / 8 TB/s.  `events` = the same fraction as bench.py reports it from HIP events in the same run.\n",
-           "| workload | kernel row | launches/step | timed-region mean ns | algorithmic bytes/step | frac (trace) | frac (events) | trace/events |", "|---|---|---|---|---|---|---|---|"]
-    for workload, roofline, elements in entries:
-        scheme = KERNELS.get("dictionary" if workload == "dictionary_zipf" else workload)
+           "timed region = the last 10 (headline: 20) steps' dispatches of the workload's decoder kernel, of those that last at least half the kernel's longest dispatch;",
+           "fraction = algorithmic bytes per step / (launches per step x their mean duration) / 8 TB/s.  `events` = the same fraction as bench.py reports it from HIP events in the same run.",
+           "(A run decoder's figure is the cold one in both columns: three columns of different seeds decoded in turn.)\n",
+           "| workload | kernel | launches/step | timed-region mean ns | algorithmic bytes/step | frac (trace) | frac (events) | trace/events |", "|---|---|---|---|---|---|---|---|"]
+    # the decoder kernel of each workload: of the rows of its scheme's namespace, the one the run spent most time in (not a pre-pass)
+    def head(name):   # the kernel's name and template arguments, without its parameter list
+        name = name.replace("void ", "")
+        return name[: name.index(">(") + 1] if ">(" in name else name.split("(")[0]
+    chosen = {}
+    for workload, roofline, elements, runs in entries:
+        scheme = KERNELS.get("dictionary" if workload == "dictionary_zipf" else "delta_patched" if workload == "delta_compressed_patches" else workload)
         if scheme is None:
             continue
-        namespace = scheme.rsplit("::", 1)[0] + "::"
-        patched = "::patched::" in scheme
+        namespace, patched = scheme.rsplit("::", 1)[0] + "::", "::patched::" in scheme
         accept = ROW_FILTERS.get(workload, lambda name: True)
-        if workload in ("dictionary", "dictionary_zipf"):
-            accept = lambda name, zipf=(workload == "dictionary_zipf"): name.startswith("zipf-keyed column: ") == zipf
-        rows = [r for r in timed_rows if namespace in r[0] and ("::patched::" in r[0]) == patched and "decode_pieces" not in r[0] and "_pieces<" not in r[0] and accept(r[0]) and r[1] > 0]
-        if not rows:
+        rows = [k for k in durations_by_kernel if not k.startswith("headline alone: ") and ("::" + namespace) in head(k).split("<")[0]
+                and ("::patched::" in head(k).split("<")[0]) == patched and "decode_pieces" not in k and "_pieces<" not in k and accept(head(k))]
+        if rows:
+            chosen[workload] = max(rows, key=lambda k: sum(durations_by_kernel[k]))
+    for workload, roofline, elements, runs in entries:
+        kernel = chosen.get(workload)
+        if kernel is None:
             continue
-        name, calls, mean_ns, _ = max(rows, key=lambda r: r[3])   # the kernel of the scheme the run spent most time in: the step's decoder, not a pre-pass
         per_step = launches_per_step(workload, elements)
+        steps = 20 if workload == "dictionary" else 10
+        durations = durations_by_kernel[kernel]
+        longest = max(durations)
+        full_size = [x for x in durations if 2 * x >= longest]
+        sharing = [(w, r) for w, _, _, r in entries if chosen.get(w) == kernel]
+        if len(sharing) > 1:
+            if any(r is None for _, r in sharing) or sum(r for _, r in sharing) * per_step != len(full_size):
+                out.append("| %s | `%s` | %d | — | %d | — | %.4f | (shared kernel: %d full-size dispatches, the workloads' steps do not add up to it) |" % (
+                    workload, head(kernel).replace("cuda::kernels::", ""), per_step, roofline["algorithmic_bytes_per_launch"], roofline["frac"], len(full_size)))
+                continue
+            before = 0
+            for w, r in sharing:
+                if w == workload:
+                    full_size = full_size[before * per_step: (before + r) * per_step]
+                    break
+                before += r
+        timed = full_size[-steps * per_step:]
+        mean_ns = sum(timed) / max(len(timed), 1)
         frac = roofline["algorithmic_bytes_per_launch"] / (per_step * mean_ns * 1e-9) / 8e12
-        short = name.replace("void cuda::kernels::", "").split("(")[0]
-        out.append("| %s | `%s` | %d | %.1f | %d | %.4f | %.4f | %.3f |" % (workload, short, per_step, mean_ns, roofline["algorithmic_bytes_per_launch"], frac, roofline["frac"], frac / roofline["frac"]))
+        out.append("| %s | `%s` | %d | %.1f | %d | %.4f | %.4f | %.3f |" % (workload, head(kernel).replace("cuda::kernels::", ""), per_step, mean_ns,
+                                                                           roofline["algorithmic_bytes_per_launch"], frac, roofline["frac"], frac / roofline["frac"]))
     with open(os.path.join(OUT, ROUND + "_roofline_from_rocprof.md"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n".join(out))
@@ -147,22 +174,16 @@ def main():
     with open(os.path.join(OUT, ROUND + "_kernel_stats.csv"), "w", newline="") as f:
         w = csv.writer(f)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "TimedRegionCalls", "TimedRegionAverageNs"])
-        timed_rows = []
         for r in ours:
             d = durations_by_kernel.get("headline alone: " + r["Name"]) or durations_by_kernel.get(r["Name"], [])
             timed = timed_region(d, 20 if ("dictionary::decompress" in r["Name"] or "variable_width" in r["Name"]) else 10)
             w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
                         len(timed), "%.1f" % (sum(timed) / max(len(timed), 1))])
-            timed_rows.append((r["Name"], len(timed), sum(timed) / max(len(timed), 1), float(r["TotalDurationNs"])))
-            if "dictionary::decompress" in r["Name"] and durations_by_kernel.get("headline alone: " + r["Name"]):
-                # (in the full trace the kernel's last dispatches are the Zipf-keyed column's timed steps: the same kernel, the entry after the headline's)
-                zipf = timed_region(durations_by_kernel.get(r["Name"], []), 10)
-                timed_rows.append(("zipf-keyed column: " + r["Name"], len(zipf), sum(zipf) / max(len(zipf), 1), float(r["TotalDurationNs"])))
     bench_line = details_of(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(RAW, "bench_under_rocprof.details.json"))
     with open(os.path.join(OUT, ROUND + "_bench_under_rocprof.json"), "w") as f:
         f.write(bench_line + "\n")
 
-    roofline_from_the_trace(timed_rows, json.loads(bench_line))
+    roofline_from_the_trace(durations_by_kernel, json.loads(bench_line))
 
     # ---- calibration ---------------------------------------------------------------------------------
     known_kib = (1 << 30) / 1024.0
