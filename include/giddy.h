@@ -158,6 +158,10 @@ void         giddy_release_prepared(giddy_prepared_t* prepared);
  *   ... giddy_enqueue_batch(batch, stream) again decodes the same pieces again; giddy_batch_clear() starts another table.
  *   giddy_batch_release(batch);             <- once the launches that read its tables have run (it frees device memory: waits)
  *
+ * The tables are uploaded to, and the launch runs on, the device the batch was CREATED for, whichever device is current in the calling
+ * thread: `hip_stream` must be a stream of that device.  The first upload ALLOCATES device memory — when the launch is to be captured
+ * into a HIP graph, call giddy_batch_upload before the capture begins.
+ *
  * Pieces want what single columns want: outputs on 128-byte lines and inputs aligned for wide loads (a piece elsewhere switches the
  * whole batch to the any-alignment build of Dictionary / Frame of Reference / fixed-width Discard-Zero-Bytes); the run decoders
  * pick their build by the mean run of the whole batch. */

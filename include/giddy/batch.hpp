@@ -26,6 +26,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "giddy/api/types.hpp"
@@ -116,19 +117,23 @@ private:
 
 /// PINNED host memory for the copies of tables to devices: a process-wide pool of blocks, each re-used only once the copy that was made from it has
 /// completed (an event query, never a wait) — so a table may be re-built and uploaded again, or a function that uploaded one may return, while the
-/// copy is still in flight.  Blocks are portable (any device) and live as long as the process.
+/// copy is still in flight.  The memory is portable, but a block's EVENT belongs to the device that was current when the block was made: take() hands a
+/// block out only on that device (a process that drives several GPUs gets blocks per device), and a block whose event cannot be recorded is retired —
+/// never a wait on the host.  Blocks live as long as the process.
 class staging_pool {
 public:
-	struct block { void* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; bool in_flight = false, taken = false; };
+	struct block { void* memory = nullptr; size_t capacity = 0; hipEvent_t copied = nullptr; int device = -1; bool in_flight = false, taken = false, retired = false; };
 
 	static staging_pool& instance() { static staging_pool pool; return pool; }
 
-	/// a block of at least `bytes` that no copy is reading: fill it, enqueue the copy, then copy_enqueued()
+	/// a block of at least `bytes`, made on the current device, that no copy is reading: fill it, enqueue the copy, then copy_enqueued()
 	block* take(size_t bytes)
 	{
+		int device = -1;
+		throw_if_error(hipGetDevice(&device), "hipGetDevice for a batch's staging");
 		std::lock_guard<std::mutex> lock(mutex_);
 		for (auto& b : blocks_) {
-			if (b->taken) { continue; }
+			if (b->taken || b->retired || b->device != device) { continue; }
 			if (b->in_flight) {
 				const hipError_t status = hipEventQuery(b->copied);
 				if (status == hipSuccess) { b->in_flight = false; }
@@ -138,21 +143,34 @@ public:
 		}
 		std::unique_ptr<block> fresh(new block);
 		fresh->capacity = bytes + bytes / 4 + 4096;
+		fresh->device = device;
 		throw_if_error(hipHostMalloc(&fresh->memory, fresh->capacity, hipHostMallocPortable), "hipHostMalloc of staging for a batch's tables");
-		if (hipEventCreateWithFlags(&fresh->copied, hipEventDisableTiming) != hipSuccess) { (void) hipGetLastError(); fresh->copied = nullptr; }
+		const hipError_t status = hipEventCreateWithFlags(&fresh->copied, hipEventDisableTiming);
+		if (status != hipSuccess) { (void) hipHostFree(fresh->memory); throw_if_error(status, "hipEventCreate for a batch's staging"); }
 		fresh->taken = true;
 		blocks_.push_back(std::move(fresh));
 		return blocks_.back().get();
 	}
 
-	/// the copy out of `b` has been enqueued on `stream` (of the current device): `b` is anybody's again once it has run
+	/// the copy out of `b` has been enqueued on `stream` (of the device `b` was taken on): `b` is anybody's again once it has run.  If the event
+	/// cannot be recorded, the block is never handed out again (its memory stays valid for the copy in flight and is not freed).
 	void copy_enqueued(block* b, stream::id_t stream)
 	{
-		const bool recorded = b->copied != nullptr && hipEventRecord(b->copied, stream) == hipSuccess;
-		if (!recorded) { (void) hipGetLastError(); (void) hipStreamSynchronize(stream); }   // (no event to be had: wait for the copy itself)
+		const bool recorded = hipEventRecord(b->copied, stream) == hipSuccess;
+		if (!recorded) { (void) hipGetLastError(); }
 		std::lock_guard<std::mutex> lock(mutex_);
 		b->in_flight = recorded;
+		b->retired = !recorded;
 		b->taken = false;
+	}
+
+	/// (for tests) blocks made so far, and how many of them are retired
+	std::pair<size_t, size_t> counts()
+	{
+		std::lock_guard<std::mutex> lock(mutex_);
+		size_t retired = 0;
+		for (auto& b : blocks_) { retired += b->retired ? 1 : 0; }
+		return { blocks_.size(), retired };
 	}
 
 private:

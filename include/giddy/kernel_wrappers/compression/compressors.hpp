@@ -372,13 +372,14 @@ void kernel_t<I, U>::enqueue_launch_with(stream::id_t stream, const launch_confi
 	auto length   = (size_type_by_index_size<I>) argument<uint_t<I>>(arguments, "length");
 	const unsigned capacity = optional_argument<unsigned>(arguments, "capacity").value_or((unsigned) max_entries);
 	const unsigned slots = optional_argument<unsigned>(arguments, "hash_slots").value_or((unsigned) hash_slots);
-	if (capacity == 0 || (slots & (slots - 1)) != 0 || slots < capacity || (capacity > max_entries && (uint64_t) slots < 2 * (uint64_t) capacity)) {
+	// (at least two slots per entry for every capacity: a table that may fill completely makes every later insert probe all of it)
+	if (capacity == 0 || (slots & (slots - 1)) != 0 || (uint64_t) slots < 2 * (uint64_t) capacity) {
 		throw std::invalid_argument("dictionary construction: hash_slots must be a power of two, at least twice the capacity");
 	}
 	if (length == 0) { return; }
 	cuda::kernel::enqueue_launch(*this, stream, launch_config, states, values, status, argument<const uint_t<U>*>(arguments, "input"), length, slots, capacity);
 	auto* entries = argument<uint_t<U>*>(arguments, "dictionary_entries");
-	const launch_configuration_t over_slots((grid_dimension_t) std::min<unsigned>(slots / threads_per_block, 1u << 16), threads_per_block);
+	const launch_configuration_t over_slots((grid_dimension_t) std::min<unsigned>(std::max<unsigned>((slots + threads_per_block - 1) / threads_per_block, 1u), 1u << 16), threads_per_block);
 	if (capacity <= max_entries) {
 		auto unsorted = argument<uint_t<U>*>(arguments, "unsorted_entries");
 		cuda::enqueue_launch(reinterpret_cast<const void*>(collect_distinct<U>), stream, over_slots,

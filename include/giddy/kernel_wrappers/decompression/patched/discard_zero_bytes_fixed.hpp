@@ -44,7 +44,7 @@ public:
 		else if (!(UncompressedSize == 4 && CompressedSize == 1)) { params.resident_blocks_per_multiprocessor_cap = 4u; }
 		// (... for columns with few patches.  One whose rows wait for windows of patches from memory wants every wavefront it can have: a caller that states "num_patches"
 		// when resolving is not throttled where the ManyPatches build will be launched — <4,2,1> at 2 / 5 / 20 % of patches: 51 -> 69 / 45 -> 63 / 33 -> 47 % of the HBM peak,
-		// <4,8,1> at 5 / 20 %: 45 -> 70 / 41 -> 67, <4,4,2>: 66 -> 77 / 57 -> 70 — tools/experiments/dzbf_patched_residency.sh)
+		// <4,8,1> at 5 / 20 %: 45 -> 70 / 41 -> 67, <4,4,2>: 66 -> 77 / 57 -> 70 — docs/history/r05.md)
 		if (sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::discard_zero_bytes_fixed)) {
 			params.resident_blocks_per_multiprocessor_cap = nullopt;
 		}

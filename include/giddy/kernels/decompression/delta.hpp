@@ -252,7 +252,7 @@ __device__ __forceinline__ void wave_per_segment(
 
 /// wave path for 1-byte deltas of 8-byte elements, where a row's input is only 128 bytes: the chunk's whole input
 /// (at most 4 KiB) arrives first, as 16-byte-per-lane loads, and is handed out row by row through wave-private LDS.
-/// (Measured with the bare access pattern, tools/stream_probe4.hip: 68 % of peak with 2-byte loads per row, 73 % with
+/// (Measured with the bare access pattern, round 4's stream probe — docs/history/r04.md: 68 % of peak with 2-byte loads per row, 73 % with
 /// wide loads through LDS; the decoder itself: 63 -> see DESIGN.md.)
 template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_per_segment_with_staged_input(
@@ -469,7 +469,7 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk_of(uint64_t L)
 	return segments_per_wave_chunk((L + traits::row - 1) / traits::row);
 }
 
-/// Chunks of the lane-placed path.  A wavefront's chunk had better be EXACTLY rows_per_chunk rows (measured, tools/run_ragged_delta.sh with
+/// Chunks of the lane-placed path.  A wavefront's chunk had better be EXACTLY rows_per_chunk rows (measured in round 4, docs/history/r04.md, with
 /// builds with other values of rows_per_chunk: chunks of 16 or 32 rows 73 % of the HBM peak, of 21, 24, 30, 31, 33, 48 rows 62-66 % — whole-row segments
 /// of 10 or 12 rows, three or two to a chunk, sit there too; neither the base addresses' alignment nor the number of workgroups explains it,
 /// and the bytes moved are the same).  So where whole segments do not make such a chunk the chunks are WINDOWS of rows_per_chunk rows of the column

@@ -94,7 +94,14 @@ __device__ __forceinline__ void translate(
 	};
 	auto produce_one = [&](uint64_t, key_type key) { return lookup(key); };
 	if constexpr (!AnyAlignment && by_wave_chunks<Patches::enabled, UncompressedSize, DictionaryIndexSize, RestagedDictionary>()) {   // (any alignment: tiles only)
-		stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging, grid);
+		if constexpr (Patches::enabled) {
+			stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, stage_keys_up_to<UncompressedSize>()>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, chunk_staging, grid);
+		}
+		else {
+			// (the plain kernels never have room to stage a chunk's keys: said at compile time, so that the pipelined chunk loop holds no registers for that form —
+			// with both forms compiled in, plain <*,8,2> fell from 76 to 61 % of the HBM peak)
+			stream_tiles::transform_and_patch<key_type, value_type, stream_tiles::rows_in_flight, 0>(decompressed, compressed_input, n, produce_group, produce_one, patches, after_loads, nullptr, grid);
+		}
 	}
 	else {
 		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment, LooksUpThroughMemory>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);

@@ -38,7 +38,7 @@ __host__ __device__ inline uint64_t segments_per_wave_chunk(uint64_t segment_len
 	// (1-byte columns: a tile is 4 KiB of output, and a wavefront that lives for one of them spends its life on its first loads — several
 	// segments in a row, entered once: run_expansion::narrow_chunk_bytes of output per trip)
 	if (segment_length >= run_expansion::tile_length) {
-		const uint64_t fit = element_size == 1 ? (uint64_t) run_expansion::narrow_chunk_bytes / segment_length : 1;   // (wider columns: one segment — two per trip +0.5 cold, four -10; 2-byte columns with two, round 5: within the noise of +-2.5 — tools/experiments/two_byte_run_trips.sh)
+		const uint64_t fit = element_size == 1 ? (uint64_t) run_expansion::narrow_chunk_bytes / segment_length : 1;   // (wider columns: one segment — two per trip +0.5 cold, four -10; 2-byte columns with two, round 5: within the noise of +-2.5 — docs/history/r05.md)
 		return fit > 1 ? fit : 1;
 	}
 	// (segments of more than half a tile go two at a time: two tiles with a carry beat one half-empty tile — 52 -> 66 % at 3000)

@@ -179,8 +179,18 @@ def dictionary(column, key_dtype=np.uint8, entries=None, index_size=4):
     sorted on the device (dictionary_entries())."""
     n, usize, ksize = column.numel(), column.element_size(), _size(key_dtype)
     if entries is None:
-        # (wide keys: room for as many entries as the column could have, up to 2^24 — a dictionary of more is no compression; pass `entries` for one)
-        entries = dictionary_entries(column, limit=min(1 << (8 * ksize), max(1, n), 1 << 24) if ksize > 2 else 1 << (8 * ksize), index_size=index_size)
+        limit = min(1 << (8 * ksize), max(1, n), 1 << 24) if ksize > 2 else 1 << (8 * ksize)
+        if limit > (1 << 16):
+            # Wide keys: the 65 536-entry construction FIRST (a hash set of 2^18 slots: 3 MiB) — most columns' dictionaries fit it.  Only a column that
+            # overflows it pays for the large one: room for as many entries as the column could have, up to 2^24 — four hash slots per entry, i.e. up to
+            # 2^26 slots = 256 MiB of states + 512 MiB of values, zero-filled, and the bitonic network over 2^24 entries.  (A dictionary of more than
+            # 2^24 entries is no compression; pass `entries` for one, or for a column whose cardinality is known.)
+            try:
+                entries = dictionary_entries(column, limit=1 << 16, index_size=index_size)
+            except Unrepresentable:
+                entries = dictionary_entries(column, limit=limit, index_size=index_size)
+        else:
+            entries = dictionary_entries(column, limit=limit, index_size=index_size)
     if entries.numel() > (1 << (8 * ksize)):
         raise Unrepresentable("too many distinct values for the key type")
     out = {"compressed_input": torch.empty(n, dtype=_SIGNED[ksize], device=column.device), "dictionary_entries": entries, "length": n,

@@ -301,6 +301,8 @@ int giddy_batch_upload(giddy_batch_t* batch, void* hip_stream)
 	return guarded([&] {
 		if (batch == nullptr || !batch->wrapper) { throw std::invalid_argument("null batch"); }
 		if (batch->device_id == GIDDY_NOMINAL_MI355X_DEVICE) { throw std::logic_error("a batch created for the nominal device has no device to be uploaded to"); }
+		// (the tables go to the device the batch was created for — `hip_stream` must be one of its streams —, whichever device is current for the caller)
+		cuda::device::current::scoped_override_t<> on_the_batchs_device(batch->device_id);
 		batch->on_device.upload(batch->table, static_cast<hipStream_t>(hip_stream));
 		batch->uploaded = true;
 	});
@@ -310,8 +312,10 @@ int giddy_enqueue_batch(giddy_batch_t* batch, void* hip_stream)
 {
 	return guarded([&] {
 		if (batch == nullptr || !batch->wrapper) { throw std::invalid_argument("null batch"); }
+		if (batch->device_id == GIDDY_NOMINAL_MI355X_DEVICE) { throw std::logic_error("a batch created for the nominal device cannot be launched"); }
+		cuda::device::current::scoped_override_t<> on_the_batchs_device(batch->device_id);
 		if (!batch->uploaded) {
-			if (batch->device_id == GIDDY_NOMINAL_MI355X_DEVICE) { throw std::logic_error("a batch created for the nominal device cannot be launched"); }
+			// (allocates device memory: inside a stream capture call giddy_batch_upload BEFORE the capture begins — include/giddy.h)
 			batch->on_device.upload(batch->table, static_cast<hipStream_t>(hip_stream));
 			batch->uploaded = true;
 		}
