@@ -35,17 +35,7 @@ __global__ void anchors_of_parts(uint_t<UncompressedSize>* __restrict__ part_anc
 	}
 }
 
-/// the current device's properties, asked of the runtime once per device and process (not per host thread: the pipeline's worker threads are new every call)
-inline const device::properties_t& current_device_properties()
-{
-	enum : int { most_devices = 64 };
-	static device::properties_t cached[most_devices];
-	static std::once_flag asked[most_devices];
-	const int id = device::current::get().id();
-	if (id < 0 || id >= most_devices) { static thread_local device::properties_t uncached; uncached = device::get(id).properties(); return uncached; }
-	std::call_once(asked[id], [id] { cached[id] = device::get(id).properties(); });
-	return cached[id];
-}
+using cuda::current_device_properties;   // (kernel_wrappers/common.hpp)
 
 /// switches read from the environment ONCE per process (not on the launch path)
 struct environment {

@@ -6,6 +6,8 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
+#include "giddy/kernel_wrappers/decompression/delta.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 
 namespace cuda {
@@ -71,6 +73,18 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 	auto segment_length    = argument<index_type>(arguments, "segment_length");
 	auto num_patches       = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
+
+	// (where the plain decoder followed by the scatter is the faster way — 2-byte outputs, bands of patch densities: patched/decode_then_scatter.hpp)
+	if constexpr (UncompressedSize == 2) {
+		if (decompression::patched::decode_then_scatter_is_faster(decompression::patched::family_t::delta, UncompressedSize, (uint64_t) num_patches, (uint64_t) length)) {
+			arguments_type resolution;
+			resolution["length"] = (size_t) length;
+			resolution["segment_length"] = (size_t) segment_length;
+			decompression::patched::decode_then_scatter<delta::kernel_t<IndexSize, UncompressedSize, CompressedSize>, IndexSize, UncompressedSize>(
+				stream, launch_config, arguments, resolution, decompressed, patch_values, patch_positions, (size_type) num_patches);
+			return;
+		}
+	}
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
 	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::delta);

@@ -6,6 +6,8 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
+#include "giddy/kernel_wrappers/decompression/dictionary.hpp"
 #include "giddy/kernels/decompression/dictionary.hpp"
 
 namespace cuda {
@@ -93,6 +95,20 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
 	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / UncompressedSize, sorted_patches::together_from::dictionary);
+	// (where the plain decoder followed by the scatter is the faster way — 8-byte values beside a staged dictionary of 16 KiB or more in the ManyPatches build; 2-byte values
+	// from a third of the elements patched on: patched/decode_then_scatter.hpp)
+	if constexpr (UncompressedSize == 8 || UncompressedSize == 2) {
+		if (decompression::patched::decode_then_scatter_is_faster(decompression::patched::family_t::dictionary, UncompressedSize, (uint64_t) num_patches, (uint64_t) length,
+			caching ? (size_t) num_dictionary_entries * UncompressedSize : 0, many_patches)) {
+			arguments_type resolution;
+			resolution["num_dictionary_entries"] = (size_t) num_dictionary_entries;
+			resolution["data_length"] = (size_t) length;
+			if (maybe_cache) { resolution["cache_input_data_in_shared_mem"] = maybe_cache.value(); }
+			decompression::patched::decode_then_scatter<dictionary::kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>, IndexSize, UncompressedSize>(
+				stream, launch_config, arguments, resolution, decompressed, patch_values, patch_positions, (size_type) num_patches);
+			return;
+		}
+	}
 	cuda::enqueue_launch(many_patches ? reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, DictionaryIndexSize, true>) : reinterpret_cast<const void*>(patched::decompress<IndexSize, UncompressedSize, DictionaryIndexSize>), stream, launch_config,
 		decompressed, compressed_input, dictionary_entries, patch_values, patch_positions,
 		length, num_dictionary_entries, (size_type) num_patches, caching, chunk_key_staging);

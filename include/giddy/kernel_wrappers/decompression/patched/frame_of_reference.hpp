@@ -5,6 +5,8 @@
 #pragma once
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
+#include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
+#include "giddy/kernel_wrappers/decompression/frame_of_reference.hpp"
 #include "giddy/kernels/decompression/frame_of_reference.hpp"
 
 namespace cuda {
@@ -64,6 +66,18 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 	auto segment_length             = argument<index_type>(arguments, "segment_length");
 	auto num_patches                = argument<index_type>(arguments, "num_patches");
 	auto patch_positions = decompression::patched::positions<IndexSize>(stream, arguments, num_patches);   // plain, or expanded from compressed ones
+
+	// (where the plain decoder followed by the scatter is the faster way — 2-byte outputs, bands of patch densities: patched/decode_then_scatter.hpp)
+	if constexpr (sizeof(Uncompressed) == 2) {
+		if (decompression::patched::decode_then_scatter_is_faster(decompression::patched::family_t::frame_of_reference, 2, (uint64_t) num_patches, (uint64_t) length)) {
+			arguments_type resolution;
+			resolution["length"] = (size_t) length;
+			resolution["segment_length"] = (size_t) segment_length;
+			decompression::patched::decode_then_scatter<frame_of_reference::kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>, IndexSize, 2>(
+				stream, launch_config, arguments, resolution, reinterpret_cast<uint_t<2>*>(decompressed), reinterpret_cast<const uint_t<2>*>(patch_values), patch_positions, (size_type) num_patches);
+			return;
+		}
+	}
 
 	// (columns with several patches to a row of 64 lanes' elements: the build in which every lane looks for its own patches — on_device/sorted_patches.hpp)
 	const bool many_patches = sorted_patches::many_patches_per_row((uint64_t) num_patches, (uint64_t) length, 16 / (unsigned) sizeof(Uncompressed), sorted_patches::together_from::frame_of_reference);

@@ -49,6 +49,54 @@ __global__ void scatter(
 	for (uint64_t i = num_groups * G + global_thread; i < n; i += num_threads) { target[indices[i]] = data[i]; }
 }
 
+/// The same for ASCENDING indices that may REPEAT: of equal indices the LAST one's datum is written (what a sequential scatter leaves, and what the fused
+/// decompress-and-patch kernels promise — `scatter` above races on repeats).  An extension without a wrapper of its own: launched by the fused wrappers where the
+/// plain decoder followed by a scatter is the faster way (kernel_wrappers/decompression/patched/decode_then_scatter.hpp), at grid stride under any configuration.
+template <unsigned OutputIndexSize, unsigned ElementSize>
+__global__ void scatter_ascending(
+	uint_t<ElementSize>*            __restrict__  target,
+	const uint_t<ElementSize>*      __restrict__  data,
+	const uint_t<OutputIndexSize>*  __restrict__  indices,
+	uint64_t                                      data_length)
+{
+	using namespace memory_access;
+	using element_type = uint_t<ElementSize>;
+	using index_type = uint_t<OutputIndexSize>;
+	constexpr unsigned G = detail::patches_per_lane;
+	const uint64_t n = data_length;
+	const bool vectorizable = is_aligned(data, G * ElementSize >= 16 ? 16 : G * ElementSize)
+		&& is_aligned(indices, G * OutputIndexSize >= 16 ? 16 : G * OutputIndexSize);
+	const uint64_t num_groups = vectorizable ? n / G : 0;
+	const uint64_t global_thread = (uint64_t) blockIdx.x * blockDim.x + threadIdx.x;
+	const uint64_t num_threads = (uint64_t) gridDim.x * blockDim.x;
+
+	// (a wavefront's lanes take consecutive groups; the trip count is the wavefront's, so that every lane is there for the shuffle)
+	const unsigned lane = wave64::lane_id();
+	for (uint64_t first_of_wave = global_thread - lane; first_of_wave < num_groups; first_of_wave += num_threads) {
+		const uint64_t g = first_of_wave + lane;
+		const bool active = g < num_groups;
+		group<index_type, G> where;
+		group<element_type, G> what;
+		if (active) { where = load_group<index_type, G>(indices + g * G); what = load_group<element_type, G>(data + g * G); }
+		else { where[0] = 0; }
+		// the index behind the group: the next lane's first — out of its register; the wavefront's last active lane asks memory
+		const index_type neighbours = (index_type) __shfl_down((unsigned long long) where[0], 1, 64);
+		if (!active) { continue; }
+		const bool has_next = (g + 1) * G < n;
+		const bool neighbour_has_it = lane != wave64::size - 1 && g + 1 < num_groups;
+		const index_type next = neighbour_has_it ? neighbours : (has_next ? indices[(g + 1) * G] : (index_type) 0);
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) {
+			const bool repeated = j + 1 < G ? where[j + 1] == where[j] : (has_next && next == where[j]);
+			if (!repeated) { target[where[j]] = what[j]; }
+		}
+	}
+	for (uint64_t i = num_groups * G + global_thread; i < n; i += num_threads) {
+		if (i + 1 < n && indices[i + 1] == indices[i]) { continue; }
+		target[indices[i]] = data[i];
+	}
+}
+
 template <unsigned OutputIndexSize, unsigned ElementSize, unsigned InputIndexSize,
 	serialization_factor_t SerializationFactor = DefaultSerializationFactor>
 class launch_config_resolution_params_t final : public kernels::launch_config_resolution_params_t {

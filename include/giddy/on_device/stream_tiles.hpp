@@ -284,6 +284,66 @@ struct alignas(16) chunk_input_storage {
 	In inputs[Enabled ? chunk_staging_waves : 1][Enabled ? elements : 1];
 };
 
+/// The rows of a WHOLE chunk in the row form (rows_per_chunk rows, the first R of them already requested into `current`), as straight-line code: no bound in
+/// sight, every load and store of the chunk unconditional, so that the compiler can wait for a row's input by COUNT (CDNA4 counts vector memory operations in
+/// order: `s_waitcnt vmcnt(n)` with the newer requests still in flight).  The bounded loop the ragged last chunk takes wraps every load and store in a
+/// wave-uniform branch; behind a branch the count is unknown and every wait becomes vmcnt(0) — which waits for the next rows' loads just issued AND for the
+/// stores before (they are counted too): a chunk was eight serialized round trips (round 6, read off the ISA: plain Dictionary <4,8,2> 61 -> 76 % of the HBM peak).
+/// (All 32 rows of an 8-byte chunk spelled out cost 15-18 registers — addresses kept for every row — and a spill in fused Dictionary <4,8,8>: hence pairs around a loop.)
+template <typename In, typename Out, unsigned R, typename ProduceGroup, typename Patches>
+__device__ __forceinline__ void rows_of_a_whole_chunk(
+	Out* __restrict__ out, const In* __restrict__ in, uint64_t first_row, unsigned lane, memory_access::group<In, group_size<Out>::value> (&current)[R],
+	ProduceGroup& produce_group, Patches& patches)
+{
+	using namespace memory_access;
+	constexpr unsigned G = group_size<Out>::value;
+	constexpr unsigned rows_per_chunk = rows_per_chunk_for<Out>();
+	constexpr unsigned row = wave64::size * G;
+	static_assert(rows_per_chunk % R == 0, "a whole chunk is a whole number of groups of R rows");
+	constexpr unsigned groups = rows_per_chunk / R;   // groups of R rows: group g is requested while group g - 1 is produced and stored
+	auto request = [&](group<In, G> (&into)[R], unsigned g) {
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { into[k] = load_group<In, G>(in + (first_row + g * R + k) * row + lane * G); }
+	};
+	auto produce_and_store = [&](const group<In, G> (&from)[R], unsigned g) {
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) {
+			const uint64_t r = first_row + g * R + k;
+			const uint64_t p = r * row + lane * G;
+			group<Out, G> outputs;
+			produce_group(p, from[k], outputs);
+			patches.template apply_to_row<G>(r * row, lane, outputs);
+			store_group(out + p, outputs);
+			// narrow elements: G look-ups per row — keep the rows' look-ups from being hoisted above one another (all 4 x 16 of a 1-byte column in flight at once spill)
+			if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
+		}
+	};
+	group<In, G> other[R];
+	if constexpr (groups == 1) { produce_and_store(current, 0); }
+	else if constexpr (groups % 2 != 0 || groups == 2) {
+		// (few groups: all of them spelled out, the two buffers taking turns)
+		#pragma unroll
+		for (unsigned g = 0; g < groups; g++) {
+			if (g % 2 == 0) { if (g + 1 < groups) { request(other, g + 1); } produce_and_store(current, g); }
+			else { if (g + 1 < groups) { request(current, g + 1); } produce_and_store(other, g); }
+		}
+	}
+	else {
+		// PAIRS of groups around a loop, the two buffers taking turns with no copy between them (a copy of a buffer would wait for its loads); the last pair, which
+		// requests nothing behind it, spelled out after the loop — so nothing inside the loop is conditional either
+		#pragma unroll 1
+		for (unsigned g = 0; g + 2 < groups; g += 2) {
+			request(other, g + 1);
+			produce_and_store(current, g);
+			request(current, g + 2);
+			produce_and_store(other, g + 1);
+		}
+		request(other, groups - 1);
+		produce_and_store(current, groups - 2);
+		produce_and_store(other, groups - 1);
+	}
+}
+
 template <typename In, typename Out, unsigned RowsInFlight = rows_in_flight, unsigned StageUpToBytesPerLane = 2,
 	typename ProduceGroup, typename ProduceOne, typename Patches, typename AfterLoads = nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void transform_and_patch(
@@ -309,6 +369,10 @@ __device__ __forceinline__ void transform_and_patch(
 	constexpr unsigned chunk_input_bytes = rows_per_chunk * row * sizeof(In);
 	const bool may_stage = stage_chunk_input && staging != nullptr && wave64::index_in_block() < chunk_staging_waves && is_aligned(in, 16);
 
+	// (rows_of_a_whole_chunk for decoders WITHOUT patches only — the plain Dictionary of 8-byte values: 61 -> 76 % of the HBM peak.  With a cursor of patches in the rows the
+	// waits are conservative behind its branches either way, and the straight-line form measured slower where rows carry many patches: fused FOR <4,4,2,linear> -8 points and
+	// fused DZB-fixed <4,2,1> -6 from 2 % of patches on, nothing gained below: profiles/r06_fused_regret.txt, first table against the second)
+	constexpr bool whole_chunks_in_straight_line = !Patches::enabled;
 	constexpr bool has_hook = !std::is_same<AfterLoads, nothing_to_do>::value;
 	if constexpr (has_hook) {
 		// The same chunk loop software-pipelined, so that the hook (a side table's trip through LDS and its BARRIER) is called from one place that every
@@ -328,6 +392,10 @@ __device__ __forceinline__ void transform_and_patch(
 				const piece_t* source = reinterpret_cast<const piece_t*>(in + first_row * row);
 				#pragma unroll
 				for (unsigned i = 0; i < pieces_per_lane; i++) { pieces[i] = source[i * wave64::size + lane]; }
+			}
+			else if (whole_chunks_in_straight_line && end_row - first_row == rows_per_chunk) {   // (a whole chunk: nothing conditional about its loads — rows_of_a_whole_chunk)
+				#pragma unroll
+				for (unsigned k = 0; k < R; k++) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }
 			}
 			else {
 				#pragma unroll
@@ -358,6 +426,9 @@ __device__ __forceinline__ void transform_and_patch(
 						store_group(out + p, outputs);
 					}
 				}
+			}
+			else if (whole_chunks_in_straight_line && end_row - first_row == rows_per_chunk) {   // wave-uniform
+				rows_of_a_whole_chunk<In, Out, R>(out, in, first_row, lane, current, produce_group, patches);
 			}
 			else {
 				for (uint64_t r = first_row; r < end_row; r += R) {
@@ -416,6 +487,13 @@ __device__ __forceinline__ void transform_and_patch(
 		}
 		group<In, G> current[R], next[R];
 		patches.begin_seek(first_row * row, lane);   // (its probes go out ahead of the first rows' loads, the rest behind them)
+		if (whole_chunks_in_straight_line && end_row - first_row == rows_per_chunk) {   // wave-uniform: a whole chunk, nothing conditional about its loads and stores
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }
+			patches.finish_seek(lane);
+			rows_of_a_whole_chunk<In, Out, R>(out, in, first_row, lane, current, produce_group, patches);
+			continue;
+		}
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) {
 			if (first_row + k < end_row) { current[k] = load_group<In, G>(in + (first_row + k) * row + lane * G); }

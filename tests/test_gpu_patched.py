@@ -41,6 +41,10 @@ def _patches(n, how, value_dtype, index_size, seed):
         positions = np.unique(marks[(marks >= 0) & (marks < n)])
     elif how == "duplicates":
         positions = np.sort(r.integers(0, n, size=max(2, n // 50)))     # many repeats
+    elif how == "repeats_at_one_percent":   # 1 % of patches drawn with replacement from a smaller pool: many equal positions, at a density where the
+        # 2-byte wrappers launch the plain decoder + scatter_ascending instead of their fused kernel (kernel_wrappers/decompression/patched/decode_then_scatter.hpp)
+        pool = np.sort(r.choice(n, size=max(1, n // 150), replace=False))
+        positions = np.sort(r.choice(pool, size=max(2, n // 100), replace=True))
     elif how == "clustered":  # a few hundred consecutive patches, then nothing for a long while
         starts = r.integers(0, max(1, n - 300), size=max(1, n // 100000 + 1))
         positions = np.unique(np.concatenate([np.arange(s, min(n, s + 300)) for s in starts]))
@@ -58,7 +62,7 @@ def _expected(decoded, positions, values):
     return out
 
 
-PATCH_SHAPES = ["none", "sparse", "dense", "all", "edges", "duplicates", "clustered"]
+PATCH_SHAPES = ["none", "sparse", "dense", "all", "edges", "duplicates", "clustered", "repeats_at_one_percent"]
 DELTA_TUPLES = [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)]
 
 
@@ -485,3 +489,21 @@ def test_fused_decoder_with_compressed_positions_is_graph_capturable():
     graph.replay()
     torch.cuda.synchronize()
     assert np.array_equal(g.host(out, ud, n), expect)
+
+
+def test_the_two_launch_rule_is_what_the_wrappers_document():
+    """decode_then_scatter_is_faster (patched/decode_then_scatter.hpp), restated: the parity tests above cover both ways only if their shapes fall on both
+    sides of it — 'sparse' (0.1 %), 'repeats_at_one_percent', 'duplicates' (2 %), 'dense' (35 %) and 'all' do for every 2-byte family."""
+    def two_launches(family, usize, density, staged=0, many=False):
+        if family == "dictionary" and usize == 8 and many and staged >= 16384:
+            return True
+        if family == "dictionary" and usize == 8 and not many and staged >= 8192 and density >= 0.008:
+            return True
+        if usize != 2:
+            return False
+        return {"delta": 0.0015 <= density < 0.015 or density >= 0.15, "frame_of_reference": 0.004 <= density < 0.015 or density >= 0.35,
+                "model": density < 0.004 or density >= 0.35, "dictionary": density >= 0.35, "discard_zero_bytes_fixed": False}[family]
+    for family in ("delta", "frame_of_reference", "model", "dictionary"):
+        ways = {two_launches(family, 2, d) for d in (0.001, 0.01, 0.02, 0.36, 1.0)}
+        assert ways == {True, False}, family
+    assert two_launches("dictionary", 8, 0.02, staged=3000 * 8, many=True) and not two_launches("dictionary", 8, 0.02, staged=256 * 8, many=True)

@@ -30,18 +30,24 @@ for (o, i) in ((0, 0), (1, 0), (1, 1), (4, 4), (1025, 3)):
     ms = sw.timeit(lambda: schemes.frame_of_reference(out, offs, refs, n, Lf, launch_config=cfg, **kw))
     expect = (refs[:n // Lf].view(-1, 1) + offs.view(-1, Lf).to(torch.int32)).view(-1)
     report("frame_of_reference<4,4,2,c>", "out +%d, offsets +%d elements" % (o, i), ms, 6 * n + 4 * (n // Lf), bool((expect == out).all()))
-# Delta <4,4,1>, segments of 4096
-L = 4096
-d_all = sw.rand_bits(n + 64, 1, g)
-for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1)):
-    d = d_all[i:i + n]; out = out_all[o:o + n]
-    du = sw.unsigned(d, 1); per_seg = du.view(n // L, L).sum(dim=1)
-    anchors64 = (1 << 20) + torch.cumsum(per_seg, 0) - per_seg; anchors = anchors64.to(torch.int32)
-    kw = dict(uncompressed_size=4, compressed_size=1, index_size=4, stream=st)
-    cfg = schemes.delta(out, d, anchors, n, L, **kw)
-    ms = sw.timeit(lambda: schemes.delta(out, d, anchors, n, L, launch_config=cfg, **kw))
-    expect = (torch.cumsum(du.view(-1, L), dim=1) + anchors64[:, None]).view(-1).to(torch.int32)
-    report("delta<4,4,1> L=4096", "out +%d, deltas +%d elements" % (o, i), ms, 5 * n + 4 * (n // L), bool((expect == out).all()))
+# Delta, segments of up to 32 rows (the any-alignment windows) and beyond (round 6: windows whose base comes from a pre-pass)
+d_all = {1: sw.rand_bits(n + 64, 1, g), 2: sw.rand_bits(n + 64, 2, g)}
+outs = {4: out_all, 8: torch.empty(n + 2048, dtype=torch.int64, device=sw.DEV)}
+for (U, C, L) in ((4, 1, 4096), (4, 1, 16384), (4, 1, 65536), (8, 2, 4096), (8, 2, 8192), (8, 2, 65536), (8, 2, 10000), (4, 1, 1 << 20)):
+    m = n // L * L
+    for (o, i) in ((0, 0), (1, 0), (0, 1), (1, 1)):
+        d = d_all[C][i:i + m]; out = outs[U][o:o + m]
+        du = sw.unsigned(d, C); per_seg = du.view(m // L, L).sum(dim=1)
+        anchors64 = (1 << 20) + torch.cumsum(per_seg, 0) - per_seg; anchors = anchors64.to(sw.INT[U])
+        kw = dict(uncompressed_size=U, compressed_size=C, index_size=4, stream=st)
+        cfg = schemes.delta(out, d, anchors, m, L, **kw)
+        ms = sw.timeit(lambda: schemes.delta(out, d, anchors, m, L, launch_config=cfg, **kw))
+        ok = True
+        for lo in range(0, m, max(L, (1 << 24) // L * L)):
+            hi = min(m, lo + max(L, (1 << 24) // L * L))
+            expect = (torch.cumsum(du[lo:hi].view(-1, L), dim=1) + anchors64[lo // L: hi // L, None]).view(-1).to(sw.INT[U])
+            ok = ok and bool((expect == out[lo:hi]).all())
+        report("delta<4,%d,%d> L=%d" % (U, C, L), "out +%d, deltas +%d elements" % (o, i), ms, (U + C) * m + U * (m // L), ok)
 # run lengths <4,4,2,4>
 lengths, starts = sw._runs(n, 32, g, 65535); count = len(lengths)
 values = (torch.arange(count, device=sw.DEV) * 2654435761 % (1 << 31)).to(torch.int32)
