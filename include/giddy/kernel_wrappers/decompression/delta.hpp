@@ -168,6 +168,27 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
 				decompressed, compressed_input, anchor_values, length, segment_length);
 			return;
 		}
+		// ... and LONGER segments at such addresses (round 6): the windows' bases from a pre-pass over the deltas — two small launches and scratch for two values per
+		// window —, then the same windows (kernels/decompression/delta.hpp, decompress_windows_at_any_alignment): 17-21 % of the HBM peak element by element -> see
+		// profiles/r06_unaligned_bases.txt.  No scratch to be had (or segments of more than 2^16 windows: the pre-pass adds a segment's windows up per window): element by element.
+		constexpr uint64_t window = (uint64_t) detail::rows_per_chunk * traits::row;
+		if ((!memory_access::is_aligned(decompressed, 16) || !memory_access::is_aligned(compressed_input, traits::E * CompressedSize))
+			&& length > 0 && (uint64_t) segment_length > window && (uint64_t) segment_length / window <= (1u << 16)) {
+			const uint64_t windows = util::div_rounding_up((uint64_t) length, window);
+			stream_scratch::lease scratch(stream);
+			if (windows <= 0x7FFFFFFFull && scratch.take(2 * windows * sizeof(uncompressed_type))) {
+				auto* tail_sums = static_cast<uncompressed_type*>(scratch.memory());
+				auto* window_bases = tail_sums + windows;
+				const launch_configuration_t per_window((grid_dimension_t) util::div_rounding_up(windows, (uint64_t) detail::any_length_waves), detail::any_length_waves * warp_size);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(window_tail_sums<IndexSize, UncompressedSize, CompressedSize>), stream, per_window,
+					tail_sums, compressed_input, length, segment_length);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(bases_of_windows<IndexSize, UncompressedSize, CompressedSize>), stream, per_window,
+					window_bases, static_cast<const uncompressed_type*>(tail_sums), anchor_values, length, segment_length);
+				cuda::enqueue_launch(reinterpret_cast<const void*>(decompress_windows_at_any_alignment<IndexSize, UncompressedSize, CompressedSize>), stream, per_window,
+					decompressed, compressed_input, anchor_values, length, segment_length, static_cast<const uncompressed_type*>(window_bases));
+				return;
+			}
+		}
 	}
 
 	// Long segments — more rows than a wavefront takes by itself — as tiles of their own, chained by a decoupled look-back through

@@ -80,7 +80,7 @@ __global__ void scatter_ascending(
 		if (active) { where = load_group<index_type, G>(indices + g * G); what = load_group<element_type, G>(data + g * G); }
 		else { where[0] = 0; }
 		// the index behind the group: the next lane's first — out of its register; the wavefront's last active lane asks memory
-		const index_type neighbours = (index_type) __shfl_down((unsigned long long) where[0], 1, 64);
+		const index_type neighbours = sizeof(index_type) <= 4 ? (index_type) __shfl_down((unsigned) where[0], 1, 64) : (index_type) __shfl_down((unsigned long long) where[0], 1, 64);
 		if (!active) { continue; }
 		const bool has_next = (g + 1) * G < n;
 		const bool neighbour_has_it = lane != wave64::size - 1 && g + 1 < num_groups;

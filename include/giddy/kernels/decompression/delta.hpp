@@ -710,11 +710,13 @@ __host__ __device__ inline bool any_length_by_windows(uint64_t L)
 /// `AnyAlignment` (decompress_at_any_alignment): `out` and `in` aligned for their elements only.  Rows follow the output's 1 KiB boundaries as before — every row but the
 /// window's first is then stored 16 bytes per lane at aligned addresses, wherever the column begins; the first one, up to the boundary, goes element by element; the
 /// rows' loads are 16 bytes per lane at whatever address (gfx950 takes them).
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole>
+/// `LongSegments`: L > a window (decompress_windows_at_any_alignment: the value before each window from `window_bases`); otherwise L <= a window (the callers see to it)
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole, bool LongSegments = false>
 __device__ __forceinline__ void wave_windows_of_any_segments(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
 	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases,   // (LDS: traits::row entries, this wavefront's)
-	Grid grid = Grid())
+	Grid grid = Grid(),
+	const uint_t<UncompressedSize>* __restrict__ window_bases = nullptr)   // (segments LONGER than a window: the value before each window's first element, from window_tail_sums / bases_of_windows below)
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -729,8 +731,9 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	constexpr uint64_t window = (uint64_t) rows_per_chunk * traits::row;
 	const uint64_t num_chunks = (n + window - 1) / window;
-	const unsigned segment_length = (unsigned) L;
+	const unsigned segment_length = (unsigned) L;   // (only used where L <= window)
 	const float segments_per_element = 1.0f / (float) segment_length;
+	constexpr bool long_segments = LongSegments;   // (L > window: at most ONE segment begins inside a window)
 
 	struct row_bounds { uint64_t start, end; };   // wave-uniform
 	struct row_places { unsigned segment, within; U start_anchor[E]; };   // per lane: its first element's segment (of the chunk) and place in it; the anchors of the segments its elements begin
@@ -750,9 +753,25 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 			walk_start = r.end;
 			return r;
 		};
+		// (long segments: the window holds at most ONE segment start — `boundary`, or its own first element — and an element's place is a 32-bit comparison of
+		// positions relative to the window: `within` is not kept there)
+		const unsigned no_position = 0xFFFFFFFFu;
+		const unsigned boundary_in_window = origin + L < chunk_end ? (unsigned) (origin + L - chunk_start) : no_position;
+		const bool window_begins_a_segment = origin == chunk_start;
 		auto place = [&](const row_bounds& b) {
 			row_places where;
 			const uint64_t p = b.start + (uint64_t) lane * E;
+			if (long_segments) {
+				const unsigned q = (unsigned) (p - chunk_start);
+				where.segment = q >= boundary_in_window ? 1u : 0u;
+				where.within = 0;
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) {
+					const bool begins = q + j == boundary_in_window || (window_begins_a_segment && q + j == 0);
+					where.start_anchor[j] = (p + j < b.end && begins) ? anchors[first_segment + (q + j >= boundary_in_window ? 1u : 0u)] : (U) 0;
+				}
+				return where;
+			}
 			const unsigned past_origin = (unsigned) (p - origin);
 			where.segment = (unsigned) (((float) past_origin + 0.5f) * segments_per_element);   // (exact: see wave_rows_of_short_segments)
 			where.within = past_origin - where.segment * segment_length;
@@ -771,7 +790,8 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 		patches.begin_seek(chunk_start, lane);
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].template load<AnyAlignment>(in, bounds[k].start, bounds[k].end, lane); places[k] = place(bounds[k]); }
-		if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
+		if (origin < chunk_start && window_bases != nullptr) { carry = window_bases[c]; }
+		else if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
 			sum_type sum = 0;
 			const uint64_t aligned_origin = origin / E * E;   // (16-byte loads: the elements of the first group that lie before the segment are left out)
 			for (uint64_t at = aligned_origin; at < chunk_start; at += 4 * traits::row) {
@@ -802,13 +822,28 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 				// 1. the elements that begin a segment leave its base — anchor less the row's prefix before it — in the table
 				unsigned segment = places[k].segment, within = places[k].within;
 				unsigned segment_of[E]; bool begins_in_row[E];
-				#pragma unroll
-				for (unsigned j = 0; j < E; j++) {
-					const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
-					if (p + j < bounds[k].end && within == 0) { segment_bases[segment - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
-					segment_of[j] = segment;
-					begins_in_row[j] = (unsigned) (p - origin) + j - within >= row_past_origin;   // where the element's segment begins, against where the row does
-					if (++within == segment_length) { within = 0; segment++; }
+				if (long_segments) {
+					const unsigned q = (unsigned) (p - chunk_start), row_in_window = (unsigned) (bounds[k].start - chunk_start);
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) {
+						const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
+						const bool behind_boundary = q + j >= boundary_in_window;
+						const bool begins = q + j == boundary_in_window || (window_begins_a_segment && q + j == 0);
+						segment_of[j] = behind_boundary ? 1u : 0u;
+						if (p + j < bounds[k].end && begins) { segment_bases[segment_of[j] - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
+						// where the element's segment begins, against where the row does
+						begins_in_row[j] = behind_boundary ? boundary_in_window >= row_in_window : (window_begins_a_segment && row_in_window == 0);
+					}
+				}
+				else {
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) {
+						const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
+						if (p + j < bounds[k].end && within == 0) { segment_bases[segment - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
+						segment_of[j] = segment;
+						begins_in_row[j] = (unsigned) (p - origin) + j - within >= row_past_origin;   // where the element's segment begins, against where the row does
+						if (++within == segment_length) { within = 0; segment++; }
+					}
 				}
 				wave64::lds_fence();
 				// 2. every element: its segment's base, or on from the previous row
@@ -1123,6 +1158,109 @@ __global__ void decompress_at_any_alignment(
 		return;
 	}
 	detail::segmented<IndexSize, UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, n, L, sorted_patches::none());
+}
+
+// ---- segments longer than a window at any alignment (round 6) -------------------------------------------------------------------
+//
+// decompress_at_any_alignment's windows add up, for a window that begins inside a segment, that segment's deltas before the window: fine while a segment is at most a
+// window (32 rows), hopeless beyond (a segment of S windows reads its input S / 2 times) — such columns went element by element (17-21 % of the HBM peak).  Here the value
+// before every window comes from a PRE-PASS instead, whatever the segment length: (1) window_tail_sums — a wavefront per window adds up the window's deltas from the segment
+// boundary inside it (there is at most one: L > window) or from its start; (2) bases_of_windows — a wavefront per window adds its segment's anchor and the tail sums of the
+// windows between the segment's start and itself; (3) the windows path with the bases given.  The deltas are read twice: (2 C + U) / (C + U) of the bytes.
+namespace detail {
+
+/// sums of every 64 lanes' partial sums, wave-wide, in the uncompressed type (wrapping as the decoder's own sums do)
+template <typename U>
+__device__ __forceinline__ U wave_sum(U mine)
+{
+	#pragma unroll
+	for (unsigned d = 32; d > 0; d >>= 1) { mine = (U) (mine + (U) __shfl_xor(mine, d, 64)); }
+	return mine;
+}
+
+} // namespace detail
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void __launch_bounds__(256) window_tail_sums(
+	uint_t<UncompressedSize>*        __restrict__  tail_sums,          // one per window of detail::rows_per_chunk rows
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length)
+{
+	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	constexpr unsigned E = traits::E;
+	constexpr uint64_t window = (uint64_t) detail::rows_per_chunk * traits::row;
+	const uint64_t n = length, L = segment_length;
+	const uint64_t num_windows = (n + window - 1) / window;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	for (uint64_t c = wave; c < num_windows; c += num_waves) {
+		const uint64_t start = c * window, end = start + window < n ? start + window : n;
+		const uint64_t boundary = (start + L - 1) / L * L;   // the first segment start at or behind the window's
+		const uint64_t from = boundary < end ? boundary : start;
+		const uint64_t aligned_from = from / E * E;   // (a lane's group of E elements: those before `from` are left out)
+		U sum = 0;
+		for (uint64_t at = aligned_from; at < end; at += 4 * traits::row) {
+			detail::row_t<UncompressedSize, CompressedSize> rows[4];
+			#pragma unroll
+			for (unsigned k = 0; k < 4; k++) { rows[k].template load<true>(compressed_input, at + (uint64_t) k * traits::row, end, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < 4; k++) {
+				const uint64_t q = at + (uint64_t) k * traits::row + (uint64_t) lane * E;
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) { sum = (U) (sum + ((q + j >= from && q + j < end) ? (U) rows[k].deltas[j] : (U) 0)); }
+			}
+		}
+		sum = detail::wave_sum(sum);
+		if (lane == 0) { tail_sums[c] = sum; }
+	}
+}
+
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void __launch_bounds__(256) bases_of_windows(
+	uint_t<UncompressedSize>*        __restrict__  window_bases,       // [c]: the value before window c's first element where the window begins inside a segment (else unused)
+	const uint_t<UncompressedSize>*  __restrict__  tail_sums,
+	const uint_t<UncompressedSize>*  __restrict__  anchor_values,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length)
+{
+	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	constexpr uint64_t window = (uint64_t) detail::rows_per_chunk * traits::row;
+	const uint64_t n = length, L = segment_length;
+	const uint64_t num_windows = (n + window - 1) / window;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	for (uint64_t c = wave; c < num_windows; c += num_waves) {
+		const uint64_t start = c * window;
+		const uint64_t segment = start / L, origin = segment * L;
+		if (origin == start) { continue; }   // (wave-uniform: the window begins a segment)
+		U sum = 0;
+		for (uint64_t w = origin / window + lane; w < c; w += wave64::size) { sum = (U) (sum + tail_sums[w]); }
+		sum = detail::wave_sum(sum);
+		if (lane == 0) { window_bases[c] = (U) (anchor_values[segment] + sum); }
+	}
+}
+
+/// decompress_at_any_alignment for segments of MORE than detail::rows_per_chunk rows, given the windows' bases (workgroups of up to 4 wavefronts)
+template <unsigned IndexSize, unsigned UncompressedSize, unsigned CompressedSize>
+__global__ void decompress_windows_at_any_alignment(
+	uint_t<UncompressedSize>*        __restrict__  decompressed,
+	const uint_t<CompressedSize>*    __restrict__  compressed_input,
+	const uint_t<UncompressedSize>*  __restrict__  anchor_values,
+	size_type_by_index_size<IndexSize>             length,
+	size_type_by_index_size<IndexSize>             segment_length,
+	const uint_t<UncompressedSize>*  __restrict__  window_bases)
+{
+	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
+	if (length == 0 || (uint64_t) segment_length <= (uint64_t) detail::rows_per_chunk * traits::row || wave64::per_block() > detail::any_length_waves) { return; }
+	__shared__ uint_t<UncompressedSize> bases_of_segments[detail::any_length_waves][traits::row];
+	detail::wave_windows_of_any_segments<UncompressedSize, CompressedSize, sorted_patches::none, true, launch_grid::whole, true>(
+		decompressed, compressed_input, anchor_values, length, segment_length, sorted_patches::none(), bases_of_segments[wave64::index_in_block()],
+		launch_grid::whole(), window_bases);
 }
 
 // ---- long segments: tiles chained by a decoupled look-back ---------------------------------------------------------------

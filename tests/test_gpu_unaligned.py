@@ -173,15 +173,18 @@ def test_discard_zero_bytes_fixed_at_any_alignment(usize, csize):
 @pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
 def test_delta_at_any_alignment(usize, csize):
     """Delta's build for columns at an odd element offset (kernels/decompression/delta.hpp, decompress_at_any_alignment): windows of the column whose rows follow the
-    output's boundaries — segment lengths that are and are not multiples of a lane's elements or of a row, shorter than a row, as long as the 32 rows the build
-    takes, and longer (the element-wise path); outputs and deltas at several element offsets"""
+    output's boundaries — segment lengths that are and are not multiples of a lane's elements or of a row, shorter than a row, as long as the 32 rows a window
+    takes, and longer (the windows' bases then come from a pre-pass: decompress_windows_at_any_alignment); outputs and deltas at several element offsets"""
     import gpu_util as g
     from libgiddy_amd import schemes
     st = g.stream()
     ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
     guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
     row = 64 * 16 // usize
-    for n, seglen in ((1, 4), (19, 4), (5000, 7), (70001, 48), (70001, row), (300007, 1000), (300007, 4096), (300007, 32 * row), (150001, 32 * row + 8), (70001, 100000)):
+    for n, seglen in ((1, 4), (19, 4), (5000, 7), (70001, 48), (70001, row), (300007, 1000), (300007, 4096), (300007, 32 * row), (150001, 32 * row + 8), (70001, 100000),
+                      # (round 6: segments longer than the 32-row window — windows whose bases come from the pre-pass: whole and ragged multiples of the window, lengths that are
+                      # not multiples of a lane's elements, one boundary early / late in a window, a column shorter than its one segment)
+                      (300007, 64 * row), (300007, 32 * row + 1), (1000003, 5 * 32 * row + 3), (700001, 33 * row), (1 << 20, 1 << 18), ((1 << 20) + 5, 3 * 32 * row - 1), (100003, 1 << 20)):
         f, truth = cases.delta_case(n, seglen, ud, cd, seed=n + usize + csize, base=(1 << (8 * usize - 2)))
         anchors = g.dev(f["anchor_values"])
         for out_offset, in_offset in _OFFSETS + ((16 // usize, 1),):
