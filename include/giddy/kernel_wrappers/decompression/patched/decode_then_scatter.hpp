@@ -13,6 +13,10 @@
 #include "giddy/kernels/data_layout/scatter.hpp"
 #include "giddy/on_device/sorted_patches.hpp"
 
+#include <memory>
+#include <stdexcept>
+#include <string>
+
 namespace cuda {
 namespace kernels {
 namespace decompression {
@@ -39,15 +43,24 @@ inline bool decode_then_scatter_is_faster(family_t family, unsigned element_size
 	}
 }
 
-/// The two launches on `stream`.  `arguments`: the fused wrapper's own map (the plain wrapper reads its keys out of it); `plain_resolution_arguments`: what the plain
-/// wrapper's resolve_launch_configuration takes; `fused_config`: the configuration the caller resolved for the fused kernel — a caller's block-size limit is read
-/// off it and kept.
-template <typename PlainWrapper, unsigned IndexSize, unsigned ElementSize>
+/// The two launches on `stream`.  `PatchedWrapper`: the fused wrapper that calls — the plain one is the factory's, under the fused wrapper's key less "patched::"
+/// (produced once per fused wrapper type: the plain decoders are not instantiated a second time in the fused wrappers' translation units); `arguments`: the fused
+/// wrapper's own map (the plain wrapper reads its keys out of it); `plain_resolution_arguments`: what the plain wrapper's resolve_launch_configuration takes;
+/// `fused_config`: the configuration the caller resolved for the fused kernel — a caller's block-size limit is read off it and kept.
+template <typename PatchedWrapper, unsigned IndexSize, unsigned ElementSize>
 inline void decode_then_scatter(stream::id_t stream, const launch_configuration_t& fused_config, const kernel_t::arguments_type& arguments,
 	const kernel_t::arguments_type& plain_resolution_arguments, uint_t<ElementSize>* decompressed, const uint_t<ElementSize>* patch_values,
 	const uint_t<IndexSize>* patch_positions, size_type_by_index_size<IndexSize> num_patches)
 {
-	static const PlainWrapper plain;
+	static const std::unique_ptr<cuda::registered::kernel_t> plain_wrapper = [] {
+		std::string key = cuda::registered::detail::factory_key_of(util::type_name<PatchedWrapper>());
+		const std::string marker = "patched::";
+		const auto at = key.find(marker);
+		if (at == std::string::npos) { throw std::logic_error("not a fused wrapper's key: " + key); }
+		key.erase(at, marker.length());
+		return cuda::registered::kernel_t::produceSubclass(key);
+	}();
+	const cuda::registered::kernel_t& plain = *plain_wrapper;
 	static const device_function::attributes_t plain_attributes = plain.get_device_function().attributes();
 	const auto& properties = current_device_properties();
 	launch_configuration_limits_t limits { nullopt, nullopt, nullopt };

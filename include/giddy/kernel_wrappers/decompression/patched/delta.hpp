@@ -7,7 +7,6 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
-#include "giddy/kernel_wrappers/decompression/delta.hpp"
 #include "giddy/kernels/decompression/delta.hpp"
 
 namespace cuda {
@@ -80,7 +79,7 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::enqueue_launch_with(
 			arguments_type resolution;
 			resolution["length"] = (size_t) length;
 			resolution["segment_length"] = (size_t) segment_length;
-			decompression::patched::decode_then_scatter<delta::kernel_t<IndexSize, UncompressedSize, CompressedSize>, IndexSize, UncompressedSize>(
+			decompression::patched::decode_then_scatter<kernel_t<IndexSize, UncompressedSize, CompressedSize>, IndexSize, UncompressedSize>(
 				stream, launch_config, arguments, resolution, decompressed, patch_values, patch_positions, (size_type) num_patches);
 			return;
 		}

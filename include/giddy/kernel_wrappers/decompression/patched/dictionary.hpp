@@ -7,7 +7,6 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
-#include "giddy/kernel_wrappers/decompression/dictionary.hpp"
 #include "giddy/kernels/decompression/dictionary.hpp"
 
 namespace cuda {
@@ -104,7 +103,7 @@ void kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>::enqueue_launch_
 			resolution["num_dictionary_entries"] = (size_t) num_dictionary_entries;
 			resolution["data_length"] = (size_t) length;
 			if (maybe_cache) { resolution["cache_input_data_in_shared_mem"] = maybe_cache.value(); }
-			decompression::patched::decode_then_scatter<dictionary::kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>, IndexSize, UncompressedSize>(
+			decompression::patched::decode_then_scatter<kernel_t<IndexSize, UncompressedSize, DictionaryIndexSize>, IndexSize, UncompressedSize>(
 				stream, launch_config, arguments, resolution, decompressed, patch_values, patch_positions, (size_type) num_patches);
 			return;
 		}

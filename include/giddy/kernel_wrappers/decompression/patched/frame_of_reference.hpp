@@ -6,7 +6,6 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
-#include "giddy/kernel_wrappers/decompression/frame_of_reference.hpp"
 #include "giddy/kernels/decompression/frame_of_reference.hpp"
 
 namespace cuda {
@@ -73,7 +72,7 @@ void kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>::enqueue_
 			arguments_type resolution;
 			resolution["length"] = (size_t) length;
 			resolution["segment_length"] = (size_t) segment_length;
-			decompression::patched::decode_then_scatter<frame_of_reference::kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>, IndexSize, 2>(
+			decompression::patched::decode_then_scatter<kernel_t<IndexSize, Uncompressed, Compressed, UnaryModelFunction>, IndexSize, 2>(
 				stream, launch_config, arguments, resolution, reinterpret_cast<uint_t<2>*>(decompressed), reinterpret_cast<const uint_t<2>*>(patch_values), patch_positions, (size_type) num_patches);
 			return;
 		}

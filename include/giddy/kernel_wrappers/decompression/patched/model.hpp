@@ -7,7 +7,6 @@
 #include "giddy/kernel_wrappers/common.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/patch_positions.hpp"
 #include "giddy/kernel_wrappers/decompression/patched/decode_then_scatter.hpp"
-#include "giddy/kernel_wrappers/decompression/model.hpp"
 #include "giddy/kernels/decompression/model.hpp"
 
 namespace cuda {
@@ -69,7 +68,7 @@ void kernel_t<IndexSize, Uncompressed, UnaryModelFunction>::enqueue_launch_with(
 		if (decompression::patched::decode_then_scatter_is_faster(decompression::patched::family_t::model, 2, (uint64_t) num_patches, (uint64_t) length)) {
 			arguments_type resolution;
 			resolution["length"] = (size_t) length;
-			decompression::patched::decode_then_scatter<model::kernel_t<IndexSize, Uncompressed, UnaryModelFunction>, IndexSize, 2>(
+			decompression::patched::decode_then_scatter<kernel_t<IndexSize, Uncompressed, UnaryModelFunction>, IndexSize, 2>(
 				stream, launch_config, arguments, resolution, reinterpret_cast<uint_t<2>*>(decompressed), reinterpret_cast<const uint_t<2>*>(patch_values), patch_positions, (size_type) num_patches);
 			return;
 		}

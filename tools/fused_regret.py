@@ -127,12 +127,14 @@ def main():
                 schemes.scatter(check, pval, pidx, count, **skw)
             ms_fused = sw.timeit(lambda: fused(out, pval, pidx, count))
             ms_two = sw.timeit(two_launches)
+            ms_plain = sw.timeit(lambda: plain(check)) if "--parts" in sys.argv else None
             frac = lambda ms: nbytes / ms / 1e6 / 80.0
             regret = max(0.0, frac(ms_two) - frac(ms_fused))
             if regret > worst[0]:
                 worst = (regret, "%s at %g" % (name, density))
             print("%-44s patches %-7g fused %5.1f   decode + scatter %5.1f   regret %4.1f  (relative %4.1f %%)  %s" % (
-                name, density, frac(ms_fused), frac(ms_two), regret, 100.0 * regret / frac(ms_two), "ok" if ok else "MISMATCH"), flush=True)
+                name, density, frac(ms_fused), frac(ms_two), regret, 100.0 * regret / frac(ms_two), "ok" if ok else "MISMATCH") +
+                ("" if ms_plain is None else "   [ms: fused %.3f, two launches %.3f, the plain decoder alone %.3f]" % (ms_fused, ms_two, ms_plain)), flush=True)
         del out, check
         torch.cuda.empty_cache()
     print("# worst regret: %.1f points (%s)" % worst)

@@ -11,10 +11,14 @@
    flag at three call sites of the tile loop (different wavefronts could arrive at different s_barrier instructions).  Now stream_tiles calls the hook from one place outside
    its loops; the scan asserts what that gives: every dictionary kernel holds at most TWO s_barrier instructions (the overlapped staging's, and the plain staging loop's of
    the other branch), none of them inside a loop (no backward branch across it).
+4. FULL WAITS INSIDE LOOPS (informative): `s_waitcnt vmcnt(0)` on a cycle of the control-flow graph.  CDNA4 counts vector memory operations in order, and a wait for the rows
+   requested a trip ago should leave the newer requests in flight (`vmcnt(n)`); behind a wave-uniform branch around a load or a store the compiler no longer knows the count
+   and waits for everything — the next rows' loads AND the stores before.  Round 6 found the plain Dictionary <4,8,2>'s chunk loop that way (61 -> 76 % of the HBM peak once
+   whole chunks ran straight-line code).  Listed per kernel family: decompressors with the most such waits.  `--loops` prints the table.
 """
 import collections, glob, os, re, shutil, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
-library = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libgiddy_amd", "libgiddy_amd.so")
+library = sys.argv[1] if len(sys.argv) > 1 and not sys.argv[1].startswith("--") else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libgiddy_amd", "libgiddy_amd.so")
 SCC_WRITER = re.compile(r"^s_(and|or|xor|andn2|orn2|nand|nor|xnor|add|sub|addc|subb|cmp|bitcmp|lshl|lshr|ashr|bfe|abs|min|max|not|wqm|bcnt|ff|flbit|absdiff|cmpk|addk|mulk|quadmask)[a-z0-9_]*\b")
 ARITHMETIC = re.compile(r"^s_(add|sub|addc|subb|lshl|lshr|ashr|addk|mulk|bfe|abs|min|max|absdiff)[a-z0-9_]*\b")
 
@@ -28,7 +32,7 @@ def family(name):
 
 
 serialized, stale = collections.defaultdict(list), collections.defaultdict(list)
-listing = collections.defaultdict(list)   # dictionary kernels: (address, instruction, branch target relative to the kernel's symbol or None)
+listing = collections.defaultdict(list)   # decompressors: (address, instruction, branch target relative to the kernel's symbol or None)
 kernels = 0
 kernel_start = {}
 with tempfile.TemporaryDirectory() as scratch:
@@ -49,7 +53,7 @@ with tempfile.TemporaryDirectory() as scratch:
             if kernel is None or not instruction:
                 continue
             index += 1
-            if "dictionary" in kernel:
+            if "decompress" in kernel or "piece_body" in kernel:
                 comment = line.split("//")[1] if "//" in line else ""
                 address = re.match(r"\s*([0-9A-Fa-f]+):", comment)
                 if address:
@@ -110,7 +114,7 @@ def barriers_in_cycles(start, instructions):
 
 
 bad_barriers, barrier_counts = [], collections.Counter()
-dictionary_kernels = [k for k in listing if "decompress" in demangled(k).split("(")[0] or "piece_body" in demangled(k).split("(")[0]]
+dictionary_kernels = [k for k in listing if "dictionary" in k and ("decompress" in demangled(k).split("(")[0] or "piece_body" in demangled(k).split("(")[0])]
 for k in dictionary_kernels:
     count, in_cycles = barriers_in_cycles(kernel_start[k], listing[k])
     barrier_counts[count] += 1
@@ -120,4 +124,43 @@ print("3. dictionary decoders: %d kernels, s_barrier instructions per kernel %s;
     len(dictionary_kernels), sorted(barrier_counts.items()), len(bad_barriers)))
 for k, count, inside in bad_barriers[:10]:
     print("   %s: %d s_barrier, %d inside a loop" % (demangled(k)[:140], count, inside))
+if "--loops" in sys.argv:
+    def full_waits_in_cycles(start, instructions):
+        addresses = [a for a, _, _ in instructions]
+        leaders = {addresses[0]}
+        for i, (a, text, target) in enumerate(instructions):
+            if text.startswith(("s_cbranch", "s_branch", "s_endpgm")):
+                if i + 1 < len(instructions):
+                    leaders.add(addresses[i + 1])
+                if target is not None:
+                    leaders.add(start + target)
+        block_of, successors, current = {}, collections.defaultdict(set), None
+        for i, (a, text, target) in enumerate(instructions):
+            if a in leaders:
+                if current is not None and not instructions[i - 1][1].startswith(("s_branch", "s_endpgm")):
+                    successors[current].add(a)
+                current = a
+            block_of[a] = current
+            if target is not None:
+                successors[current].add(start + target)
+        cyclic = {}
+        def on_a_cycle(block):
+            if block not in cyclic:
+                seen, stack, found = set(), list(successors[block]), False
+                while stack and not found:
+                    b = stack.pop()
+                    if b == block: found = True
+                    elif b not in seen: seen.add(b); stack.extend(successors[b])
+                cyclic[block] = found
+            return cyclic[block]
+        waits = [a for a, text, _ in instructions if text.startswith("s_waitcnt") and "vmcnt(0)" in text]
+        return len(waits), sum(1 for a in waits if on_a_cycle(block_of[a]))
+    print("4. s_waitcnt vmcnt(0) on a cycle of the control-flow graph (of all such waits), decompressors, most first:")
+    rows = []
+    for k in listing:
+        if k in kernel_start and listing[k]:
+            total, in_loops = full_waits_in_cycles(kernel_start[k], listing[k])
+            rows.append((in_loops, total, demangled(k).replace("void cuda::kernels::", "").split("(")[0]))
+    for in_loops, total, name in sorted(rows, reverse=True)[:int(os.environ.get("SCAN_TOP", "60"))]:
+        print("   %3d of %3d  %s" % (in_loops, total, name[:150]))
 sys.exit(1 if stale or bad_barriers else 0)
