@@ -85,10 +85,26 @@ __global__ void scatter_ascending(
 		const bool has_next = (g + 1) * G < n;
 		const bool neighbour_has_it = lane != wave64::size - 1 && g + 1 < num_groups;
 		const index_type next = neighbour_has_it ? neighbours : (has_next ? indices[(g + 1) * G] : (index_type) 0);
+		bool repeated[G];
 		#pragma unroll
-		for (unsigned j = 0; j < G; j++) {
-			const bool repeated = j + 1 < G ? where[j + 1] == where[j] : (has_next && next == where[j]);
-			if (!repeated) { target[where[j]] = what[j]; }
+		for (unsigned j = 0; j < G; j++) { repeated[j] = j + 1 < G ? where[j + 1] == where[j] : (has_next && next == where[j]); }
+		// The stores are UNCONDITIONAL wherever the lane has one patch that is not repeated: a repeated one is sent to that patch's place with that patch's datum (the same
+		// lane storing the same thing twice) — a store inside a branch makes the compiler wait for every earlier store before it (vmcnt(0): the count is unknown behind a
+		// branch), and four such waits a lane cost this kernel 25 % against `scatter` (profiles/r06_fused_regret.txt).  A lane whose patches ALL repeat — a run of equal
+		// positions longer than the lane — is rare: then the wavefront takes the branches.
+		unsigned safe = G;
+		#pragma unroll
+		for (unsigned j = 0; j < G; j++) { if (!repeated[j]) { safe = j; } }
+		if (wave64::ballot(safe == G) == 0) {
+			index_type safe_where = where[0]; element_type safe_what = what[0];
+			#pragma unroll
+			for (unsigned j = 1; j < G; j++) { if (safe == j) { safe_where = where[j]; safe_what = what[j]; } }
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { target[repeated[j] ? safe_where : where[j]] = repeated[j] ? safe_what : what[j]; }
+		}
+		else {
+			#pragma unroll
+			for (unsigned j = 0; j < G; j++) { if (!repeated[j]) { target[where[j]] = what[j]; } }
 		}
 	}
 	for (uint64_t i = num_groups * G + global_thread; i < n; i += num_threads) {

@@ -73,6 +73,15 @@ template <unsigned UncompressedSize, unsigned DictionaryIndexSize> constexpr boo
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize>
 using chunk_key_storage = stream_tiles::chunk_input_storage<uint_t<DictionaryIndexSize>, uint_t<UncompressedSize>, stages_chunk_keys<UncompressedSize, DictionaryIndexSize>()>;
 
+/// 16-byte stores per lane per tile: 4 (stream_tiles::steps_per_tile) — 8 where a dictionary of 2-byte keys is re-staged per workgroup for 2- and 4-byte values: up to 8 KiB /
+/// 16 KiB of dictionary staged per 32 / 64 KiB of output instead of per 16 / 32 (round 6, same-box: <*,2,2> 68 -> 70.5 %, <*,4,2> 75 -> 77 % of the HBM peak; every other
+/// instantiation loses with 8: <*,8,1> -10 points, <*,4,4> -5, 1-byte keys -1 ... -3).  Kernel and launch parameters agree.
+template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary>
+constexpr unsigned steps_per_tile_for()
+{
+	return (RestagedDictionary && DictionaryIndexSize == 2 && UncompressedSize >= 2 && UncompressedSize <= 4) ? 8u : (unsigned) stream_tiles::steps_per_tile;
+}
+
 /// (`LooksUpThroughMemory`: the dictionary is not in LDS — a tile's look-ups all go out before its first store)
 template <unsigned UncompressedSize, unsigned DictionaryIndexSize, bool RestagedDictionary = false, bool AnyAlignment = false, bool LooksUpThroughMemory = false, typename Lookup, typename Patches, typename AfterLoads = stream_tiles::nothing_to_do, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void translate(
@@ -104,7 +113,7 @@ __device__ __forceinline__ void translate(
 		}
 	}
 	else {
-		stream_tiles::transform<key_type, value_type, stream_tiles::steps_per_tile, memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment, LooksUpThroughMemory>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);
+		stream_tiles::transform<key_type, value_type, steps_per_tile_for<UncompressedSize, DictionaryIndexSize, RestagedDictionary>(), memory_access::wide_output_policy<sizeof(value_type)>(GIDDY_DICT_STORE_POLICY), AnyAlignment, LooksUpThroughMemory>(decompressed, compressed_input, n, produce_group, produce_one, after_loads, stream_tiles::nothing_to_prepare(), grid);
 	}
 }
 
@@ -312,6 +321,7 @@ public:
 		const bool by_chunks = detail::by_wave_chunks<false, UncompressedSize, DictionaryIndexSize, false>() ||
 			(restaged && detail::by_wave_chunks<false, UncompressedSize, DictionaryIndexSize, true>());
 		const unsigned elements_per_thread_per_tile = by_chunks ? stream_tiles::elements_per_thread_per_chunk<uint_t<UncompressedSize>>()
+			: restaged ? stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>, detail::steps_per_tile_for<UncompressedSize, DictionaryIndexSize, true>()>()
 			: stream_tiles::elements_per_thread_per_tile<uint_t<UncompressedSize>>();
 		grid_construction_resolution  = thread;
 		length                        = util::div_rounding_up(data_length, elements_per_thread_per_tile);
