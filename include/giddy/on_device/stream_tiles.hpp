@@ -31,12 +31,12 @@ struct nothing_to_do { __device__ __forceinline__ void operator()() const { } };
 
 /// out[p] = produce(p, in[p]) for p < n.  `produce_group(first_position, inputs, outputs)` handles G
 /// consecutive elements at once (it may hoist per-group work such as a segment lookup).
-/// `after_loads()` is called by every thread of the workgroup EXACTLY ONCE, from ONE place in the function that is not inside a loop
-/// or a condition — behind the loads of the workgroup's first tile (if it has one), before the first produce: the place for a side
-/// table's trip through LDS with its barrier, so that the table's latency overlaps the tile's own loads.  (A decoder that passes one
-/// gets the loop in its software-pipelined form, `pipelined_tiles` below: the same order of memory operations, with the call hoisted
-/// out of the loop — until round 6 the hook ran per tile, guarded by a flag, and its __syncthreads() was reached from three call
-/// sites, which is outside what HIP promises for a barrier.)
+/// `after_loads()` is called by every thread of the workgroup EXACTLY ONCE and never inside a loop — behind the loads of the workgroup's
+/// first tile (if it has one), before the first produce: the place for a side table's trip through LDS with its barrier, so that the
+/// table's latency overlaps the tile's own loads.  In transform() there are two such places — the first tile whole, or not — chosen by a
+/// condition that is the same for every thread of the workgroup (which is what HIP asks of a barrier in conditional code); in
+/// transform_and_patch(), where wavefronts differ in their chunks, there is ONE.  (Until round 6 the hook ran per tile and per chunk,
+/// guarded by a flag: a workgroup's wavefronts could arrive at different s_barrier instructions.)
 struct no_context { };
 struct nothing_to_prepare { __device__ __forceinline__ no_context operator()(uint64_t) const { return no_context(); } };
 
@@ -65,8 +65,8 @@ __host__ __forceinline__ bool wants_any_alignment_build(const Out* out, const In
 	return (reinterpret_cast<uintptr_t>(out) & 127) != 0 || (reinterpret_cast<uintptr_t>(in) & (in_bytes - 1)) != 0;
 }
 
-/// transform()'s tile loop for a decoder with an `after_loads` hook, software-pipelined so that the hook is called from one place: the first tile's loads,
-/// the hook, then { produce and store the tile; the next tile's loads } while there are tiles.  Every quantity the loop branches on (the tile index, whether a
+/// transform()'s tile loop for a decoder with an `after_loads` hook, arranged so that the hook is called from one place: the first tile's loads, the hook, the first
+/// tile's produces and stores — then the workgroup's other tiles as transform() itself takes them.  Every quantity the loop branches on (the tile index, whether a
 /// tile is whole) is the same for all the threads of a workgroup.  `lead`: elements in front of the first group (the AnyAlignment build), else 0.
 template <typename In, typename Out, unsigned K, int Stores, bool AnyAlignment, typename ProduceGroup, typename AfterLoads, typename Grid>
 __device__ __forceinline__ void pipelined_tiles(
@@ -91,11 +91,11 @@ __device__ __forceinline__ void pipelined_tiles(
 			}
 		}
 	};
-	uint64_t tile = grid.block();
-	bool more = tile * groups_per_tile < num_groups;
-	if (more) { load_tile(tile); }
-	after_loads();
-	while (more) {
+	// ONLY THE FIRST TILE is taken apart around the hook.  The tiles behind it — a workgroup has them when the column has more tiles than the grid may have workgroups:
+	// 8-byte values from 2^30 elements on — keep loads, produces and stores in ONE block each: with every tile's loads issued at the end of the trip before (the first
+	// version of this loop) they sat behind a branch, the wait for them became vmcnt(0), and that waits for the previous tile's write-through stores as well
+	// (Dictionary <*,8,1> at 2^30: 76 -> 62 % of the HBM peak; at 2^28, one tile per workgroup, nothing showed).
+	auto produce_and_store_tile = [&](uint64_t tile) {
 		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
 		if ((tile + 1) * groups_per_tile <= num_groups) {
 			// a whole tile (every tile but possibly the last): no per-step bounds checks
@@ -120,9 +120,51 @@ __device__ __forceinline__ void pipelined_tiles(
 				store_group<Stores>(out + g * G, outputs);
 			}
 		}
-		tile += grid.blocks();
-		more = tile * groups_per_tile < num_groups;
-		if (more) { load_tile(tile); }
+	};
+	uint64_t tile = grid.block();
+	const bool any = tile * groups_per_tile < num_groups;   // (the same for every thread of the workgroup, as is `whole` below: they come from blockIdx and the column's length)
+	if (any && (tile + 1) * groups_per_tile <= num_groups) {
+		// the usual case — the workgroup's first tile is a whole one — in ONE block: loads, hook, produces and stores.  (With the loads inside a branch of their own and the
+		// hook behind its join, narrow inputs — 1-byte keys of 8-byte values, a 2-byte load per step that is unpacked into its group — were waited for and unpacked BEFORE
+		// the hook's barrier: the overlap of the two round trips this hook exists for was gone, Dictionary <*,8,1> 76 -> 62-68 % of the HBM peak at 2^30.)
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) { inputs[k] = load(first_group + (uint64_t) k * blockDim.x); }
+		after_loads();
+		#pragma unroll
+		for (unsigned k = 0; k < K; k++) {
+			const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+			group<Out, G> outputs;
+			produce_group(lead + g * G, inputs[k], outputs);
+			store_group<Stores>(out + g * G, outputs);
+			if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
+		}
+	}
+	else {
+		// (no tile for this workgroup — the hook still runs: the column's scalar tail looks things up too —, or a ragged one)
+		if (any) { load_tile(tile); }
+		after_loads();
+		if (any) { produce_and_store_tile(tile); }
+	}
+	if (!any) { return; }
+	for (tile += grid.blocks(); tile * groups_per_tile < num_groups; tile += grid.blocks()) {
+		const uint64_t first_group = tile * groups_per_tile + threadIdx.x;
+		if ((tile + 1) * groups_per_tile <= num_groups) {
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) { inputs[k] = load(first_group + (uint64_t) k * blockDim.x); }
+			#pragma unroll
+			for (unsigned k = 0; k < K; k++) {
+				const uint64_t g = first_group + (uint64_t) k * blockDim.x;
+				group<Out, G> outputs;
+				produce_group(lead + g * G, inputs[k], outputs);
+				store_group<Stores>(out + g * G, outputs);
+				if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }
+			}
+		}
+		else {
+			load_tile(tile);
+			produce_and_store_tile(tile);
+		}
 	}
 }
 
@@ -375,9 +417,9 @@ __device__ __forceinline__ void transform_and_patch(
 	constexpr bool whole_chunks_in_straight_line = !Patches::enabled;
 	constexpr bool has_hook = !std::is_same<AfterLoads, nothing_to_do>::value;
 	if constexpr (has_hook) {
-		// The same chunk loop software-pipelined, so that the hook (a side table's trip through LDS and its BARRIER) is called from one place that every
-		// wavefront of the workgroup passes exactly once, whatever its number of chunks and whichever of the two forms its chunks take: the first chunk's
-		// seek probes and loads, the hook, then { the chunk; the next chunk's probes and loads } while there are chunks.
+		// The same chunk loop arranged so that the hook (a side table's trip through LDS and its BARRIER) is called from one place that every wavefront of the
+		// workgroup passes exactly once, whatever its number of chunks and whichever of the two forms its chunks take: the first chunk's seek probes and loads,
+		// the hook, the first chunk's rows — then the wavefront's other chunks.
 		using piece_t = typename chunk<16>::type;
 		constexpr unsigned pieces_per_lane = stage_chunk_input ? chunk_input_bytes / 16 / wave64::size : 1;
 		static_assert(!stage_chunk_input || (pieces_per_lane >= 1 && chunk_input_bytes % (16 * wave64::size) == 0), "a chunk's input is a whole number of 16-byte pieces per lane");
@@ -404,54 +446,58 @@ __device__ __forceinline__ void transform_and_patch(
 				}
 			}
 		};
-		uint64_t c = wave;
-		if (c < num_chunks) { issue(c); }
+		// ONLY THE FIRST CHUNK is taken apart around the hook; a wavefront's other chunks (a column of more chunks than the grid may have wavefronts) request their rows at
+		// the top of their own trip, as the loop below this one does — requested at the end of the trip before, the loads sit behind a branch and the wait for them also
+		// waits for the previous chunk's stores (pipelined_tiles, above).
+		auto rows_of_the_chunk = [&](uint64_t c) {
+				const uint64_t first_row = c * rows_per_chunk, end_row = end_of(first_row);
+				patches.finish_seek(lane);
+				if (comes_through_lds(first_row)) {
+					if constexpr (stage_chunk_input) {
+						In* mine = staging->inputs[wave64::index_in_block()];
+						wave64::lds_fence();   // (the previous chunk's rows have been read)
+						#pragma unroll
+						for (unsigned i = 0; i < pieces_per_lane; i++) { reinterpret_cast<piece_t*>(mine)[i * wave64::size + lane] = pieces[i]; }
+						wave64::lds_fence();
+						for (uint64_t r = first_row; r < end_row; r++) {
+							const uint64_t p = r * row + lane * G;
+							const group<In, G> inputs = load_group<In, G>(mine + (r - first_row) * row + lane * G);
+							group<Out, G> outputs;
+							produce_group(p, inputs, outputs);
+							patches.template apply_to_row<G>(r * row, lane, outputs);
+							store_group(out + p, outputs);
+						}
+					}
+				}
+				else if (whole_chunks_in_straight_line && end_row - first_row == rows_per_chunk) {   // wave-uniform
+					rows_of_a_whole_chunk<In, Out, R>(out, in, first_row, lane, current, produce_group, patches);
+				}
+				else {
+					for (uint64_t r = first_row; r < end_row; r += R) {
+						#pragma unroll
+						for (unsigned k = 0; k < R; k++) {
+							if (r + R + k < end_row) { next[k] = load_group<In, G>(in + (r + R + k) * row + lane * G); }
+						}
+						#pragma unroll
+						for (unsigned k = 0; k < R; k++) {
+							if (r + k >= end_row) { continue; }   // wave-uniform
+							const uint64_t p = (r + k) * row + lane * G;
+							group<Out, G> outputs;
+							produce_group(p, current[k], outputs);
+							patches.template apply_to_row<G>((r + k) * row, lane, outputs);
+							store_group(out + p, outputs);
+							if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }   // (as below)
+						}
+						#pragma unroll
+						for (unsigned k = 0; k < R; k++) { current[k] = next[k]; }
+					}
+				}
+		};
+		if (wave < num_chunks) { issue(wave); }
 		after_loads();
-		while (c < num_chunks) {
-			const uint64_t first_row = c * rows_per_chunk, end_row = end_of(first_row);
-			patches.finish_seek(lane);
-			if (comes_through_lds(first_row)) {
-				if constexpr (stage_chunk_input) {
-					In* mine = staging->inputs[wave64::index_in_block()];
-					wave64::lds_fence();   // (the previous chunk's rows have been read)
-					#pragma unroll
-					for (unsigned i = 0; i < pieces_per_lane; i++) { reinterpret_cast<piece_t*>(mine)[i * wave64::size + lane] = pieces[i]; }
-					wave64::lds_fence();
-					for (uint64_t r = first_row; r < end_row; r++) {
-						const uint64_t p = r * row + lane * G;
-						const group<In, G> inputs = load_group<In, G>(mine + (r - first_row) * row + lane * G);
-						group<Out, G> outputs;
-						produce_group(p, inputs, outputs);
-						patches.template apply_to_row<G>(r * row, lane, outputs);
-						store_group(out + p, outputs);
-					}
-				}
-			}
-			else if (whole_chunks_in_straight_line && end_row - first_row == rows_per_chunk) {   // wave-uniform
-				rows_of_a_whole_chunk<In, Out, R>(out, in, first_row, lane, current, produce_group, patches);
-			}
-			else {
-				for (uint64_t r = first_row; r < end_row; r += R) {
-					#pragma unroll
-					for (unsigned k = 0; k < R; k++) {
-						if (r + R + k < end_row) { next[k] = load_group<In, G>(in + (r + R + k) * row + lane * G); }
-					}
-					#pragma unroll
-					for (unsigned k = 0; k < R; k++) {
-						if (r + k >= end_row) { continue; }   // wave-uniform
-						const uint64_t p = (r + k) * row + lane * G;
-						group<Out, G> outputs;
-						produce_group(p, current[k], outputs);
-						patches.template apply_to_row<G>((r + k) * row, lane, outputs);
-						store_group(out + p, outputs);
-						if (G >= 8) { __builtin_amdgcn_sched_barrier(0); }   // (as below)
-					}
-					#pragma unroll
-					for (unsigned k = 0; k < R; k++) { current[k] = next[k]; }
-				}
-			}
-			c += num_waves;
-			if (c < num_chunks) { issue(c); }
+		if (wave < num_chunks) {
+			rows_of_the_chunk(wave);
+			for (uint64_t c = wave + num_waves; c < num_chunks; c += num_waves) { issue(c); rows_of_the_chunk(c); }
 		}
 	}
 	else

@@ -9,8 +9,9 @@
    arithmetic instruction, with a VOPC compare into VCC in between.
 3. BARRIERS OF THE DICTIONARY DECODERS: the staged dictionary's trip through LDS overlaps the first tile's key loads, which until round 6 put its __syncthreads() behind a
    flag at three call sites of the tile loop (different wavefronts could arrive at different s_barrier instructions).  Now stream_tiles calls the hook from one place outside
-   its loops; the scan asserts what that gives: every dictionary kernel holds at most TWO s_barrier instructions (the overlapped staging's, and the plain staging loop's of
-   the other branch), none of them inside a loop (no backward branch across it).
+   its loops; the scan asserts what that gives: every dictionary kernel holds at most THREE s_barrier instructions (the overlapped staging's — for a whole first tile, and for
+   a ragged or absent one: a workgroup-uniform choice —, and the plain staging loop's of the other branch; the chunk-wise kernels: two), none of them on a cycle of the
+   control-flow graph.
 4. FULL WAITS INSIDE LOOPS (informative): `s_waitcnt vmcnt(0)` on a cycle of the control-flow graph.  CDNA4 counts vector memory operations in order, and a wait for the rows
    requested a trip ago should leave the newer requests in flight (`vmcnt(n)`); behind a wave-uniform branch around a load or a store the compiler no longer knows the count
    and waits for everything — the next rows' loads AND the stores before.  Round 6 found the plain Dictionary <4,8,2>'s chunk loop that way (61 -> 76 % of the HBM peak once
@@ -118,9 +119,9 @@ dictionary_kernels = [k for k in listing if "dictionary" in k and ("decompress" 
 for k in dictionary_kernels:
     count, in_cycles = barriers_in_cycles(kernel_start[k], listing[k])
     barrier_counts[count] += 1
-    if count > 2 or in_cycles:
+    if count > 3 or in_cycles:
         bad_barriers.append((k, count, in_cycles))
-print("3. dictionary decoders: %d kernels, s_barrier instructions per kernel %s; more than two, or one inside a loop: %d kernels" % (
+print("3. dictionary decoders: %d kernels, s_barrier instructions per kernel %s; more than three, or one inside a loop: %d kernels" % (
     len(dictionary_kernels), sorted(barrier_counts.items()), len(bad_barriers)))
 for k, count, inside in bad_barriers[:10]:
     print("   %s: %d s_barrier, %d inside a loop" % (demangled(k)[:140], count, inside))

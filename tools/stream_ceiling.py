@@ -29,7 +29,9 @@ def shim():
 
 
 # (reserved LDS per workgroup -> resident workgroups per CU; store policy) the loop is tried with: the decoders' own launch shapes
-SHAPES = [(0, 1), (0, 2), (26624, 2), (39936, 2), (53248, 2)]
+# (0: whatever fits — 8 workgroups of 256 threads a CU; 26 624: 6 a CU, the headline's launch; 39 936: 4; 53 248: 3; 79 872: 2 — a copy's reads and writes want FEWER
+# workgroups in flight than a decoder's: 5.6 TB/s unthrottled, 6.1 at 3 a CU)
+SHAPES = [(0, 1), (0, 2), (26624, 2), (39936, 2), (53248, 2), (79872, 2)]
 
 
 def measure(log2n=30, repetitions=10):

@@ -114,16 +114,21 @@ def roofline_from_the_trace(durations_by_kernel, bench):
         full_size = [x for x in durations if 2 * x >= longest]
         sharing = [(w, r) for w, _, _, r in entries if chosen.get(w) == kernel]
         if len(sharing) > 1:
-            if any(r is None for _, r in sharing) or sum(r for _, r in sharing) * per_step != len(full_size):
+            # (a workload launches its step a few more times than it counts — its constructor's launch that resolves the configuration, a verification's —: up to four
+            # steps per workload are allowed for and placed at the BEGINNING of each workload's stretch, where they are; the timed region is a stretch's END)
+            counted = None if any(r is None for _, r in sharing) else sum(r for _, r in sharing) * per_step
+            extra = None if counted is None else len(full_size) - counted
+            if extra is None or extra < 0 or extra > 4 * per_step * len(sharing):
                 out.append("| %s | `%s` | %d | — | %d | — | %.4f | (shared kernel: %d full-size dispatches, the workloads' steps do not add up to it) |" % (
                     workload, head(kernel).replace("cuda::kernels::", ""), per_step, roofline["algorithmic_bytes_per_launch"], roofline["frac"], len(full_size)))
                 continue
             before = 0
-            for w, r in sharing:
+            for position, (w, r) in enumerate(sharing):
+                uncounted = extra // len(sharing) + (1 if position < extra % len(sharing) else 0)
                 if w == workload:
-                    full_size = full_size[before * per_step: (before + r) * per_step]
+                    full_size = full_size[before: before + uncounted + r * per_step]
                     break
-                before += r
+                before += uncounted + r * per_step
         timed = full_size[-steps * per_step:]
         mean_ns = sum(timed) / max(len(timed), 1)
         frac = roofline["algorithmic_bytes_per_launch"] / (per_step * mean_ns * 1e-9) / 8e12
