@@ -169,7 +169,7 @@ void kernel_t<IndexSize, UncompressedSize, CompressedSize>::launch(
 			return;
 		}
 		// ... and LONGER segments at such addresses (round 6): the windows' bases from a pre-pass over the deltas — two small launches and scratch for two values per
-		// window —, then the same windows (kernels/decompression/delta.hpp, decompress_windows_at_any_alignment): 17-21 % of the HBM peak element by element -> see
+		// window —, then the same windows (kernels/decompression/delta.hpp, decompress_windows_at_any_alignment): 17-21 % of the HBM peak element by element -> 51-64 %,
 		// profiles/r06_unaligned_bases.txt.  No scratch to be had (or segments of more than 2^16 windows: the pre-pass adds a segment's windows up per window): element by element.
 		constexpr uint64_t window = (uint64_t) detail::rows_per_chunk * traits::row;
 		if ((!memory_access::is_aligned(decompressed, 16) || !memory_access::is_aligned(compressed_input, traits::E * CompressedSize))

@@ -710,13 +710,11 @@ __host__ __device__ inline bool any_length_by_windows(uint64_t L)
 /// `AnyAlignment` (decompress_at_any_alignment): `out` and `in` aligned for their elements only.  Rows follow the output's 1 KiB boundaries as before — every row but the
 /// window's first is then stored 16 bytes per lane at aligned addresses, wherever the column begins; the first one, up to the boundary, goes element by element; the
 /// rows' loads are 16 bytes per lane at whatever address (gfx950 takes them).
-/// `LongSegments`: L > a window (decompress_windows_at_any_alignment: the value before each window from `window_bases`); otherwise L <= a window (the callers see to it)
-template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole, bool LongSegments = false>
+template <unsigned UncompressedSize, unsigned CompressedSize, typename Patches, bool AnyAlignment = false, typename Grid = launch_grid::whole>
 __device__ __forceinline__ void wave_windows_of_any_segments(
 	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
 	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, Patches patches, uint_t<UncompressedSize>* segment_bases,   // (LDS: traits::row entries, this wavefront's)
-	Grid grid = Grid(),
-	const uint_t<UncompressedSize>* __restrict__ window_bases = nullptr)   // (segments LONGER than a window: the value before each window's first element, from window_tail_sums / bases_of_windows below)
+	Grid grid = Grid())
 {
 	using traits = row_traits<UncompressedSize, CompressedSize>;
 	using U = typename traits::uncompressed_type;
@@ -731,9 +729,8 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 	const uint64_t num_waves = (uint64_t) grid.blocks() * wave64::per_block();
 	constexpr uint64_t window = (uint64_t) rows_per_chunk * traits::row;
 	const uint64_t num_chunks = (n + window - 1) / window;
-	const unsigned segment_length = (unsigned) L;   // (only used where L <= window)
+	const unsigned segment_length = (unsigned) L;
 	const float segments_per_element = 1.0f / (float) segment_length;
-	constexpr bool long_segments = LongSegments;   // (L > window: at most ONE segment begins inside a window)
 
 	struct row_bounds { uint64_t start, end; };   // wave-uniform
 	struct row_places { unsigned segment, within; U start_anchor[E]; };   // per lane: its first element's segment (of the chunk) and place in it; the anchors of the segments its elements begin
@@ -753,25 +750,9 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 			walk_start = r.end;
 			return r;
 		};
-		// (long segments: the window holds at most ONE segment start — `boundary`, or its own first element — and an element's place is a 32-bit comparison of
-		// positions relative to the window: `within` is not kept there)
-		const unsigned no_position = 0xFFFFFFFFu;
-		const unsigned boundary_in_window = origin + L < chunk_end ? (unsigned) (origin + L - chunk_start) : no_position;
-		const bool window_begins_a_segment = origin == chunk_start;
 		auto place = [&](const row_bounds& b) {
 			row_places where;
 			const uint64_t p = b.start + (uint64_t) lane * E;
-			if (long_segments) {
-				const unsigned q = (unsigned) (p - chunk_start);
-				where.segment = q >= boundary_in_window ? 1u : 0u;
-				where.within = 0;
-				#pragma unroll
-				for (unsigned j = 0; j < E; j++) {
-					const bool begins = q + j == boundary_in_window || (window_begins_a_segment && q + j == 0);
-					where.start_anchor[j] = (p + j < b.end && begins) ? anchors[first_segment + (q + j >= boundary_in_window ? 1u : 0u)] : (U) 0;
-				}
-				return where;
-			}
 			const unsigned past_origin = (unsigned) (p - origin);
 			where.segment = (unsigned) (((float) past_origin + 0.5f) * segments_per_element);   // (exact: see wave_rows_of_short_segments)
 			where.within = past_origin - where.segment * segment_length;
@@ -790,8 +771,7 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 		patches.begin_seek(chunk_start, lane);
 		#pragma unroll
 		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].template load<AnyAlignment>(in, bounds[k].start, bounds[k].end, lane); places[k] = place(bounds[k]); }
-		if (origin < chunk_start && window_bases != nullptr) { carry = window_bases[c]; }
-		else if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
+		if (origin < chunk_start) {   // (wave-uniform) the window begins inside a segment: the value before its first element
 			sum_type sum = 0;
 			const uint64_t aligned_origin = origin / E * E;   // (16-byte loads: the elements of the first group that lie before the segment are left out)
 			for (uint64_t at = aligned_origin; at < chunk_start; at += 4 * traits::row) {
@@ -822,28 +802,13 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 				// 1. the elements that begin a segment leave its base — anchor less the row's prefix before it — in the table
 				unsigned segment = places[k].segment, within = places[k].within;
 				unsigned segment_of[E]; bool begins_in_row[E];
-				if (long_segments) {
-					const unsigned q = (unsigned) (p - chunk_start), row_in_window = (unsigned) (bounds[k].start - chunk_start);
-					#pragma unroll
-					for (unsigned j = 0; j < E; j++) {
-						const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
-						const bool behind_boundary = q + j >= boundary_in_window;
-						const bool begins = q + j == boundary_in_window || (window_begins_a_segment && q + j == 0);
-						segment_of[j] = behind_boundary ? 1u : 0u;
-						if (p + j < bounds[k].end && begins) { segment_bases[segment_of[j] - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
-						// where the element's segment begins, against where the row does
-						begins_in_row[j] = behind_boundary ? boundary_in_window >= row_in_window : (window_begins_a_segment && row_in_window == 0);
-					}
-				}
-				else {
-					#pragma unroll
-					for (unsigned j = 0; j < E; j++) {
-						const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
-						if (p + j < bounds[k].end && within == 0) { segment_bases[segment - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
-						segment_of[j] = segment;
-						begins_in_row[j] = (unsigned) (p - origin) + j - within >= row_past_origin;   // where the element's segment begins, against where the row does
-						if (++within == segment_length) { within = 0; segment++; }
-					}
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) {
+					const scan_type before_element = rows[k].prefix[j] - (scan_type) rows[k].deltas[j];
+					if (p + j < bounds[k].end && within == 0) { segment_bases[segment - first_segment_of_row] = (U) (places[k].start_anchor[j] - (U) before_element); }
+					segment_of[j] = segment;
+					begins_in_row[j] = (unsigned) (p - origin) + j - within >= row_past_origin;   // where the element's segment begins, against where the row does
+					if (++within == segment_length) { within = 0; segment++; }
 				}
 				wave64::lds_fence();
 				// 2. every element: its segment's base, or on from the previous row
@@ -869,6 +834,103 @@ __device__ __forceinline__ void wave_windows_of_any_segments(
 			}
 			#pragma unroll
 			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; places[k] = next_places[k]; }
+		}
+	}
+}
+
+/// Segments LONGER than a window, at any alignment (decompress_windows_at_any_alignment): windows of rows_per_chunk rows that follow the output's 1 KiB boundaries as above,
+/// the value before each window's first element given (`window_bases`, from the pre-pass) — and, since a window holds at most ONE segment start, everything in registers:
+/// an element at or behind the start counts from the new segment's anchor less the row's prefix before the start (one read_lane), the others go on from the carry.
+template <unsigned UncompressedSize, unsigned CompressedSize>
+__device__ __forceinline__ void wave_windows_of_long_segments(
+	uint_t<UncompressedSize>* __restrict__ out, const uint_t<CompressedSize>* __restrict__ in,
+	const uint_t<UncompressedSize>* __restrict__ anchors, uint64_t n, uint64_t L, const uint_t<UncompressedSize>* __restrict__ window_bases)
+{
+	using traits = row_traits<UncompressedSize, CompressedSize>;
+	using U = typename traits::uncompressed_type;
+	using scan_type = typename traits::scan_type;
+	constexpr unsigned E = traits::E;
+	constexpr unsigned R = 2;
+	constexpr unsigned log2_E = E == 8 ? 3 : (E == 4 ? 2 : 1);
+	constexpr uint64_t window = (uint64_t) rows_per_chunk * traits::row;
+	const unsigned lane = wave64::lane_id();
+	const uint64_t wave = (uint64_t) blockIdx.x * wave64::per_block() + wave64::index_in_block();
+	const uint64_t num_waves = (uint64_t) gridDim.x * wave64::per_block();
+	const uint64_t num_windows = (n + window - 1) / window;
+	sorted_patches::none no_patches;
+	struct row_bounds { uint64_t start, end; };   // wave-uniform
+
+	for (uint64_t c = wave; c < num_windows; c += num_waves) {
+		const uint64_t chunk_start = c * window;
+		const uint64_t chunk_end = chunk_start + window < n ? chunk_start + window : n;
+		const uint64_t first_segment = chunk_start / L, origin = first_segment * L;
+		// the one segment start the window may hold: its own first element, or `origin + L` inside it
+		const bool begins_a_segment = origin == chunk_start;
+		const uint64_t boundary = begins_a_segment ? chunk_start : origin + L;   // (>= chunk_end: none)
+		const bool has_boundary = boundary < chunk_end;
+		U anchor_at_boundary = 0;
+		if (has_boundary) { anchor_at_boundary = anchors[begins_a_segment ? first_segment : first_segment + 1]; }   // wave-uniform: a scalar load
+		U carry = 0;
+		if (!begins_a_segment) { carry = window_bases[c]; }
+		const uint64_t misplaced = (reinterpret_cast<uintptr_t>(out + chunk_start) / sizeof(U)) % traits::row;
+		const uint64_t head = misplaced == 0 ? traits::row : traits::row - misplaced;
+		uint64_t walk_start = chunk_start;
+		auto take_row = [&]() {
+			row_bounds r;
+			r.start = walk_start;
+			const uint64_t length = walk_start == chunk_start ? head : traits::row;
+			r.end = walk_start + length < chunk_end ? walk_start + length : chunk_end;
+			walk_start = r.end;
+			return r;
+		};
+		row_t<UncompressedSize, CompressedSize> rows[R], next[R];
+		row_bounds bounds[R], next_bounds[R];
+		#pragma unroll
+		for (unsigned k = 0; k < R; k++) { bounds[k] = take_row(); rows[k].template load<true>(in, bounds[k].start, bounds[k].end, lane); }
+		while (bounds[0].start < chunk_end) {
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { next_bounds[k] = take_row(); next[k].template load<true>(in, next_bounds[k].start, next_bounds[k].end, lane); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].scan(); }
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) {
+				if (bounds[k].start >= chunk_end) { continue; }   // wave-uniform
+				const uint64_t p = bounds[k].start + (uint64_t) lane * E;
+				const bool boundary_in_row = has_boundary && boundary >= bounds[k].start && boundary < bounds[k].end;   // wave-uniform
+				memory_access::group<U, E> values;
+				U new_base = 0;
+				unsigned boundary_in_lanes = 0xFFFFFFFFu;   // the boundary's place in the row, in elements
+				if (boundary_in_row) {
+					boundary_in_lanes = (unsigned) (boundary - bounds[k].start);
+					// the row's prefix before the boundary: the inclusive prefix of the element before it (0 at the row's first element)
+					scan_type before = 0;
+					if (boundary_in_lanes != 0) {
+						const unsigned at = boundary_in_lanes - 1, slot = at & (E - 1);
+						scan_type mine = rows[k].prefix[0];
+						#pragma unroll
+						for (unsigned j = 1; j < E; j++) { if (slot == j) { mine = rows[k].prefix[j]; } }
+						before = wave64::read_lane(mine, at >> log2_E);
+					}
+					new_base = (U) (anchor_at_boundary - (U) before);
+				}
+				const unsigned q = lane * E;
+				#pragma unroll
+				for (unsigned j = 0; j < E; j++) { values[j] = (U) ((q + j >= boundary_in_lanes ? new_base : carry) + (U) rows[k].prefix[j]); }
+				// the value of the row's last element: the next row's carry
+				const unsigned last_lane = (unsigned) ((bounds[k].end - bounds[k].start + E - 1) >> log2_E) - 1;
+				const unsigned last_slot = (unsigned) ((bounds[k].end - bounds[k].start - 1) & (E - 1));
+				U last_value = values[0];
+				#pragma unroll
+				for (unsigned j = 1; j < E; j++) { if (last_slot == j) { last_value = values[j]; } }
+				carry = wave64::read_lane(last_value, last_lane);
+				if (bounds[k].start == chunk_start && !memory_access::is_aligned(out + chunk_start, 16)) {   // (wave-uniform: the row up to the output's boundary)
+					#pragma unroll
+					for (unsigned j = 0; j < E; j++) { if (p + j < bounds[k].end) { out[p + j] = values[j]; } }
+				}
+				else { rows[k].store_values(out, bounds[k].start, bounds[k].end, lane, values, no_patches); }
+			}
+			#pragma unroll
+			for (unsigned k = 0; k < R; k++) { rows[k].deltas = next[k].deltas; bounds[k] = next_bounds[k]; }
 		}
 	}
 }
@@ -1256,11 +1318,8 @@ __global__ void decompress_windows_at_any_alignment(
 	const uint_t<UncompressedSize>*  __restrict__  window_bases)
 {
 	using traits = detail::row_traits<UncompressedSize, CompressedSize>;
-	if (length == 0 || (uint64_t) segment_length <= (uint64_t) detail::rows_per_chunk * traits::row || wave64::per_block() > detail::any_length_waves) { return; }
-	__shared__ uint_t<UncompressedSize> bases_of_segments[detail::any_length_waves][traits::row];
-	detail::wave_windows_of_any_segments<UncompressedSize, CompressedSize, sorted_patches::none, true, launch_grid::whole, true>(
-		decompressed, compressed_input, anchor_values, length, segment_length, sorted_patches::none(), bases_of_segments[wave64::index_in_block()],
-		launch_grid::whole(), window_bases);
+	if (length == 0 || (uint64_t) segment_length <= (uint64_t) detail::rows_per_chunk * traits::row) { return; }
+	detail::wave_windows_of_long_segments<UncompressedSize, CompressedSize>(decompressed, compressed_input, anchor_values, length, segment_length, window_bases);
 }
 
 // ---- long segments: tiles chained by a decoupled look-back ---------------------------------------------------------------
