@@ -198,6 +198,37 @@ def test_delta_at_any_alignment(usize, csize):
             assert len(bad) == 0, (n, seglen, out_offset, in_offset, bad[:5])
 
 
+@pytest.mark.parametrize("usize,csize", [(2, 1), (4, 1), (4, 2), (8, 1), (8, 2), (8, 4)])
+def test_delta_long_segments_at_random_offsets(usize, csize):
+    """decompress_windows_at_any_alignment (segments longer than the 32-row window, bases from the pre-pass) over random lengths, segment lengths and element
+    offsets: the boundary early, late and absent in a window, windows that begin segments, a ragged last window, columns of a single window"""
+    import gpu_util as g
+    from libgiddy_amd import schemes
+    st = g.stream()
+    ud, cd = np.dtype("u%d" % usize), np.dtype("u%d" % csize)
+    guard = np.frombuffer(bytes([0xCD] * usize), dtype=ud)[0]
+    window = 32 * 64 * 16 // usize
+    r = cases.rng(1234 + usize * 10 + csize)
+    for trial in range(24):
+        seglen = int(r.integers(window + 1, 6 * window))
+        if trial % 3 == 0:
+            seglen = int(r.integers(1, 5)) * window + int(r.integers(0, 2)) * (16 // usize)   # whole windows, or a lane's group more
+        n = int(r.integers(1, 12 * window))
+        out_offset, in_offset = int(r.integers(0, 3 * 16 // usize)), int(r.integers(0, 17))
+        if out_offset % (16 // usize) == 0 and in_offset % (16 // usize) == 0:
+            out_offset += 1   # (aligned addresses take the ordinary paths)
+        f, truth = cases.delta_case(n, seglen, ud, cd, seed=trial + usize, base=(1 << (8 * usize - 2)))
+        anchors = g.dev(f["anchor_values"])
+        in_buffer = g.dev(np.concatenate([np.zeros(in_offset, cd), f["compressed_input"]]))
+        out_buffer = g.dev_empty(out_offset + n + 8, ud)
+        schemes.delta(out_buffer.data_ptr() + out_offset * usize, in_buffer.data_ptr() + in_offset * csize, anchors, n, seglen,
+                      uncompressed_size=usize, compressed_size=csize, stream=st)
+        full = g.host(out_buffer, ud, out_offset + n + 8)
+        assert (full[:out_offset] == guard).all() and (full[out_offset + n:] == guard).all(), (n, seglen, out_offset, in_offset, "wrote outside the output")
+        bad = np.flatnonzero(full[out_offset:out_offset + n] != truth)
+        assert len(bad) == 0, (n, seglen, out_offset, in_offset, bad[:5])
+
+
 @pytest.mark.parametrize("usize", [1, 2, 4, 8])
 def test_run_decoders_store_their_rows_at_any_output_offset(usize):
     """run lengths and run positions (absolute, relative) into outputs 1, 3 and 5 elements past a 16-byte boundary: a tile's rows are stored 16 bytes per lane at
