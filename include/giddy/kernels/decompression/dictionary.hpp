@@ -179,6 +179,15 @@ __device__ __forceinline__ void decompress(
 			}
 			__syncthreads();
 		};
+		if constexpr (Patches::enabled) {
+			// The fused kernels stage BEFORE their chunk loop, with nothing overlapped: a wavefront's chunk begins with the seek's dependent round trips, beside which
+			// the dictionary's one is not seen — same-box, every fused instantiation equal to the overlapped form it replaces, <4,4,1> at 2^30 with 0.1 % of patches
+			// 81.0 / 81.2 / 78.7 against 81.2 / 78.9 / 81.0 % of the HBM peak, where the hook inside the chunk loop (one place, first chunk taken apart) gave 78.8 / 72.0 / 78.2.
+			stage();
+			translate<UncompressedSize, DictionaryIndexSize, true, AnyAlignment>(
+				decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stream_tiles::nothing_to_do(), grid);
+			return;
+		}
 		translate<UncompressedSize, DictionaryIndexSize, true, AnyAlignment>(
 			decompressed, compressed_input, length, [staged](key_type key) { return staged[key]; }, patches, chunk_staging, stage, grid);
 	}
