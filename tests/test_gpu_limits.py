@@ -88,3 +88,36 @@ def test_all_schemes_under_limits(limits):
         g.dev(c["scatter_position_offset_bytes"]), g.dev(c["scatter_position_anchors"]), 1024, c["num_scatter_position_runs"], 5000,
         stream=st, limits=lim))
     assert (g.host(t, np.uint32, n) == expect).all()
+
+
+@pytest.mark.parametrize("limits", LIMITS)
+def test_fused_wrappers_two_launches_under_limits(limits):
+    """Where a fused decompress-and-patch wrapper launches the plain decoder + scatter_ascending instead of its fused kernel (2-byte outputs at 1 % of patches:
+    kernel_wrappers/decompression/patched/decode_then_scatter.hpp) a caller's block-size limit carries over to both launches, and the result is the fused one's."""
+    import gpu_util as g
+    from libgiddy_amd import schemes, registered as r
+    from oracle import oracle
+    lim = r.launch_configuration_limits_t(**limits)
+    st = g.stream()
+    n = 300001
+    rng = cases.rng(77)
+    positions = np.sort(rng.choice(n, size=n // 100, replace=False)).astype(np.uint32)
+    # Delta <4,2,1>
+    f, truth = cases.delta_case(n, 4096, np.dtype("u2"), np.dtype("u1"), seed=5)
+    values = rng.integers(0, 65535, size=len(positions), endpoint=True).astype(np.uint16)
+    expect = oracle.scatter(truth.copy(), values, positions, threads=1)
+    out = g.dev_empty(n, np.uint16)
+    cfg = schemes.patched_delta(out, g.dev(f["compressed_input"]), g.dev(f["anchor_values"]), g.dev(values), g.dev(positions), n, 4096, len(positions),
+                                uncompressed_size=2, compressed_size=1, index_size=4, stream=st, limits=lim)
+    if "block_size" in limits:
+        assert cfg.block_dimensions[0] <= limits["block_size"]
+    assert (g.host(out, np.uint16, n) == expect).all()
+    # Model <4,short,linear> with 0.1 % of patches (two launches below 0.4 %)
+    few = np.ascontiguousarray(positions[::10])
+    signed_values = rng.integers(-30000, 30000, size=len(few)).astype(np.int16)
+    coefficients = np.array([-12345, 37], dtype=np.int16)
+    decoded = oracle.model(coefficients, n, np.dtype("i2"), "linear", model_index_size=4)
+    expect = oracle.scatter(decoded.copy(), signed_values, few, threads=1)
+    out = g.dev_empty(n, np.int16)
+    schemes.patched_model(out, coefficients, g.dev(signed_values), g.dev(few), n, len(few), uncompressed_size=2, model="linear", index_size=4, stream=st, limits=lim)
+    assert (g.host(out, np.int16, n) == expect).all()
