@@ -754,6 +754,12 @@ def main():
                 entry["ms_per_step"] = pc["ms_three_columns_in_turn"]
             if args.extras == "all" and name in ("frame_of_reference", "delta_patched", "run_length_encoding", "discard_zero_bytes_variable"):
                 line.setdefault("small_columns", {})[name] = small_columns(name, w, device)
+            # the same stream with the identity in place of the decoder, where the workload's traffic has one of the measured shapes
+            shape = {"dictionary_zipf": "widen_1_to_4", "frame_of_reference": "widen_2_to_4", "delta_patched": "widen_2_to_8", "discard_zero_bytes_fixed": "widen_2_to_8"}.get(name)
+            measured = line["roofline"].get("measured_ceiling", {}) if shape else {}
+            if shape and (shape + "_GBps") in measured:
+                entry["roofline"]["measured_stream_GBps"] = measured[shape + "_GBps"]
+                entry["roofline"]["frac_of_measured_stream"] = round(entry["roofline"]["achieved"] / measured[shape + "_GBps"], 4)
             if not args.no_cpu_baseline:
                 entry["cpu_baseline"] = cpu_baseline(w, min(w.n, 1 << (args.cpu_sample_log2 - 1)))
             entry["step_runs"] = w.step_runs

@@ -3,6 +3,7 @@
 // ("a measured on-box copy ceiling").  Two shapes:
 //   stream_copy      4 bytes in : 4 bytes out per element   (a plain copy)
 //   stream_widen     1 byte  in : 4 bytes out per element   (Dictionary<4,4,1>'s and DZB-fixed<4,4,1>'s traffic without their arithmetic)
+//   stream_widen_2_to_4 / _2_to_8   2 bytes in : 4 / 8 bytes out   (Frame of reference <4,int,short>'s; Delta <4,8,2>'s and DZB-fixed <4,8,2>'s)
 // Measurement infrastructure behind ctypes (tools/stream_ceiling.py); not part of libgiddy_amd.so.
 #include <hip/hip_runtime.h>
 
@@ -44,3 +45,5 @@ int launch(void* out, const void* in, uint64_t n, void* stream, uint32_t dynamic
 
 extern "C" int stream_copy(void* out, const void* in, uint64_t elements_of_4_bytes, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint32_t, uint32_t>(out, in, elements_of_4_bytes, stream, dynamic_lds, stores); }
 extern "C" int stream_widen(void* out, const void* in, uint64_t elements, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint8_t, uint32_t>(out, in, elements, stream, dynamic_lds, stores); }
+extern "C" int stream_widen_2_to_4(void* out, const void* in, uint64_t elements, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint16_t, uint32_t>(out, in, elements, stream, dynamic_lds, stores); }
+extern "C" int stream_widen_2_to_8(void* out, const void* in, uint64_t elements, void* stream, uint32_t dynamic_lds, int stores) { return launch<uint16_t, uint64_t>(out, in, elements, stream, dynamic_lds, stores); }

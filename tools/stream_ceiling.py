@@ -1,5 +1,5 @@
 """The measured streaming ceiling of this box (tests/cpp/stream_ceiling.hip): the library's own tile loop with the identity in place of a decoder,
-as a plain copy (4 B in : 4 B out) and as Dictionary<4,4,1>'s traffic shape (1 B in : 4 B out).  GB/s of bytes read + written, by HIP events on the launch stream."""
+as a plain copy (4 B in : 4 B out) and in the decoders' traffic shapes (1 B : 4 B Dictionary<4,4,1>, 2 B : 4 B Frame of reference, 2 B : 8 B Delta / DZB-fixed <4,8,2>).  GB/s of bytes read + written, by HIP events on the launch stream."""
 import ctypes
 import os
 import subprocess
@@ -22,7 +22,7 @@ def shim():
         if not os.path.exists(SHIM):
             raise FileNotFoundError("tests/cpp/bin/libstream_ceiling.so is not built (python -c 'import __graft_entry__ as g; g.build_cpp_test_tools()')")
         _shim = ctypes.CDLL(SHIM)
-        for f in (_shim.stream_copy, _shim.stream_widen):
+        for f in (_shim.stream_copy, _shim.stream_widen, _shim.stream_widen_2_to_4, _shim.stream_widen_2_to_8):
             f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
             f.restype = ctypes.c_int
     return _shim
@@ -41,9 +41,11 @@ def measure(log2n=30, repetitions=10):
     s = shim()
     n = 1 << log2n
     stream = torch.cuda.current_stream().cuda_stream
-    out = torch.empty(n, dtype=torch.int32, device="cuda")
     results = {}
-    for name, fn, in_bytes in (("copy", s.stream_copy, 4), ("widen_1_to_4", s.stream_widen, 1)):
+    for name, fn, in_bytes, out_dtype in (("copy", s.stream_copy, 4, torch.int32), ("widen_1_to_4", s.stream_widen, 1, torch.int32),
+                                          ("widen_2_to_4", s.stream_widen_2_to_4, 2, torch.int32), ("widen_2_to_8", s.stream_widen_2_to_8, 2, torch.int64)):
+        out = torch.empty(n, dtype=out_dtype, device="cuda")
+        out_bytes = out.element_size()
         source = torch.randint(0, 127, (n * in_bytes,), dtype=torch.int8, device="cuda")
         by_shape = {}
         for lds, stores in SHAPES:
@@ -56,16 +58,16 @@ def measure(log2n=30, repetitions=10):
                 begin.record(); fn(out.data_ptr(), source.data_ptr(), n, stream, lds, stores); end.record()
             torch.cuda.synchronize()
             ms = sorted(b.elapsed_time(e) for b, e in events)[repetitions // 2]
-            by_shape["lds=%d,stores=%s" % (lds, "sc1_nt" if stores == 2 else "nt")] = round((in_bytes + 4) * n / ms / 1e6, 1)
+            by_shape["lds=%d,stores=%s" % (lds, "sc1_nt" if stores == 2 else "nt")] = round((in_bytes + out_bytes) * n / ms / 1e6, 1)
         # (the identity is checked once: what was timed is a copy)
-        expected = source[: 1 << 20].to(torch.int32) if in_bytes == 1 else source.view(torch.int32)[: 1 << 20]
+        narrow = {1: torch.int8, 2: torch.int16, 4: torch.int32}[in_bytes]
+        expected = source.view(narrow)[: 1 << 20].to(out_dtype)
         assert bool((out[: 1 << 20] == expected).all())
         best = max(by_shape, key=by_shape.get)
         results[name + "_GBps"] = by_shape[best]
         results[name + "_best_shape"] = best
         results[name + "_by_shape"] = by_shape
-        del source
-    del out
+        del source, out
     torch.cuda.empty_cache()
     return results
 
