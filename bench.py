@@ -600,13 +600,21 @@ def strong_scaling_leg(name, log2n, args, rank, world, device, backend, barrier,
                                                     "what the decode itself would scale like; NOT a measured scaling curve — no 8-GPU node has been available")
     if gather and world > 1:
         expected = getattr(whole, "values", None) if rank == 0 else None   # (DZB-V keeps the column it compressed)
+        # (the optional collective is reported beside the decode and never part of `value`: a failure in it — it has only ever been rehearsed over gloo, no
+        # multi-GPU node having been available — must not cost the line; an exception is reported in its place)
         if backend == "nccl":
-            entry["gather"] = time_gather(shard.output, counts, rank, world, device, barrier, expected=expected)
+            try:
+                entry["gather"] = time_gather(shard.output, counts, rank, world, device, barrier, expected=expected)
+            except Exception as problem:
+                entry["gather"] = {"failed": repr(problem)}
         else:   # (the one-GPU rehearsal: gloo moves host tensors)
             entry["gather"] = time_gather(shard.output.cpu(), counts, rank, world, torch.device("cpu"), barrier, repetitions=1,
                                           expected=expected.cpu() if expected is not None else None)
             entry["gather"]["note"] = "REHEARSAL over gloo through host copies: checks the flow, says nothing about xGMI"
-        entry["gather_compressed"] = time_gather_compressed(whole, shard, counts, rank, world, device, barrier, expected=expected, through_host=backend != "nccl")
+        try:
+            entry["gather_compressed"] = time_gather_compressed(whole, shard, counts, rank, world, device, barrier, expected=expected, through_host=backend != "nccl")
+        except Exception as problem:
+            entry["gather_compressed"] = {"failed": repr(problem)}
         if backend != "nccl":
             entry["gather_compressed"]["note"] = "REHEARSAL over gloo through host copies: checks the flow, says nothing about xGMI"
     del shard, whole
@@ -699,7 +707,10 @@ def main():
         line["small_columns"] = {args.workload: small_columns(args.workload, work, device)}
     if args.gather and world > 1:
         count = min(n, 1 << args.gather_log2n)
-        line["gather"] = time_gather(work.output.view(-1)[:count], [count] * world, rank, world, device, barrier)
+        try:
+            line["gather"] = time_gather(work.output.view(-1)[:count], [count] * world, rank, world, device, barrier)
+        except Exception as problem:
+            line["gather"] = {"failed": repr(problem)}
 
     if rank == 0 and world == 1:
         ceiling = measured_copy_ceiling()
