@@ -11,7 +11,7 @@
    flag at three call sites of the tile loop (different wavefronts could arrive at different s_barrier instructions).  Now stream_tiles calls the hook from one place outside
    its loops; the scan asserts what that gives: every dictionary kernel holds at most THREE s_barrier instructions (the overlapped staging's — for a whole first tile, and for
    a ragged or absent one: a workgroup-uniform choice —, and the plain staging loop's of the other branch; the chunk-wise kernels: two), none of them on a cycle of the
-   control-flow graph.
+   control-flow graph, none behind a narrowing write of EXEC in its basic block.
 4. FULL WAITS INSIDE LOOPS (informative): `s_waitcnt vmcnt(0)` on a cycle of the control-flow graph.  CDNA4 counts vector memory operations in order, and a wait for the rows
    requested a trip ago should leave the newer requests in flight (`vmcnt(n)`); behind a wave-uniform branch around a load or a store the compiler no longer knows the count
    and waits for everything — the next rows' loads AND the stores before.  Round 6 found the plain Dictionary <4,8,2>'s chunk loop that way (61 -> 76 % of the HBM peak once
@@ -111,7 +111,21 @@ def barriers_in_cycles(start, instructions):
                 seen.add(b); stack.extend(successors[b])
         return False
     found = [a for a, text, _ in instructions if text.startswith("s_barrier")]
-    return len(found), sum(1 for a in found if on_a_cycle(block_of[a]))
+    # ... and none under a narrowed EXEC, as far as a basic block shows it: the last instruction before the barrier (in its block) that writes EXEC, if there is one,
+    # is the restoring `s_or_b64 exec, exec, saved` of a finished `if`, not a narrowing s_and_saveexec / s_and / s_andn2 / s_mov into exec
+    narrowed = 0
+    index_of = {a: i for i, (a, _, _) in enumerate(instructions)}
+    for a in found:
+        i = index_of[a] - 1
+        while i >= 0 and block_of[instructions[i][0]] == block_of[a]:
+            text = instructions[i][1]
+            writes_exec = re.match(r"^s_[a-z0-9_]+\s+exec\b", text) or text.startswith(("s_and_saveexec", "s_or_saveexec", "s_andn2_saveexec"))
+            if writes_exec:
+                if not text.startswith("s_or_b64 exec, exec,"):
+                    narrowed += 1
+                break
+            i -= 1
+    return len(found), sum(1 for a in found if on_a_cycle(block_of[a])) + narrowed
 
 
 bad_barriers, barrier_counts = [], collections.Counter()
