@@ -147,6 +147,7 @@ def timed_steps(work, steps, warmup, barrier, per_step_events=True):
     elapsed = time.perf_counter() - t0
     barrier()
     per_launch_ms = [b.elapsed_time(e) for b, e in events]
+    timed_steps.last_median_launch_ms = sorted(per_launch_ms)[len(per_launch_ms) // 2] if per_step_events else None   # (SURVEY.md section 8(d) asks for the median; `frac` is of the mean)
     return elapsed, sum(per_launch_ms) / steps
 
 
@@ -220,7 +221,8 @@ def roofline(work, mean_launch_ms, traffic):
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": work.kernel, "algorithmic_bytes_per_launch": work.algorithmic_bytes,
-            "mean_launch_ms": round(mean_launch_ms, 4)}
+            "mean_launch_ms": round(mean_launch_ms, 4),
+            "median_launch_ms": round(timed_steps.last_median_launch_ms, 4) if getattr(timed_steps, "last_median_launch_ms", None) else None}
 
 
 DETAILS_FILE = "bench_details.json"
@@ -758,7 +760,7 @@ def main():
                 warm = entry["roofline"]
                 entry["placement_and_cache"] = pc
                 entry["roofline"] = roofline(w, pc["ms_three_columns_in_turn"], committed_traffic(w.kernel, w.algorithmic_bytes, getattr(w, "workload_name", None)))
-                entry["roofline"].update({"input": "cold: three columns of different seeds decoded in turn into one output, one HIP event pair around the %d launches" % (3 * steps),
+                entry["roofline"].update({"median_launch_ms": None, "input": "cold: three columns of different seeds decoded in turn into one output, one HIP event pair around the %d launches" % (3 * steps),
                                           "frac_input_in_infinity_cache": warm["frac"], "mean_launch_ms_input_in_infinity_cache": warm["mean_launch_ms"]})
                 entry["decompressed_GBps_input_in_infinity_cache"], entry["ms_per_step_input_in_infinity_cache"] = entry["decompressed_GBps"], entry["ms_per_step"]
                 entry["decompressed_GBps"] = round(w.decompressed_bytes / (pc["ms_three_columns_in_turn"] * 1e-3) / 1e9, 1)
