@@ -88,6 +88,7 @@ def roofline_from_the_trace(durations_by_kernel, bench):
            "fraction = algorithmic bytes per step / (launches per step x their mean duration) / 8 TB/s.  `events` = the same fraction as bench.py reports it from HIP events in the same run.",
            "(A run decoder's figure is the cold one in both columns: three columns of different seeds decoded in turn.)\n",
            "| workload | kernel | launches/step | timed-region mean ns | algorithmic bytes/step | frac (trace) | frac (events) | trace/events |", "|---|---|---|---|---|---|---|---|"]
+    records = []
     # the decoder kernel of each workload: of the rows of its scheme's namespace, the one the run spent most time in (not a pre-pass)
     def head(name):   # the kernel's name and template arguments, without its parameter list
         name = name.replace("void ", "")
@@ -132,11 +133,14 @@ def roofline_from_the_trace(durations_by_kernel, bench):
         timed = full_size[-steps * per_step:]
         mean_ns = sum(timed) / max(len(timed), 1)
         frac = roofline["algorithmic_bytes_per_launch"] / (per_step * mean_ns * 1e-9) / 8e12
+        records.append({"workload": workload, "kernel": kernel, "launches_per_step": per_step, "timed_calls": len(timed), "mean_ns": mean_ns,
+                        "algorithmic_bytes_per_step": roofline["algorithmic_bytes_per_launch"], "frac_trace": frac, "frac_events": roofline["frac"]})
         out.append("| %s | `%s` | %d | %.1f | %d | %.4f | %.4f | %.3f |" % (workload, head(kernel).replace("cuda::kernels::", ""), per_step, mean_ns,
                                                                            roofline["algorithmic_bytes_per_launch"], frac, roofline["frac"], frac / roofline["frac"]))
     with open(os.path.join(OUT, ROUND + "_roofline_from_rocprof.md"), "w") as f:
         f.write("\n".join(out) + "\n")
     print("\n".join(out))
+    return records
 
 
 def records_of_the_passes():
@@ -176,19 +180,30 @@ def main():
                 durations_by_kernel.setdefault("headline alone: " + r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     except OSError:
         pass
-    with open(os.path.join(OUT, ROUND + "_kernel_stats.csv"), "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "TimedRegionCalls", "TimedRegionAverageNs"])
-        for r in ours:
-            d = durations_by_kernel.get("headline alone: " + r["Name"]) or durations_by_kernel.get(r["Name"], [])
-            timed = timed_region(d, 20 if ("dictionary::decompress" in r["Name"] or "variable_width" in r["Name"]) else 10)
-            w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"],
-                        len(timed), "%.1f" % (sum(timed) / max(len(timed), 1))])
     bench_line = details_of(os.path.join(RAW, "bench_under_rocprof.json"), os.path.join(RAW, "bench_under_rocprof.details.json"))
     with open(os.path.join(OUT, ROUND + "_bench_under_rocprof.json"), "w") as f:
         f.write(bench_line + "\n")
-
-    roofline_from_the_trace(durations_by_kernel, json.loads(bench_line))
+    records = roofline_from_the_trace(durations_by_kernel, json.loads(bench_line))
+    by_kernel = {}
+    for record in records:
+        by_kernel.setdefault(record["kernel"], []).append(record)
+    # One row per kernel of the stats — and, for a decoder kernel, one row per WORKLOAD that launches it, with THAT workload's timed region (its last 10 / 20 steps'
+    # full-size dispatches, told apart from the other workloads' by the steps each launched), its algorithmic bytes per step and the fraction of the 8 TB/s peak they give:
+    # every roofline fraction of the bench line can be recomputed from this file alone.
+    with open(os.path.join(OUT, ROUND + "_kernel_stats.csv"), "w", newline="") as f:
+        w = csv.writer(f)
+        w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev", "Workload", "LaunchesPerStep", "TimedRegionCalls", "TimedRegionAverageNs",
+                    "AlgorithmicBytesPerStep", "FracOfPeakFromTrace", "FracOfPeakByEvents"])
+        for r in ours:
+            common = [r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]]
+            if r["Name"] in by_kernel:
+                for record in by_kernel[r["Name"]]:
+                    w.writerow(common + [record["workload"], record["launches_per_step"], record["timed_calls"], "%.1f" % record["mean_ns"],
+                                         record["algorithmic_bytes_per_step"], "%.4f" % record["frac_trace"], "%.4f" % record["frac_events"]])
+            else:
+                d = durations_by_kernel.get(r["Name"], [])
+                timed = timed_region(d, 10)
+                w.writerow(common + ["", "", len(timed), "%.1f" % (sum(timed) / max(len(timed), 1)), "", "", ""])
 
     # ---- calibration ---------------------------------------------------------------------------------
     known_kib = (1 << 30) / 1024.0
